@@ -1,0 +1,129 @@
+/*
+ * libturboae_hip.so - C ABI of the MI355X-native TurboAE rate-1/3 CNN inference path.
+ *
+ * The reference (yihanjiang/turboae) is pure Python/PyTorch and has NO FFI/plugin layer; the seam
+ * a drop-in must honour is the Python call
+ *     x_dec, codes = Channel_AE.forward(input, fwd_noise)            channel_ae.py:20-73
+ * plus model.enc(X) (trainer.py:152,243), enc/dec.set_interleaver (channel_ae.py:35-36) and the
+ * metrics errors_ber / errors_bler (utils.py:6-18,49-66).  Each entry point below names the
+ * reference interface it replaces.  The Python binding a maintainer would add is
+ * turboae_amd/_lib.py (ctypes) + turboae_amd/channel_ae.py; see INTEGRATION.md.
+ *
+ * Conventions
+ *  - every tensor pointer is a DEVICE pointer (HBM resident) to contiguous little-endian fp32 in
+ *    the reference's own layouts: u (B,L,1), noise / codes / received (B,L,3), x_dec (B,L,1);
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); all calls are asynchronous
+ *    on it, allocate nothing and never synchronise, so a caller may capture them in a hipGraph;
+ *  - a handle is single-owner (not thread-safe), bound to the device current at tae_create;
+ *  - every function returns 0 on success or a negative TAE_E* code; tae_last_error() gives the
+ *    message for the calling thread.  Shape mismatches are rejected, never silently re-viewed
+ *    (the reference hard-codes args.batch_size views, decoders.py:221).
+ */
+#ifndef TURBOAE_HIP_H_
+#define TURBOAE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAE_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define TAE_API __attribute__((visibility("default")))
+#else
+#define TAE_API
+#endif
+
+enum {
+    TAE_OK = 0,
+    TAE_EINVAL = -1,    /* bad argument / unsupported configuration */
+    TAE_EHIP = -2,      /* HIP runtime error (message in tae_last_error) */
+    TAE_ENOMEM = -3,
+    TAE_ESTATE = -4     /* call sequence error (e.g. batch larger than reserved) */
+};
+
+/* Flags the hot path reads from the reference's argparse namespace (get_args.py:73-122). */
+typedef struct tae_config {
+    int32_t struct_size;      /* = sizeof(tae_config), for ABI evolution */
+    int32_t block_len;        /* -block_len        get_args.py:122 */
+    int32_t enc_num_layer;    /* -enc_num_layer    get_args.py:93  */
+    int32_t enc_num_unit;     /* -enc_num_unit     get_args.py:98  */
+    int32_t enc_kernel_size;  /* -enc_kernel_size  get_args.py:89  (must be 5) */
+    int32_t dec_num_layer;    /* -dec_num_layer    get_args.py:94  */
+    int32_t dec_num_unit;     /* -dec_num_unit     get_args.py:97  */
+    int32_t dec_kernel_size;  /* -dec_kernel_size  get_args.py:90  (must be 5) */
+    int32_t num_iteration;    /* -num_iteration    get_args.py:82  */
+    int32_t num_iter_ft;      /* -num_iter_ft      get_args.py:84  */
+    int32_t extrinsic;        /* -extrinsic        get_args.py:83  */
+    int32_t enc_act;          /* -enc_act: 0 = elu (default), 1 = linear   get_args.py:100 */
+    int32_t max_batch;        /* blocks per call the workspace is sized for (grown by tae_reserve) */
+} tae_config;
+
+typedef struct tae_handle tae_handle;
+
+/* Number of fp32 values tae_create expects in `weights` for this configuration (canonical order:
+ * turboae_amd/weights.py canonical_entries; PyTorch layouts of the reference state_dict,
+ * SURVEY.md Appendix B).  Returns 0 for an unsupported configuration. */
+TAE_API size_t tae_num_weights(const tae_config* cfg);
+
+/* Replaces model construction + load_state_dict (main.py:146-172).  `weights` is a HOST pointer to
+ * the canonical fp32 blob; it is re-tiled into MFMA fragment order and uploaded.  The interleaver
+ * is initialised to the identity; call tae_set_interleaver before use. */
+TAE_API int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, tae_handle** out);
+TAE_API int tae_destroy(tae_handle* h);
+
+/* Grow the internal workspace to `max_batch` blocks (allocates; not stream-ordered; call outside
+ * timed / captured regions). */
+TAE_API int tae_reserve(tae_handle* h, int32_t max_batch);
+
+/* Replaces enc.set_interleaver + dec.set_interleaver (channel_ae.py:35-36, encoders.py:340-341,
+ * decoders.py:202-204).  `p` is a HOST array with p[i] in [0,L), a permutation; L must equal
+ * block_len.  out[:, i, :] = in[:, p[i], :] (interleavers.py:15-21). */
+TAE_API int tae_set_interleaver(tae_handle* h, const int32_t* p, int32_t L);
+
+/* Replaces Channel_AE.forward (channel_ae.py:20-73, AWGN branch :41-42):
+ *   codes = enc(u) ; received = codes + noise ; x_dec = dec(received).
+ * power_constraint statistics are taken over exactly the B blocks of this call
+ * (encoders.py:107-108), as in the reference.  codes may be NULL. */
+TAE_API int tae_forward(tae_handle* h, const float* u, const float* noise, float* x_dec, float* codes, int32_t B, void* stream);
+
+/* Replaces model.enc(X) = ENC_interCNN.forward incl. power_constraint (encoders.py:351-377). */
+TAE_API int tae_encode(tae_handle* h, const float* u, float* codes, int32_t B, void* stream);
+
+/* Split form for multi-GPU sharding: x_tx (B,L,3) is the encoder output BEFORE
+ * power_constraint; stats3 (device, 3 doubles) receives (sum, sum of squares, count) of this
+ * shard.  The caller all-reduces stats3 over ranks (SUM), then calls tae_normalize. */
+TAE_API int tae_encode_prenorm(tae_handle* h, const float* u, float* x_tx, double* stats3, int32_t B, void* stream);
+
+/* codes = (x_tx - mean) / std with mean / unbiased std derived from stats3 (encoders.py:107-116);
+ * received = codes + noise (channel_ae.py:42).  codes, or noise+received, may be NULL. */
+TAE_API int tae_normalize(tae_handle* h, const float* x_tx, const double* stats3, const float* noise, float* codes,
+                  float* received, int32_t B, void* stream);
+
+/* Replaces model.dec(received) = DEC_LargeCNN.forward (decoders.py:206-269). */
+TAE_API int tae_decode(tae_handle* h, const float* received, float* x_dec, int32_t B, void* stream);
+
+/* Replaces errors_ber / errors_bler (utils.py:6-18,49-66) as integer counts ACCUMULATED into
+ * counts2 (device, 2 x uint64): [0] += bit errors, [1] += blocks with >= 1 bit error. */
+TAE_API int tae_count_errors(tae_handle* h, const float* x_dec, const float* u, int32_t B, uint64_t* counts2, void* stream);
+
+/* Replaces the test-input draws of trainer.test (trainer.py:167-169; channels.py:27-35;
+ * utils.py:69-70): u ~ Bernoulli(0.5) as {0,1} floats, noise = 10^(-snr_db/20) * N(0,1), from the
+ * counter-based Philox4x32-10 streams of turboae_amd/philox.py.  `first_block` is the GLOBAL index
+ * of the first block, so any shard reproduces the single-device stream.  Either output may be NULL. */
+TAE_API int tae_generate_inputs(tae_handle* h, float* u, float* noise, int32_t B, int64_t first_block, uint64_t seed_bits,
+                        uint64_t seed_noise, float snr_db, void* stream);
+
+/* Blocks per workgroup and dynamic LDS bytes of the fused kernels (for DESIGN / bench reporting). */
+TAE_API int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_t* lds_bytes);
+
+TAE_API const char* tae_last_error(void);
+TAE_API int tae_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TURBOAE_HIP_H_ */

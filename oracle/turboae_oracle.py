@@ -1,0 +1,171 @@
+"""ORACLE - test infrastructure only.  NOT part of the product path.
+
+CPU restatement (PyTorch-CPU fp32, ``torch.nn.functional`` ops only) of the reference hot path
+``Channel_AE.forward`` = ``ENC_interCNN`` -> ``power_constraint`` -> AWGN add -> ``DEC_LargeCNN``
+for yihanjiang/turboae, written from the reference's behaviour, each function citing the
+reference file:line it follows.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module, and only as the checker / CPU baseline.
+
+Parity pin: the reference has no tests or golden vectors for this path, so the
+pin is the reference itself imported in the build container: ``oracle/make_golden.py`` runs the
+real ``Channel_AE`` (``oracle/ref_harness.py``) and this restatement on identical weights/inputs,
+asserts equality (<= 2e-6) and commits the reference's outputs as fixtures under
+``tests/golden/``; ``tests/test_oracle_golden.py`` re-checks this module against those fixtures
+everywhere (no reference needed).
+
+The arithmetic lives in PyTorch ATen (oneDNN conv / elu / addmm / std), a third-party dependency of
+the reference (README.md:16 "PyTorch 1.0", no lockfile); semantics restated here are the
+documented ``Conv1d`` / ``ELU`` / ``Linear`` / ``std(unbiased)`` ones.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------------
+# permutation: commpy/channelcoding/interleavers.py:77-82 (RandInterlv), used at
+# channel_ae.py:32-36 with seed 0 on every forward, and main.py:123-127.
+def rand_interleaver(block_len: int, seed: int = 0) -> np.ndarray:
+    return np.random.mtrand.RandomState(seed).permutation(np.arange(block_len)).astype(np.int64)
+
+
+# interleavers.py:15-21  out[:, i, :] = in[:, p[i], :]
+def interleave(x: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    return x[:, p, :]
+
+
+# interleavers.py:29-33,43-48  inv[p[i]] = i ; out[:, j, :] = in[:, inv[j], :]
+def deinterleave(x: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    inv = torch.empty_like(p)
+    inv[p] = torch.arange(p.numel(), dtype=p.dtype)
+    return x[:, inv, :]
+
+
+# cnn_utils.py:36-46 (SameShapeConv1d.forward; ctor :6-34): x (B,L,C) -> transpose -> for each layer
+# ELU(conv1d(pad=k//2)) -> transpose back.  ELU on every layer, alpha=1.
+def same_shape_conv1d(x: torch.Tensor, w: Dict[str, torch.Tensor], prefix: str, num_layer: int) -> torch.Tensor:
+    h = x.transpose(1, 2)
+    for l in range(num_layer):
+        wt = w[f"{prefix}.cnns.{l}.weight"]
+        h = F.elu(F.conv1d(h, wt, w[f"{prefix}.cnns.{l}.bias"], stride=1, padding=wt.shape[2] // 2))
+    return h.transpose(1, 2)
+
+
+# encoders.py:102-125 (power_constraint, block_norm branch): (x - mean(x)) * 1.0 / std(x), mean and
+# unbiased std over ALL B*L*3 elements.
+def power_constraint(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    mean = torch.mean(x)
+    std = torch.std(x)
+    return (x - mean) * 1.0 / std, mean, std
+
+
+def _enc_act(x: torch.Tensor, enc_act: str) -> torch.Tensor:
+    # encoders.py:87-100 (only 'elu' and 'linear' are supported by the HIP path)
+    if enc_act == "elu":
+        return F.elu(x)
+    if enc_act == "linear":
+        return x
+    raise ValueError(enc_act)
+
+
+# encoders.py:351-377 (ENC_interCNN.forward), non-Dense branch.
+def encode_prenorm(u: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor, enc_num_layer: int,
+                   enc_act: str = "elu") -> torch.Tensor:
+    s = 2.0 * u - 1.0
+    b1 = _enc_act(F.linear(same_shape_conv1d(s, w, "enc.enc_cnn_1", enc_num_layer),
+                           w["enc.enc_linear_1.weight"], w["enc.enc_linear_1.bias"]), enc_act)
+    b2 = _enc_act(F.linear(same_shape_conv1d(s, w, "enc.enc_cnn_2", enc_num_layer),
+                           w["enc.enc_linear_2.weight"], w["enc.enc_linear_2.bias"]), enc_act)
+    b3 = _enc_act(F.linear(same_shape_conv1d(interleave(s, p), w, "enc.enc_cnn_3", enc_num_layer),
+                           w["enc.enc_linear_3.weight"], w["enc.enc_linear_3.bias"]), enc_act)
+    return torch.cat([b1, b2, b3], dim=2)
+
+
+def encode(u, w, p, enc_num_layer, enc_act="elu"):
+    codes, _, _ = power_constraint(encode_prenorm(u, w, p, enc_num_layer, enc_act))
+    return codes
+
+
+# decoders.py:206-269 (DEC_LargeCNN.forward), extrinsic per decoders.py:235-236,246-247.
+def decode(received: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor, dec_num_layer: int,
+           num_iteration: int, num_iter_ft: int, extrinsic: int = 1,
+           taps: Optional[dict] = None) -> torch.Tensor:
+    B, L, _ = received.shape
+    r_sys = received[:, :, 0:1]
+    r_sys_int = interleave(r_sys, p)
+    r_par1 = received[:, :, 1:2]
+    r_par2 = received[:, :, 2:3]
+    prior = torch.zeros((B, L, num_iter_ft), dtype=received.dtype)
+    for it in range(num_iteration - 1):
+        h = same_shape_conv1d(torch.cat([r_sys, r_par1, prior], dim=2), w, f"dec.dec1_cnns.{it}", dec_num_layer)
+        x_plr = F.linear(h, w[f"dec.dec1_outputs.{it}.weight"], w[f"dec.dec1_outputs.{it}.bias"])
+        if extrinsic:
+            x_plr = x_plr - prior
+        x_plr_int = interleave(x_plr, p)
+        h = same_shape_conv1d(torch.cat([r_sys_int, r_par2, x_plr_int], dim=2), w, f"dec.dec2_cnns.{it}", dec_num_layer)
+        x_plr = F.linear(h, w[f"dec.dec2_outputs.{it}.weight"], w[f"dec.dec2_outputs.{it}.bias"])
+        if extrinsic:
+            x_plr = x_plr - x_plr_int
+        prior = deinterleave(x_plr, p)
+        if taps is not None:
+            taps[f"prior_{it}"] = prior.clone()
+    it = num_iteration - 1
+    h = same_shape_conv1d(torch.cat([r_sys, r_par1, prior], dim=2), w, f"dec.dec1_cnns.{it}", dec_num_layer)
+    x_plr = F.linear(h, w[f"dec.dec1_outputs.{it}.weight"], w[f"dec.dec1_outputs.{it}.bias"])
+    if extrinsic:
+        x_plr = x_plr - prior
+    x_plr_int = interleave(x_plr, p)
+    h = same_shape_conv1d(torch.cat([r_sys_int, r_par2, x_plr_int], dim=2), w, f"dec.dec2_cnns.{it}", dec_num_layer)
+    logit_int = F.linear(h, w[f"dec.dec2_outputs.{it}.weight"], w[f"dec.dec2_outputs.{it}.bias"])
+    logits = deinterleave(logit_int, p)
+    if taps is not None:
+        taps["logits"] = logits.clone()
+    return torch.sigmoid(logits)
+
+
+# channel_ae.py:20-73 (Channel_AE.forward), AWGN branch (:41-42), rec_quantize off.
+def channel_ae_forward(u: torch.Tensor, fwd_noise: torch.Tensor, w: Dict[str, torch.Tensor], cfg: dict,
+                       taps: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cfg keys: block_len, enc_num_layer, dec_num_layer, num_iteration, num_iter_ft, extrinsic, enc_act."""
+    with torch.no_grad():
+        p = torch.from_numpy(rand_interleaver(u.shape[1], cfg.get("interleaver_seed", 0)))
+        x_tx = encode_prenorm(u, w, p, cfg["enc_num_layer"], cfg.get("enc_act", "elu"))
+        codes, mean, std = power_constraint(x_tx)
+        received = codes + fwd_noise
+        x_dec = decode(received, w, p, cfg["dec_num_layer"], cfg["num_iteration"], cfg["num_iter_ft"],
+                       cfg.get("extrinsic", 1), taps)
+        if taps is not None:
+            taps["x_tx"] = x_tx.clone()
+            taps["mean"] = mean.clone()
+            taps["std"] = std.clone()
+        return x_dec, codes
+
+
+# utils.py:6-18 (errors_ber): mean(round(y) != round(yhat)); torch.round is half-to-even.
+def errors_ber(y_true: torch.Tensor, y_pred: torch.Tensor) -> float:
+    ne = torch.ne(torch.round(y_true.reshape(y_true.shape[0], -1)), torch.round(y_pred.reshape(y_pred.shape[0], -1)))
+    return float(ne.float().sum() / ne.numel())
+
+
+# utils.py:49-66 (errors_bler): fraction of blocks with at least one bit error.
+def errors_bler(y_true: torch.Tensor, y_pred: torch.Tensor) -> float:
+    ne = torch.ne(torch.round(y_true.reshape(y_true.shape[0], -1)), torch.round(y_pred.reshape(y_pred.shape[0], -1)))
+    return float((ne.sum(dim=1) > 0).float().mean())
+
+
+def error_counts(y_true: torch.Tensor, y_pred: torch.Tensor) -> Tuple[int, int]:
+    ne = torch.ne(torch.round(y_true.reshape(y_true.shape[0], -1)), torch.round(y_pred.reshape(y_pred.shape[0], -1)))
+    return int(ne.sum()), int((ne.sum(dim=1) > 0).sum())
+
+
+# utils.py:69-70
+def snr_db2sigma(snr_db: float) -> float:
+    return 10 ** (-snr_db * 1.0 / 20)
+
+
+def to_torch(sd: Dict[str, np.ndarray]) -> Dict[str, torch.Tensor]:
+    return {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in sd.items()}

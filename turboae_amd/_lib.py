@@ -1,0 +1,79 @@
+"""ctypes binding of libturboae_hip.so (C ABI: include/turboae_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, an exception
+is raised.  The product path never routes through ``oracle/`` or any CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libturboae_hip.so")
+
+TAE_ABI_VERSION = 1
+
+
+class TaeConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "struct_size", "block_len", "enc_num_layer", "enc_num_unit", "enc_kernel_size",
+        "dec_num_layer", "dec_num_unit", "dec_kernel_size", "num_iteration", "num_iter_ft",
+        "extrinsic", "enc_act", "max_batch")]
+
+
+# name -> (restype, argtypes); every symbol declared in include/turboae_hip.h
+_P = C.c_void_p
+SIGNATURES = {
+    "tae_abi_version": (C.c_int, []),
+    "tae_last_error": (C.c_char_p, []),
+    "tae_num_weights": (C.c_size_t, [C.POINTER(TaeConfig)]),
+    "tae_create": (C.c_int, [C.POINTER(TaeConfig), _P, C.c_size_t, C.POINTER(_P)]),
+    "tae_destroy": (C.c_int, [_P]),
+    "tae_reserve": (C.c_int, [_P, C.c_int32]),
+    "tae_set_interleaver": (C.c_int, [_P, _P, C.c_int32]),
+    "tae_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, _P]),
+    "tae_encode": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
+    "tae_encode_prenorm": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P]),
+    "tae_normalize": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    "tae_decode": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
+    "tae_count_errors": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
+    "tae_generate_inputs": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64, C.c_float, _P]),
+    "tae_kernel_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class TurboAEError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises if it has not been built (``__graft_entry__.build()``
+    or ``make -C turboae_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # PyTorch-ROCm wheels bundle their own libamdhip64; it must be the first HIP runtime mapped into
+    # the process so that this library's NEEDED libamdhip64.so.7 resolves to the same copy (two HIP
+    # runtimes in one process see no devices).  torch is the host plumbing here anyway.
+    import torch  # noqa: F401
+    if not os.path.isfile(LIB_PATH):
+        raise TurboAEError(f"{LIB_PATH} not found: build it with `make -C turboae_amd/csrc` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.tae_abi_version() != TAE_ABI_VERSION:
+        raise TurboAEError("libturboae_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().tae_last_error()
+        raise TurboAEError(f"libturboae_hip error {rc}: {msg.decode() if msg else '?'}")

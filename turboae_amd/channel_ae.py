@@ -1,0 +1,268 @@
+"""Host-side mirror of the reference's ``Channel_AE`` for the MI355X HIP path.
+
+``Channel_AE_HIP(args_or_cfg, state_dict)`` exposes the same surface the reference's eval loop uses
+(trainer.py:135-248, main.py:146-172):
+
+    model.eval(); model.to(device)
+    x_dec, codes = model(X, fwd_noise)        # Channel_AE.forward, channel_ae.py:20-73
+    codes = model.enc(X)                      # ENC_interCNN.forward, encoders.py:351-377
+    x_dec = model.dec(received)               # DEC_LargeCNN.forward, decoders.py:206-269
+    model.enc.set_interleaver(p); model.dec.set_interleaver(p); model.enc.set_parallel()
+    model.load_state_dict(sd); model.state_dict()
+
+All arithmetic runs in libturboae_hip.so through the C ABI (include/turboae_hip.h); torch is used
+only for device memory and streams.  There is no CPU fallback: tensors must live on a ROCm device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import TurboAEConfig
+from .interleaver import rand_interleaver
+from . import weights as W
+
+_ENC_ACT = {"elu": 0, "linear": 1}
+
+
+def _as_cfg(args_or_cfg) -> TurboAEConfig:
+    if isinstance(args_or_cfg, TurboAEConfig):
+        return args_or_cfg
+    if isinstance(args_or_cfg, dict):
+        return TurboAEConfig(**args_or_cfg)
+    return TurboAEConfig.from_args(args_or_cfg)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Engine:
+    """Owns the tae_handle (weights + workspace on one GPU)."""
+
+    def __init__(self, cfg: TurboAEConfig, state_dict: Dict[str, object], device: torch.device, max_batch: int):
+        cfg.validate()
+        if device.type != "cuda":
+            raise _lib.TurboAEError("Channel_AE_HIP needs a ROCm GPU device (no CPU fallback)")
+        self.cfg = cfg
+        self.device = device
+        self.lib = _lib.load()
+        self._state = W.check_state_dict(cfg, state_dict)
+        blob = W.pack_blob(cfg, self._state)
+        c = _lib.TaeConfig(C.sizeof(_lib.TaeConfig), cfg.block_len, cfg.enc_num_layer, cfg.enc_num_unit,
+                           cfg.enc_kernel_size, cfg.dec_num_layer, cfg.dec_num_unit, cfg.dec_kernel_size,
+                           cfg.num_iteration, cfg.num_iter_ft, cfg.extrinsic, _ENC_ACT[cfg.enc_act], max_batch)
+        n = self.lib.tae_num_weights(C.byref(c))
+        if n != blob.size:
+            raise _lib.TurboAEError(f"weight count mismatch: library wants {n}, blob has {blob.size}")
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(self.lib.tae_create(C.byref(c), blob.ctypes.data_as(C.c_void_p), blob.size, C.byref(h)))
+        self.h = h
+        self.cap = max_batch
+        self.p_array: Optional[np.ndarray] = None
+        self.set_interleaver(rand_interleaver(cfg.block_len, cfg.interleaver_seed))
+
+    def close(self) -> None:
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.tae_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_interleaver(self, p_array) -> None:
+        p = np.ascontiguousarray(np.asarray(p_array).reshape(-1), dtype=np.int32)
+        if self.p_array is not None and p.shape == self.p_array.shape and np.array_equal(p, self.p_array):
+            return
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.tae_set_interleaver(self.h, p.ctypes.data_as(C.c_void_p), int(p.size)))
+        self.p_array = p
+
+    def reserve(self, B: int) -> None:
+        if B > self.cap:
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.tae_reserve(self.h, int(B)))
+            self.cap = B
+
+    def kernel_info(self) -> Tuple[int, int]:
+        nb, lds = C.c_int32(), C.c_int32()
+        _lib.check(self.lib.tae_kernel_info(self.h, C.byref(nb), C.byref(lds)))
+        return nb.value, lds.value
+
+    # ---- tensor helpers
+    def _in(self, t: torch.Tensor, last: int, name: str) -> torch.Tensor:
+        L = self.cfg.block_len
+        if t.dim() != 3 or t.shape[1] != L or t.shape[2] != last:
+            raise ValueError(f"{name} must have shape (B, {L}, {last}), got {tuple(t.shape)}")
+        if t.device != self.device:
+            t = t.to(self.device)
+        return t.contiguous().float()
+
+    def _out(self, B: int, last: int) -> torch.Tensor:
+        return torch.empty((B, self.cfg.block_len, last), dtype=torch.float32, device=self.device)
+
+
+class _EncView:
+    """model.enc: callable like ENC_interCNN (encoders.py:306-377)."""
+
+    def __init__(self, eng: _Engine):
+        self._e = eng
+
+    def set_interleaver(self, p_array) -> None:        # encoders.py:340-341
+        self._e.set_interleaver(p_array)
+
+    def set_parallel(self) -> None:                    # encoders.py:343-349: DataParallel wrappers; nothing to do
+        pass
+
+    def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
+        e = self._e
+        u = e._in(inputs, 1, "inputs")
+        B = u.shape[0]
+        e.reserve(B)
+        codes = e._out(B, 3)
+        with torch.cuda.device(e.device):
+            _lib.check(e.lib.tae_encode(e.h, _ptr(u), _ptr(codes), B, _stream()))
+        return codes
+
+    forward = __call__
+
+
+class _DecView:
+    """model.dec: callable like DEC_LargeCNN (decoders.py:157-269)."""
+
+    def __init__(self, eng: _Engine):
+        self._e = eng
+
+    def set_interleaver(self, p_array) -> None:        # decoders.py:202-204
+        self._e.set_interleaver(p_array)
+
+    def set_parallel(self) -> None:                    # decoders.py:194-199
+        pass
+
+    def __call__(self, received: torch.Tensor) -> torch.Tensor:
+        e = self._e
+        rx = e._in(received, 3, "received")
+        B = rx.shape[0]
+        e.reserve(B)
+        x_dec = e._out(B, 1)
+        with torch.cuda.device(e.device):
+            _lib.check(e.lib.tae_decode(e.h, _ptr(rx), _ptr(x_dec), B, _stream()))
+        return x_dec
+
+    forward = __call__
+
+
+class Channel_AE_HIP:
+    """Drop-in for ``Channel_AE(args, enc, dec)`` on the AWGN / rate-1/3 CNN eval path."""
+
+    def __init__(self, args_or_cfg, state_dict: Dict[str, object], device: Optional[torch.device] = None,
+                 max_batch: int = 500, is_same_interleaver: int = 1):
+        cfg = _as_cfg(args_or_cfg)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.cfg = cfg
+        self.is_same_interleaver = is_same_interleaver
+        self._eng = _Engine(cfg, state_dict, torch.device(device), max_batch)
+        self.enc = _EncView(self._eng)
+        self.dec = _DecView(self._eng)
+        self.this_device = self._eng.device
+
+    # -- torch.nn.Module look-alikes used by main.py / trainer.py
+    def eval(self):
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self._eng.device and torch.device(device).type != "cuda":
+            raise _lib.TurboAEError("Channel_AE_HIP cannot move to a non-GPU device")
+        return self
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: torch.from_numpy(v.copy()) for k, v in self._eng._state.items()}
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        old = self._eng
+        self._eng = _Engine(self.cfg, state_dict, old.device, old.cap)
+        self._eng.set_interleaver(old.p_array)
+        self.enc._e = self._eng
+        self.dec._e = self._eng
+        old.close()
+        return self
+
+    def kernel_info(self):
+        return self._eng.kernel_info()
+
+    def forward(self, input: torch.Tensor, fwd_noise: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        e = self._eng
+        if self.is_same_interleaver:   # channel_ae.py:32-36: RandInterlv(block_len, 0) on every call
+            e.set_interleaver(rand_interleaver(self.cfg.block_len, 0))
+        u = e._in(input, 1, "input")
+        noise = e._in(fwd_noise, 3, "fwd_noise")
+        B = u.shape[0]
+        if noise.shape[0] != B:
+            raise ValueError("input and fwd_noise batch sizes differ")
+        e.reserve(B)
+        x_dec, codes = e._out(B, 1), e._out(B, 3)
+        with torch.cuda.device(e.device):
+            _lib.check(e.lib.tae_forward(e.h, _ptr(u), _ptr(noise), _ptr(x_dec), _ptr(codes), B, _stream()))
+        return x_dec, codes
+
+    __call__ = forward
+
+    # -- split form used for multi-GPU sharding
+    def encode_prenorm(self, input: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        e = self._eng
+        u = e._in(input, 1, "input")
+        B = u.shape[0]
+        e.reserve(B)
+        x_tx = e._out(B, 3)
+        stats = torch.empty(3, dtype=torch.float64, device=e.device)
+        with torch.cuda.device(e.device):
+            _lib.check(e.lib.tae_encode_prenorm(e.h, _ptr(u), _ptr(x_tx), _ptr(stats), B, _stream()))
+        return x_tx, stats
+
+    def normalize(self, x_tx: torch.Tensor, stats: torch.Tensor, fwd_noise: Optional[torch.Tensor] = None,
+                  want_codes: bool = True):
+        e = self._eng
+        x = e._in(x_tx, 3, "x_tx")
+        B = x.shape[0]
+        noise = None if fwd_noise is None else e._in(fwd_noise, 3, "fwd_noise")
+        codes = e._out(B, 3) if want_codes else None
+        rx = e._out(B, 3) if noise is not None else None
+        st = stats.to(device=e.device, dtype=torch.float64).contiguous()
+        with torch.cuda.device(e.device):
+            _lib.check(e.lib.tae_normalize(e.h, _ptr(x), _ptr(st), _ptr(noise), _ptr(codes), _ptr(rx), B, _stream()))
+        return codes, rx
+
+    def count_errors(self, x_dec: torch.Tensor, u: torch.Tensor, counts: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Accumulate (bit errors, block errors) (utils.py:6-18,49-66) into a device int64[2] tensor."""
+        e = self._eng
+        xd = e._in(x_dec, 1, "x_dec")
+        uu = e._in(u, 1, "u")
+        if counts is None:
+            counts = torch.zeros(2, dtype=torch.int64, device=e.device)
+        with torch.cuda.device(e.device):
+            _lib.check(e.lib.tae_count_errors(e.h, _ptr(xd), _ptr(uu), xd.shape[0], _ptr(counts), _stream()))
+        return counts
+
+    def generate_inputs(self, B: int, snr_db: float, seed: int, first_block: int = 0,
+                        seed_noise: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Device-side test inputs (replaces trainer.py:167-169), Philox streams of turboae_amd/philox.py."""
+        e = self._eng
+        u, noise = e._out(B, 1), e._out(B, 3)
+        sn = seed if seed_noise is None else seed_noise
+        with torch.cuda.device(e.device):
+            _lib.check(e.lib.tae_generate_inputs(e.h, _ptr(u), _ptr(noise), B, int(first_block), int(seed), int(sn),
+                                                 float(snr_db), _stream()))
+        return u, noise

@@ -1,0 +1,68 @@
+"""Configuration of the TurboAE rate-1/3 CNN hot path.
+
+Field names follow the reference's flat argparse namespace (get_args.py:73-122) so a
+reference ``args`` object can be converted with :meth:`TurboAEConfig.from_args`.
+Only the flags the hot path reads ("config / flags") are kept.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, asdict
+
+
+@dataclass(frozen=True)
+class TurboAEConfig:
+    block_len: int = 100          # get_args.py:122
+    code_rate_k: int = 1          # get_args.py:73
+    code_rate_n: int = 3          # get_args.py:74
+    enc_num_layer: int = 2        # get_args.py:93
+    enc_num_unit: int = 100       # get_args.py:98
+    enc_kernel_size: int = 5      # get_args.py:89
+    dec_num_layer: int = 5        # get_args.py:94
+    dec_num_unit: int = 100       # get_args.py:97
+    dec_kernel_size: int = 5      # get_args.py:90
+    num_iteration: int = 6        # get_args.py:82
+    num_iter_ft: int = 5          # get_args.py:84
+    extrinsic: int = 1            # get_args.py:83
+    enc_act: str = "elu"          # get_args.py:100 ("only elu works")
+    interleaver_seed: int = 0     # channel_ae.py:33 (RandInterlv(block_len, 0))
+
+    def validate(self) -> None:
+        if self.code_rate_k != 1 or self.code_rate_n != 3:
+            raise ValueError("only the rate-1/3 code (code_rate_k=1, code_rate_n=3) is on the hot path")
+        if self.enc_kernel_size != 5 or self.dec_kernel_size != 5:
+            raise ValueError("HIP path implements kernel_size=5 (the reference default and all BASELINE configs)")
+        if self.enc_act not in ("elu", "linear"):
+            raise ValueError("enc_act must be 'elu' (reference default) or 'linear'")
+        if self.enc_num_unit != self.dec_num_unit:
+            raise ValueError("enc_num_unit must equal dec_num_unit (one channel width per build)")
+        if self.enc_num_unit not in (32, 64, 100):
+            raise ValueError("channel width must be one of 32, 64, 100 (instantiated kernel widths)")
+        if not (1 <= self.num_iter_ft <= 6):
+            raise ValueError("num_iter_ft must be in 1..6 (7-channel decoder input is padded to 8)")
+        if self.num_iteration < 1 or self.enc_num_layer < 1 or self.dec_num_layer < 1:
+            raise ValueError("layer / iteration counts must be >= 1")
+        if self.block_len < 1:
+            raise ValueError("block_len must be >= 1")
+
+    @staticmethod
+    def from_args(args) -> "TurboAEConfig":
+        """Build from a reference-style argparse namespace (get_args.py)."""
+        names = TurboAEConfig.__dataclass_fields__.keys()
+        kw = {n: getattr(args, n) for n in names if hasattr(args, n)}
+        cfg = TurboAEConfig(**kw)
+        return cfg
+
+    def to_dict(self) -> dict:
+        return asdict(self)
+
+    # ---- algorithmic work per information bit (SURVEY.md section 8d / BASELINE.md section 3)
+    def macs_per_bit(self) -> dict:
+        ke, kd = self.enc_kernel_size, self.dec_kernel_size
+        ue, ud, f = self.enc_num_unit, self.dec_num_unit, self.num_iter_ft
+        enc = 3 * (1 * ke * ue + (self.enc_num_layer - 1) * ue * ke * ue + ue)
+        stack = (2 + f) * kd * ud + (self.dec_num_layer - 1) * ud * kd * ud
+        dec = 2 * self.num_iteration * stack + (2 * self.num_iteration - 1) * ud * f + ud
+        return {"enc": enc, "dec": dec, "total": enc + dec}
+
+    def flops_per_bit(self) -> int:
+        return 2 * self.macs_per_bit()["total"]

@@ -1,0 +1,375 @@
+// libturboae_hip.so - host side of the C ABI declared in include/turboae_hip.h.
+// Owns the packed weights, the interleaver tables and the workspace; every compute entry point is
+// a short sequence of asynchronous kernel launches on the caller's stream (graph-capturable).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+
+#include "../../include/turboae_hip.h"
+#include "turboae_internal.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define TAE_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) return fail(TAE_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+struct Layout {
+    int U, CT, CP, nch_mid, midf, l0f;
+    explicit Layout(int u) : U(u) {
+        CT = (U + 15) / 16;
+        CP = CT * 16;
+        nch_mid = (5 * U + 7) / 8;
+        midf = nch_mid * CT * 128;
+        l0f = 5 * CT * 128;
+    }
+    size_t stack_stride(int n_layer) const { return (size_t)l0f + CP + (size_t)(n_layer - 1) * (midf + CP) + 8 * CP + 8; }
+};
+
+// Tile one Conv1d weight (U, cin, 5) into MFMA A-fragment order [chunk][ct][lane][2]:
+// lane (i = lane & 15, kq = lane >> 4) of k-step s holds W'[co = ct*16 + i][k = 8*chunk + 2*kq + s]
+// with k = tap * cin_pad + ci (tap-major), zero outside the real tensor.
+void pack_conv(const float* W, int U, int cin, int cin_pad, int nch, int CT, float* dst) {
+    for (int c = 0; c < nch; ++c)
+        for (int ct = 0; ct < CT; ++ct)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int s = 0; s < 2; ++s) {
+                    const int co = ct * 16 + (lane & 15);
+                    const int k = 8 * c + 2 * (lane >> 4) + s;
+                    const int j = k / cin_pad, ci = k % cin_pad;
+                    float v = 0.0f;
+                    if (co < U && j < 5 && ci < cin) v = W[((size_t)co * cin + ci) * 5 + j];
+                    dst[(((size_t)c * CT + ct) * 64 + lane) * 2 + s] = v;
+                }
+}
+
+// canonical stack (conv layers then Linear head) -> packed stack; returns floats consumed from src
+size_t pack_stack(const float* src, const Layout& lo, int n_layer, int cin0, int nout, float* dst) {
+    const float* s = src;
+    float* d = dst;
+    for (int l = 0; l < n_layer; ++l) {
+        const int cin = l == 0 ? cin0 : lo.U;
+        if (l == 0) { pack_conv(s, lo.U, cin, 8, 5, lo.CT, d); d += lo.l0f; }
+        else { pack_conv(s, lo.U, cin, lo.U, lo.nch_mid, lo.CT, d); d += lo.midf; }
+        s += (size_t)lo.U * cin * 5;
+        for (int c = 0; c < lo.CP; ++c) d[c] = c < lo.U ? s[c] : 0.0f;
+        d += lo.CP;
+        s += lo.U;
+    }
+    for (int f = 0; f < 8; ++f)
+        for (int c = 0; c < lo.CP; ++c) d[f * lo.CP + c] = (f < nout && c < lo.U) ? s[(size_t)f * lo.U + c] : 0.0f;
+    d += 8 * lo.CP;
+    s += (size_t)nout * lo.U;
+    for (int f = 0; f < 8; ++f) d[f] = f < nout ? s[f] : 0.0f;
+    s += nout;
+    return (size_t)(s - src);
+}
+
+}  // namespace
+
+struct tae_handle {
+    tae_config cfg;
+    int device = 0;
+    int U = 0, nb = 0, lds_bytes = 0;
+    uint32_t enc_stride = 0, dec_stride = 0;
+    float* d_wenc = nullptr;
+    float* d_wdec = nullptr;
+    int32_t* d_perm = nullptr;
+    int32_t* d_inv = nullptr;
+    // workspace
+    int32_t cap = 0;
+    float* d_xtx = nullptr;
+    float* d_rx = nullptr;
+    double* d_partials = nullptr;
+    double* d_stats = nullptr;
+};
+
+namespace {
+
+int check_cfg(const tae_config* c) {
+    if (!c) return fail(TAE_EINVAL, "config is NULL");
+    if (c->struct_size != (int32_t)sizeof(tae_config)) return fail(TAE_EINVAL, "tae_config.struct_size mismatch (ABI)");
+    if (c->enc_kernel_size != 5 || c->dec_kernel_size != 5) return fail(TAE_EINVAL, "only kernel_size 5 is supported");
+    if (c->enc_num_unit != c->dec_num_unit) return fail(TAE_EINVAL, "enc_num_unit must equal dec_num_unit");
+    if (c->enc_num_unit != 100 && c->enc_num_unit != 64 && c->enc_num_unit != 32)
+        return fail(TAE_EINVAL, "channel width must be 32, 64 or 100");
+    if (c->enc_num_layer < 1 || c->dec_num_layer < 1 || c->num_iteration < 1) return fail(TAE_EINVAL, "layer/iteration counts must be >= 1");
+    if (c->num_iter_ft < 1 || c->num_iter_ft > 6) return fail(TAE_EINVAL, "num_iter_ft must be in 1..6");
+    if (c->block_len < 1) return fail(TAE_EINVAL, "block_len must be >= 1");
+    if (c->enc_act != 0 && c->enc_act != 1) return fail(TAE_EINVAL, "enc_act must be 0 (elu) or 1 (linear)");
+    return TAE_OK;
+}
+
+size_t num_weights(const tae_config* c) {
+    const size_t U = c->enc_num_unit, F = c->num_iter_ft;
+    size_t n = 0;
+    for (int s = 0; s < 3; ++s) {
+        for (int l = 0; l < c->enc_num_layer; ++l) n += U * (l == 0 ? 1 : U) * 5 + U;
+        n += U + 1;
+    }
+    for (int it = 0; it < c->num_iteration; ++it)
+        for (int half = 0; half < 2; ++half) {
+            for (int l = 0; l < c->dec_num_layer; ++l) n += U * (l == 0 ? 2 + F : U) * 5 + U;
+            const size_t nout = (half == 1 && it == c->num_iteration - 1) ? 1 : F;
+            n += nout * U + nout;
+        }
+    return n;
+}
+
+int choose_nb(int U, int L, int* lds_out) {
+    const int max_pos = tae::fused_max_positions();
+    int nb = max_pos / L;
+    while (nb >= 1 && tae::fused_lds_bytes(U, L, nb) > 160 * 1024) --nb;
+    if (nb < 1) return 0;
+    *lds_out = tae::fused_lds_bytes(U, L, nb);
+    return nb;
+}
+
+int check_batch(tae_handle* h, int32_t B) {
+    if (!h) return fail(TAE_EINVAL, "handle is NULL");
+    if (B < 1) return fail(TAE_EINVAL, "batch must be >= 1");
+    if (B > h->cap) return fail(TAE_ESTATE, "batch exceeds reserved workspace; call tae_reserve first");
+    return TAE_OK;
+}
+
+tae::FusedParams base_params(const tae_handle* h, int32_t B) {
+    tae::FusedParams P;
+    memset(&P, 0, sizeof(P));
+    P.perm = h->d_perm;
+    P.inv = h->d_inv;
+    P.B = B;
+    P.L = h->cfg.block_len;
+    P.nb = h->nb;
+    P.n_iter = h->cfg.num_iteration;
+    P.F = h->cfg.num_iter_ft;
+    P.extrinsic = h->cfg.extrinsic;
+    P.act = h->cfg.enc_act;
+    P.lds_bytes = h->lds_bytes;
+    return P;
+}
+
+int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st) {
+    tae::FusedParams P = base_params(h, B);
+    P.wpack = h->d_wenc;
+    P.in = u;
+    P.out = xtx;
+    P.partials = h->d_partials;
+    P.n_layer = h->cfg.enc_num_layer;
+    P.stack_stride = h->enc_stride;
+    const int grid = (B + h->nb - 1) / h->nb;
+    TAE_HIP(tae::launch_fused(h->U, false, P, grid, st));
+    TAE_HIP(tae::launch_reduce_partials(h->d_partials, grid, (double)B * h->cfg.block_len * 3.0, stats, st));
+    return TAE_OK;
+}
+
+int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st) {
+    tae::FusedParams P = base_params(h, B);
+    P.wpack = h->d_wdec;
+    P.in = rx;
+    P.out = xdec;
+    P.n_layer = h->cfg.dec_num_layer;
+    P.stack_stride = h->dec_stride;
+    const int grid = (B + h->nb - 1) / h->nb;
+    TAE_HIP(tae::launch_fused(h->U, true, P, grid, st));
+    return TAE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tae_abi_version(void) { return TAE_ABI_VERSION; }
+
+const char* tae_last_error(void) { return g_err.c_str(); }
+
+size_t tae_num_weights(const tae_config* cfg) {
+    if (check_cfg(cfg) != TAE_OK) return 0;
+    return num_weights(cfg);
+}
+
+int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, tae_handle** out) {
+    if (!out) return fail(TAE_EINVAL, "out is NULL");
+    *out = nullptr;
+    int rc = check_cfg(cfg);
+    if (rc != TAE_OK) return rc;
+    if (!weights) return fail(TAE_EINVAL, "weights is NULL");
+    if (n_weights != num_weights(cfg)) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "weights blob has %zu floats, configuration needs %zu", n_weights, num_weights(cfg));
+        return fail(TAE_EINVAL, buf);
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(TAE_EHIP, "no HIP device available: libturboae_hip needs an AMD GPU (no CPU fallback)");
+    tae_handle* h = new tae_handle();
+    h->cfg = *cfg;
+    h->U = cfg->enc_num_unit;
+    (void)hipGetDevice(&h->device);
+    h->nb = choose_nb(h->U, cfg->block_len, &h->lds_bytes);
+    if (h->nb < 1) {
+        delete h;
+        return fail(TAE_EINVAL, "block_len too large for the whole-block fused kernels (max 320 positions per workgroup)");
+    }
+    const Layout lo(h->U);
+    const int F = cfg->num_iter_ft;
+    h->enc_stride = (uint32_t)lo.stack_stride(cfg->enc_num_layer);
+    h->dec_stride = (uint32_t)lo.stack_stride(cfg->dec_num_layer);
+    std::vector<float> penc((size_t)3 * h->enc_stride, 0.0f), pdec((size_t)2 * cfg->num_iteration * h->dec_stride, 0.0f);
+    const float* src = weights;
+    for (int s = 0; s < 3; ++s) src += pack_stack(src, lo, cfg->enc_num_layer, 1, 1, penc.data() + (size_t)s * h->enc_stride);
+    for (int it = 0; it < cfg->num_iteration; ++it)
+        for (int half = 0; half < 2; ++half) {
+            const int nout = (half == 1 && it == cfg->num_iteration - 1) ? 1 : F;
+            src += pack_stack(src, lo, cfg->dec_num_layer, 2 + F, nout, pdec.data() + (size_t)(2 * it + half) * h->dec_stride);
+        }
+    if ((size_t)(src - weights) != n_weights) {
+        delete h;
+        return fail(TAE_EINVAL, "internal: weight walk mismatch");
+    }
+    const int L = cfg->block_len;
+    std::vector<int32_t> ident(L);
+    for (int i = 0; i < L; ++i) ident[i] = i;
+#define TAE_HIP_H(expr)                                                                            \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) { tae_destroy(h); return fail(TAE_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } \
+    } while (0)
+    TAE_HIP_H(hipMalloc(&h->d_wenc, penc.size() * sizeof(float)));
+    TAE_HIP_H(hipMalloc(&h->d_wdec, pdec.size() * sizeof(float)));
+    TAE_HIP_H(hipMalloc(&h->d_perm, L * sizeof(int32_t)));
+    TAE_HIP_H(hipMalloc(&h->d_inv, L * sizeof(int32_t)));
+    TAE_HIP_H(hipMalloc(&h->d_stats, 4 * sizeof(double)));
+    TAE_HIP_H(hipMemcpy(h->d_wenc, penc.data(), penc.size() * sizeof(float), hipMemcpyHostToDevice));
+    TAE_HIP_H(hipMemcpy(h->d_wdec, pdec.data(), pdec.size() * sizeof(float), hipMemcpyHostToDevice));
+    TAE_HIP_H(hipMemcpy(h->d_perm, ident.data(), L * sizeof(int32_t), hipMemcpyHostToDevice));
+    TAE_HIP_H(hipMemcpy(h->d_inv, ident.data(), L * sizeof(int32_t), hipMemcpyHostToDevice));
+#undef TAE_HIP_H
+    rc = tae_reserve(h, cfg->max_batch > 0 ? cfg->max_batch : 1);
+    if (rc != TAE_OK) { tae_destroy(h); return rc; }
+    *out = h;
+    return TAE_OK;
+}
+
+int tae_destroy(tae_handle* h) {
+    if (!h) return TAE_OK;
+    (void)hipFree(h->d_wenc); (void)hipFree(h->d_wdec); (void)hipFree(h->d_perm); (void)hipFree(h->d_inv);
+    (void)hipFree(h->d_xtx); (void)hipFree(h->d_rx); (void)hipFree(h->d_partials); (void)hipFree(h->d_stats);
+    delete h;
+    return TAE_OK;
+}
+
+int tae_reserve(tae_handle* h, int32_t max_batch) {
+    if (!h) return fail(TAE_EINVAL, "handle is NULL");
+    if (max_batch < 1) return fail(TAE_EINVAL, "max_batch must be >= 1");
+    if (max_batch <= h->cap) return TAE_OK;
+    TAE_HIP(hipDeviceSynchronize());
+    (void)hipFree(h->d_xtx); (void)hipFree(h->d_rx); (void)hipFree(h->d_partials);
+    h->d_xtx = h->d_rx = nullptr; h->d_partials = nullptr; h->cap = 0;
+    const size_t n3 = (size_t)max_batch * h->cfg.block_len * 3;
+    const size_t grid = ((size_t)max_batch + h->nb - 1) / h->nb;
+    TAE_HIP(hipMalloc(&h->d_xtx, n3 * sizeof(float)));
+    TAE_HIP(hipMalloc(&h->d_rx, n3 * sizeof(float)));
+    TAE_HIP(hipMalloc(&h->d_partials, grid * 2 * sizeof(double)));
+    h->cap = max_batch;
+    return TAE_OK;
+}
+
+int tae_set_interleaver(tae_handle* h, const int32_t* p, int32_t L) {
+    if (!h || !p) return fail(TAE_EINVAL, "NULL argument");
+    if (L != h->cfg.block_len) return fail(TAE_EINVAL, "interleaver length must equal block_len");
+    std::vector<int32_t> inv(L, -1);
+    for (int i = 0; i < L; ++i) {
+        if (p[i] < 0 || p[i] >= L || inv[p[i]] != -1) return fail(TAE_EINVAL, "p is not a permutation of 0..L-1");
+        inv[p[i]] = i;   // interleavers.py:29-33
+    }
+    TAE_HIP(hipDeviceSynchronize());
+    TAE_HIP(hipMemcpy(h->d_perm, p, L * sizeof(int32_t), hipMemcpyHostToDevice));
+    TAE_HIP(hipMemcpy(h->d_inv, inv.data(), L * sizeof(int32_t), hipMemcpyHostToDevice));
+    return TAE_OK;
+}
+
+int tae_encode_prenorm(tae_handle* h, const float* u, float* x_tx, double* stats3, int32_t B, void* stream) {
+    int rc = check_batch(h, B);
+    if (rc != TAE_OK) return rc;
+    if (!u || !x_tx || !stats3) return fail(TAE_EINVAL, "NULL tensor");
+    return run_encoder(h, u, x_tx, stats3, B, (hipStream_t)stream);
+}
+
+int tae_normalize(tae_handle* h, const float* x_tx, const double* stats3, const float* noise, float* codes, float* received,
+                  int32_t B, void* stream) {
+    int rc = check_batch(h, B);
+    if (rc != TAE_OK) return rc;
+    if (!x_tx || !stats3) return fail(TAE_EINVAL, "NULL tensor");
+    if ((received != nullptr) != (noise != nullptr)) return fail(TAE_EINVAL, "noise and received must be given together");
+    if (!codes && !received) return fail(TAE_EINVAL, "nothing to write");
+    TAE_HIP(tae::launch_normalize(x_tx, stats3, noise, codes, received, (size_t)B * h->cfg.block_len * 3, (hipStream_t)stream));
+    return TAE_OK;
+}
+
+int tae_encode(tae_handle* h, const float* u, float* codes, int32_t B, void* stream) {
+    int rc = check_batch(h, B);
+    if (rc != TAE_OK) return rc;
+    if (!u || !codes) return fail(TAE_EINVAL, "NULL tensor");
+    rc = run_encoder(h, u, h->d_xtx, h->d_stats, B, (hipStream_t)stream);
+    if (rc != TAE_OK) return rc;
+    return tae_normalize(h, h->d_xtx, h->d_stats, nullptr, codes, nullptr, B, stream);
+}
+
+int tae_decode(tae_handle* h, const float* received, float* x_dec, int32_t B, void* stream) {
+    int rc = check_batch(h, B);
+    if (rc != TAE_OK) return rc;
+    if (!received || !x_dec) return fail(TAE_EINVAL, "NULL tensor");
+    return run_decoder(h, received, x_dec, B, (hipStream_t)stream);
+}
+
+int tae_forward(tae_handle* h, const float* u, const float* noise, float* x_dec, float* codes, int32_t B, void* stream) {
+    int rc = check_batch(h, B);
+    if (rc != TAE_OK) return rc;
+    if (!u || !noise || !x_dec) return fail(TAE_EINVAL, "NULL tensor");
+    hipStream_t st = (hipStream_t)stream;
+    rc = run_encoder(h, u, h->d_xtx, h->d_stats, B, st);
+    if (rc != TAE_OK) return rc;
+    rc = tae_normalize(h, h->d_xtx, h->d_stats, noise, codes, h->d_rx, B, stream);
+    if (rc != TAE_OK) return rc;
+    return run_decoder(h, h->d_rx, x_dec, B, st);
+}
+
+int tae_count_errors(tae_handle* h, const float* x_dec, const float* u, int32_t B, uint64_t* counts2, void* stream) {
+    if (!h || !x_dec || !u || !counts2) return fail(TAE_EINVAL, "NULL argument");
+    if (B < 1) return fail(TAE_EINVAL, "batch must be >= 1");
+    TAE_HIP(tae::launch_count_errors(x_dec, u, B, h->cfg.block_len, (unsigned long long*)counts2, (hipStream_t)stream));
+    return TAE_OK;
+}
+
+int tae_generate_inputs(tae_handle* h, float* u, float* noise, int32_t B, int64_t first_block, uint64_t seed_bits,
+                        uint64_t seed_noise, float snr_db, void* stream) {
+    if (!h) return fail(TAE_EINVAL, "handle is NULL");
+    if (B < 1 || first_block < 0) return fail(TAE_EINVAL, "bad block range");
+    if (!u && !noise) return fail(TAE_EINVAL, "nothing to write");
+    const float sigma = (float)pow(10.0, -(double)snr_db / 20.0);   // utils.py:69-70
+    const size_t L = h->cfg.block_len;
+    TAE_HIP(tae::launch_gen_inputs(u, noise, (size_t)B * L, (size_t)first_block * L, seed_bits, seed_noise, sigma, (hipStream_t)stream));
+    return TAE_OK;
+}
+
+int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_t* lds_bytes) {
+    if (!h) return fail(TAE_EINVAL, "handle is NULL");
+    if (blocks_per_workgroup) *blocks_per_workgroup = h->nb;
+    if (lds_bytes) *lds_bytes = h->lds_bytes;
+    return TAE_OK;
+}
+
+}  // extern "C"

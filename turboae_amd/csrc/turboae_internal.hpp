@@ -1,0 +1,38 @@
+// Internal host<->kernel interface of libturboae_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <algorithm>
+
+namespace tae {
+
+// Arguments of the fused encoder / decoder kernels (one workgroup = nb whole codeword blocks).
+struct FusedParams {
+    const float* wpack;     // packed weights of this network (encoder: 3 stacks, decoder: 2*n_iter stacks)
+    const int32_t* perm;    // p[L]   (interleavers.py:15-21)
+    const int32_t* inv;     // inv[L] (interleavers.py:29-33)
+    const float* in;        // encoder: u (B,L,1); decoder: received (B,L,3)
+    float* out;             // encoder: x_tx (B,L,3) before power_constraint; decoder: x_dec (B,L,1)
+    double* partials;       // encoder: [grid][2] = (sum, sumsq) of x_tx per workgroup
+    int32_t B, L, nb;       // batch, block_len, blocks per workgroup
+    int32_t n_layer;        // conv layers per stack
+    int32_t n_iter;         // decoder iterations
+    int32_t F;              // num_iter_ft
+    int32_t extrinsic;
+    int32_t act;            // encoder output activation: 0 = elu, 1 = linear
+    uint32_t stack_stride;  // floats between consecutive stacks in wpack
+    int32_t lds_bytes;
+};
+
+hipError_t launch_fused(int U, bool decoder, const FusedParams& P, int grid, hipStream_t st);
+hipError_t launch_reduce_partials(const double* partials, int n, double count, double* stats, hipStream_t st);
+hipError_t launch_normalize(const float* xtx, const double* stats, const float* noise, float* codes, float* rx, size_t n,
+                            hipStream_t st);
+hipError_t launch_count_errors(const float* xdec, const float* u, int B, int L, unsigned long long* counts, hipStream_t st);
+hipError_t launch_gen_inputs(float* u, float* noise, size_t n_bits, size_t bit_offset, unsigned long long seed_bits,
+                             unsigned long long seed_noise, float sigma, hipStream_t st);
+int fused_lds_bytes(int U, int L, int nb);
+int fused_max_positions();
+
+}  // namespace tae
