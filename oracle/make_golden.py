@@ -1,0 +1,137 @@
+"""ORACLE support - build-container only.  Generates tests/golden/* from the REAL reference.
+
+    python oracle/make_golden.py            # needs /root/reference (read-only)
+
+For every case it (1) builds the reference Channel_AE(ENC_interCNN, DEC_LargeCNN) exactly as
+main.py does (oracle/ref_harness.py), loads weights from the portable generator
+(turboae_amd/weights.py) with strict=True, runs the reference forward on Philox inputs; (2) runs
+oracle/turboae_oracle.py on the same weights/inputs and ASSERTS equality within 2e-6 (codes) /
+5e-6 (x_dec) - the reference itself wobbles at ~5e-7 across thread counts;
+(3) writes the reference's outputs as a fixture.  Fixtures hold data only (inputs + expected
+outputs + the generator seed of the weights); no reference source travels.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_harness as R            # noqa: E402
+from oracle import turboae_oracle as O         # noqa: E402
+from turboae_amd import philox, weights as W   # noqa: E402
+from turboae_amd.config import TurboAEConfig   # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+CASES = [
+    # name, config overrides, B, weight seed, gain, snr_db
+    ("fwd_enc2dec5_u100_L100_b4", dict(), 4, 7, 1.0, 2.0),
+    ("fwd_enc5dec5_u100_L100_b3", dict(enc_num_layer=5), 3, 8, 1.0, 1.0),
+    ("fwd_u32_L100_b8", dict(enc_num_unit=32, dec_num_unit=32), 8, 9, 1.0, 0.0),
+    ("fwd_u64_L40_b5_it2", dict(enc_num_unit=64, dec_num_unit=64, block_len=40, num_iteration=2, dec_num_layer=2,
+                                 enc_num_layer=1), 5, 10, 1.0, 3.0),
+    ("fwd_u32_L64_b6_ft3_noext", dict(enc_num_unit=32, dec_num_unit=32, block_len=64, num_iteration=3, num_iter_ft=3,
+                                       extrinsic=0, dec_num_layer=3), 6, 11, 1.0, -1.5),
+    ("fwd_u100_L1000_b2", dict(block_len=1000), 2, 12, 1.0, 2.0),
+    ("fwd_u100_L150_b3_it2", dict(block_len=150, num_iteration=2), 3, 13, 1.0, 2.0),
+]
+
+
+def make_inputs(B, L, snr_db, seed):
+    u = philox.random_bits(seed, 0, B * L).reshape(B, L, 1)
+    noise = (np.float32(O.snr_db2sigma(snr_db)) * philox.random_normal(seed, 0, B * L * 3)).reshape(B, L, 3).astype(np.float32)
+    return u, noise
+
+
+def run_case(name, over, B, wseed, gain, snr_db, manifest):
+    cfg = TurboAEConfig(**over)
+    sd = W.generate_state_dict(cfg, seed=wseed, gain=gain)
+    u, noise = make_inputs(B, cfg.block_len, snr_db, seed=100 + wseed)
+    model, _ = R.build_reference_model(cfg.to_dict(), B)
+    R.load_weights(model, sd)
+    x_ref, c_ref = R.reference_forward(model, u, noise)
+    taps = {}
+    x_or, c_or = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict(), taps)
+    dx = float(np.abs(x_ref - x_or.numpy()).max())
+    dc = float(np.abs(c_ref - c_or.numpy()).max())
+    assert dc <= 2e-6 and dx <= 5e-6, (name, dc, dx)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), u=u, noise=noise, x_dec=x_ref, codes=c_ref,
+                        logits=taps["logits"].numpy(), x_tx=taps["x_tx"].numpy(),
+                        mean=taps["mean"].numpy(), std=taps["std"].numpy())
+    manifest["cases"][name] = {"config": cfg.to_dict(), "B": B, "weight_seed": wseed, "gain": gain, "snr_db": snr_db,
+                               "input_seed": 100 + wseed, "oracle_vs_reference_max_abs": {"x_dec": dx, "codes": dc},
+                               "ber_reference": O.errors_ber(torch.from_numpy(u), torch.from_numpy(x_ref))}
+    print(f"{name}: oracle-vs-reference max|dx|={dx:.2e} max|dc|={dc:.2e}")
+
+
+def interleavers(manifest):
+    R._import_reference()
+    import commpy.channelcoding.interleavers as RI          # the reference's own RandInterlv
+    for L in (100, 1000, 40, 64, 150):
+        p = np.asarray(RI.RandInterlv(L, 0).p_array)
+        assert np.array_equal(p, O.rand_interleaver(L, 0))
+        np.save(os.path.join(GOLD, f"interleaver_L{L}_seed0.npy"), p.astype(np.int16))
+    manifest["interleaver_first12"] = {"100": RI.RandInterlv(100, 0).p_array[:12].tolist(),
+                                       "1000": RI.RandInterlv(1000, 0).p_array[:12].tolist()}
+
+
+def trained(manifest, pt_path):
+    """Convert a short-trained reference checkpoint (oracle/train_fixture.py) into a fixture:
+    weights rounded to fp16 (the rounded values ARE the fixture weights), plus reference outputs
+    on a fixed batch at 2 dB and a BER measured by the reference on more blocks."""
+    cfg = TurboAEConfig()
+    obj = torch.load(pt_path, map_location="cpu", weights_only=False)
+    sd = obj.state_dict() if hasattr(obj, "state_dict") else obj
+    sd = W.check_state_dict(cfg, sd)
+    sd = {k: v.astype(np.float16).astype(np.float32) for k, v in sd.items()}
+    blob16 = W.pack_blob(cfg, sd).astype(np.float16)
+    B = 200
+    u, noise = make_inputs(B, 100, 2.0, seed=424242)
+    model, _ = R.build_reference_model(cfg.to_dict(), B)
+    R.load_weights(model, sd)
+    x_ref, c_ref = R.reference_forward(model, u, noise)
+    x_or, c_or = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict())
+    dx = float(np.abs(x_ref - x_or.numpy()).max())
+    dc = float(np.abs(c_ref - c_or.numpy()).max())
+    assert dc <= 2e-6 and dx <= 5e-6, (dc, dx)
+    bit_err, blk_err = O.error_counts(torch.from_numpy(u), torch.from_numpy(x_ref))
+    np.savez_compressed(os.path.join(GOLD, "trained_enc2dec5_u100.npz"), weights_fp16=blob16,
+                        x_dec_first8=x_ref[:8], codes_first8=c_ref[:8],
+                        hard_bits=np.packbits((x_ref > 0.5).astype(np.uint8).reshape(-1)))
+    manifest["trained"] = {"config": cfg.to_dict(), "B": B, "snr_db": 2.0, "input_seed": 424242,
+                           "bit_errors": bit_err, "block_errors": blk_err, "ber": bit_err / (B * 100.0),
+                           "oracle_vs_reference_max_abs": {"x_dec": dx, "codes": dc},
+                           "note": "reference main.py short-trained in the build container (oracle/train_fixture.py)"}
+    print(f"trained: BER@2dB={bit_err / (B * 100.0):.4e} blocks_in_error={blk_err}/{B} dx={dx:.2e} dc={dc:.2e}")
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    mpath = os.path.join(GOLD, "MANIFEST.json")
+    manifest = {"cases": {}}
+    if os.path.isfile(mpath):
+        with open(mpath) as fh:
+            manifest = json.load(fh)
+        manifest.setdefault("cases", {})
+    only_trained = len(sys.argv) > 2 and sys.argv[1] == "--trained"
+    if not only_trained:
+        manifest["environment"] = {"torch": torch.__version__, "numpy": np.__version__,
+                                   "threads": torch.get_num_threads(),
+                                   "generated_by": "oracle/make_golden.py against /root/reference"}
+        interleavers(manifest)
+        for case in CASES:
+            run_case(*case, manifest)
+    else:
+        trained(manifest, sys.argv[2])
+    with open(mpath, "w") as fh:
+        json.dump(manifest, fh, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -132,7 +132,10 @@ def channel_ae_forward(u: torch.Tensor, fwd_noise: torch.Tensor, w: Dict[str, to
                        taps: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """cfg keys: block_len, enc_num_layer, dec_num_layer, num_iteration, num_iter_ft, extrinsic, enc_act."""
     with torch.no_grad():
-        p = torch.from_numpy(rand_interleaver(u.shape[1], cfg.get("interleaver_seed", 0)))
+        if cfg.get("p_array") is not None:      # enc/dec.set_interleaver(p) (channel_ae.py:35-36)
+            p = torch.from_numpy(np.asarray(cfg["p_array"], dtype=np.int64))
+        else:
+            p = torch.from_numpy(rand_interleaver(u.shape[1], cfg.get("interleaver_seed", 0)))
         x_tx = encode_prenorm(u, w, p, cfg["enc_num_layer"], cfg.get("enc_act", "elu"))
         codes, mean, std = power_constraint(x_tx)
         received = codes + fwd_noise

@@ -53,3 +53,166 @@ def test_forward_matches_oracle_shapes(gpu_device, U, L, nl_enc, nl_dec, iters):
     xd, codes, xo, co, _ = run_both(cfg, sd, u, noise, gpu_device)
     assert np.abs(codes - co).max() <= ATOL_CODES
     assert np.abs(xd - xo).max() <= ATOL_XDEC
+
+
+# ------------------------------------------------------------------------------------------------
+# against the golden vectors produced by the REAL reference (oracle/make_golden.py)
+import json
+import os
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+with open(os.path.join(GOLD, "MANIFEST.json")) as _fh:
+    MANIFEST = json.load(_fh)
+
+
+@pytest.mark.parametrize("name", sorted(MANIFEST["cases"]))
+def test_forward_matches_reference_golden(gpu_device, name):
+    from turboae_amd import Channel_AE_HIP
+    meta = MANIFEST["cases"][name]
+    cfg = TurboAEConfig(**meta["config"])
+    sd = W.generate_state_dict(cfg, seed=meta["weight_seed"], gain=meta["gain"])
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=meta["B"])
+    xd, codes = model(torch.from_numpy(g["u"]).to(gpu_device), torch.from_numpy(g["noise"]).to(gpu_device))
+    assert np.abs(codes.cpu().numpy() - g["codes"]).max() <= ATOL_CODES
+    assert np.abs(xd.cpu().numpy() - g["x_dec"]).max() <= ATOL_XDEC
+    flips = (xd.cpu().numpy() > 0.5) != (g["x_dec"] > 0.5)
+    assert np.all(np.abs(g["logits"][flips]) < 1e-4)
+
+
+def test_enc_dec_views_and_split_path(gpu_device):
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig()
+    sd = W.generate_state_dict(cfg, seed=7, gain=1.0)
+    B = 10
+    u, noise = make_inputs(B, cfg.block_len, seed=21)
+    ud, nd = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    xd, codes = model(ud, nd)
+    codes2 = model.enc(ud)                       # model.enc(X) (trainer.py:243)
+    assert torch.equal(codes, codes2)
+    xd2 = model.dec(codes + nd)                  # channel_ae.py:42,71
+    assert torch.equal(xd, xd2)
+    x_tx, stats = model.encode_prenorm(ud)
+    codes3, rx = model.normalize(x_tx, stats, nd)
+    assert torch.equal(codes3, codes) and torch.equal(rx, codes + nd)
+    assert float(stats[2]) == B * cfg.block_len * 3
+    # power constraint really normalises (encoders.py:107-116)
+    assert abs(float(codes.mean())) < 1e-5 and abs(float(codes.std()) - 1.0) < 1e-5
+    # idempotence / run-to-run determinism
+    xd3, codes4 = model(ud, nd)
+    assert torch.equal(xd3, xd) and torch.equal(codes4, codes)
+
+
+def test_decoder_is_block_independent_and_batch_ragged(gpu_device):
+    """Blocks never see each other in the decoder (zero padding at block edges), so any sub-batch
+    must decode bit-identically, whatever the workgroup packing (3 blocks per workgroup)."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig()
+    sd = W.generate_state_dict(cfg, seed=7, gain=1.0)
+    B = 1000
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    u, noise = model.generate_inputs(B, 2.0, seed=77)
+    rx = model.enc(u) + noise
+    full = model.dec(rx)
+    for lo, hi in ((0, 1), (1, 3), (5, 12), (997, 1000), (2, 1000)):
+        part = model.dec(rx[lo:hi].contiguous())
+        assert torch.equal(part, full[lo:hi]), (lo, hi)
+
+
+def test_custom_interleaver(gpu_device):
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(enc_num_unit=32, dec_num_unit=32, num_iteration=2)
+    sd = W.generate_state_dict(cfg, seed=4, gain=1.0)
+    p = np.random.RandomState(123).permutation(cfg.block_len)
+    u, noise = make_inputs(4, cfg.block_len, seed=31)
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4, is_same_interleaver=0)
+    model.enc.set_interleaver(p)
+    model.dec.set_interleaver(p)
+    xd, codes = model(torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device))
+    ocfg = cfg.to_dict()
+    ocfg["p_array"] = p
+    xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), ocfg)
+    assert np.abs(codes.cpu().numpy() - co.numpy()).max() <= ATOL_CODES
+    assert np.abs(xd.cpu().numpy() - xo.numpy()).max() <= ATOL_XDEC
+    with pytest.raises(Exception):
+        model.enc.set_interleaver(np.zeros(cfg.block_len, dtype=np.int32))     # not a permutation
+
+
+def test_device_inputs_match_host_philox(gpu_device):
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(enc_num_unit=32, dec_num_unit=32, num_iteration=1)
+    model = Channel_AE_HIP(cfg, W.generate_state_dict(cfg, 1), device=gpu_device, max_batch=8)
+    B, L = 37, cfg.block_len
+    first = 1234567
+    u, noise = model.generate_inputs(B, 2.0, seed=99, first_block=first, seed_noise=100)
+    want_u = philox.random_bits(99, first * L, B * L).reshape(B, L, 1)
+    want_n = (np.float32(O.snr_db2sigma(2.0)) * philox.random_normal(100, first * L * 3, B * L * 3)).reshape(B, L, 3)
+    assert np.array_equal(u.cpu().numpy(), want_u)
+    d = np.abs(noise.cpu().numpy() - want_n)
+    assert d.max() <= 5e-7       # fp64 Box-Muller on both sides: equal up to rare fp32 rounding ties
+    assert (d > 0).mean() < 1e-3
+
+
+def test_error_counts(gpu_device):
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(enc_num_unit=32, dec_num_unit=32, num_iteration=1)
+    model = Channel_AE_HIP(cfg, W.generate_state_dict(cfg, 1), device=gpu_device, max_batch=8)
+    B, L = 257, cfg.block_len
+    rs = np.random.RandomState(5)
+    u = (rs.rand(B, L, 1) > 0.5).astype(np.float32)
+    xh = rs.rand(B, L, 1).astype(np.float32)
+    xh[3] = 0.25 + 0.5 * u[3]          # a correct block
+    xh[4, 7, 0] = 0.5                  # exactly 0.5 rounds to 0 (half-to-even, utils.py:9)
+    counts = model.count_errors(torch.from_numpy(xh).to(gpu_device), torch.from_numpy(u).to(gpu_device))
+    counts = model.count_errors(torch.from_numpy(xh).to(gpu_device), torch.from_numpy(u).to(gpu_device), counts)
+    be, ble = O.error_counts(torch.from_numpy(u), torch.from_numpy(xh))
+    assert counts.cpu().tolist() == [2 * be, 2 * ble]
+
+
+def test_rejects_bad_shapes(gpu_device):
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(enc_num_unit=32, dec_num_unit=32, num_iteration=1)
+    model = Channel_AE_HIP(cfg, W.generate_state_dict(cfg, 1), device=gpu_device, max_batch=4)
+    with pytest.raises(ValueError):
+        model(torch.zeros(2, 99, 1, device=gpu_device), torch.zeros(2, 99, 3, device=gpu_device))
+    with pytest.raises(ValueError):
+        model(torch.zeros(2, 100, 1, device=gpu_device), torch.zeros(3, 100, 3, device=gpu_device))
+
+
+@pytest.mark.parametrize("seg_t", [None, "37", "16"])
+def test_segmented_path_is_bit_identical_to_fused(gpu_device, monkeypatch, seg_t):
+    """The long-block (segmented, halo-recompute) kernels sum every dot product in the same order as
+    the whole-block kernels, so on a short block both paths must agree bit for bit."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(num_iteration=2)
+    sd = W.generate_state_dict(cfg, seed=7, gain=1.0)
+    u, noise = make_inputs(7, cfg.block_len, seed=51)
+    ud, nd = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
+    fused = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=7)
+    xf, cf = fused(ud, nd)
+    monkeypatch.setenv("TAE_FORCE_SEGMENTED", "1")
+    if seg_t:
+        monkeypatch.setenv("TAE_SEG_T", seg_t)
+    seg = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=7)
+    assert seg.kernel_info()[0] == 0
+    xs, cs = seg(ud, nd)
+    assert torch.equal(cs, cf)
+    assert torch.equal(xs, xf)
+
+
+def test_long_block_round_trip_properties(gpu_device):
+    """block_len=1000 (BASELINE configs[3] shape): decoder block independence and determinism at a
+    size the oracle would need minutes for."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(block_len=1000)
+    sd = W.generate_state_dict(cfg, seed=12, gain=1.0)
+    B = 40
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    u, noise = model.generate_inputs(B, 2.0, seed=5)
+    codes = model.enc(u)
+    assert abs(float(codes.mean())) < 1e-5 and abs(float(codes.std()) - 1.0) < 1e-5
+    rx = codes + noise
+    full = model.dec(rx)
+    assert torch.equal(model.dec(rx[3:9].contiguous()), full[3:9])
+    assert torch.equal(model.dec(rx), full)

@@ -1,0 +1,100 @@
+"""Host-side logic: Philox known answers, weight naming / packing, config accounting."""
+import numpy as np
+import pytest
+
+from turboae_amd import TurboAEConfig, philox, weights as W
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors for philox4x32-10
+    kat = [
+        ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+        ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+         (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+    ]
+    for ctr, key, want in kat:
+        got = philox.philox4x32_10(*[np.array([c], dtype=np.uint32) for c in ctr], key[0], key[1])
+        assert tuple(int(g[0]) for g in got) == want
+
+
+def test_philox_streams_are_sliceable():
+    a = philox.random_u32(5, philox.STREAM_BITS, 0, 1000)
+    b = philox.random_u32(5, philox.STREAM_BITS, 333, 100)
+    assert np.array_equal(a[333:433], b)
+    n = philox.random_normal(9, 0, 4000)
+    m = philox.random_normal(9, 1001, 50)
+    assert np.array_equal(n[1001:1051], m)
+    assert abs(float(n.mean())) < 0.06 and abs(float(n.std()) - 1.0) < 0.05
+    bits = philox.random_bits(3, 0, 10000)
+    assert set(np.unique(bits)) == {0.0, 1.0} and abs(bits.mean() - 0.5) < 0.03
+
+
+def test_param_count_matches_reference():
+    # enc 152 403 + dec 2 453 656 = 2 606 059 params, 162 tensors (enc2/dec5)
+    cfg = TurboAEConfig()
+    ents = W.canonical_entries(cfg)
+    assert len(ents) == 162
+    assert W.num_params(cfg) == 2606059
+    enc = sum(int(np.prod(s)) for k, s in ents if k.startswith("enc."))
+    assert enc == 152403
+
+
+def test_macs_per_bit_accounting():
+    # SURVEY.md section 8d
+    cfg = TurboAEConfig()
+    m = cfg.macs_per_bit()
+    assert m == {"enc": 151800, "dec": 2447600, "total": 2599400}
+    assert cfg.flops_per_bit() == 5198800
+    assert TurboAEConfig(enc_num_layer=5).flops_per_bit() == 6098800
+
+
+def test_strip_and_add_module():
+    cfg = TurboAEConfig(enc_num_unit=32, dec_num_unit=32)
+    sd = W.generate_state_dict(cfg, 1)
+    wrapped = W.add_module(sd)
+    assert "enc.enc_cnn_1.module.cnns.0.weight" in wrapped
+    assert "dec.dec2_outputs.5.module.bias" in wrapped
+    assert set(W.strip_module(wrapped)) == set(sd)
+    chk = W.check_state_dict(cfg, wrapped)
+    assert all(np.array_equal(chk[k], sd[k]) for k in sd)
+
+
+def test_blob_roundtrip_and_strictness(tmp_path):
+    cfg = TurboAEConfig(enc_num_unit=32, dec_num_unit=32, num_iteration=2)
+    sd = W.generate_state_dict(cfg, 2)
+    blob = W.pack_blob(cfg, sd)
+    assert blob.size == W.num_params(cfg)
+    back = W.unpack_blob(cfg, blob)
+    assert all(np.array_equal(back[k], sd[k]) for k in sd)
+    W.save_blob(str(tmp_path / "w.bin"), cfg, sd)
+    cfg2, sd2 = W.load_blob(str(tmp_path / "w.bin"))
+    assert cfg2 == cfg and all(np.array_equal(sd2[k], sd[k]) for k in sd)
+    bad = dict(sd)
+    bad.pop("enc.enc_linear_1.bias")
+    with pytest.raises(ValueError):
+        W.check_state_dict(cfg, bad)
+    bad = dict(sd)
+    bad["dec.dec1_outputs.0.weight"] = np.zeros((4, 32), np.float32)
+    with pytest.raises(ValueError):
+        W.check_state_dict(cfg, bad)
+
+
+def test_generated_weights_are_reproducible():
+    cfg = TurboAEConfig(enc_num_unit=32, dec_num_unit=32)
+    a, b = W.generate_state_dict(cfg, 5), W.generate_state_dict(cfg, 5)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    c = W.generate_state_dict(cfg, 6)
+    assert not np.array_equal(a["enc.enc_cnn_1.cnns.0.weight"], c["enc.enc_cnn_1.cnns.0.weight"])
+    w = a["dec.dec1_cnns.0.cnns.1.weight"]
+    assert abs(float(w.std()) - 1.0 / np.sqrt(32 * 5)) < 0.01      # variance-preserving scale
+
+
+def test_config_validation():
+    TurboAEConfig().validate()
+    with pytest.raises(ValueError):
+        TurboAEConfig(enc_kernel_size=3).validate()
+    with pytest.raises(ValueError):
+        TurboAEConfig(enc_num_unit=48, dec_num_unit=48).validate()
+    with pytest.raises(ValueError):
+        TurboAEConfig(code_rate_n=2).validate()

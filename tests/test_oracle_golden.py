@@ -1,0 +1,74 @@
+"""The oracle restatement vs the golden vectors produced by the REAL reference
+(oracle/make_golden.py).  Runs everywhere (no reference, no GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import turboae_oracle as O
+from turboae_amd import TurboAEConfig, weights as W, rand_interleaver
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+with open(os.path.join(GOLD, "MANIFEST.json")) as fh:
+    MANIFEST = json.load(fh)
+
+# CPU time: L=1000 case is ~10x the others; keep all, they finish in seconds.
+CASES = sorted(MANIFEST["cases"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_fixture(name):
+    meta = MANIFEST["cases"][name]
+    cfg = TurboAEConfig(**meta["config"])
+    sd = W.generate_state_dict(cfg, seed=meta["weight_seed"], gain=meta["gain"])
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    taps = {}
+    x, c = O.channel_ae_forward(torch.from_numpy(g["u"]), torch.from_numpy(g["noise"]), O.to_torch(sd), cfg.to_dict(), taps)
+    # the reference itself is not bit-deterministic across thread counts: <= 5e-7 / 6e-8
+    assert np.abs(c.numpy() - g["codes"]).max() <= 2e-6
+    assert np.abs(x.numpy() - g["x_dec"]).max() <= 5e-6
+    assert np.abs(taps["x_tx"].numpy() - g["x_tx"]).max() <= 2e-6
+    assert abs(float(taps["mean"]) - float(g["mean"])) <= 1e-6
+    assert abs(float(taps["std"]) - float(g["std"])) <= 1e-6
+
+
+@pytest.mark.parametrize("L", [40, 64, 100, 150, 1000])
+def test_interleaver_matches_reference(L):
+    p = np.load(os.path.join(GOLD, f"interleaver_L{L}_seed0.npy")).astype(np.int64)
+    assert np.array_equal(p, O.rand_interleaver(L, 0))
+    assert np.array_equal(p, rand_interleaver(L, 0))
+    assert sorted(p.tolist()) == list(range(L))
+
+
+def test_interleaver_known_prefix():
+    # SURVEY.md F7 [measured against the reference]
+    assert rand_interleaver(100, 0)[:12].tolist() == [26, 86, 2, 55, 75, 93, 16, 73, 54, 95, 53, 92]
+    assert rand_interleaver(1000, 0)[:12].tolist() == [993, 859, 298, 553, 672, 971, 27, 231, 306, 706, 496, 558]
+
+
+def test_interleave_deinterleave_roundtrip():
+    p = torch.from_numpy(O.rand_interleaver(100, 0))
+    x = torch.randn(3, 100, 5)
+    assert torch.equal(O.deinterleave(O.interleave(x, p), p), x)
+    y = O.interleave(x, p)
+    assert torch.equal(y[:, 7, :], x[:, int(p[7]), :])
+
+
+def test_metrics_definitions():
+    u = torch.tensor([[[0.], [1.], [1.], [0.]], [[1.], [1.], [0.], [0.]]])
+    xh = torch.tensor([[[0.2], [0.7], [0.5], [0.1]], [[0.9], [0.6], [0.4], [0.49]]])   # 0.5 rounds to 0 (half-to-even)
+    assert O.errors_ber(u, xh) == pytest.approx(1 / 8)
+    assert O.errors_bler(u, xh) == pytest.approx(0.5)
+    assert O.error_counts(u, xh) == (1, 1)
+    assert O.snr_db2sigma(2.0) == pytest.approx(0.7943282347)
+
+
+def test_power_constraint_is_global_unbiased():
+    x = torch.randn(4, 10, 3)
+    y, m, s = O.power_constraint(x)
+    assert float(y.mean()) == pytest.approx(0.0, abs=1e-6)
+    assert float(y.std()) == pytest.approx(1.0, abs=1e-5)
+    n = x.numel()
+    assert float(s) == pytest.approx(float(torch.sqrt(((x - x.mean()) ** 2).sum() / (n - 1))), rel=1e-6)

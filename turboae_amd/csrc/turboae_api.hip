@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <math.h>
 #include <string>
 #include <vector>
@@ -84,6 +85,8 @@ struct tae_handle {
     tae_config cfg;
     int device = 0;
     int U = 0, nb = 0, lds_bytes = 0;
+    // long-block (segmented) path, used when a whole block does not fit one workgroup (nb == 0)
+    int enc_T = 0, enc_nseg = 0, enc_lds = 0, dec_T = 0, dec_nseg = 0, dec_lds = 0;
     uint32_t enc_stride = 0, dec_stride = 0;
     float* d_wenc = nullptr;
     float* d_wdec = nullptr;
@@ -95,6 +98,8 @@ struct tae_handle {
     float* d_rx = nullptr;
     double* d_partials = nullptr;
     double* d_stats = nullptr;
+    float* d_e0 = nullptr;   // long-block path: extrinsic exchange buffers (B, L, 8)
+    float* d_e1 = nullptr;
 };
 
 namespace {
@@ -138,6 +143,20 @@ int choose_nb(int U, int L, int* lds_out) {
     return nb;
 }
 
+// Segment geometry of the long-block path: T centre positions + 2*H halo positions <= max positions.
+bool choose_seg(int U, int L, int n_layer, int* T, int* nseg, int* lds) {
+    const int H = 2 * n_layer;
+    int tmax = tae::fused_max_positions() - 2 * H;
+    while (tmax >= 16 && tae::seg_lds_bytes(U, tmax, n_layer) > 160 * 1024) tmax -= 16;
+    if (tmax < 16) return false;
+    const char* cap = getenv("TAE_SEG_T");
+    if (cap && atoi(cap) >= 1 && atoi(cap) < tmax) tmax = atoi(cap);
+    *nseg = (L + tmax - 1) / tmax;
+    *T = (L + *nseg - 1) / *nseg;      // balanced segments
+    *lds = tae::seg_lds_bytes(U, *T, n_layer);
+    return true;
+}
+
 int check_batch(tae_handle* h, int32_t B) {
     if (!h) return fail(TAE_EINVAL, "handle is NULL");
     if (B < 1) return fail(TAE_EINVAL, "batch must be >= 1");
@@ -161,7 +180,62 @@ tae::FusedParams base_params(const tae_handle* h, int32_t B) {
     return P;
 }
 
+tae::SegParams seg_params(const tae_handle* h, int32_t B) {
+    tae::SegParams P;
+    memset(&P, 0, sizeof(P));
+    P.perm = h->d_perm;
+    P.inv = h->d_inv;
+    P.B = B;
+    P.L = h->cfg.block_len;
+    P.F = h->cfg.num_iter_ft;
+    P.extrinsic = h->cfg.extrinsic;
+    P.act = h->cfg.enc_act;
+    return P;
+}
+
+int run_encoder_long(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st) {
+    tae::SegParams P = seg_params(h, B);
+    P.wpack = h->d_wenc;
+    P.in = u;
+    P.out = xtx;
+    P.partials = h->d_partials;
+    P.mode = 0;
+    P.T = h->enc_T;
+    P.nseg = h->enc_nseg;
+    P.n_layer = h->cfg.enc_num_layer;
+    P.stack_stride = h->enc_stride;
+    P.lds_bytes = h->enc_lds;
+    const int grid = 3 * B * h->enc_nseg;
+    TAE_HIP(tae::launch_seg(h->U, P, grid, st));
+    TAE_HIP(tae::launch_reduce_partials(h->d_partials, grid, (double)B * h->cfg.block_len * 3.0, stats, st));
+    return TAE_OK;
+}
+
+int run_decoder_long(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st) {
+    tae::SegParams P = seg_params(h, B);
+    P.wpack = h->d_wdec;
+    P.in = rx;
+    P.out = xdec;
+    P.mode = 1;
+    P.T = h->dec_T;
+    P.nseg = h->dec_nseg;
+    P.n_layer = h->cfg.dec_num_layer;
+    P.stack_stride = h->dec_stride;
+    P.lds_bytes = h->dec_lds;
+    const int n_stack = 2 * h->cfg.num_iteration;
+    const int grid = B * h->dec_nseg;
+    for (int s = 0; s < n_stack; ++s) {
+        P.stack = s;
+        P.last = (s == n_stack - 1);
+        P.eprev = (s & 1) ? h->d_e0 : h->d_e1;
+        P.ecur = (s & 1) ? h->d_e1 : h->d_e0;
+        TAE_HIP(tae::launch_seg(h->U, P, grid, st));
+    }
+    return TAE_OK;
+}
+
 int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st) {
+    if (h->nb < 1) return run_encoder_long(h, u, xtx, stats, B, st);
     tae::FusedParams P = base_params(h, B);
     P.wpack = h->d_wenc;
     P.in = u;
@@ -176,6 +250,7 @@ int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_
 }
 
 int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st) {
+    if (h->nb < 1) return run_decoder_long(h, rx, xdec, B, st);
     tae::FusedParams P = base_params(h, B);
     P.wpack = h->d_wdec;
     P.in = rx;
@@ -219,9 +294,17 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     h->U = cfg->enc_num_unit;
     (void)hipGetDevice(&h->device);
     h->nb = choose_nb(h->U, cfg->block_len, &h->lds_bytes);
+    // Testing knobs (documented in DESIGN.md): TAE_FORCE_SEGMENTED=1 selects the long-block path even
+    // when whole blocks fit; TAE_SEG_T=<n> caps the centre length of a segment.
+    const char* force_seg = getenv("TAE_FORCE_SEGMENTED");
+    if (force_seg && force_seg[0] == '1') h->nb = 0;
     if (h->nb < 1) {
-        delete h;
-        return fail(TAE_EINVAL, "block_len too large for the whole-block fused kernels (max 320 positions per workgroup)");
+        h->nb = 0;
+        if (!choose_seg(h->U, cfg->block_len, cfg->enc_num_layer, &h->enc_T, &h->enc_nseg, &h->enc_lds) ||
+            !choose_seg(h->U, cfg->block_len, cfg->dec_num_layer, &h->dec_T, &h->dec_nseg, &h->dec_lds)) {
+            delete h;
+            return fail(TAE_EINVAL, "too many conv layers for the segmented long-block kernels (halo exceeds the panel)");
+        }
     }
     const Layout lo(h->U);
     const int F = cfg->num_iter_ft;
@@ -267,6 +350,7 @@ int tae_destroy(tae_handle* h) {
     if (!h) return TAE_OK;
     (void)hipFree(h->d_wenc); (void)hipFree(h->d_wdec); (void)hipFree(h->d_perm); (void)hipFree(h->d_inv);
     (void)hipFree(h->d_xtx); (void)hipFree(h->d_rx); (void)hipFree(h->d_partials); (void)hipFree(h->d_stats);
+    (void)hipFree(h->d_e0); (void)hipFree(h->d_e1);
     delete h;
     return TAE_OK;
 }
@@ -276,10 +360,15 @@ int tae_reserve(tae_handle* h, int32_t max_batch) {
     if (max_batch < 1) return fail(TAE_EINVAL, "max_batch must be >= 1");
     if (max_batch <= h->cap) return TAE_OK;
     TAE_HIP(hipDeviceSynchronize());
-    (void)hipFree(h->d_xtx); (void)hipFree(h->d_rx); (void)hipFree(h->d_partials);
-    h->d_xtx = h->d_rx = nullptr; h->d_partials = nullptr; h->cap = 0;
+    (void)hipFree(h->d_xtx); (void)hipFree(h->d_rx); (void)hipFree(h->d_partials); (void)hipFree(h->d_e0); (void)hipFree(h->d_e1);
+    h->d_xtx = h->d_rx = h->d_e0 = h->d_e1 = nullptr; h->d_partials = nullptr; h->cap = 0;
     const size_t n3 = (size_t)max_batch * h->cfg.block_len * 3;
-    const size_t grid = ((size_t)max_batch + h->nb - 1) / h->nb;
+    const size_t grid = h->nb >= 1 ? ((size_t)max_batch + h->nb - 1) / h->nb : (size_t)3 * max_batch * h->enc_nseg;
+    if (h->nb < 1) {
+        const size_t n8 = (size_t)max_batch * h->cfg.block_len * 8;
+        TAE_HIP(hipMalloc(&h->d_e0, n8 * sizeof(float)));
+        TAE_HIP(hipMalloc(&h->d_e1, n8 * sizeof(float)));
+    }
     TAE_HIP(hipMalloc(&h->d_xtx, n3 * sizeof(float)));
     TAE_HIP(hipMalloc(&h->d_rx, n3 * sizeof(float)));
     TAE_HIP(hipMalloc(&h->d_partials, grid * 2 * sizeof(double)));
@@ -368,7 +457,7 @@ int tae_generate_inputs(tae_handle* h, float* u, float* noise, int32_t B, int64_
 int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_t* lds_bytes) {
     if (!h) return fail(TAE_EINVAL, "handle is NULL");
     if (blocks_per_workgroup) *blocks_per_workgroup = h->nb;
-    if (lds_bytes) *lds_bytes = h->lds_bytes;
+    if (lds_bytes) *lds_bytes = h->nb >= 1 ? h->lds_bytes : h->dec_lds;
     return TAE_OK;
 }
 

@@ -25,6 +25,27 @@ struct FusedParams {
     int32_t lds_bytes;
 };
 
+// Arguments of the per-stack segmented kernel used when a block does not fit one workgroup.
+struct SegParams {
+    const float* wpack;     // packed weights of the network
+    const int32_t* perm;
+    const int32_t* inv;
+    const float* in;        // encoder: u (B,L,1); decoder: received (B,L,3)
+    const float* eprev;     // decoder: previous stack's extrinsic outputs (B,L,8), own-domain order
+    float* ecur;            // decoder: this stack's extrinsic outputs (B,L,8)
+    float* out;             // encoder: x_tx (B,L,3); last decoder stack: x_dec (B,L,1)
+    double* partials;       // encoder: [grid][2]
+    int32_t mode;           // 0 = encoder (3 stacks in one launch), 1 = decoder (one stack per launch)
+    int32_t stack;          // decoder stack index 0..2*n_iter-1
+    int32_t last;           // decoder: final half-iteration
+    int32_t B, L, T, nseg;  // T = centre positions per segment, nseg = segments per block
+    int32_t n_layer, F, extrinsic, act;
+    uint32_t stack_stride;
+    int32_t lds_bytes;
+};
+
+hipError_t launch_seg(int U, const SegParams& P, int grid, hipStream_t st);
+int seg_lds_bytes(int U, int T, int n_layer);
 hipError_t launch_fused(int U, bool decoder, const FusedParams& P, int grid, hipStream_t st);
 hipError_t launch_reduce_partials(const double* partials, int n, double count, double* stats, hipStream_t st);
 hipError_t launch_normalize(const float* xtx, const double* stats, const float* noise, float* codes, float* rx, size_t n,

@@ -122,7 +122,8 @@ struct TileCtx {
     int rowbase[PT];  // panel row of position 0 of the same block
     int t[PT];        // index inside the block
     int blk[PT];      // block index inside the workgroup
-    bool valid[PT];
+    bool valid[PT];   // in-block row of the panel: its activations are written back
+    bool center[PT];  // position whose stack output this workgroup owns (== valid for whole blocks)
 };
 
 // Runs one SameShapeConv1d stack (cnn_utils.py:36-46) followed by its Linear head for the
@@ -225,7 +226,7 @@ __device__ __forceinline__ void run_stack(const float* __restrict__ wstack, int 
             const float send = hi16 ? k4[j] : k4[2 + j];
             k2[j] = keep + __shfl_xor(send, 16);
         }
-        if (tc.valid[p]) {
+        if (tc.center[p]) {
             epi(p, 2 * q, k2[0] + bq0);
             epi(p, 2 * q + 1, k2[1] + bq1);
         }
@@ -244,6 +245,7 @@ __device__ __forceinline__ void make_tiles(TileCtx<PT>& tc, int wave, int lane, 
         const int b = mm / L;
         const int t = mm - b * L;
         tc.valid[p] = v;
+        tc.center[p] = v;
         tc.blk[p] = b;
         tc.t[p] = t;
         tc.rowbase[p] = b * (L + 2) + 2;
@@ -395,6 +397,111 @@ __global__ __launch_bounds__(kThreads, 1) void enc_kernel(FusedParams P) {
     if (tid == 0) { P.partials[2 * blockIdx.x] = red[0]; P.partials[2 * blockIdx.x + 1] = red[kThreads]; }
 }
 
+
+// =============================================================================================
+// Long blocks (block_len > 320, e.g. BASELINE configs[3] block_len=1000): a block's activations no
+// longer fit one workgroup's LDS, so each SameShapeConv1d stack runs as its own launch over
+// (block, segment) workgroups.  A segment owns T centre positions and loads H = 2*n_layer halo
+// positions on each side (one conv layer widens the receptive field by 2); the panel is updated in
+// place exactly as in the whole-block kernels, rows outside the block stay zero (Conv1d zero
+// padding), and garbage from the panel edges creeps inwards 2 rows per layer, never reaching the
+// centre.  The F extrinsic values per position travel between stacks through the (B, L, 8) fp32
+// exchange buffers in HBM; (de)interleaving is the gather on the read side.
+template <int U, int PT>
+__global__ __launch_bounds__(kThreads, 1) void seg_kernel(SegParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = P.L, H = 2 * P.n_layer, NP = P.T + 2 * H;
+    const int rows = NP + 4;
+    float* ACT = reinterpret_cast<float*>(smem);
+    float* X = ACT + (size_t)(rows + 1) * U;
+    int bid = blockIdx.x;
+    int stack = P.stack;
+    if (P.mode == 0) { stack = bid % 3; bid /= 3; }
+    const int seg = bid % P.nseg, b = bid / P.nseg;
+    const int s0 = seg * P.T;
+    const int tlen = min(P.T, L - s0);
+    const bool odd = (stack & 1) != 0;
+
+    zero_lds(smem, P.lds_bytes, tid);
+    __syncthreads();
+    for (int m = tid; m < NP; m += kThreads) {
+        const int t = s0 - H + m;
+        if (t < 0 || t >= L) continue;
+        float* xr = X + (size_t)(2 + m) * kXW;
+        if (P.mode == 0) {
+            const int src = (stack == 2) ? P.perm[t] : t;                           // encoders.py:369
+            xr[0] = 2.0f * P.in[(size_t)b * L + src] - 1.0f;                         // encoders.py:362
+        } else {
+            const float* rx = P.in + (size_t)b * L * 3;
+            xr[0] = odd ? rx[(size_t)P.perm[t] * 3] : rx[(size_t)t * 3];            // r_sys_int / r_sys
+            xr[1] = rx[(size_t)t * 3 + (odd ? 2 : 1)];                              // r_par2 / r_par1
+            if (stack > 0) {
+                // dec2 reads q[p[i]] (interleave, decoders.py:238); dec1 reads q2[inv[j]] (deinterleave, :249)
+                const int g = odd ? P.perm[t] : P.inv[t];
+                const float* e = P.eprev + ((size_t)b * L + g) * 8;
+                for (int f = 0; f < P.F; ++f) xr[2 + f] = e[f];
+            }
+        }
+    }
+    __syncthreads();
+
+    TileCtx<PT> tc;
+    {
+        const int n = lane & 15;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int m = (wave * PT + p) * 16 + n;
+            const int t = s0 - H + m;
+            const bool v = (m < NP) && (t >= 0) && (t < L);
+            tc.valid[p] = v;
+            tc.center[p] = v && (t >= s0) && (t < s0 + tlen);
+            tc.blk[p] = b;
+            tc.t[p] = v ? t : 0;
+            tc.rowbase[p] = 2;
+            tc.row[p] = v ? 2 + m : 2;
+        }
+    }
+    const float* wstack = P.wpack + (size_t)stack * P.stack_stride;
+    if (P.mode == 0) {
+        const bool act_elu = P.act == 0;
+        double sum = 0.0, sumsq = 0.0;
+        float* xtx = P.out + (size_t)b * L * 3;
+        run_stack<U, PT>(wstack, P.n_layer, smem, ACT, X, tc, lane, [&](int p, int f, float v) {
+            if (f == 0) {
+                if (act_elu) v = elu1(v);
+                xtx[(size_t)tc.t[p] * 3 + stack] = v;
+                sum += (double)v;
+                sumsq += (double)v * (double)v;
+            }
+        });
+        double* red = reinterpret_cast<double*>(smem);
+        red[tid] = sum;
+        red[kThreads + tid] = sumsq;
+        __syncthreads();
+        for (int off = kThreads / 2; off > 0; off >>= 1) {
+            if (tid < off) { red[tid] += red[tid + off]; red[kThreads + tid] += red[kThreads + tid + off]; }
+            __syncthreads();
+        }
+        if (tid == 0) { P.partials[2 * blockIdx.x] = red[0]; P.partials[2 * blockIdx.x + 1] = red[kThreads]; }
+    } else if (!P.last) {
+        const int F = P.F;
+        const bool extrinsic = P.extrinsic != 0;
+        float* ecur = P.ecur + (size_t)b * L * 8;
+        run_stack<U, PT>(wstack, P.n_layer, smem, ACT, X, tc, lane, [&](int p, int f, float v) {
+            if (f < F) {
+                if (extrinsic) v -= X[tc.row[p] * kXW + 2 + f];
+                ecur[(size_t)tc.t[p] * 8 + f] = v;
+            }
+        });
+    } else {
+        float* xdec = P.out + (size_t)b * L;
+        run_stack<U, PT>(wstack, P.n_layer, smem, ACT, X, tc, lane, [&](int p, int f, float v) {
+            if (f == 0) xdec[P.perm[tc.t[p]]] = 1.0f / (1.0f + expf(-v));    // sigmoid(deinterleave), decoders.py:267
+        });
+    }
+}
+
 // =============================================================================================
 // stats[0..2] = (sum, sumsq, count) over this rank's shard, summed in fixed order.
 __global__ void reduce_partials_kernel(const double* __restrict__ partials, int n, double count, double* __restrict__ stats) {
@@ -509,6 +616,34 @@ hipError_t launch_fused(int U, bool decoder, const FusedParams& P, int grid, hip
         case 32: return launch_fused_u<32>(decoder, P, grid, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+
+template <int U>
+static hipError_t launch_seg_u(const SegParams& P, int grid, hipStream_t st) {
+    constexpr int PT = 5;
+    auto k = seg_kernel<U, PT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg(int U, const SegParams& P, int grid, hipStream_t st) {
+    switch (U) {
+        case 100: return launch_seg_u<100>(P, grid, st);
+        case 64: return launch_seg_u<64>(P, grid, st);
+        case 32: return launch_seg_u<32>(P, grid, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+int seg_lds_bytes(int U, int T, int n_layer) {
+    const int rows = T + 4 * n_layer + 4;
+    size_t b = (size_t)(rows + 1) * U * 4 + (size_t)(rows + 1) * kXW * 4;
+    b = (b + 15) & ~(size_t)15;
+    if (b < 2 * kThreads * sizeof(double)) b = 2 * kThreads * sizeof(double);
+    return (int)b;
 }
 
 hipError_t launch_reduce_partials(const double* partials, int n, double count, double* stats, hipStream_t st) {
