@@ -216,3 +216,59 @@ def test_long_block_round_trip_properties(gpu_device):
     full = model.dec(rx)
     assert torch.equal(model.dec(rx[3:9].contiguous()), full[3:9])
     assert torch.equal(model.dec(rx), full)
+
+
+def test_trained_weights_ber_matches_reference(gpu_device):
+    """BER-meaningful check on the short-trained REAL reference model: hard decisions, bit/block error
+    counts and BER must match the reference's (north_star: BER within 1e-4 at SNR = 2 dB)."""
+    from turboae_amd import Channel_AE_HIP
+    g = np.load(os.path.join(GOLD, "trained_enc2dec5_u100.npz"))
+    meta = MANIFEST["trained"]
+    cfg = TurboAEConfig(**meta["config"])
+    sd = W.unpack_blob(cfg, g["weights_fp16"].astype(np.float32))
+    B, L = meta["B"], cfg.block_len
+    u = philox.random_bits(meta["input_seed"], 0, B * L).reshape(B, L, 1)
+    noise = (np.float32(O.snr_db2sigma(meta["snr_db"])) *
+             philox.random_normal(meta["input_seed"], 0, B * L * 3)).reshape(B, L, 3).astype(np.float32)
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    ud = torch.from_numpy(u).to(gpu_device)
+    xd, codes = model(ud, torch.from_numpy(noise).to(gpu_device))
+    assert np.abs(codes.cpu().numpy()[:8] - g["codes_first8"]).max() <= ATOL_CODES
+    assert np.abs(xd.cpu().numpy()[:8] - g["x_dec_first8"]).max() <= ATOL_XDEC
+    hard_ref = np.unpackbits(g["hard_bits"])[: B * L].reshape(B, L)
+    hard = (xd.cpu().numpy()[:, :, 0] > 0.5).astype(np.uint8)
+    flips = int((hard != hard_ref).sum())
+    assert flips <= 2, flips                      # only logits within fp32 noise of 0 may flip
+    counts = model.count_errors(xd, ud).cpu().tolist()
+    assert abs(counts[0] - meta["bit_errors"]) <= 2
+    assert abs(counts[0] / (B * L) - meta["ber"]) <= 1e-4
+    assert abs(counts[1] - meta["block_errors"]) <= 2
+
+
+def test_eval_sweep_matches_oracle_on_trained_weights(gpu_device, capsys):
+    """trainer.test restated (turboae_amd/evaluate.py) vs the oracle run on the SAME Philox inputs."""
+    from turboae_amd import Channel_AE_HIP, evaluate
+    g = np.load(os.path.join(GOLD, "trained_enc2dec5_u100.npz"))
+    cfg = TurboAEConfig(**MANIFEST["trained"]["config"])
+    sd = W.unpack_blob(cfg, g["weights_fp16"].astype(np.float32))
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=50)
+    res = evaluate.test(model, snr_test_start=0.0, snr_test_end=2.0, snr_points=2, num_block=100, batch_size=50, seed=77)
+    out = capsys.readouterr().out
+    assert "Test SNR 0.0 with ber " in out and "final results on SNRs " in out and "encoder power is" in out
+    L = cfg.block_len
+    w = O.to_torch(sd)
+    for si, snr in enumerate(res["snrs"]):
+        be_tot, ble_tot = 0, 0
+        for b in range(2):
+            first = (si * 2 + b) * 50
+            u = torch.from_numpy(philox.random_bits(77, first * L, 50 * L).reshape(50, L, 1))
+            noise = torch.from_numpy((np.float32(O.snr_db2sigma(snr)) * philox.random_normal(77, first * L * 3, 50 * L * 3)).reshape(50, L, 3))
+            x, _ = O.channel_ae_forward(u, noise, w, cfg.to_dict())
+            be, ble = O.error_counts(u, x)
+            be_tot += be
+            ble_tot += ble
+        assert abs(res["bit_errors"][si] - be_tot) <= 2
+        assert abs(res["block_errors"][si] - ble_tot) <= 1
+        assert abs(res["ber"][si] - be_tot / (100.0 * L)) <= 1e-4
+    assert res["ber"][0] > res["ber"][1] > 0.0          # BER falls with SNR on the trained model
+    assert abs(res["enc_power"] - 1.0) < 1e-4

@@ -72,3 +72,32 @@ def test_power_constraint_is_global_unbiased():
     assert float(y.std()) == pytest.approx(1.0, abs=1e-5)
     n = x.numel()
     assert float(s) == pytest.approx(float(torch.sqrt(((x - x.mean()) ** 2).sum() / (n - 1))), rel=1e-6)
+
+
+def _trained():
+    g = np.load(os.path.join(GOLD, "trained_enc2dec5_u100.npz"))
+    meta = MANIFEST["trained"]
+    cfg = TurboAEConfig(**meta["config"])
+    sd = W.unpack_blob(cfg, g["weights_fp16"].astype(np.float32))
+    return g, meta, cfg, sd
+
+
+def test_oracle_matches_reference_on_trained_weights():
+    """Short-trained REAL reference model (oracle/train_fixture.py): BER-meaningful decisions."""
+    from turboae_amd import philox
+    g, meta, cfg, sd = _trained()
+    B, L = 64, cfg.block_len        # first 64 of the fixture's 200 blocks (CPU time)
+    u = philox.random_bits(meta["input_seed"], 0, meta["B"] * L).reshape(meta["B"], L, 1)
+    noise = (np.float32(O.snr_db2sigma(meta["snr_db"])) *
+             philox.random_normal(meta["input_seed"], 0, meta["B"] * L * 3)).reshape(meta["B"], L, 3).astype(np.float32)
+    # power_constraint couples the whole batch (encoders.py:107-108): encode all 200, decode the first 64
+    w = O.to_torch(sd)
+    with torch.no_grad():
+        p = torch.from_numpy(O.rand_interleaver(L, 0))
+        codes = O.encode(torch.from_numpy(u), w, p, cfg.enc_num_layer)
+        x = O.decode(codes[:B] + torch.from_numpy(noise[:B]), w, p, cfg.dec_num_layer, cfg.num_iteration, cfg.num_iter_ft)
+    assert np.abs(codes.numpy()[:8] - g["codes_first8"]).max() <= 2e-6
+    assert np.abs(x.numpy()[:8] - g["x_dec_first8"]).max() <= 5e-6
+    hard_ref = np.unpackbits(g["hard_bits"])[: meta["B"] * L].reshape(meta["B"], L)[:B]
+    assert np.array_equal((x.numpy()[:, :, 0] > 0.5).astype(np.uint8), hard_ref)
+    assert meta["ber"] == pytest.approx(1.44e-2, rel=0.05)

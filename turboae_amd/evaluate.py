@@ -1,0 +1,111 @@
+"""Eval sweep of the reference restated for the HIP path: ``trainer.test`` (trainer.py:135-248).
+
+Same protocol - ``snr_points`` SNRs from ``snr_test_start`` to ``snr_test_end`` (trainer.py:157-158),
+``num_block / batch_size`` batches per SNR (trainer.py:165), BER = mean over batches of the per-batch
+bit error rate, BLER likewise (trainer.py:176-177,215-216), the same printed lines
+(``Test SNR <snr> with ber <x> with bler <y>``, trainer.py:217; final lists :230-235) and the
+encoder-power epilogue (trainer.py:238-248) - with three deliberate differences:
+  * inputs come from the counter-based Philox streams on the device instead of the unseeded host
+    RNG (trainer.py:167-169), keyed by (seed, snr index, global block index);
+  * the accidental extra forward per SNR point (trainer.py:194-213, dies with NameError and prints
+    'no pos BER specified.') is not run;
+  * with torch.distributed initialised every batch is sharded over the ranks by block; the
+    power-constraint statistics and the error counts are all-reduced (turboae_amd/distributed.py), so
+    the numbers equal the single-GPU ones.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from .distributed import all_reduce_sum_, shard_bounds
+
+
+def snr_db2sigma(snr_db: float) -> float:      # utils.py:69-70
+    return 10 ** (-snr_db * 1.0 / 20)
+
+
+def snr_sigma2db(sigma: float) -> float:       # utils.py:72-76
+    return -20.0 * math.log(sigma, 10)
+
+
+def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_points: int = 12, num_block: int = 1000,
+         batch_size: int = 100, seed: int = 20190001, verbose: bool = True, enc_power_epilogue: bool = True) -> Dict[str, List[float]]:
+    """model: turboae_amd.Channel_AE_HIP.  Returns {'snrs', 'ber', 'bler', 'bit_errors', 'block_errors', 'enc_power'}."""
+    import torch.distributed as dist
+    rank, world = 0, 1
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(), dist.get_world_size()
+    say = print if (verbose and rank == 0) else (lambda *a, **k: None)
+    L = model.cfg.block_len
+    if snr_points > 1:
+        step = (snr_test_end - snr_test_start) * 1.0 / (snr_points - 1)
+    else:
+        step = 0.0
+    snrs = [step * i + snr_test_start for i in range(snr_points)]
+    say("SNRS", snrs)
+    num_test_batch = int(num_block / batch_size)
+    lo, hi = shard_bounds(batch_size, rank, world)
+    nloc = hi - lo
+    dev = model.this_device
+    ber_res, bler_res, bit_res, blk_res = [], [], [], []
+    for si, snr in enumerate(snrs):
+        test_ber, test_bler = 0.0, 0.0
+        tot = torch.zeros(2, dtype=torch.int64, device=dev)
+        for batch_idx in range(num_test_batch):
+            first = (si * num_test_batch + batch_idx) * batch_size + lo       # global block index of this shard
+            counts = torch.zeros(2, dtype=torch.int64, device=dev)
+            if nloc > 0:
+                u, noise = model.generate_inputs(nloc, snr, seed=seed, first_block=first)
+                x_tx, stats = model.encode_prenorm(u)
+            else:
+                stats = torch.zeros(3, dtype=torch.float64, device=dev)
+            all_reduce_sum_(stats)                                            # batch-global mean/std (encoders.py:107-108)
+            if nloc > 0:
+                _, rx = model.normalize(x_tx, stats, noise, want_codes=False)
+                x_dec = model.dec(rx)
+                model.count_errors(x_dec, u, counts)
+            all_reduce_sum_(counts)
+            c = counts.cpu().tolist()
+            test_ber += c[0] / float(batch_size * L)                           # errors_ber, utils.py:6-18
+            test_bler += c[1] / float(batch_size)                              # errors_bler, utils.py:49-66
+            tot += counts
+        test_ber /= num_test_batch
+        test_bler /= num_test_batch
+        say("Test SNR", snr, "with ber ", float(test_ber), "with bler", float(test_bler))
+        ber_res.append(float(test_ber))
+        bler_res.append(float(test_bler))
+        t = tot.cpu().tolist()
+        bit_res.append(int(t[0]))
+        blk_res.append(int(t[1]))
+    say("final results on SNRs ", snrs)
+    say("BER", ber_res)
+    say("BLER", bler_res)
+    out = {"snrs": snrs, "ber": ber_res, "bler": bler_res, "bit_errors": bit_res, "block_errors": blk_res}
+    if enc_power_epilogue:
+        # trainer.py:238-248: mean over batches of std(model.enc(X)); 1.0 for the power-normalised encoder
+        enc_power = 0.0
+        for idx in range(num_test_batch):
+            first = ((snr_points + 0) * num_test_batch + idx) * batch_size + lo
+            stats = torch.zeros(3, dtype=torch.float64, device=dev)
+            if nloc > 0:
+                u, _ = model.generate_inputs(nloc, 0.0, seed=seed, first_block=first)
+                x_tx, stats = model.encode_prenorm(u)
+            all_reduce_sum_(stats)
+            loc = torch.zeros(3, dtype=torch.float64, device=dev)
+            if nloc > 0:
+                codes, _ = model.normalize(x_tx, stats)
+                c = codes.double()
+                loc = torch.stack([c.sum(), (c * c).sum(), torch.tensor(float(c.numel()), dtype=torch.float64, device=dev)])
+            all_reduce_sum_(loc)
+            s, ss, n = loc.cpu().tolist()
+            enc_power += math.sqrt(max((ss - s * s / n) / (n - 1.0), 0.0))
+        enc_power /= float(num_test_batch)
+        say("encoder power is", enc_power)
+        adj = [snr_sigma2db(snr_db2sigma(item) / enc_power) for item in snrs]
+        say("adjusted SNR should be", adj)
+        out["enc_power"] = enc_power
+        out["adjusted_snrs"] = adj
+    return out
