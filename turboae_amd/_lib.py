@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libturboae_hip.so")
+LIB_PATH = os.environ.get("TAE_LIB", os.path.join(_HERE, "lib", "libturboae_hip.so"))   # TAE_LIB: kernel-variant experiments
 
 TAE_ABI_VERSION = 1
 

@@ -28,33 +28,50 @@ int fail(int code, const std::string& msg) {
         if (e__ != hipSuccess) return fail(TAE_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
 
-struct Layout {
-    int U, CT, CP, nch_mid, midf, l0f;
+struct Layout {   // must mirror tae::Geo<U> in turboae_kernels.hip
+    int U, CTM, VCH, CP, nch_mid, midf, l0f, midr, l0r;
     explicit Layout(int u) : U(u) {
-        CT = (U + 15) / 16;
-        CP = CT * 16;
+#ifndef TAE_VALU_REM
+#define TAE_VALU_REM 0
+#endif
+        CTM = TAE_VALU_REM ? U / 16 : (U + 15) / 16;
+        VCH = TAE_VALU_REM ? U - 16 * (U / 16) : 0;
+        CP = ((U + 15) / 16) * 16;
         nch_mid = (5 * U + 7) / 8;
-        midf = nch_mid * CT * 128;
-        l0f = 5 * CT * 128;
+        midf = nch_mid * CTM * 128;
+        l0f = 5 * CTM * 128;
+        midr = nch_mid * VCH * 8;
+        l0r = 5 * VCH * 8;
     }
-    size_t stack_stride(int n_layer) const { return (size_t)l0f + CP + (size_t)(n_layer - 1) * (midf + CP) + 8 * CP + 8; }
+    size_t stack_stride(int n_layer) const {
+        return (size_t)l0f + CP + l0r + (size_t)(n_layer - 1) * (midf + CP + midr) + 8 * CP + 8;
+    }
 };
 
-// Tile one Conv1d weight (U, cin, 5) into MFMA A-fragment order [chunk][ct][lane][2]:
-// lane (i = lane & 15, kq = lane >> 4) of k-step s holds W'[co = ct*16 + i][k = 8*chunk + 2*kq + s]
-// with k = tap * cin_pad + ci (tap-major), zero outside the real tensor.
-void pack_conv(const float* W, int U, int cin, int cin_pad, int nch, int CT, float* dst) {
+// im2col-flattened weight W'[co][k], k = tap * cin_pad + ci (tap-major), zero outside the real tensor.
+inline float wflat(const float* W, int U, int cin, int cin_pad, int co, int k) {
+    const int j = k / cin_pad, ci = k % cin_pad;
+    return (co < U && j < 5 && ci < cin) ? W[((size_t)co * cin + ci) * 5 + j] : 0.0f;
+}
+
+// Tile the first 16*CTM output channels of one Conv1d weight (U, cin, 5) into MFMA A-fragment order
+// [chunk][ct][lane][2]: lane (i = lane & 15, kq = lane >> 4) of k-step s holds
+// W'[co = ct*16 + i][k = 8*chunk + 2*kq + s].
+void pack_conv(const float* W, int U, int cin, int cin_pad, int nch, int CTM, float* dst) {
     for (int c = 0; c < nch; ++c)
-        for (int ct = 0; ct < CT; ++ct)
+        for (int ct = 0; ct < CTM; ++ct)
             for (int lane = 0; lane < 64; ++lane)
-                for (int s = 0; s < 2; ++s) {
-                    const int co = ct * 16 + (lane & 15);
-                    const int k = 8 * c + 2 * (lane >> 4) + s;
-                    const int j = k / cin_pad, ci = k % cin_pad;
-                    float v = 0.0f;
-                    if (co < U && j < 5 && ci < cin) v = W[((size_t)co * cin + ci) * 5 + j];
-                    dst[(((size_t)c * CT + ct) * 64 + lane) * 2 + s] = v;
-                }
+                for (int s = 0; s < 2; ++s)
+                    dst[(((size_t)c * CTM + ct) * 64 + lane) * 2 + s] =
+                        wflat(W, U, cin, cin_pad, ct * 16 + (lane & 15), 8 * c + 2 * (lane >> 4) + s);
+}
+
+// Remainder channels (vector-ALU side): [chunk][VCH][8], W'[co = 16*CTM + ch][k = 8*chunk + kk].
+void pack_rem(const float* W, int U, int cin, int cin_pad, int nch, int CTM, int VCH, float* dst) {
+    for (int c = 0; c < nch; ++c)
+        for (int ch = 0; ch < VCH; ++ch)
+            for (int kk = 0; kk < 8; ++kk)
+                dst[((size_t)c * VCH + ch) * 8 + kk] = wflat(W, U, cin, cin_pad, 16 * CTM + ch, 8 * c + kk);
 }
 
 // canonical stack (conv layers then Linear head) -> packed stack; returns floats consumed from src
@@ -63,12 +80,16 @@ size_t pack_stack(const float* src, const Layout& lo, int n_layer, int cin0, int
     float* d = dst;
     for (int l = 0; l < n_layer; ++l) {
         const int cin = l == 0 ? cin0 : lo.U;
-        if (l == 0) { pack_conv(s, lo.U, cin, 8, 5, lo.CT, d); d += lo.l0f; }
-        else { pack_conv(s, lo.U, cin, lo.U, lo.nch_mid, lo.CT, d); d += lo.midf; }
-        s += (size_t)lo.U * cin * 5;
-        for (int c = 0; c < lo.CP; ++c) d[c] = c < lo.U ? s[c] : 0.0f;
+        const int cin_pad = l == 0 ? 8 : lo.U;
+        const int nch = l == 0 ? 5 : lo.nch_mid;
+        pack_conv(s, lo.U, cin, cin_pad, nch, lo.CTM, d);
+        d += l == 0 ? lo.l0f : lo.midf;
+        const float* b = s + (size_t)lo.U * cin * 5;
+        for (int c = 0; c < lo.CP; ++c) d[c] = c < lo.U ? b[c] : 0.0f;
         d += lo.CP;
-        s += lo.U;
+        pack_rem(s, lo.U, cin, cin_pad, nch, lo.CTM, lo.VCH, d);
+        d += l == 0 ? lo.l0r : lo.midr;
+        s = b + lo.U;
     }
     for (int f = 0; f < 8; ++f)
         for (int c = 0; c < lo.CP; ++c) d[f * lo.CP + c] = (f < nout && c < lo.U) ? s[(size_t)f * lo.U + c] : 0.0f;

@@ -37,22 +37,21 @@
 namespace tae {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+// constant address space: wave-uniform loads through it become scalar (s_load) instructions
+using cfloat = const float __attribute__((address_space(4)));
 
 // ELU(alpha=1) = x > 0 ? x : expm1(x)  (F.elu, cnn_utils.py:26,43).  Branch-free expm1 for x <= 0:
-// degree-8 Taylor for x >= -0.35 (truncation < 2e-9 relative), exp(x) - 1 below that, where
-// |result| >= 0.29 so the cancellation costs < 3e-7 relative.  ~16 VALU ops, no divergence.
+// degree-5 Taylor for x >= -0.125 (truncation x^5/720 < 5e-8 relative), exp(x) - 1 below that, where
+// |result| >= 0.1175 so the cancellation costs < 6e-7 relative (absolute error <= 7e-8 everywhere).
+// 12 VALU ops, no divergence.  Large positive x may produce inf in the discarded branches, never NaN.
 __device__ __forceinline__ float elu1(float x) {
-    const float xm = fminf(x, 0.0f);
-    float p = 2.4801587e-5f;             // 1/8!
-    p = fmaf(p, xm, 1.9841270e-4f);      // 1/7!
-    p = fmaf(p, xm, 1.3888889e-3f);      // 1/6!
-    p = fmaf(p, xm, 8.3333333e-3f);      // 1/5!
-    p = fmaf(p, xm, 4.1666667e-2f);      // 1/4!
-    p = fmaf(p, xm, 1.6666667e-1f);      // 1/3!
-    p = fmaf(p, xm, 0.5f);
-    p = fmaf(p * xm, xm, xm);            // x + x^2 * (1/2 + ...)
-    const float e = __expf(xm) - 1.0f;
-    const float neg = xm < -0.35f ? e : p;
+    float p = fmaf(x, 8.3333333e-3f, 4.1666667e-2f);   // 1/5!, 1/4!
+    p = fmaf(p, x, 1.6666667e-1f);                     // 1/3!
+    p = fmaf(p, x, 0.5f);
+    p = fmaf(p, x, 1.0f);
+    p = p * x;
+    const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f) - 1.0f;
+    const float neg = x < -0.125f ? e : p;
     return x > 0.0f ? x : neg;
 }
 
@@ -60,60 +59,134 @@ __device__ __forceinline__ f32x4 mfma16x16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// One K-chunk (8 k values = 2 MFMA k-steps) for a PT x CT grid of 16x16 output tiles.
-template <int CT, int PT>
-__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[PT][CT], const float2 (&a)[CT], const float2 (&b)[PT]) {
-#pragma unroll
-    for (int p = 0; p < PT; ++p)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[p][ct] = mfma16x16x4(a[ct].x, b[p].x, acc[p][ct]);
-#pragma unroll
-    for (int p = 0; p < PT; ++p)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[p][ct] = mfma16x16x4(a[ct].y, b[p].y, acc[p][ct]);
+// 16 independent 4x4 outer products: lane 4*blk + i supplies A[blk][i] and B[blk][i];
+// lane 4*blk + j receives D[blk][0..3][j].
+__device__ __forceinline__ f32x4 mfma4x4x1(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 
-template <int CT, int PT>
-__device__ __forceinline__ void load_frags(float2 (&a)[CT], float2 (&b)[PT], const float2* __restrict__ wf,
-                                           const char* lds, const uint32_t (&baddr)[PT], int c) {
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) a[ct] = wf[(c * CT + ct) * 64];
-#pragma unroll
-    for (int p = 0; p < PT; ++p) b[p] = *reinterpret_cast<const float2*>(lds + baddr[p] + 32u * (uint32_t)c);
-}
-
-// acc += W (CT*16 x 8*nch) * im2col (8*nch x PT*16), software-pipelined one chunk ahead.
-// wf  : this lane's pointer into the layer's A fragments ([chunk][ct][lane] float2)
-// baddr: per position tile, LDS byte address of (row-2)*stride + 8*kq for this lane
-template <int CT, int PT>
-__device__ __forceinline__ void conv_accumulate(f32x4 (&acc)[PT][CT], const float2* __restrict__ wf, const char* lds,
-                                                const uint32_t (&baddr)[PT], int nch) {
-    float2 a0[CT], b0[PT], a1[CT], b1[PT];
-    load_frags<CT, PT>(a0, b0, wf, lds, baddr, 0);
-    int c = 0;
-    for (; c + 2 <= nch; c += 2) {
-        load_frags<CT, PT>(a1, b1, wf, lds, baddr, c + 1);
-        mma_chunk<CT, PT>(acc, a0, b0);
-        const int cn = (c + 2 < nch) ? c + 2 : nch - 1;   // clamp: harmless re-load of the last chunk
-        load_frags<CT, PT>(a0, b0, wf, lds, baddr, cn);
-        mma_chunk<CT, PT>(acc, a1, b1);
-    }
-    if (c < nch) mma_chunk<CT, PT>(acc, a0, b0);
-}
+// Build-time experiment switches (defaults = shipped configuration).
+#ifndef TAE_VALU_REM
+#define TAE_VALU_REM 0      // 0 (shipped): remainder channels (U % 16) ride a padded extra 16x16 tile; 1: on 4x4x1 MFMAs (measured slower: ~44 cycles per v_mfma_f32_4x4x1_16b_f32 on gfx950)
+#endif
 
 template <int U>
 struct Geo {
-    static constexpr int CT = (U + 15) / 16;       // 16-wide output-channel tiles
-    static constexpr int CP = CT * 16;             // padded channel count
-    static constexpr int NCH_MID = (5 * U + 7) / 8;  // K chunks of a U->U layer
-    static constexpr int NCH_L0 = 5;               // K chunks of the first layer (5 taps x 8 padded inputs)
-    static constexpr int MIDF = NCH_MID * CT * 128;  // floats of A fragments per U->U layer
-    static constexpr int L0F = NCH_L0 * CT * 128;
+    static constexpr int CTM = TAE_VALU_REM ? U / 16 : (U + 15) / 16;   // 16-wide output-channel tiles on the matrix cores
+    static constexpr int VCH = TAE_VALU_REM ? U - 16 * (U / 16) : 0;    // remainder channels, computed with 4x4x1 MFMAs
+    static constexpr int CP = ((U + 15) / 16) * 16;  // padded channel count (bias / Linear head rows)
+    static constexpr int NCH_MID = (5 * U + 7) / 8;  // K chunks (8 k each) of a U->U layer
+    static constexpr int NCH_L0 = 5;                 // K chunks of the first layer (5 taps x 8 padded inputs)
+    static constexpr int MIDF = NCH_MID * CTM * 128; // floats of A fragments per U->U layer
+    static constexpr int L0F = NCH_L0 * CTM * 128;
+    static constexpr int MIDR = NCH_MID * VCH * 8;   // floats of remainder-channel weights [chunk][VCH][8]
+    static constexpr int L0R = NCH_L0 * VCH * 8;
+    static_assert(VCH == 0 || VCH == 4, "remainder path = one 4-row MFMA block");
 };
 
 constexpr int kWaves = 4;
 constexpr int kThreads = 64 * kWaves;
 constexpr int kXW = 8;  // floats per row of the XA / XB input panels
+
+// Operands of one K-chunk (8 k values = 2 MFMA k-steps) for a wave's PT x CTM grid of 16x16 tiles,
+// plus the remainder channels: U = 16*CTM + VCH, and the VCH = 4 remainder channels (96..99 for
+// U = 100) would waste 75 % of a 7th 16x16 tile, so they run on v_mfma_f32_4x4x1_16b_f32 instead
+// (16 independent 4x4 outer products per instruction, K = 1, 2 passes): the 4 channels are the A
+// rows of every block and each lane brings its OWN position as a B column, so one instruction
+// covers 64 positions x 4 channels at full matrix-pipe efficiency:
+//   group A: lane l owns position 16*(l>>4) + (l&15) of tiles 0..3;
+//   group B: lane l owns position (l&15) of tile PT-1 (the four lane groups duplicate each other).
+// Both groups run the same k-ordered chain, so a block's result does not depend on where in a
+// workgroup it sits.  (Measured alternative: the same FMAs on the vector ALU cost ~8 matrix-pipe
+// cycles each - fp32 VALU FMAs do not overlap fp32 MFMAs - and were a net loss.)
+template <int CTM, int PT, int VCH>
+struct Ops {
+    float2 a[CTM];
+    float2 b[PT];
+    f32x4 xa[2], xb[2];      // 8 consecutive im2col values of the lane's group-A / group-B position
+    f32x4 wr[2];             // 8 consecutive weights of remainder channel (lane & 3)
+};
+
+template <int VCH>
+struct VAddr {
+    uint32_t a, b;            // LDS byte address of (row-2)*stride for the lane's group-A / group-B position
+    const float* remv;        // per lane: remainder weights [chunk][VCH][8] + (lane & 3) * 8
+};
+
+// A fragments (global, L2-resident weights) of chunk c
+template <int CTM, int PT, int VCH>
+__device__ __forceinline__ void load_w(Ops<CTM, PT, VCH>& o, const float2* __restrict__ wf, const VAddr<VCH>& va, int c) {
+#pragma unroll
+    for (int ct = 0; ct < CTM; ++ct) o.a[ct] = wf[(c * CTM + ct) * 64];
+    if constexpr (VCH > 0) {
+        o.wr[0] = *reinterpret_cast<const f32x4*>(va.remv + c * VCH * 8);
+        o.wr[1] = *reinterpret_cast<const f32x4*>(va.remv + c * VCH * 8 + 4);
+    }
+}
+
+// B fragments (LDS activations) of chunk c
+template <int CTM, int PT, int VCH>
+__device__ __forceinline__ void load_x(Ops<CTM, PT, VCH>& o, const char* lds, const uint32_t (&baddr)[PT],
+                                       const VAddr<VCH>& va, int c) {
+#pragma unroll
+    for (int p = 0; p < PT; ++p) o.b[p] = *reinterpret_cast<const float2*>(lds + baddr[p] + 32u * (uint32_t)c);
+    if constexpr (VCH > 0) {
+        o.xa[0] = *reinterpret_cast<const f32x4*>(lds + va.a + 32u * (uint32_t)c);
+        o.xa[1] = *reinterpret_cast<const f32x4*>(lds + va.a + 32u * (uint32_t)c + 16u);
+        o.xb[0] = *reinterpret_cast<const f32x4*>(lds + va.b + 32u * (uint32_t)c);
+        o.xb[1] = *reinterpret_cast<const f32x4*>(lds + va.b + 32u * (uint32_t)c + 16u);
+    }
+}
+
+template <int CTM, int PT, int VCH>
+__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[PT][CTM], f32x4 (&accA)[8], f32x4 (&accB)[8], const Ops<CTM, PT, VCH>& o) {
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+#pragma unroll
+        for (int ct = 0; ct < CTM; ++ct) acc[p][ct] = mfma16x16x4(o.a[ct].x, o.b[p].x, acc[p][ct]);
+    if constexpr (VCH > 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            accA[k] = mfma4x4x1(o.wr[0][k], o.xa[0][k], accA[k]);
+            accB[k] = mfma4x4x1(o.wr[0][k], o.xb[0][k], accB[k]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+#pragma unroll
+        for (int ct = 0; ct < CTM; ++ct) acc[p][ct] = mfma16x16x4(o.a[ct].y, o.b[p].y, acc[p][ct]);
+    if constexpr (VCH > 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            accA[4 + k] = mfma4x4x1(o.wr[1][k], o.xa[1][k], accA[4 + k]);
+            accB[4 + k] = mfma4x4x1(o.wr[1][k], o.xb[1][k], accB[4 + k]);
+        }
+    }
+}
+
+// acc += W (16*CTM x 8*nch) * im2col (8*nch x PT*16) (+ the remainder channels), software-pipelined
+// one chunk ahead.  `o0` arrives with the chunk-0 WEIGHT fragments already loaded (prefetched across
+// the previous layer's epilogue and barriers).
+// wf   : this lane's pointer into the layer's A fragments ([chunk][ct][lane] float2)
+// baddr: per position tile, LDS byte address of (row-2)*stride + 8*kq for this lane
+template <int CTM, int PT, int VCH>
+__device__ __forceinline__ void conv_accumulate(f32x4 (&acc)[PT][CTM], f32x4 (&accA)[8], f32x4 (&accB)[8], Ops<CTM, PT, VCH>& o0,
+                                                const float2* __restrict__ wf, const char* lds,
+                                                const uint32_t (&baddr)[PT], const VAddr<VCH>& va, int nch) {
+    Ops<CTM, PT, VCH> o1;
+    load_x<CTM, PT, VCH>(o0, lds, baddr, va, 0);
+    int c = 0;
+    for (; c + 2 <= nch; c += 2) {
+        load_w<CTM, PT, VCH>(o1, wf, va, c + 1);
+        load_x<CTM, PT, VCH>(o1, lds, baddr, va, c + 1);
+        mma_chunk<CTM, PT, VCH>(acc, accA, accB, o0);
+        const int cn = (c + 2 < nch) ? c + 2 : nch - 1;   // clamp: harmless re-load of the last chunk
+        load_w<CTM, PT, VCH>(o0, wf, va, cn);
+        load_x<CTM, PT, VCH>(o0, lds, baddr, va, cn);
+        mma_chunk<CTM, PT, VCH>(acc, accA, accB, o1);
+    }
+    if (c < nch) mma_chunk<CTM, PT, VCH>(acc, accA, accB, o0);
+}
 
 // Per-lane view of the position tiles a wave owns.
 template <int PT>
@@ -126,56 +199,124 @@ struct TileCtx {
     bool center[PT];  // position whose stack output this workgroup owns (== valid for whole blocks)
 };
 
+// Reduce 8 per-lane partial outputs over the 4 lane groups (q = lane >> 4) of a position with a
+// reduce-scatter butterfly: afterwards lane group q holds outputs f = 2q (k2[0]) and f = 2q + 1 (k2[1]).
+__device__ __forceinline__ void butterfly8(const float (&part)[8], bool hi32, bool hi16, float (&k2)[2]) {
+    float k4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float keep = hi32 ? part[4 + j] : part[j];
+        const float send = hi32 ? part[j] : part[4 + j];
+        k4[j] = keep + __shfl_xor(send, 32);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float keep = hi16 ? k4[2 + j] : k4[j];
+        const float send = hi16 ? k4[j] : k4[2 + j];
+        k2[j] = keep + __shfl_xor(send, 16);
+    }
+}
+
+// Weight-side state a stack hands to the next one: chunk-0 A fragments of the NEXT conv layer,
+// fetched before the current layer's epilogue so their L2 latency hides behind it.
+template <int U, int PT>
+struct Prefetch {
+    Ops<Geo<U>::CTM, PT, Geo<U>::VCH> o;
+};
+
 // Runs one SameShapeConv1d stack (cnn_utils.py:36-46) followed by its Linear head for the
 // workgroup's blocks.  `epi(p, f, value)` is called for output feature f (0..7) of this lane's
 // position in tile p by the lane that owns (p, f): lane group q owns f = 2q and f = 2q + 1.
+// `wnext` = packed base of the stack that runs next in this kernel (nullptr if none): its first
+// layer's chunk-0 weights are prefetched into `pf` before the head epilogue.
+//
+// Packed stack layout (floats), written by turboae_api.hip::pack_stack:
+//   per layer: A fragments [chunk][CTM][64][2] | bias [CP] | remainder weights [chunk][VCH][8]
+//   then Linear head weights [8][CP] | Linear bias [8]
 template <int U, int PT, class Epi>
-__device__ __forceinline__ void run_stack(const float* __restrict__ wstack, int n_layer, char* smem, float* ACT,
-                                          const float* Xin, const TileCtx<PT>& tc, int lane, Epi epi) {
+__device__ __forceinline__ void run_stack(const float* __restrict__ wstack, const float* __restrict__ wnext, int n_layer,
+                                          char* smem, float* ACT, const float* Xin, const TileCtx<PT>& tc, int lane,
+                                          Prefetch<U, PT>& pf, Epi epi) {
     using G = Geo<U>;
-    constexpr int CT = G::CT;
+    constexpr int CTM = G::CTM, VCH = G::VCH;
+    static_assert(VCH == 0 || PT == 5, "remainder-channel mapping assumes 4 + 1 position tiles per wave");
     const int q = lane >> 4;
-    f32x4 acc[PT][CT];
+    f32x4 acc[PT][CTM];
+    f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+    f32x4 accA8[8], accB8[8];   // one accumulator per k mod 8: no back-to-back dependent 4x4x1 MFMAs
+    // group-A position of this lane = its position in tile q; group-B position = its position in tile PT-1
+    int rowA = tc.row[0];
+    bool validA = tc.valid[0];
+    if constexpr (VCH > 0) {
+        rowA = (q == 0) ? tc.row[0] : (q == 1) ? tc.row[1] : (q == 2) ? tc.row[2] : tc.row[3];
+        validA = (q == 0) ? tc.valid[0] : (q == 1) ? tc.valid[1] : (q == 2) ? tc.valid[2] : tc.valid[3];
+    }
     const float* wl = wstack;
     for (int l = 0; l < n_layer; ++l) {
         const bool first = (l == 0);
         const int fragf = first ? G::L0F : G::MIDF;
+        const int remf = first ? G::L0R : G::MIDR;
         const float* bias = wl + fragf;
         // accumulators start at the bias (Conv1d bias=True, cnn_utils.py:15-17)
         {
-            f32x4 b4[CT];
+            f32x4 b4[CTM];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) b4[ct] = *reinterpret_cast<const f32x4*>(bias + ct * 16 + 4 * q);
+            for (int ct = 0; ct < CTM; ++ct) b4[ct] = *reinterpret_cast<const f32x4*>(bias + ct * 16 + 4 * q);
 #pragma unroll
             for (int p = 0; p < PT; ++p)
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[p][ct] = b4[ct];
+                for (int ct = 0; ct < CTM; ++ct) acc[p][ct] = b4[ct];
+            if constexpr (VCH > 0) {
+                accA8[0] = accB8[0] = *reinterpret_cast<const f32x4*>(bias + 16 * CTM);
+#pragma unroll
+                for (int k = 1; k < 8; ++k) accA8[k] = accB8[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         uint32_t baddr[PT];
-        if (first) {
-            const uint32_t xoff = (uint32_t)(reinterpret_cast<const char*>(Xin) - smem);
+        VAddr<VCH> va;
+        va.remv = bias + G::CP + (lane & 3) * 8;
+        const uint32_t stride = first ? (uint32_t)(kXW * 4) : (uint32_t)(U * 4);
+        const uint32_t poff = (uint32_t)(reinterpret_cast<const char*>(first ? Xin : ACT) - smem);
 #pragma unroll
-            for (int p = 0; p < PT; ++p) baddr[p] = xoff + (uint32_t)(tc.row[p] - 2) * (kXW * 4) + 8u * q;
-            conv_accumulate<CT, PT>(acc, reinterpret_cast<const float2*>(wl) + lane, smem, baddr, G::NCH_L0);
-        } else {
-            const uint32_t aoff = (uint32_t)(reinterpret_cast<const char*>(ACT) - smem);
-#pragma unroll
-            for (int p = 0; p < PT; ++p) baddr[p] = aoff + (uint32_t)(tc.row[p] - 2) * (U * 4) + 8u * q;
-            conv_accumulate<CT, PT>(acc, reinterpret_cast<const float2*>(wl) + lane, smem, baddr, G::NCH_MID);
+        for (int p = 0; p < PT; ++p) baddr[p] = poff + (uint32_t)(tc.row[p] - 2) * stride + 8u * q;
+        va.a = poff + (uint32_t)(rowA - 2) * stride;
+        va.b = poff + (uint32_t)(tc.row[PT - 1] - 2) * stride;
+        conv_accumulate<CTM, PT, VCH>(acc, accA8, accB8, pf.o, reinterpret_cast<const float2*>(wl) + lane, smem, baddr, va,
+                                      first ? G::NCH_L0 : G::NCH_MID);
+        if constexpr (VCH > 0) {   // fixed-order pairwise sum of the 8 partial accumulators
+            accA = ((accA8[0] + accA8[1]) + (accA8[2] + accA8[3])) + ((accA8[4] + accA8[5]) + (accA8[6] + accA8[7]));
+            accB = ((accB8[0] + accB8[1]) + (accB8[2] + accB8[3])) + ((accB8[4] + accB8[5]) + (accB8[6] + accB8[7]));
         }
-        wl += fragf + G::CP;
+        wl += fragf + G::CP + remf;
+        // prefetch the next conv layer's chunk-0 weights (this stack's next layer, or the next stack's first)
+        {
+            const bool more = (l + 1 < n_layer);
+            const float* wn = more ? wl : wnext;
+            if (wn != nullptr) {
+                const int nfrag = more ? G::MIDF : G::L0F;
+                VAddr<VCH> vn;
+                vn.a = vn.b = 0;
+                vn.remv = wn + nfrag + G::CP + (lane & 3) * 8;
+                load_w<CTM, PT, VCH>(pf.o, reinterpret_cast<const float2*>(wn) + lane, vn, 0);
+            }
+        }
         if (l + 1 < n_layer) {
             // in-place panel update: everyone must have finished reading the old activations
             if (!first) __syncthreads();
 #pragma unroll
             for (int p = 0; p < PT; ++p) {
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
+                for (int ct = 0; ct < CTM; ++ct) {
                     f32x4 v = acc[p][ct];
                     v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
-                    const int ch = ct * 16 + 4 * q;
-                    if (tc.valid[p] && ch < U) *reinterpret_cast<f32x4*>(ACT + tc.row[p] * U + ch) = v;
+                    if (tc.valid[p] && ct * 16 + 4 * q < U) *reinterpret_cast<f32x4*>(ACT + tc.row[p] * U + ct * 16 + 4 * q) = v;
                 }
+            }
+            if constexpr (VCH > 0) {
+                f32x4 va4 = {elu1(accA.x), elu1(accA.y), elu1(accA.z), elu1(accA.w)};
+                f32x4 vb4 = {elu1(accB.x), elu1(accB.y), elu1(accB.z), elu1(accB.w)};
+                if (validA) *reinterpret_cast<f32x4*>(ACT + rowA * U + 16 * CTM) = va4;
+                if (tc.valid[PT - 1] && q == 0) *reinterpret_cast<f32x4*>(ACT + tc.row[PT - 1] * U + 16 * CTM) = vb4;
             }
             __syncthreads();
         }
@@ -188,7 +329,7 @@ __device__ __forceinline__ void run_stack(const float* __restrict__ wstack, int 
 #pragma unroll
         for (int f = 0; f < 8; ++f) part[p][f] = 0.0f;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
+    for (int ct = 0; ct < CTM; ++ct) {
         f32x4 w4[8];
 #pragma unroll
         for (int f = 0; f < 8; ++f) w4[f] = *reinterpret_cast<const f32x4*>(wl + f * G::CP + ct * 16 + 4 * q);
@@ -205,26 +346,35 @@ __device__ __forceinline__ void run_stack(const float* __restrict__ wstack, int 
             }
         }
     }
-    // Reduce the 8 partial outputs over the 4 lane groups (q) of each position with a
-    // reduce-scatter butterfly: afterwards lane group q holds outputs f = 2q and f = 2q + 1.
+    // remainder channels: one lane per position holds their contribution (group A: the lane of tile q,
+    // group B: lane group 0 of tile PT-1); it is routed to the owning lane through a second butterfly
+    // whose other inputs are exact zeros, so the result does not depend on which lane produced it.
+    float ca[8], cb[8];
+    if constexpr (VCH > 0) {
+        const f32x4 ea = {elu1(accA.x), elu1(accA.y), elu1(accA.z), elu1(accA.w)};
+        const f32x4 eb = {elu1(accB.x), elu1(accB.y), elu1(accB.z), elu1(accB.w)};
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wl + f * G::CP + 16 * CTM);
+            ca[f] = fmaf(ea.w, w.w, fmaf(ea.z, w.z, fmaf(ea.y, w.y, ea.x * w.x)));
+            cb[f] = fmaf(eb.w, w.w, fmaf(eb.z, w.z, fmaf(eb.y, w.y, eb.x * w.x)));
+        }
+    }
     const float* lb = wl + 8 * G::CP;
     const float bq0 = lb[2 * q], bq1 = lb[2 * q + 1];
     const bool hi32 = (q & 2) != 0, hi16 = (q & 1) != 0;
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
-        float k4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float keep = hi32 ? part[p][4 + j] : part[p][j];
-            const float send = hi32 ? part[p][j] : part[p][4 + j];
-            k4[j] = keep + __shfl_xor(send, 32);
-        }
         float k2[2];
+        butterfly8(part[p], hi32, hi16, k2);
+        if constexpr (VCH > 0) {
+            float rp[8], r2[2];
+            const bool mine = (p < PT - 1) ? (q == p) : (q == 0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float keep = hi16 ? k4[2 + j] : k4[j];
-            const float send = hi16 ? k4[j] : k4[2 + j];
-            k2[j] = keep + __shfl_xor(send, 16);
+            for (int f = 0; f < 8; ++f) rp[f] = mine ? ((p < PT - 1) ? ca[f] : cb[f]) : 0.0f;
+            butterfly8(rp, hi32, hi16, r2);
+            k2[0] += r2[0];
+            k2[1] += r2[1];
         }
         if (tc.center[p]) {
             epi(p, 2 * q, k2[0] + bq0);
@@ -232,6 +382,16 @@ __device__ __forceinline__ void run_stack(const float* __restrict__ wstack, int 
         }
     }
     __syncthreads();
+}
+
+// chunk-0 weights of a stack's first layer (used once per kernel, before the first stack)
+template <int U, int PT>
+__device__ __forceinline__ void prefetch_first(Prefetch<U, PT>& pf, const float* wstack, int lane) {
+    using G = Geo<U>;
+    VAddr<G::VCH> vn;
+    vn.a = vn.b = 0;
+    vn.remv = wstack + G::L0F + G::CP + (lane & 3) * 8;
+    load_w<G::CTM, PT, G::VCH>(pf.o, reinterpret_cast<const float2*>(wstack) + lane, vn, 0);
 }
 
 template <int PT>
@@ -315,6 +475,8 @@ __global__ __launch_bounds__(kThreads, 1) void dec_kernel(FusedParams P) {
     const int F = P.F;
     const bool extrinsic = P.extrinsic != 0;
     float* xdec = P.out + (size_t)blk0 * L;
+    Prefetch<U, PT> pf;
+    prefetch_first<U, PT>(pf, P.wpack, lane);
     for (int s = 0; s < n_stack; ++s) {
         const float* Xin = (s & 1) ? pn.XB : pn.XA;
         float* Xout = (s & 1) ? pn.XA : pn.XB;
@@ -323,7 +485,7 @@ __global__ __launch_bounds__(kThreads, 1) void dec_kernel(FusedParams P) {
         const int* ptab = (s & 1) ? pn.PERM : pn.INV;
         const float* wstack = P.wpack + (size_t)s * P.stack_stride;
         if (s + 1 < n_stack) {
-            run_stack<U, PT>(wstack, P.n_layer, smem, pn.ACT, Xin, tc, lane, [&](int p, int f, float v) {
+            run_stack<U, PT>(wstack, wstack + P.stack_stride, P.n_layer, smem, pn.ACT, Xin, tc, lane, pf, [&](int p, int f, float v) {
                 if (f < F) {
                     if (extrinsic) v -= Xin[tc.row[p] * kXW + 2 + f];   // decoders.py:235-236,246-247
                     Xout[(tc.rowbase[p] + ptab[tc.t[p]]) * kXW + 2 + f] = v;
@@ -331,7 +493,7 @@ __global__ __launch_bounds__(kThreads, 1) void dec_kernel(FusedParams P) {
             });
         } else {
             // last half-iteration: Linear(U->1), no extrinsic subtraction, sigmoid(deinterleave) (decoders.py:262-267)
-            run_stack<U, PT>(wstack, P.n_layer, smem, pn.ACT, Xin, tc, lane, [&](int p, int f, float v) {
+            run_stack<U, PT>(wstack, nullptr, P.n_layer, smem, pn.ACT, Xin, tc, lane, pf, [&](int p, int f, float v) {
                 if (f == 0) xdec[tc.blk[p] * L + ptab[tc.t[p]]] = 1.0f / (1.0f + expf(-v));
             });
         }
@@ -372,10 +534,13 @@ __global__ __launch_bounds__(kThreads, 1) void enc_kernel(FusedParams P) {
     float* xtx = P.out + (size_t)blk0 * L * 3;
     const bool act_elu = P.act == 0;
     double sum = 0.0, sumsq = 0.0;
+    Prefetch<U, PT> pf;
+    prefetch_first<U, PT>(pf, P.wpack, lane);
     for (int s = 0; s < 3; ++s) {
         const float* Xin = (s == 2) ? pn.XB : pn.XA;
         const float* wstack = P.wpack + (size_t)s * P.stack_stride;
-        run_stack<U, PT>(wstack, P.n_layer, smem, pn.ACT, Xin, tc, lane, [&](int p, int f, float v) {
+        run_stack<U, PT>(wstack, s < 2 ? wstack + P.stack_stride : nullptr, P.n_layer, smem, pn.ACT, Xin, tc, lane, pf,
+                         [&](int p, int f, float v) {
             if (f == 0) {
                 if (act_elu) v = elu1(v);                      // enc_act (encoders.py:364)
                 xtx[(size_t)(tc.blk[p] * L + tc.t[p]) * 3 + s] = v;   // x_p2 stays in interleaved order (encoders.py:371-373)
@@ -463,11 +628,13 @@ __global__ __launch_bounds__(kThreads, 1) void seg_kernel(SegParams P) {
         }
     }
     const float* wstack = P.wpack + (size_t)stack * P.stack_stride;
+    Prefetch<U, PT> pf;
+    prefetch_first<U, PT>(pf, wstack, lane);
     if (P.mode == 0) {
         const bool act_elu = P.act == 0;
         double sum = 0.0, sumsq = 0.0;
         float* xtx = P.out + (size_t)b * L * 3;
-        run_stack<U, PT>(wstack, P.n_layer, smem, ACT, X, tc, lane, [&](int p, int f, float v) {
+        run_stack<U, PT>(wstack, nullptr, P.n_layer, smem, ACT, X, tc, lane, pf, [&](int p, int f, float v) {
             if (f == 0) {
                 if (act_elu) v = elu1(v);
                 xtx[(size_t)tc.t[p] * 3 + stack] = v;
@@ -488,7 +655,7 @@ __global__ __launch_bounds__(kThreads, 1) void seg_kernel(SegParams P) {
         const int F = P.F;
         const bool extrinsic = P.extrinsic != 0;
         float* ecur = P.ecur + (size_t)b * L * 8;
-        run_stack<U, PT>(wstack, P.n_layer, smem, ACT, X, tc, lane, [&](int p, int f, float v) {
+        run_stack<U, PT>(wstack, nullptr, P.n_layer, smem, ACT, X, tc, lane, pf, [&](int p, int f, float v) {
             if (f < F) {
                 if (extrinsic) v -= X[tc.row[p] * kXW + 2 + f];
                 ecur[(size_t)tc.t[p] * 8 + f] = v;
@@ -496,7 +663,7 @@ __global__ __launch_bounds__(kThreads, 1) void seg_kernel(SegParams P) {
         });
     } else {
         float* xdec = P.out + (size_t)b * L;
-        run_stack<U, PT>(wstack, P.n_layer, smem, ACT, X, tc, lane, [&](int p, int f, float v) {
+        run_stack<U, PT>(wstack, nullptr, P.n_layer, smem, ACT, X, tc, lane, pf, [&](int p, int f, float v) {
             if (f == 0) xdec[P.perm[tc.t[p]]] = 1.0f / (1.0f + expf(-v));    // sigmoid(deinterleave), decoders.py:267
         });
     }
