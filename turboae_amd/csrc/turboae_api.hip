@@ -29,23 +29,15 @@ int fail(int code, const std::string& msg) {
     } while (0)
 
 struct Layout {   // must mirror tae::Geo<U> in turboae_kernels.hip
-    int U, CTM, VCH, CP, nch_mid, midf, l0f, midr, l0r;
+    int U, CT, CP, nch_mid, midf, l0f;
     explicit Layout(int u) : U(u) {
-#ifndef TAE_VALU_REM
-#define TAE_VALU_REM 0
-#endif
-        CTM = TAE_VALU_REM ? U / 16 : (U + 15) / 16;
-        VCH = TAE_VALU_REM ? U - 16 * (U / 16) : 0;
-        CP = ((U + 15) / 16) * 16;
+        CT = (U + 15) / 16;
+        CP = CT * 16;
         nch_mid = (5 * U + 7) / 8;
-        midf = nch_mid * CTM * 128;
-        l0f = 5 * CTM * 128;
-        midr = nch_mid * VCH * 8;
-        l0r = 5 * VCH * 8;
+        midf = nch_mid * CT * 128;
+        l0f = 5 * CT * 128;
     }
-    size_t stack_stride(int n_layer) const {
-        return (size_t)l0f + CP + l0r + (size_t)(n_layer - 1) * (midf + CP + midr) + 8 * CP + 8;
-    }
+    size_t stack_stride(int n_layer) const { return (size_t)l0f + CP + (size_t)(n_layer - 1) * (midf + CP) + 8 * CP + 8; }
 };
 
 // im2col-flattened weight W'[co][k], k = tap * cin_pad + ci (tap-major), zero outside the real tensor.
@@ -54,24 +46,20 @@ inline float wflat(const float* W, int U, int cin, int cin_pad, int co, int k) {
     return (co < U && j < 5 && ci < cin) ? W[((size_t)co * cin + ci) * 5 + j] : 0.0f;
 }
 
-// Tile the first 16*CTM output channels of one Conv1d weight (U, cin, 5) into MFMA A-fragment order
-// [chunk][ct][lane][2]: lane (i = lane & 15, kq = lane >> 4) of k-step s holds
-// W'[co = ct*16 + i][k = 8*chunk + 2*kq + s].
-void pack_conv(const float* W, int U, int cin, int cin_pad, int nch, int CTM, float* dst) {
+// Tile one Conv1d weight (U, cin, 5) into MFMA A-fragment order.  Lane (i = lane & 15, kq = lane >> 4)
+// of k-step s of chunk c holds W'[co = ct*16 + i][k = 8*c + 2*kq + s].  Per chunk the channel tiles are
+// stored in pairs so that one 16-byte load fetches two tiles: [pair j][lane][ct=2j: s0 s1 | ct=2j+1: s0 s1],
+// followed (odd CT) by the last tile as [lane][s0 s1].
+void pack_conv(const float* W, int U, int cin, int cin_pad, int nch, int CT, float* dst) {
     for (int c = 0; c < nch; ++c)
-        for (int ct = 0; ct < CTM; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
             for (int lane = 0; lane < 64; ++lane)
-                for (int s = 0; s < 2; ++s)
-                    dst[(((size_t)c * CTM + ct) * 64 + lane) * 2 + s] =
-                        wflat(W, U, cin, cin_pad, ct * 16 + (lane & 15), 8 * c + 2 * (lane >> 4) + s);
-}
-
-// Remainder channels (vector-ALU side): [chunk][VCH][8], W'[co = 16*CTM + ch][k = 8*chunk + kk].
-void pack_rem(const float* W, int U, int cin, int cin_pad, int nch, int CTM, int VCH, float* dst) {
-    for (int c = 0; c < nch; ++c)
-        for (int ch = 0; ch < VCH; ++ch)
-            for (int kk = 0; kk < 8; ++kk)
-                dst[((size_t)c * VCH + ch) * 8 + kk] = wflat(W, U, cin, cin_pad, 16 * CTM + ch, 8 * c + kk);
+                for (int s = 0; s < 2; ++s) {
+                    size_t idx = (size_t)c * CT * 128;
+                    if (ct < 2 * (CT / 2)) idx += (size_t)(ct / 2) * 256 + lane * 4 + (ct % 2) * 2 + s;
+                    else idx += (size_t)(CT / 2) * 256 + lane * 2 + s;
+                    dst[idx] = wflat(W, U, cin, cin_pad, ct * 16 + (lane & 15), 8 * c + 2 * (lane >> 4) + s);
+                }
 }
 
 // canonical stack (conv layers then Linear head) -> packed stack; returns floats consumed from src
@@ -80,16 +68,12 @@ size_t pack_stack(const float* src, const Layout& lo, int n_layer, int cin0, int
     float* d = dst;
     for (int l = 0; l < n_layer; ++l) {
         const int cin = l == 0 ? cin0 : lo.U;
-        const int cin_pad = l == 0 ? 8 : lo.U;
-        const int nch = l == 0 ? 5 : lo.nch_mid;
-        pack_conv(s, lo.U, cin, cin_pad, nch, lo.CTM, d);
+        pack_conv(s, lo.U, cin, l == 0 ? 8 : lo.U, l == 0 ? 5 : lo.nch_mid, lo.CT, d);
         d += l == 0 ? lo.l0f : lo.midf;
-        const float* b = s + (size_t)lo.U * cin * 5;
-        for (int c = 0; c < lo.CP; ++c) d[c] = c < lo.U ? b[c] : 0.0f;
+        s += (size_t)lo.U * cin * 5;
+        for (int c = 0; c < lo.CP; ++c) d[c] = c < lo.U ? s[c] : 0.0f;
         d += lo.CP;
-        pack_rem(s, lo.U, cin, cin_pad, nch, lo.CTM, lo.VCH, d);
-        d += l == 0 ? lo.l0r : lo.midr;
-        s = b + lo.U;
+        s += lo.U;
     }
     for (int f = 0; f < 8; ++f)
         for (int c = 0; c < lo.CP; ++c) d[f * lo.CP + c] = (f < nout && c < lo.U) ? s[(size_t)f * lo.U + c] : 0.0f;
@@ -109,6 +93,7 @@ struct tae_handle {
     // long-block (segmented) path, used when a whole block does not fit one workgroup (nb == 0)
     int enc_T = 0, enc_nseg = 0, enc_lds = 0, dec_T = 0, dec_nseg = 0, dec_lds = 0;
     uint32_t enc_stride = 0, dec_stride = 0;
+    uint32_t enc_bytes = 0, dec_bytes = 0;
     float* d_wenc = nullptr;
     float* d_wdec = nullptr;
     int32_t* d_perm = nullptr;
@@ -225,6 +210,7 @@ int run_encoder_long(tae_handle* h, const float* u, float* xtx, double* stats, i
     P.nseg = h->enc_nseg;
     P.n_layer = h->cfg.enc_num_layer;
     P.stack_stride = h->enc_stride;
+    P.wpack_bytes = h->enc_bytes;
     P.lds_bytes = h->enc_lds;
     const int grid = 3 * B * h->enc_nseg;
     TAE_HIP(tae::launch_seg(h->U, P, grid, st));
@@ -242,6 +228,7 @@ int run_decoder_long(tae_handle* h, const float* rx, float* xdec, int32_t B, hip
     P.nseg = h->dec_nseg;
     P.n_layer = h->cfg.dec_num_layer;
     P.stack_stride = h->dec_stride;
+    P.wpack_bytes = h->dec_bytes;
     P.lds_bytes = h->dec_lds;
     const int n_stack = 2 * h->cfg.num_iteration;
     const int grid = B * h->dec_nseg;
@@ -264,6 +251,7 @@ int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_
     P.partials = h->d_partials;
     P.n_layer = h->cfg.enc_num_layer;
     P.stack_stride = h->enc_stride;
+    P.wpack_bytes = h->enc_bytes;
     const int grid = (B + h->nb - 1) / h->nb;
     TAE_HIP(tae::launch_fused(h->U, false, P, grid, st));
     TAE_HIP(tae::launch_reduce_partials(h->d_partials, grid, (double)B * h->cfg.block_len * 3.0, stats, st));
@@ -278,6 +266,7 @@ int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStrea
     P.out = xdec;
     P.n_layer = h->cfg.dec_num_layer;
     P.stack_stride = h->dec_stride;
+    P.wpack_bytes = h->dec_bytes;
     const int grid = (B + h->nb - 1) / h->nb;
     TAE_HIP(tae::launch_fused(h->U, true, P, grid, st));
     return TAE_OK;
@@ -332,6 +321,8 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     h->enc_stride = (uint32_t)lo.stack_stride(cfg->enc_num_layer);
     h->dec_stride = (uint32_t)lo.stack_stride(cfg->dec_num_layer);
     std::vector<float> penc((size_t)3 * h->enc_stride, 0.0f), pdec((size_t)2 * cfg->num_iteration * h->dec_stride, 0.0f);
+    h->enc_bytes = (uint32_t)(penc.size() * sizeof(float));
+    h->dec_bytes = (uint32_t)(pdec.size() * sizeof(float));
     const float* src = weights;
     for (int s = 0; s < 3; ++s) src += pack_stack(src, lo, cfg->enc_num_layer, 1, 1, penc.data() + (size_t)s * h->enc_stride);
     for (int it = 0; it < cfg->num_iteration; ++it)

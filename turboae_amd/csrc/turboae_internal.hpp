@@ -22,6 +22,7 @@ struct FusedParams {
     int32_t extrinsic;
     int32_t act;            // encoder output activation: 0 = elu, 1 = linear
     uint32_t stack_stride;  // floats between consecutive stacks in wpack
+    uint32_t wpack_bytes;   // size of the packed weight buffer (buffer-resource bound)
     int32_t lds_bytes;
 };
 
@@ -41,6 +42,7 @@ struct SegParams {
     int32_t B, L, T, nseg;  // T = centre positions per segment, nseg = segments per block
     int32_t n_layer, F, extrinsic, act;
     uint32_t stack_stride;
+    uint32_t wpack_bytes;
     int32_t lds_bytes;
 };
 

@@ -37,155 +37,165 @@
 namespace tae {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-// constant address space: wave-uniform loads through it become scalar (s_load) instructions
-using cfloat = const float __attribute__((address_space(4)));
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
-// ELU(alpha=1) = x > 0 ? x : expm1(x)  (F.elu, cnn_utils.py:26,43).  Branch-free expm1 for x <= 0:
-// degree-5 Taylor for x >= -0.125 (truncation x^5/720 < 5e-8 relative), exp(x) - 1 below that, where
-// |result| >= 0.1175 so the cancellation costs < 6e-7 relative (absolute error <= 7e-8 everywhere).
-// 12 VALU ops, no divergence.  Large positive x may produce inf in the discarded branches, never NaN.
+// ELU(alpha=1) = x > 0 ? x : expm1(x)  (F.elu, cnn_utils.py:26,43) as max(x, exp(min(x,0)) - 1):
+// 5 VALU ops, branch- and compare-free (on gfx950 every VALU op issued by a wave that is streaming
+// fp32 MFMAs costs ~5 matrix-pipe cycles, v_cmp / v_exp ~9: tools/probes/mfma_valu_probe.hip).
+// Absolute error <= 1.2e-7 for every x (one rounding of exp near 1, one of the subtraction); the
+// relative error for tiny negative x is not preserved (expm1 would return ~x), which is below the
+// rounding noise of the 500-term fp32 dot products that consume these activations.
 __device__ __forceinline__ float elu1(float x) {
-    float p = fmaf(x, 8.3333333e-3f, 4.1666667e-2f);   // 1/5!, 1/4!
-    p = fmaf(p, x, 1.6666667e-1f);                     // 1/3!
-    p = fmaf(p, x, 0.5f);
-    p = fmaf(p, x, 1.0f);
-    p = p * x;
-    const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f) - 1.0f;
-    const float neg = x < -0.125f ? e : p;
-    return x > 0.0f ? x : neg;
+    const float e = __builtin_amdgcn_exp2f(fminf(x, 0.0f) * 1.44269504088896341f) - 1.0f;
+    return fmaxf(x, e);
 }
 
 __device__ __forceinline__ f32x4 mfma16x16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// 16 independent 4x4 outer products: lane 4*blk + i supplies A[blk][i] and B[blk][i];
-// lane 4*blk + j receives D[blk][0..3][j].
-__device__ __forceinline__ f32x4 mfma4x4x1(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
-}
-
-// Build-time experiment switches (defaults = shipped configuration).
-#ifndef TAE_VALU_REM
-#define TAE_VALU_REM 0      // 0 (shipped): remainder channels (U % 16) ride a padded extra 16x16 tile; 1: on 4x4x1 MFMAs (measured slower: ~44 cycles per v_mfma_f32_4x4x1_16b_f32 on gfx950)
+#ifndef TAE_X
+#define TAE_X 0   // timing-experiment bitmask (results become wrong): 1 no layer barriers, 2 no panel writes, 4 no ELU, 8 no weight loads in loop, 16 no LDS reads in loop
 #endif
 
 template <int U>
 struct Geo {
-    static constexpr int CTM = TAE_VALU_REM ? U / 16 : (U + 15) / 16;   // 16-wide output-channel tiles on the matrix cores
-    static constexpr int VCH = TAE_VALU_REM ? U - 16 * (U / 16) : 0;    // remainder channels, computed with 4x4x1 MFMAs
-    static constexpr int CP = ((U + 15) / 16) * 16;  // padded channel count (bias / Linear head rows)
+    static constexpr int CT = (U + 15) / 16;         // 16-wide output-channel tiles
+    static constexpr int CP = CT * 16;               // padded channel count
     static constexpr int NCH_MID = (5 * U + 7) / 8;  // K chunks (8 k each) of a U->U layer
     static constexpr int NCH_L0 = 5;                 // K chunks of the first layer (5 taps x 8 padded inputs)
-    static constexpr int MIDF = NCH_MID * CTM * 128; // floats of A fragments per U->U layer
-    static constexpr int L0F = NCH_L0 * CTM * 128;
-    static constexpr int MIDR = NCH_MID * VCH * 8;   // floats of remainder-channel weights [chunk][VCH][8]
-    static constexpr int L0R = NCH_L0 * VCH * 8;
-    static_assert(VCH == 0 || VCH == 4, "remainder path = one 4-row MFMA block");
+    static constexpr int CS = CT * 128;              // floats of A fragments per chunk
+    static constexpr int MIDF = NCH_MID * CS;        // floats of A fragments per U->U layer
+    static constexpr int L0F = NCH_L0 * CS;
 };
 
 constexpr int kWaves = 4;
 constexpr int kThreads = 64 * kWaves;
 constexpr int kXW = 8;  // floats per row of the XA / XB input panels
 
-// Operands of one K-chunk (8 k values = 2 MFMA k-steps) for a wave's PT x CTM grid of 16x16 tiles,
-// plus the remainder channels: U = 16*CTM + VCH, and the VCH = 4 remainder channels (96..99 for
-// U = 100) would waste 75 % of a 7th 16x16 tile, so they run on v_mfma_f32_4x4x1_16b_f32 instead
-// (16 independent 4x4 outer products per instruction, K = 1, 2 passes): the 4 channels are the A
-// rows of every block and each lane brings its OWN position as a B column, so one instruction
-// covers 64 positions x 4 channels at full matrix-pipe efficiency:
-//   group A: lane l owns position 16*(l>>4) + (l&15) of tiles 0..3;
-//   group B: lane l owns position (l&15) of tile PT-1 (the four lane groups duplicate each other).
-// Both groups run the same k-ordered chain, so a block's result does not depend on where in a
-// workgroup it sits.  (Measured alternative: the same FMAs on the vector ALU cost ~8 matrix-pipe
-// cycles each - fp32 VALU FMAs do not overlap fp32 MFMAs - and were a net loss.)
-template <int CTM, int PT, int VCH>
+// Operands of one K-chunk (8 k values = 2 MFMA k-steps) for a wave's PT x CT grid of 16x16 tiles.
+template <int CT, int PT>
 struct Ops {
-    float2 a[CTM];
+    float2 a[CT];
     float2 b[PT];
-    f32x4 xa[2], xb[2];      // 8 consecutive im2col values of the lane's group-A / group-B position
-    f32x4 wr[2];             // 8 consecutive weights of remainder channel (lane & 3)
 };
 
-template <int VCH>
-struct VAddr {
-    uint32_t a, b;            // LDS byte address of (row-2)*stride for the lane's group-A / group-B position
-    const float* remv;        // per lane: remainder weights [chunk][VCH][8] + (lane & 3) * 8
-};
-
-// A fragments (global, L2-resident weights) of chunk c
-template <int CTM, int PT, int VCH>
-__device__ __forceinline__ void load_w(Ops<CTM, PT, VCH>& o, const float2* __restrict__ wf, const VAddr<VCH>& va, int c) {
+// Weight (A) fragments of one chunk through a buffer resource: wave-uniform SGPR byte offset `soff`,
+// per-lane VGPR offset `voff` (lane * 16), everything else immediates - no vector-ALU address
+// arithmetic.  Packed chunk layout: channel tiles in pairs [pair][lane][ct even: k0 k1 | ct odd: k0 k1]
+// (one 16-byte load per pair) and, for odd CT, a trailing [lane][k0 k1] tile at (CT/2) * 1024 bytes.
+template <int CT, int PT>
+__device__ __forceinline__ void load_w(Ops<CT, PT>& o, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+    if (TAE_X & 8) { asm volatile("" :: "s"(soff)); return; }
 #pragma unroll
-    for (int ct = 0; ct < CTM; ++ct) o.a[ct] = wf[(c * CTM + ct) * 64];
-    if constexpr (VCH > 0) {
-        o.wr[0] = *reinterpret_cast<const f32x4*>(va.remv + c * VCH * 8);
-        o.wr[1] = *reinterpret_cast<const f32x4*>(va.remv + c * VCH * 8 + 4);
+    for (int j = 0; j < CT / 2; ++j) {
+        // (bit_cast the whole vector: element-wise bit_cast of v[i] is mis-folded by this clang)
+        const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + j * 1024, soff, 0));
+        o.a[2 * j] = float2{f.x, f.y};
+        o.a[2 * j + 1] = float2{f.z, f.w};
+    }
+    if constexpr (CT % 2 == 1) {
+        const f32x2 f = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (voff >> 1) + (CT / 2) * 1024, soff, 0));
+        o.a[CT - 1] = float2{f.x, f.y};
     }
 }
 
-// B fragments (LDS activations) of chunk c
-template <int CTM, int PT, int VCH>
-__device__ __forceinline__ void load_x(Ops<CTM, PT, VCH>& o, const char* lds, const uint32_t (&baddr)[PT],
-                                       const VAddr<VCH>& va, int c) {
+// Activation (B) fragments: one ds_read_b64 per position tile at running base + immediate.
+template <int CT, int PT, int OFF>
+__device__ __forceinline__ void load_x(Ops<CT, PT>& o, const char* lds, const uint32_t (&cur)[PT]) {
+    if (TAE_X & 16) return;
 #pragma unroll
-    for (int p = 0; p < PT; ++p) o.b[p] = *reinterpret_cast<const float2*>(lds + baddr[p] + 32u * (uint32_t)c);
-    if constexpr (VCH > 0) {
-        o.xa[0] = *reinterpret_cast<const f32x4*>(lds + va.a + 32u * (uint32_t)c);
-        o.xa[1] = *reinterpret_cast<const f32x4*>(lds + va.a + 32u * (uint32_t)c + 16u);
-        o.xb[0] = *reinterpret_cast<const f32x4*>(lds + va.b + 32u * (uint32_t)c);
-        o.xb[1] = *reinterpret_cast<const f32x4*>(lds + va.b + 32u * (uint32_t)c + 16u);
-    }
+    for (int p = 0; p < PT; ++p) o.b[p] = *reinterpret_cast<const float2*>(lds + cur[p] + OFF);
 }
 
-template <int CTM, int PT, int VCH>
-__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[PT][CTM], f32x4 (&accA)[8], f32x4 (&accB)[8], const Ops<CTM, PT, VCH>& o) {
+#ifndef TAE_SPREAD
+#define TAE_SPREAD 1
+#endif
+// Issue-order hint for one chunk region {weight loads + LDS reads of a later chunk, MFMAs of this one}:
+// spread the vector-memory loads evenly through the MFMA stream.  The four waves of a workgroup
+// fetch the same fragments at nearly the same time; issued back to back the 1 KB loads saturate the
+// CU's 64 B/clk texture-address path and the MFMAs queued behind them in program order wait.
+template <int CT, int PT>
+__device__ __forceinline__ void spread_loads() {
+#if TAE_SPREAD
+    constexpr int NM = 2 * PT * CT, NV = (CT + 1) / 2, ND = PT;
+    constexpr int GV = NM / (2 * NV);          // MFMAs between vector-memory loads (first half of the chunk)
+    constexpr int GD = (NM - NV * GV) / ND;    // MFMAs between LDS reads (second half)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, GV, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, GD, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM - NV * GV - ND * GD, 0);
+#endif
+}
+
+template <int CT, int PT>
+__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[PT][CT], const Ops<CT, PT>& o) {
 #pragma unroll
     for (int p = 0; p < PT; ++p)
 #pragma unroll
-        for (int ct = 0; ct < CTM; ++ct) acc[p][ct] = mfma16x16x4(o.a[ct].x, o.b[p].x, acc[p][ct]);
-    if constexpr (VCH > 0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            accA[k] = mfma4x4x1(o.wr[0][k], o.xa[0][k], accA[k]);
-            accB[k] = mfma4x4x1(o.wr[0][k], o.xb[0][k], accB[k]);
-        }
-    }
+        for (int ct = 0; ct < CT; ++ct) acc[p][ct] = mfma16x16x4(o.a[ct].x, o.b[p].x, acc[p][ct]);
 #pragma unroll
     for (int p = 0; p < PT; ++p)
 #pragma unroll
-        for (int ct = 0; ct < CTM; ++ct) acc[p][ct] = mfma16x16x4(o.a[ct].y, o.b[p].y, acc[p][ct]);
-    if constexpr (VCH > 0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            accA[4 + k] = mfma4x4x1(o.wr[1][k], o.xa[1][k], accA[4 + k]);
-            accB[4 + k] = mfma4x4x1(o.wr[1][k], o.xb[1][k], accB[4 + k]);
-        }
-    }
+        for (int ct = 0; ct < CT; ++ct) acc[p][ct] = mfma16x16x4(o.a[ct].y, o.b[p].y, acc[p][ct]);
 }
 
-// acc += W (16*CTM x 8*nch) * im2col (8*nch x PT*16) (+ the remainder channels), software-pipelined
-// one chunk ahead.  `o0` arrives with the chunk-0 WEIGHT fragments already loaded (prefetched across
-// the previous layer's epilogue and barriers).
-// wf   : this lane's pointer into the layer's A fragments ([chunk][ct][lane] float2)
+// acc += W (16*CT x 8*NCH) * im2col (8*NCH x PT*16), software-pipelined one chunk ahead, four chunks
+// per loop iteration so that every address is a loop-carried base plus an immediate.
+// `o0` arrives with the chunk-0 WEIGHT fragments already loaded (prefetched across the previous
+// layer's epilogue and barriers).  The prefetch of chunk NCH (one past the end) is a harmless
+// over-read: weights continue into the bias block, LDS rows into the panel's slack row.
+// soff : wave-uniform byte offset of this layer's A fragments inside the packed weight buffer
 // baddr: per position tile, LDS byte address of (row-2)*stride + 8*kq for this lane
-template <int CTM, int PT, int VCH>
-__device__ __forceinline__ void conv_accumulate(f32x4 (&acc)[PT][CTM], f32x4 (&accA)[8], f32x4 (&accB)[8], Ops<CTM, PT, VCH>& o0,
-                                                const float2* __restrict__ wf, const char* lds,
-                                                const uint32_t (&baddr)[PT], const VAddr<VCH>& va, int nch) {
-    Ops<CTM, PT, VCH> o1;
-    load_x<CTM, PT, VCH>(o0, lds, baddr, va, 0);
-    int c = 0;
-    for (; c + 2 <= nch; c += 2) {
-        load_w<CTM, PT, VCH>(o1, wf, va, c + 1);
-        load_x<CTM, PT, VCH>(o1, lds, baddr, va, c + 1);
-        mma_chunk<CTM, PT, VCH>(acc, accA, accB, o0);
-        const int cn = (c + 2 < nch) ? c + 2 : nch - 1;   // clamp: harmless re-load of the last chunk
-        load_w<CTM, PT, VCH>(o0, wf, va, cn);
-        load_x<CTM, PT, VCH>(o0, lds, baddr, va, cn);
-        mma_chunk<CTM, PT, VCH>(acc, accA, accB, o1);
+template <int CT, int PT, int NCH>
+__device__ __forceinline__ void conv_accumulate(f32x4 (&acc)[PT][CT], Ops<CT, PT>& o0, __amdgpu_buffer_rsrc_t rsrc,
+                                                uint32_t voff, uint32_t soff, const char* lds, const uint32_t (&baddr)[PT]) {
+    constexpr uint32_t CSB = CT * 512;   // bytes of A fragments per chunk
+    Ops<CT, PT> o1;
+    uint32_t cur[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) cur[p] = baddr[p];
+    load_x<CT, PT, 0>(o0, lds, cur);
+    for (int it = 0; it < NCH / 4; ++it) {
+        load_w<CT, PT>(o1, rsrc, voff, soff + 1 * CSB);
+        load_x<CT, PT, 32>(o1, lds, cur);
+        mma_chunk<CT, PT>(acc, o0);
+        spread_loads<CT, PT>();
+        load_w<CT, PT>(o0, rsrc, voff, soff + 2 * CSB);
+        load_x<CT, PT, 64>(o0, lds, cur);
+        mma_chunk<CT, PT>(acc, o1);
+        spread_loads<CT, PT>();
+        load_w<CT, PT>(o1, rsrc, voff, soff + 3 * CSB);
+        load_x<CT, PT, 96>(o1, lds, cur);
+        mma_chunk<CT, PT>(acc, o0);
+        spread_loads<CT, PT>();
+        load_w<CT, PT>(o0, rsrc, voff, soff + 4 * CSB);
+        load_x<CT, PT, 128>(o0, lds, cur);
+        mma_chunk<CT, PT>(acc, o1);
+        spread_loads<CT, PT>();
+        soff += 4 * CSB;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) cur[p] += 128;
     }
-    if (c < nch) mma_chunk<CTM, PT, VCH>(acc, accA, accB, o0);
+    constexpr int TAIL = NCH % 4;     // o0 holds chunk NCH - TAIL
+    if constexpr (TAIL >= 2) {
+        load_w<CT, PT>(o1, rsrc, voff, soff + 1 * CSB);
+        load_x<CT, PT, 32>(o1, lds, cur);
+    }
+    if constexpr (TAIL >= 1) mma_chunk<CT, PT>(acc, o0);
+    if constexpr (TAIL >= 3) {
+        load_w<CT, PT>(o0, rsrc, voff, soff + 2 * CSB);
+        load_x<CT, PT, 64>(o0, lds, cur);
+    }
+    if constexpr (TAIL >= 2) mma_chunk<CT, PT>(acc, o1);
+    if constexpr (TAIL >= 3) mma_chunk<CT, PT>(acc, o0);
 }
 
 // Per-lane view of the position tiles a wave owns.
@@ -217,119 +227,91 @@ __device__ __forceinline__ void butterfly8(const float (&part)[8], bool hi32, bo
     }
 }
 
-// Weight-side state a stack hands to the next one: chunk-0 A fragments of the NEXT conv layer,
-// fetched before the current layer's epilogue so their L2 latency hides behind it.
+// Weight-side state shared by the stacks of one kernel: the buffer resource over the packed
+// weights and the chunk-0 A fragments of the NEXT conv layer, fetched before the current layer's
+// epilogue so that their L2 latency hides behind it.
 template <int U, int PT>
-struct Prefetch {
-    Ops<Geo<U>::CTM, PT, Geo<U>::VCH> o;
+struct WeightStream {
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff;                       // lane * 16
+    Ops<Geo<U>::CT, PT> o;
+    __device__ __forceinline__ void init(const float* wpack, uint32_t bytes, int lane) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wpack), 0, (int)bytes, 0x00020000);
+        voff = (uint32_t)lane * 16u;
+    }
+    __device__ __forceinline__ void prefetch(uint32_t soff) { load_w<Geo<U>::CT, PT>(o, rsrc, voff, soff); }
 };
 
 // Runs one SameShapeConv1d stack (cnn_utils.py:36-46) followed by its Linear head for the
 // workgroup's blocks.  `epi(p, f, value)` is called for output feature f (0..7) of this lane's
 // position in tile p by the lane that owns (p, f): lane group q owns f = 2q and f = 2q + 1.
-// `wnext` = packed base of the stack that runs next in this kernel (nullptr if none): its first
-// layer's chunk-0 weights are prefetched into `pf` before the head epilogue.
+// `soff` = byte offset of this stack inside the packed weights; `snext` = byte offset of the stack
+// that runs next in this kernel (or 0xffffffff): its first chunk is prefetched before the head.
 //
 // Packed stack layout (floats), written by turboae_api.hip::pack_stack:
-//   per layer: A fragments [chunk][CTM][64][2] | bias [CP] | remainder weights [chunk][VCH][8]
-//   then Linear head weights [8][CP] | Linear bias [8]
+//   per layer: A fragments [chunk][...] (see load_w) | bias [CP];  then Linear weights [8][CP] | bias [8]
 template <int U, int PT, class Epi>
-__device__ __forceinline__ void run_stack(const float* __restrict__ wstack, const float* __restrict__ wnext, int n_layer,
+__device__ __forceinline__ void run_stack(const float* __restrict__ wpack, uint32_t soff, uint32_t snext, int n_layer,
                                           char* smem, float* ACT, const float* Xin, const TileCtx<PT>& tc, int lane,
-                                          Prefetch<U, PT>& pf, Epi epi) {
+                                          WeightStream<U, PT>& ws, Epi epi) {
     using G = Geo<U>;
-    constexpr int CTM = G::CTM, VCH = G::VCH;
-    static_assert(VCH == 0 || PT == 5, "remainder-channel mapping assumes 4 + 1 position tiles per wave");
+    constexpr int CT = G::CT;
     const int q = lane >> 4;
-    f32x4 acc[PT][CTM];
-    f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
-    f32x4 accA8[8], accB8[8];   // one accumulator per k mod 8: no back-to-back dependent 4x4x1 MFMAs
-    // group-A position of this lane = its position in tile q; group-B position = its position in tile PT-1
-    int rowA = tc.row[0];
-    bool validA = tc.valid[0];
-    if constexpr (VCH > 0) {
-        rowA = (q == 0) ? tc.row[0] : (q == 1) ? tc.row[1] : (q == 2) ? tc.row[2] : tc.row[3];
-        validA = (q == 0) ? tc.valid[0] : (q == 1) ? tc.valid[1] : (q == 2) ? tc.valid[2] : tc.valid[3];
-    }
-    const float* wl = wstack;
+    f32x4 acc[PT][CT];
+    uint32_t lo = soff;      // byte offset of the current layer
     for (int l = 0; l < n_layer; ++l) {
         const bool first = (l == 0);
-        const int fragf = first ? G::L0F : G::MIDF;
-        const int remf = first ? G::L0R : G::MIDR;
-        const float* bias = wl + fragf;
+        const uint32_t fragb = (first ? G::L0F : G::MIDF) * 4u;
+        const float* bias = wpack + (lo + fragb) / 4;
         // accumulators start at the bias (Conv1d bias=True, cnn_utils.py:15-17)
         {
-            f32x4 b4[CTM];
+            f32x4 b4[CT];
 #pragma unroll
-            for (int ct = 0; ct < CTM; ++ct) b4[ct] = *reinterpret_cast<const f32x4*>(bias + ct * 16 + 4 * q);
+            for (int ct = 0; ct < CT; ++ct) b4[ct] = *reinterpret_cast<const f32x4*>(bias + ct * 16 + 4 * q);
 #pragma unroll
             for (int p = 0; p < PT; ++p)
 #pragma unroll
-                for (int ct = 0; ct < CTM; ++ct) acc[p][ct] = b4[ct];
-            if constexpr (VCH > 0) {
-                accA8[0] = accB8[0] = *reinterpret_cast<const f32x4*>(bias + 16 * CTM);
-#pragma unroll
-                for (int k = 1; k < 8; ++k) accA8[k] = accB8[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+                for (int ct = 0; ct < CT; ++ct) acc[p][ct] = b4[ct];
         }
         uint32_t baddr[PT];
-        VAddr<VCH> va;
-        va.remv = bias + G::CP + (lane & 3) * 8;
         const uint32_t stride = first ? (uint32_t)(kXW * 4) : (uint32_t)(U * 4);
         const uint32_t poff = (uint32_t)(reinterpret_cast<const char*>(first ? Xin : ACT) - smem);
 #pragma unroll
         for (int p = 0; p < PT; ++p) baddr[p] = poff + (uint32_t)(tc.row[p] - 2) * stride + 8u * q;
-        va.a = poff + (uint32_t)(rowA - 2) * stride;
-        va.b = poff + (uint32_t)(tc.row[PT - 1] - 2) * stride;
-        conv_accumulate<CTM, PT, VCH>(acc, accA8, accB8, pf.o, reinterpret_cast<const float2*>(wl) + lane, smem, baddr, va,
-                                      first ? G::NCH_L0 : G::NCH_MID);
-        if constexpr (VCH > 0) {   // fixed-order pairwise sum of the 8 partial accumulators
-            accA = ((accA8[0] + accA8[1]) + (accA8[2] + accA8[3])) + ((accA8[4] + accA8[5]) + (accA8[6] + accA8[7]));
-            accB = ((accB8[0] + accB8[1]) + (accB8[2] + accB8[3])) + ((accB8[4] + accB8[5]) + (accB8[6] + accB8[7]));
-        }
-        wl += fragf + G::CP + remf;
+        if (first) conv_accumulate<CT, PT, G::NCH_L0>(acc, ws.o, ws.rsrc, ws.voff, lo, smem, baddr);
+        else conv_accumulate<CT, PT, G::NCH_MID>(acc, ws.o, ws.rsrc, ws.voff, lo, smem, baddr);
+        lo += fragb + G::CP * 4u;
         // prefetch the next conv layer's chunk-0 weights (this stack's next layer, or the next stack's first)
         {
-            const bool more = (l + 1 < n_layer);
-            const float* wn = more ? wl : wnext;
-            if (wn != nullptr) {
-                const int nfrag = more ? G::MIDF : G::L0F;
-                VAddr<VCH> vn;
-                vn.a = vn.b = 0;
-                vn.remv = wn + nfrag + G::CP + (lane & 3) * 8;
-                load_w<CTM, PT, VCH>(pf.o, reinterpret_cast<const float2*>(wn) + lane, vn, 0);
-            }
+            const uint32_t nxt = (l + 1 < n_layer) ? lo : snext;
+            if (nxt != 0xffffffffu) ws.prefetch(nxt);
         }
         if (l + 1 < n_layer) {
             // in-place panel update: everyone must have finished reading the old activations
-            if (!first) __syncthreads();
+            if (!first && !(TAE_X & 1)) __syncthreads();
 #pragma unroll
             for (int p = 0; p < PT; ++p) {
 #pragma unroll
-                for (int ct = 0; ct < CTM; ++ct) {
+                for (int ct = 0; ct < CT; ++ct) {
                     f32x4 v = acc[p][ct];
-                    v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
-                    if (tc.valid[p] && ct * 16 + 4 * q < U) *reinterpret_cast<f32x4*>(ACT + tc.row[p] * U + ct * 16 + 4 * q) = v;
+                    if (!(TAE_X & 4)) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
+                    if (TAE_X & 2) asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                    else if (tc.valid[p] && ct * 16 + 4 * q < U) *reinterpret_cast<f32x4*>(ACT + tc.row[p] * U + ct * 16 + 4 * q) = v;
                 }
             }
-            if constexpr (VCH > 0) {
-                f32x4 va4 = {elu1(accA.x), elu1(accA.y), elu1(accA.z), elu1(accA.w)};
-                f32x4 vb4 = {elu1(accB.x), elu1(accB.y), elu1(accB.z), elu1(accB.w)};
-                if (validA) *reinterpret_cast<f32x4*>(ACT + rowA * U + 16 * CTM) = va4;
-                if (tc.valid[PT - 1] && q == 0) *reinterpret_cast<f32x4*>(ACT + tc.row[PT - 1] * U + 16 * CTM) = vb4;
-            }
-            __syncthreads();
+            if (!(TAE_X & 1)) __syncthreads();
         }
     }
     // ---- Linear head fused on the accumulators of the last conv layer (decoders.py:233,243;
-    //      encoders.py:364-371).  wl now points at lin_w [8][CP], then lin_b [8].
+    //      encoders.py:364-371): lin_w [8][CP], then lin_b [8].
+    const float* wl = wpack + lo / 4;
     float part[PT][8];
 #pragma unroll
     for (int p = 0; p < PT; ++p)
 #pragma unroll
         for (int f = 0; f < 8; ++f) part[p][f] = 0.0f;
 #pragma unroll
-    for (int ct = 0; ct < CTM; ++ct) {
+    for (int ct = 0; ct < CT; ++ct) {
         f32x4 w4[8];
 #pragma unroll
         for (int f = 0; f < 8; ++f) w4[f] = *reinterpret_cast<const f32x4*>(wl + f * G::CP + ct * 16 + 4 * q);
@@ -346,20 +328,6 @@ __device__ __forceinline__ void run_stack(const float* __restrict__ wstack, cons
             }
         }
     }
-    // remainder channels: one lane per position holds their contribution (group A: the lane of tile q,
-    // group B: lane group 0 of tile PT-1); it is routed to the owning lane through a second butterfly
-    // whose other inputs are exact zeros, so the result does not depend on which lane produced it.
-    float ca[8], cb[8];
-    if constexpr (VCH > 0) {
-        const f32x4 ea = {elu1(accA.x), elu1(accA.y), elu1(accA.z), elu1(accA.w)};
-        const f32x4 eb = {elu1(accB.x), elu1(accB.y), elu1(accB.z), elu1(accB.w)};
-#pragma unroll
-        for (int f = 0; f < 8; ++f) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(wl + f * G::CP + 16 * CTM);
-            ca[f] = fmaf(ea.w, w.w, fmaf(ea.z, w.z, fmaf(ea.y, w.y, ea.x * w.x)));
-            cb[f] = fmaf(eb.w, w.w, fmaf(eb.z, w.z, fmaf(eb.y, w.y, eb.x * w.x)));
-        }
-    }
     const float* lb = wl + 8 * G::CP;
     const float bq0 = lb[2 * q], bq1 = lb[2 * q + 1];
     const bool hi32 = (q & 2) != 0, hi16 = (q & 1) != 0;
@@ -367,31 +335,12 @@ __device__ __forceinline__ void run_stack(const float* __restrict__ wstack, cons
     for (int p = 0; p < PT; ++p) {
         float k2[2];
         butterfly8(part[p], hi32, hi16, k2);
-        if constexpr (VCH > 0) {
-            float rp[8], r2[2];
-            const bool mine = (p < PT - 1) ? (q == p) : (q == 0);
-#pragma unroll
-            for (int f = 0; f < 8; ++f) rp[f] = mine ? ((p < PT - 1) ? ca[f] : cb[f]) : 0.0f;
-            butterfly8(rp, hi32, hi16, r2);
-            k2[0] += r2[0];
-            k2[1] += r2[1];
-        }
         if (tc.center[p]) {
             epi(p, 2 * q, k2[0] + bq0);
             epi(p, 2 * q + 1, k2[1] + bq1);
         }
     }
     __syncthreads();
-}
-
-// chunk-0 weights of a stack's first layer (used once per kernel, before the first stack)
-template <int U, int PT>
-__device__ __forceinline__ void prefetch_first(Prefetch<U, PT>& pf, const float* wstack, int lane) {
-    using G = Geo<U>;
-    VAddr<G::VCH> vn;
-    vn.a = vn.b = 0;
-    vn.remv = wstack + G::L0F + G::CP + (lane & 3) * 8;
-    load_w<G::CTM, PT, G::VCH>(pf.o, reinterpret_cast<const float2*>(wstack) + lane, vn, 0);
 }
 
 template <int PT>
@@ -475,17 +424,19 @@ __global__ __launch_bounds__(kThreads, 1) void dec_kernel(FusedParams P) {
     const int F = P.F;
     const bool extrinsic = P.extrinsic != 0;
     float* xdec = P.out + (size_t)blk0 * L;
-    Prefetch<U, PT> pf;
-    prefetch_first<U, PT>(pf, P.wpack, lane);
+    WeightStream<U, PT> ws;
+    ws.init(P.wpack, P.wpack_bytes, lane);
+    ws.prefetch(0);
+    const uint32_t sstride = P.stack_stride * 4u;
     for (int s = 0; s < n_stack; ++s) {
         const float* Xin = (s & 1) ? pn.XB : pn.XA;
         float* Xout = (s & 1) ? pn.XA : pn.XB;
         // dec1 output q[t] feeds dec2 at row inv[t] (interleave, decoders.py:238);
         // dec2 output q2[i] becomes prior[p[i]] (deinterleave, decoders.py:249)
         const int* ptab = (s & 1) ? pn.PERM : pn.INV;
-        const float* wstack = P.wpack + (size_t)s * P.stack_stride;
         if (s + 1 < n_stack) {
-            run_stack<U, PT>(wstack, wstack + P.stack_stride, P.n_layer, smem, pn.ACT, Xin, tc, lane, pf, [&](int p, int f, float v) {
+            run_stack<U, PT>(P.wpack, s * sstride, (s + 1) * sstride, P.n_layer, smem, pn.ACT, Xin, tc, lane, ws,
+                             [&](int p, int f, float v) {
                 if (f < F) {
                     if (extrinsic) v -= Xin[tc.row[p] * kXW + 2 + f];   // decoders.py:235-236,246-247
                     Xout[(tc.rowbase[p] + ptab[tc.t[p]]) * kXW + 2 + f] = v;
@@ -493,7 +444,8 @@ __global__ __launch_bounds__(kThreads, 1) void dec_kernel(FusedParams P) {
             });
         } else {
             // last half-iteration: Linear(U->1), no extrinsic subtraction, sigmoid(deinterleave) (decoders.py:262-267)
-            run_stack<U, PT>(wstack, nullptr, P.n_layer, smem, pn.ACT, Xin, tc, lane, pf, [&](int p, int f, float v) {
+            run_stack<U, PT>(P.wpack, s * sstride, 0xffffffffu, P.n_layer, smem, pn.ACT, Xin, tc, lane, ws,
+                             [&](int p, int f, float v) {
                 if (f == 0) xdec[tc.blk[p] * L + ptab[tc.t[p]]] = 1.0f / (1.0f + expf(-v));
             });
         }
@@ -534,12 +486,13 @@ __global__ __launch_bounds__(kThreads, 1) void enc_kernel(FusedParams P) {
     float* xtx = P.out + (size_t)blk0 * L * 3;
     const bool act_elu = P.act == 0;
     double sum = 0.0, sumsq = 0.0;
-    Prefetch<U, PT> pf;
-    prefetch_first<U, PT>(pf, P.wpack, lane);
+    WeightStream<U, PT> ws;
+    ws.init(P.wpack, P.wpack_bytes, lane);
+    ws.prefetch(0);
+    const uint32_t sstride = P.stack_stride * 4u;
     for (int s = 0; s < 3; ++s) {
         const float* Xin = (s == 2) ? pn.XB : pn.XA;
-        const float* wstack = P.wpack + (size_t)s * P.stack_stride;
-        run_stack<U, PT>(wstack, s < 2 ? wstack + P.stack_stride : nullptr, P.n_layer, smem, pn.ACT, Xin, tc, lane, pf,
+        run_stack<U, PT>(P.wpack, s * sstride, s < 2 ? (s + 1) * sstride : 0xffffffffu, P.n_layer, smem, pn.ACT, Xin, tc, lane, ws,
                          [&](int p, int f, float v) {
             if (f == 0) {
                 if (act_elu) v = elu1(v);                      // enc_act (encoders.py:364)
@@ -627,14 +580,15 @@ __global__ __launch_bounds__(kThreads, 1) void seg_kernel(SegParams P) {
             tc.row[p] = v ? 2 + m : 2;
         }
     }
-    const float* wstack = P.wpack + (size_t)stack * P.stack_stride;
-    Prefetch<U, PT> pf;
-    prefetch_first<U, PT>(pf, wstack, lane);
+    WeightStream<U, PT> ws;
+    ws.init(P.wpack, P.wpack_bytes, lane);
+    const uint32_t soff = (uint32_t)stack * P.stack_stride * 4u;
+    ws.prefetch(soff);
     if (P.mode == 0) {
         const bool act_elu = P.act == 0;
         double sum = 0.0, sumsq = 0.0;
         float* xtx = P.out + (size_t)b * L * 3;
-        run_stack<U, PT>(wstack, nullptr, P.n_layer, smem, ACT, X, tc, lane, pf, [&](int p, int f, float v) {
+        run_stack<U, PT>(P.wpack, soff, 0xffffffffu, P.n_layer, smem, ACT, X, tc, lane, ws, [&](int p, int f, float v) {
             if (f == 0) {
                 if (act_elu) v = elu1(v);
                 xtx[(size_t)tc.t[p] * 3 + stack] = v;
@@ -655,7 +609,7 @@ __global__ __launch_bounds__(kThreads, 1) void seg_kernel(SegParams P) {
         const int F = P.F;
         const bool extrinsic = P.extrinsic != 0;
         float* ecur = P.ecur + (size_t)b * L * 8;
-        run_stack<U, PT>(wstack, nullptr, P.n_layer, smem, ACT, X, tc, lane, pf, [&](int p, int f, float v) {
+        run_stack<U, PT>(P.wpack, soff, 0xffffffffu, P.n_layer, smem, ACT, X, tc, lane, ws, [&](int p, int f, float v) {
             if (f < F) {
                 if (extrinsic) v -= X[tc.row[p] * kXW + 2 + f];
                 ecur[(size_t)tc.t[p] * 8 + f] = v;
@@ -663,7 +617,7 @@ __global__ __launch_bounds__(kThreads, 1) void seg_kernel(SegParams P) {
         });
     } else {
         float* xdec = P.out + (size_t)b * L;
-        run_stack<U, PT>(wstack, nullptr, P.n_layer, smem, ACT, X, tc, lane, pf, [&](int p, int f, float v) {
+        run_stack<U, PT>(P.wpack, soff, 0xffffffffu, P.n_layer, smem, ACT, X, tc, lane, ws, [&](int p, int f, float v) {
             if (f == 0) xdec[P.perm[tc.t[p]]] = 1.0f / (1.0f + expf(-v));    // sigmoid(deinterleave), decoders.py:267
         });
     }
