@@ -69,40 +69,67 @@ struct Geo {
     static constexpr int L0F = NCH_L0 * CS;
 };
 
-constexpr int kWaves = 4;
+// Workgroup shape: 8 waves = 2 per SIMD.  Wave w = g + 4h: g selects the position group (PT
+// position tiles), h the channel half (tiles [0, CTA) or [CTA, CT)), so the two waves that share a
+// SIMD (w and w + 4 land on the same SIMD) split one position group's channel tiles 4 + 3 and
+// every SIMD carries the same MFMA load.  Two waves per SIMD let one wave's MFMAs cover the
+// other's vector-memory issue, s_waitcnt parking, barrier skew and (vector-ALU-only) epilogues.
+constexpr int kWaves = 8;
+constexpr int kGroups = 4;                 // position groups per workgroup
 constexpr int kThreads = 64 * kWaves;
-constexpr int kXW = 8;  // floats per row of the XA / XB input panels
+constexpr int kXW = 8;                     // floats per row of the XA / XB input panels
+constexpr int kHeadSlots = kGroups * 5 * 16;   // positions per workgroup (head-combine scratch rows)
 
-// Operands of one K-chunk (8 k values = 2 MFMA k-steps) for a wave's PT x CT grid of 16x16 tiles.
-template <int CT, int PT>
+// Operands of one K-chunk (8 k values = 2 MFMA k-steps) for a wave's PT x NC grid of 16x16 tiles.
+template <int NC, int PT>
 struct Ops {
-    float2 a[CT];
+    float2 a[NC];
     float2 b[PT];
 };
 
-// Weight (A) fragments of one chunk through a buffer resource: wave-uniform SGPR byte offset `soff`,
-// per-lane VGPR offset `voff` (lane * 16), everything else immediates - no vector-ALU address
-// arithmetic.  Packed chunk layout: channel tiles in pairs [pair][lane][ct even: k0 k1 | ct odd: k0 k1]
-// (one 16-byte load per pair) and, for odd CT, a trailing [lane][k0 k1] tile at (CT/2) * 1024 bytes.
-template <int CT, int PT>
-__device__ __forceinline__ void load_w(Ops<CT, PT>& o, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+// number of load instructions load_w issues for channel tiles [C0, C0 + NC) of CTT
+constexpr int n_wloads(int CTT, int C0, int NC) {
+    int n = 0;
+    for (int i = 0; i < NC; ++i) {
+        const int ct = C0 + i;
+        const bool paired = ct < 2 * (CTT / 2);
+        if (paired && (ct % 2 == 1) && i >= 1) continue;
+        ++n;
+    }
+    return n;
+}
+
+// Weight (A) fragments of channel tiles [C0, C0 + NC) of one chunk through a buffer resource:
+// wave-uniform SGPR byte offset `soff`, per-lane VGPR offset `voff` (lane * 16), everything else
+// immediates - no vector-ALU address arithmetic.  Packed chunk layout: channel tiles in pairs
+// [pair][lane][ct even: k0 k1 | ct odd: k0 k1] (one 16-byte load fetches both) and, for odd CTT, a
+// trailing [lane][k0 k1] tile at (CTT/2) * 1024 bytes.
+template <int CTT, int C0, int NC, int PT>
+__device__ __forceinline__ void load_w(Ops<NC, PT>& o, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
     if (TAE_X & 8) { asm volatile("" :: "s"(soff)); return; }
 #pragma unroll
-    for (int j = 0; j < CT / 2; ++j) {
-        // (bit_cast the whole vector: element-wise bit_cast of v[i] is mis-folded by this clang)
-        const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + j * 1024, soff, 0));
-        o.a[2 * j] = float2{f.x, f.y};
-        o.a[2 * j + 1] = float2{f.z, f.w};
-    }
-    if constexpr (CT % 2 == 1) {
-        const f32x2 f = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (voff >> 1) + (CT / 2) * 1024, soff, 0));
-        o.a[CT - 1] = float2{f.x, f.y};
+    for (int i = 0; i < NC; ++i) {
+        const int ct = C0 + i;
+        const bool paired = ct < 2 * (CTT / 2);
+        if (paired && (ct % 2 == 1) && i >= 1) continue;      // already fetched with its even partner
+        if (paired && (ct % 2 == 0) && (i + 1 < NC)) {
+            // (bit_cast the whole vector: element-wise bit_cast of v[i] is mis-folded by this clang)
+            const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (ct / 2) * 1024, soff, 0));
+            o.a[i] = float2{f.x, f.y};
+            o.a[i + 1 < NC ? i + 1 : i] = float2{f.z, f.w};
+        } else if (paired) {
+            const f32x2 f = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff + (ct / 2) * 1024 + (ct % 2) * 8, soff, 0));
+            o.a[i] = float2{f.x, f.y};
+        } else {
+            const f32x2 f = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (voff >> 1) + (CTT / 2) * 1024, soff, 0));
+            o.a[i] = float2{f.x, f.y};
+        }
     }
 }
 
 // Activation (B) fragments: one ds_read_b64 per position tile at running base + immediate.
-template <int CT, int PT, int OFF>
-__device__ __forceinline__ void load_x(Ops<CT, PT>& o, const char* lds, const uint32_t (&cur)[PT]) {
+template <int NC, int PT, int OFF>
+__device__ __forceinline__ void load_x(Ops<NC, PT>& o, const char* lds, const uint32_t (&cur)[PT]) {
     if (TAE_X & 16) return;
 #pragma unroll
     for (int p = 0; p < PT; ++p) o.b[p] = *reinterpret_cast<const float2*>(lds + cur[p] + OFF);
@@ -112,13 +139,13 @@ __device__ __forceinline__ void load_x(Ops<CT, PT>& o, const char* lds, const ui
 #define TAE_SPREAD 1
 #endif
 // Issue-order hint for one chunk region {weight loads + LDS reads of a later chunk, MFMAs of this one}:
-// spread the vector-memory loads evenly through the MFMA stream.  The four waves of a workgroup
-// fetch the same fragments at nearly the same time; issued back to back the 1 KB loads saturate the
-// CU's 64 B/clk texture-address path and the MFMAs queued behind them in program order wait.
-template <int CT, int PT>
+// spread the vector-memory loads evenly through the MFMA stream.  The waves of a workgroup fetch the
+// same fragments at nearly the same time; issued back to back the 1 KB loads saturate the CU's
+// 64 B/clk texture-address path and the MFMAs queued behind them in program order wait.
+template <int NV, int NC, int PT>
 __device__ __forceinline__ void spread_loads() {
 #if TAE_SPREAD
-    constexpr int NM = 2 * PT * CT, NV = (CT + 1) / 2, ND = PT;
+    constexpr int NM = 2 * PT * NC, ND = PT;
     constexpr int GV = NM / (2 * NV);          // MFMAs between vector-memory loads (first half of the chunk)
     constexpr int GD = (NM - NV * GV) / ND;    // MFMAs between LDS reads (second half)
 #pragma unroll
@@ -135,67 +162,68 @@ __device__ __forceinline__ void spread_loads() {
 #endif
 }
 
-template <int CT, int PT>
-__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[PT][CT], const Ops<CT, PT>& o) {
+template <int NC, int PT>
+__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[PT][NC], const Ops<NC, PT>& o) {
 #pragma unroll
     for (int p = 0; p < PT; ++p)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[p][ct] = mfma16x16x4(o.a[ct].x, o.b[p].x, acc[p][ct]);
+        for (int ct = 0; ct < NC; ++ct) acc[p][ct] = mfma16x16x4(o.a[ct].x, o.b[p].x, acc[p][ct]);
 #pragma unroll
     for (int p = 0; p < PT; ++p)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[p][ct] = mfma16x16x4(o.a[ct].y, o.b[p].y, acc[p][ct]);
+        for (int ct = 0; ct < NC; ++ct) acc[p][ct] = mfma16x16x4(o.a[ct].y, o.b[p].y, acc[p][ct]);
 }
 
-// acc += W (16*CT x 8*NCH) * im2col (8*NCH x PT*16), software-pipelined one chunk ahead, four chunks
+// acc += W (16*NC x 8*NCH) * im2col (8*NCH x PT*16), software-pipelined one chunk ahead, four chunks
 // per loop iteration so that every address is a loop-carried base plus an immediate.
 // `o0` arrives with the chunk-0 WEIGHT fragments already loaded (prefetched across the previous
 // layer's epilogue and barriers).  The prefetch of chunk NCH (one past the end) is a harmless
 // over-read: weights continue into the bias block, LDS rows into the panel's slack row.
 // soff : wave-uniform byte offset of this layer's A fragments inside the packed weight buffer
 // baddr: per position tile, LDS byte address of (row-2)*stride + 8*kq for this lane
-template <int CT, int PT, int NCH>
-__device__ __forceinline__ void conv_accumulate(f32x4 (&acc)[PT][CT], Ops<CT, PT>& o0, __amdgpu_buffer_rsrc_t rsrc,
+template <int CTT, int C0, int NC, int PT, int NCH>
+__device__ __forceinline__ void conv_accumulate(f32x4 (&acc)[PT][NC], Ops<NC, PT>& o0, __amdgpu_buffer_rsrc_t rsrc,
                                                 uint32_t voff, uint32_t soff, const char* lds, const uint32_t (&baddr)[PT]) {
-    constexpr uint32_t CSB = CT * 512;   // bytes of A fragments per chunk
-    Ops<CT, PT> o1;
+    constexpr uint32_t CSB = CTT * 512;   // bytes of A fragments per chunk
+    constexpr int NV = n_wloads(CTT, C0, NC);
+    Ops<NC, PT> o1;
     uint32_t cur[PT];
 #pragma unroll
     for (int p = 0; p < PT; ++p) cur[p] = baddr[p];
-    load_x<CT, PT, 0>(o0, lds, cur);
+    load_x<NC, PT, 0>(o0, lds, cur);
     for (int it = 0; it < NCH / 4; ++it) {
-        load_w<CT, PT>(o1, rsrc, voff, soff + 1 * CSB);
-        load_x<CT, PT, 32>(o1, lds, cur);
-        mma_chunk<CT, PT>(acc, o0);
-        spread_loads<CT, PT>();
-        load_w<CT, PT>(o0, rsrc, voff, soff + 2 * CSB);
-        load_x<CT, PT, 64>(o0, lds, cur);
-        mma_chunk<CT, PT>(acc, o1);
-        spread_loads<CT, PT>();
-        load_w<CT, PT>(o1, rsrc, voff, soff + 3 * CSB);
-        load_x<CT, PT, 96>(o1, lds, cur);
-        mma_chunk<CT, PT>(acc, o0);
-        spread_loads<CT, PT>();
-        load_w<CT, PT>(o0, rsrc, voff, soff + 4 * CSB);
-        load_x<CT, PT, 128>(o0, lds, cur);
-        mma_chunk<CT, PT>(acc, o1);
-        spread_loads<CT, PT>();
+        load_w<CTT, C0, NC, PT>(o1, rsrc, voff, soff + 1 * CSB);
+        load_x<NC, PT, 32>(o1, lds, cur);
+        mma_chunk<NC, PT>(acc, o0);
+        spread_loads<NV, NC, PT>();
+        load_w<CTT, C0, NC, PT>(o0, rsrc, voff, soff + 2 * CSB);
+        load_x<NC, PT, 64>(o0, lds, cur);
+        mma_chunk<NC, PT>(acc, o1);
+        spread_loads<NV, NC, PT>();
+        load_w<CTT, C0, NC, PT>(o1, rsrc, voff, soff + 3 * CSB);
+        load_x<NC, PT, 96>(o1, lds, cur);
+        mma_chunk<NC, PT>(acc, o0);
+        spread_loads<NV, NC, PT>();
+        load_w<CTT, C0, NC, PT>(o0, rsrc, voff, soff + 4 * CSB);
+        load_x<NC, PT, 128>(o0, lds, cur);
+        mma_chunk<NC, PT>(acc, o1);
+        spread_loads<NV, NC, PT>();
         soff += 4 * CSB;
 #pragma unroll
         for (int p = 0; p < PT; ++p) cur[p] += 128;
     }
     constexpr int TAIL = NCH % 4;     // o0 holds chunk NCH - TAIL
     if constexpr (TAIL >= 2) {
-        load_w<CT, PT>(o1, rsrc, voff, soff + 1 * CSB);
-        load_x<CT, PT, 32>(o1, lds, cur);
+        load_w<CTT, C0, NC, PT>(o1, rsrc, voff, soff + 1 * CSB);
+        load_x<NC, PT, 32>(o1, lds, cur);
     }
-    if constexpr (TAIL >= 1) mma_chunk<CT, PT>(acc, o0);
+    if constexpr (TAIL >= 1) mma_chunk<NC, PT>(acc, o0);
     if constexpr (TAIL >= 3) {
-        load_w<CT, PT>(o0, rsrc, voff, soff + 2 * CSB);
-        load_x<CT, PT, 64>(o0, lds, cur);
+        load_w<CTT, C0, NC, PT>(o0, rsrc, voff, soff + 2 * CSB);
+        load_x<NC, PT, 64>(o0, lds, cur);
     }
-    if constexpr (TAIL >= 2) mma_chunk<CT, PT>(acc, o1);
-    if constexpr (TAIL >= 3) mma_chunk<CT, PT>(acc, o0);
+    if constexpr (TAIL >= 2) mma_chunk<NC, PT>(acc, o1);
+    if constexpr (TAIL >= 3) mma_chunk<NC, PT>(acc, o0);
 }
 
 // Per-lane view of the position tiles a wave owns.
@@ -230,34 +258,37 @@ __device__ __forceinline__ void butterfly8(const float (&part)[8], bool hi32, bo
 // Weight-side state shared by the stacks of one kernel: the buffer resource over the packed
 // weights and the chunk-0 A fragments of the NEXT conv layer, fetched before the current layer's
 // epilogue so that their L2 latency hides behind it.
-template <int U, int PT>
+template <int U, int PT, int C0, int NC>
 struct WeightStream {
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t voff;                       // lane * 16
-    Ops<Geo<U>::CT, PT> o;
+    Ops<NC, PT> o;
     __device__ __forceinline__ void init(const float* wpack, uint32_t bytes, int lane) {
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wpack), 0, (int)bytes, 0x00020000);
         voff = (uint32_t)lane * 16u;
     }
-    __device__ __forceinline__ void prefetch(uint32_t soff) { load_w<Geo<U>::CT, PT>(o, rsrc, voff, soff); }
+    __device__ __forceinline__ void prefetch(uint32_t soff) { load_w<Geo<U>::CT, C0, NC, PT>(o, rsrc, voff, soff); }
 };
 
 // Runs one SameShapeConv1d stack (cnn_utils.py:36-46) followed by its Linear head for the
-// workgroup's blocks.  `epi(p, f, value)` is called for output feature f (0..7) of this lane's
+// workgroup's blocks; this wave owns channel tiles [C0, C0 + NC) of position group g.
+// `epi(p, f, value)` is called (by the C0 == 0 wave) for output feature f (0..7) of this lane's
 // position in tile p by the lane that owns (p, f): lane group q owns f = 2q and f = 2q + 1.
 // `soff` = byte offset of this stack inside the packed weights; `snext` = byte offset of the stack
 // that runs next in this kernel (or 0xffffffff): its first chunk is prefetched before the head.
+// `HS` = head-combine scratch [kHeadSlots][8] floats: the upper channel half parks its partial
+// Linear outputs there and the lower half adds them in a fixed order.
 //
 // Packed stack layout (floats), written by turboae_api.hip::pack_stack:
 //   per layer: A fragments [chunk][...] (see load_w) | bias [CP];  then Linear weights [8][CP] | bias [8]
-template <int U, int PT, class Epi>
+template <int U, int PT, int C0, int NC, class Epi>
 __device__ __forceinline__ void run_stack(const float* __restrict__ wpack, uint32_t soff, uint32_t snext, int n_layer,
-                                          char* smem, float* ACT, const float* Xin, const TileCtx<PT>& tc, int lane,
-                                          WeightStream<U, PT>& ws, Epi epi) {
+                                          char* smem, float* ACT, const float* Xin, float* HS, const TileCtx<PT>& tc,
+                                          int g, int lane, WeightStream<U, PT, C0, NC>& ws, Epi epi) {
     using G = Geo<U>;
-    constexpr int CT = G::CT;
+    constexpr int CTT = G::CT;
     const int q = lane >> 4;
-    f32x4 acc[PT][CT];
+    f32x4 acc[PT][NC];
     uint32_t lo = soff;      // byte offset of the current layer
     for (int l = 0; l < n_layer; ++l) {
         const bool first = (l == 0);
@@ -265,21 +296,21 @@ __device__ __forceinline__ void run_stack(const float* __restrict__ wpack, uint3
         const float* bias = wpack + (lo + fragb) / 4;
         // accumulators start at the bias (Conv1d bias=True, cnn_utils.py:15-17)
         {
-            f32x4 b4[CT];
+            f32x4 b4[NC];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) b4[ct] = *reinterpret_cast<const f32x4*>(bias + ct * 16 + 4 * q);
+            for (int i = 0; i < NC; ++i) b4[i] = *reinterpret_cast<const f32x4*>(bias + (C0 + i) * 16 + 4 * q);
 #pragma unroll
             for (int p = 0; p < PT; ++p)
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[p][ct] = b4[ct];
+                for (int i = 0; i < NC; ++i) acc[p][i] = b4[i];
         }
         uint32_t baddr[PT];
         const uint32_t stride = first ? (uint32_t)(kXW * 4) : (uint32_t)(U * 4);
         const uint32_t poff = (uint32_t)(reinterpret_cast<const char*>(first ? Xin : ACT) - smem);
 #pragma unroll
         for (int p = 0; p < PT; ++p) baddr[p] = poff + (uint32_t)(tc.row[p] - 2) * stride + 8u * q;
-        if (first) conv_accumulate<CT, PT, G::NCH_L0>(acc, ws.o, ws.rsrc, ws.voff, lo, smem, baddr);
-        else conv_accumulate<CT, PT, G::NCH_MID>(acc, ws.o, ws.rsrc, ws.voff, lo, smem, baddr);
+        if (first) conv_accumulate<CTT, C0, NC, PT, G::NCH_L0>(acc, ws.o, ws.rsrc, ws.voff, lo, smem, baddr);
+        else conv_accumulate<CTT, C0, NC, PT, G::NCH_MID>(acc, ws.o, ws.rsrc, ws.voff, lo, smem, baddr);
         lo += fragb + G::CP * 4u;
         // prefetch the next conv layer's chunk-0 weights (this stack's next layer, or the next stack's first)
         {
@@ -292,11 +323,12 @@ __device__ __forceinline__ void run_stack(const float* __restrict__ wpack, uint3
 #pragma unroll
             for (int p = 0; p < PT; ++p) {
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    f32x4 v = acc[p][ct];
+                for (int i = 0; i < NC; ++i) {
+                    f32x4 v = acc[p][i];
                     if (!(TAE_X & 4)) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
+                    const int ch = (C0 + i) * 16 + 4 * q;
                     if (TAE_X & 2) asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-                    else if (tc.valid[p] && ct * 16 + 4 * q < U) *reinterpret_cast<f32x4*>(ACT + tc.row[p] * U + ct * 16 + 4 * q) = v;
+                    else if (tc.valid[p] && ch < U) *reinterpret_cast<f32x4*>(ACT + tc.row[p] * U + ch) = v;
                 }
             }
             if (!(TAE_X & 1)) __syncthreads();
@@ -311,13 +343,13 @@ __device__ __forceinline__ void run_stack(const float* __restrict__ wpack, uint3
 #pragma unroll
         for (int f = 0; f < 8; ++f) part[p][f] = 0.0f;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
+    for (int i = 0; i < NC; ++i) {
         f32x4 w4[8];
 #pragma unroll
-        for (int f = 0; f < 8; ++f) w4[f] = *reinterpret_cast<const f32x4*>(wl + f * G::CP + ct * 16 + 4 * q);
+        for (int f = 0; f < 8; ++f) w4[f] = *reinterpret_cast<const f32x4*>(wl + f * G::CP + (C0 + i) * 16 + 4 * q);
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
-            f32x4 v = acc[p][ct];
+            f32x4 v = acc[p][i];
             v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
 #pragma unroll
             for (int f = 0; f < 8; ++f) {
@@ -328,27 +360,40 @@ __device__ __forceinline__ void run_stack(const float* __restrict__ wpack, uint3
             }
         }
     }
-    const float* lb = wl + 8 * G::CP;
-    const float bq0 = lb[2 * q], bq1 = lb[2 * q + 1];
     const bool hi32 = (q & 2) != 0, hi16 = (q & 1) != 0;
+    float k2[PT][2];
 #pragma unroll
-    for (int p = 0; p < PT; ++p) {
-        float k2[2];
-        butterfly8(part[p], hi32, hi16, k2);
-        if (tc.center[p]) {
-            epi(p, 2 * q, k2[0] + bq0);
-            epi(p, 2 * q + 1, k2[1] + bq1);
+    for (int p = 0; p < PT; ++p) butterfly8(part[p], hi32, hi16, k2[p]);
+    // combine the two channel halves: upper half parks its partials, lower half adds them
+    const int n = lane & 15;
+    if constexpr (C0 != 0) {
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+            *reinterpret_cast<float2*>(HS + ((g * PT + p) * 16 + n) * 8 + 2 * q) = float2{k2[p][0], k2[p][1]};
+    }
+    __syncthreads();
+    if constexpr (C0 == 0) {
+        const float* lb = wl + 8 * G::CP;
+        const float bq0 = lb[2 * q], bq1 = lb[2 * q + 1];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            float2 other = float2{0.0f, 0.0f};
+            if constexpr (NC < CTT) other = *reinterpret_cast<const float2*>(HS + ((g * PT + p) * 16 + n) * 8 + 2 * q);
+            if (tc.center[p]) {
+                epi(p, 2 * q, (k2[p][0] + other.x) + bq0);
+                epi(p, 2 * q + 1, (k2[p][1] + other.y) + bq1);
+            }
         }
     }
     __syncthreads();
 }
 
 template <int PT>
-__device__ __forceinline__ void make_tiles(TileCtx<PT>& tc, int wave, int lane, int L, int npos) {
+__device__ __forceinline__ void make_tiles(TileCtx<PT>& tc, int g, int lane, int L, int npos) {
     const int n = lane & 15;
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
-        const int m = (wave * PT + p) * 16 + n;
+        const int m = (g * PT + p) * 16 + n;
         const bool v = m < npos;
         const int mm = v ? m : 0;
         const int b = mm / L;
@@ -368,6 +413,7 @@ struct Panels {
     float* XB;
     int* PERM;
     int* INV;
+    float* HS;       // head-combine scratch [kHeadSlots][8]
 };
 
 template <int U>
@@ -378,6 +424,7 @@ __device__ __forceinline__ Panels carve(char* smem, int rows, int L) {
     pn.XB = pn.XA + (size_t)(rows + 1) * kXW;
     pn.PERM = reinterpret_cast<int*>(pn.XB + (size_t)(rows + 1) * kXW);
     pn.INV = pn.PERM + L;
+    pn.HS = reinterpret_cast<float*>(smem + (((reinterpret_cast<char*>(pn.INV + L) - smem) + 15) & ~15));
     return pn;
 }
 
@@ -386,13 +433,58 @@ __device__ __forceinline__ void zero_lds(char* smem, int bytes, int tid) {
     for (int i = tid; i < bytes / 16; i += kThreads) reinterpret_cast<f32x4*>(smem)[i] = z;
 }
 
+// channel-tile split between the two waves of a SIMD: lower half [0, CTA), upper half [CTA, CT)
+template <int U>
+struct Split {
+    static constexpr int CT = Geo<U>::CT;
+    static constexpr int CTA = CT >= 3 ? 2 * ((CT + 2) / 4) : 1;   // even when possible, so 16-byte pair loads stay whole
+    static constexpr int CTB = CT - CTA;
+    static_assert(CTB >= 1, "both channel halves need at least one tile");
+};
+
 // =============================================================================================
 // Decoder: DEC_LargeCNN.forward (decoders.py:206-269) for nb blocks per workgroup.
+template <int U, int PT, int C0, int NC>
+__device__ __forceinline__ void dec_body(const FusedParams& P, char* smem, const Panels& pn, const TileCtx<PT>& tc,
+                                         int g, int lane, int blk0) {
+    const int L = P.L;
+    const int n_stack = 2 * P.n_iter;
+    const int F = P.F;
+    const bool extrinsic = P.extrinsic != 0;
+    float* xdec = P.out + (size_t)blk0 * L;
+    WeightStream<U, PT, C0, NC> ws;
+    ws.init(P.wpack, P.wpack_bytes, lane);
+    ws.prefetch(0);
+    const uint32_t sstride = P.stack_stride * 4u;
+    for (int s = 0; s < n_stack; ++s) {
+        const float* Xin = (s & 1) ? pn.XB : pn.XA;
+        float* Xout = (s & 1) ? pn.XA : pn.XB;
+        // dec1 output q[t] feeds dec2 at row inv[t] (interleave, decoders.py:238);
+        // dec2 output q2[i] becomes prior[p[i]] (deinterleave, decoders.py:249)
+        const int* ptab = (s & 1) ? pn.PERM : pn.INV;
+        if (s + 1 < n_stack) {
+            run_stack<U, PT, C0, NC>(P.wpack, s * sstride, (s + 1) * sstride, P.n_layer, smem, pn.ACT, Xin, pn.HS, tc, g, lane, ws,
+                                     [&](int p, int f, float v) {
+                if (f < F) {
+                    if (extrinsic) v -= Xin[tc.row[p] * kXW + 2 + f];   // decoders.py:235-236,246-247
+                    Xout[(tc.rowbase[p] + ptab[tc.t[p]]) * kXW + 2 + f] = v;
+                }
+            });
+        } else {
+            // last half-iteration: Linear(U->1), no extrinsic subtraction, sigmoid(deinterleave) (decoders.py:262-267)
+            run_stack<U, PT, C0, NC>(P.wpack, s * sstride, 0xffffffffu, P.n_layer, smem, pn.ACT, Xin, pn.HS, tc, g, lane, ws,
+                                     [&](int p, int f, float v) {
+                if (f == 0) xdec[tc.blk[p] * L + ptab[tc.t[p]]] = 1.0f / (1.0f + expf(-v));
+            });
+        }
+    }
+}
+
 template <int U, int PT>
-__global__ __launch_bounds__(kThreads, 1) void dec_kernel(FusedParams P) {
+__global__ __launch_bounds__(kThreads, 2) void dec_kernel(FusedParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using G = Geo<U>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = wave & (kGroups - 1), h = wave / kGroups;
     const int L = P.L, nb = P.nb;
     const int rows = nb * (L + 2) + 2;
     const Panels pn = carve<U>(smem, rows, L);
@@ -418,47 +510,57 @@ __global__ __launch_bounds__(kThreads, 1) void dec_kernel(FusedParams P) {
     __syncthreads();
 
     TileCtx<PT> tc;
-    make_tiles<PT>(tc, wave, lane, L, npos);
-
-    const int n_stack = 2 * P.n_iter;
-    const int F = P.F;
-    const bool extrinsic = P.extrinsic != 0;
-    float* xdec = P.out + (size_t)blk0 * L;
-    WeightStream<U, PT> ws;
-    ws.init(P.wpack, P.wpack_bytes, lane);
-    ws.prefetch(0);
-    const uint32_t sstride = P.stack_stride * 4u;
-    for (int s = 0; s < n_stack; ++s) {
-        const float* Xin = (s & 1) ? pn.XB : pn.XA;
-        float* Xout = (s & 1) ? pn.XA : pn.XB;
-        // dec1 output q[t] feeds dec2 at row inv[t] (interleave, decoders.py:238);
-        // dec2 output q2[i] becomes prior[p[i]] (deinterleave, decoders.py:249)
-        const int* ptab = (s & 1) ? pn.PERM : pn.INV;
-        if (s + 1 < n_stack) {
-            run_stack<U, PT>(P.wpack, s * sstride, (s + 1) * sstride, P.n_layer, smem, pn.ACT, Xin, tc, lane, ws,
-                             [&](int p, int f, float v) {
-                if (f < F) {
-                    if (extrinsic) v -= Xin[tc.row[p] * kXW + 2 + f];   // decoders.py:235-236,246-247
-                    Xout[(tc.rowbase[p] + ptab[tc.t[p]]) * kXW + 2 + f] = v;
-                }
-            });
-        } else {
-            // last half-iteration: Linear(U->1), no extrinsic subtraction, sigmoid(deinterleave) (decoders.py:262-267)
-            run_stack<U, PT>(P.wpack, s * sstride, 0xffffffffu, P.n_layer, smem, pn.ACT, Xin, tc, lane, ws,
-                             [&](int p, int f, float v) {
-                if (f == 0) xdec[tc.blk[p] * L + ptab[tc.t[p]]] = 1.0f / (1.0f + expf(-v));
-            });
-        }
-    }
+    make_tiles<PT>(tc, g, lane, L, npos);
+    if (__builtin_amdgcn_readfirstlane(h) == 0) dec_body<U, PT, 0, Split<U>::CTA>(P, smem, pn, tc, g, lane, blk0);
+    else dec_body<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, g, lane, blk0);
 }
 
 // =============================================================================================
 // Encoder before power normalisation: ENC_interCNN.forward (encoders.py:362-373) + per-workgroup
 // partial sums for power_constraint (encoders.py:107-108).
+template <int U, int PT, int C0, int NC>
+__device__ __forceinline__ void enc_body(const FusedParams& P, char* smem, const Panels& pn, const TileCtx<PT>& tc,
+                                         int g, int lane, int blk0, double& sum, double& sumsq) {
+    const int L = P.L;
+    float* xtx = P.out + (size_t)blk0 * L * 3;
+    const bool act_elu = P.act == 0;
+    WeightStream<U, PT, C0, NC> ws;
+    ws.init(P.wpack, P.wpack_bytes, lane);
+    ws.prefetch(0);
+    const uint32_t sstride = P.stack_stride * 4u;
+    for (int s = 0; s < 3; ++s) {
+        const float* Xin = (s == 2) ? pn.XB : pn.XA;
+        run_stack<U, PT, C0, NC>(P.wpack, s * sstride, s < 2 ? (s + 1) * sstride : 0xffffffffu, P.n_layer, smem, pn.ACT, Xin,
+                                 pn.HS, tc, g, lane, ws, [&](int p, int f, float v) {
+            if (f == 0) {
+                if (act_elu) v = elu1(v);                      // enc_act (encoders.py:364)
+                xtx[(size_t)(tc.blk[p] * L + tc.t[p]) * 3 + s] = v;   // x_p2 stays in interleaved order (encoders.py:371-373)
+                sum += (double)v;
+                sumsq += (double)v * (double)v;
+            }
+        });
+    }
+}
+
+__device__ __forceinline__ void block_reduce_stats(char* smem, int tid, double sum, double sumsq, double* partials) {
+    // deterministic fixed-order tree; the panels are dead after the last stack's closing barrier, so the
+    // reduction scratch aliases them (no static LDS: guide G17)
+    double* red = reinterpret_cast<double*>(smem);
+    red[tid] = sum;
+    red[kThreads + tid] = sumsq;
+    __syncthreads();
+    for (int off = kThreads / 2; off > 0; off >>= 1) {
+        if (tid < off) { red[tid] += red[tid + off]; red[kThreads + tid] += red[kThreads + tid + off]; }
+        __syncthreads();
+    }
+    if (tid == 0) { partials[2 * blockIdx.x] = red[0]; partials[2 * blockIdx.x + 1] = red[kThreads]; }
+}
+
 template <int U, int PT>
-__global__ __launch_bounds__(kThreads, 1) void enc_kernel(FusedParams P) {
+__global__ __launch_bounds__(kThreads, 2) void enc_kernel(FusedParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = wave & (kGroups - 1), h = wave / kGroups;
     const int L = P.L, nb = P.nb;
     const int rows = nb * (L + 2) + 2;
     const Panels pn = carve<U>(smem, rows, L);
@@ -481,40 +583,12 @@ __global__ __launch_bounds__(kThreads, 1) void enc_kernel(FusedParams P) {
     __syncthreads();
 
     TileCtx<PT> tc;
-    make_tiles<PT>(tc, wave, lane, L, npos);
-
-    float* xtx = P.out + (size_t)blk0 * L * 3;
-    const bool act_elu = P.act == 0;
+    make_tiles<PT>(tc, g, lane, L, npos);
     double sum = 0.0, sumsq = 0.0;
-    WeightStream<U, PT> ws;
-    ws.init(P.wpack, P.wpack_bytes, lane);
-    ws.prefetch(0);
-    const uint32_t sstride = P.stack_stride * 4u;
-    for (int s = 0; s < 3; ++s) {
-        const float* Xin = (s == 2) ? pn.XB : pn.XA;
-        run_stack<U, PT>(P.wpack, s * sstride, s < 2 ? (s + 1) * sstride : 0xffffffffu, P.n_layer, smem, pn.ACT, Xin, tc, lane, ws,
-                         [&](int p, int f, float v) {
-            if (f == 0) {
-                if (act_elu) v = elu1(v);                      // enc_act (encoders.py:364)
-                xtx[(size_t)(tc.blk[p] * L + tc.t[p]) * 3 + s] = v;   // x_p2 stays in interleaved order (encoders.py:371-373)
-                sum += (double)v;
-                sumsq += (double)v * (double)v;
-            }
-        });
-    }
-    // block reduction of the fp64 partial sums (deterministic order); the panels are dead after the
-    // last stack's closing barrier, so the reduction scratch aliases them (no static LDS: G17)
-    double* red = reinterpret_cast<double*>(smem);
-    red[tid] = sum;
-    red[kThreads + tid] = sumsq;
-    __syncthreads();
-    for (int off = kThreads / 2; off > 0; off >>= 1) {
-        if (tid < off) { red[tid] += red[tid + off]; red[kThreads + tid] += red[kThreads + tid + off]; }
-        __syncthreads();
-    }
-    if (tid == 0) { P.partials[2 * blockIdx.x] = red[0]; P.partials[2 * blockIdx.x + 1] = red[kThreads]; }
+    if (__builtin_amdgcn_readfirstlane(h) == 0) enc_body<U, PT, 0, Split<U>::CTA>(P, smem, pn, tc, g, lane, blk0, sum, sumsq);
+    else enc_body<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, g, lane, blk0, sum, sumsq);
+    block_reduce_stats(smem, tid, sum, sumsq, P.partials);
 }
-
 
 // =============================================================================================
 // Long blocks (block_len > 320, e.g. BASELINE configs[3] block_len=1000): a block's activations no
@@ -525,14 +599,53 @@ __global__ __launch_bounds__(kThreads, 1) void enc_kernel(FusedParams P) {
 // padding), and garbage from the panel edges creeps inwards 2 rows per layer, never reaching the
 // centre.  The F extrinsic values per position travel between stacks through the (B, L, 8) fp32
 // exchange buffers in HBM; (de)interleaving is the gather on the read side.
+template <int U, int PT, int C0, int NC>
+__device__ __forceinline__ void seg_body(const SegParams& P, char* smem, float* ACT, float* X, float* HS,
+                                         const TileCtx<PT>& tc, int g, int lane, int stack, int b, double& sum, double& sumsq) {
+    const int L = P.L;
+    WeightStream<U, PT, C0, NC> ws;
+    ws.init(P.wpack, P.wpack_bytes, lane);
+    const uint32_t soff = (uint32_t)stack * P.stack_stride * 4u;
+    ws.prefetch(soff);
+    if (P.mode == 0) {
+        const bool act_elu = P.act == 0;
+        float* xtx = P.out + (size_t)b * L * 3;
+        run_stack<U, PT, C0, NC>(P.wpack, soff, 0xffffffffu, P.n_layer, smem, ACT, X, HS, tc, g, lane, ws, [&](int p, int f, float v) {
+            if (f == 0) {
+                if (act_elu) v = elu1(v);
+                xtx[(size_t)tc.t[p] * 3 + stack] = v;
+                sum += (double)v;
+                sumsq += (double)v * (double)v;
+            }
+        });
+    } else if (!P.last) {
+        const int F = P.F;
+        const bool extrinsic = P.extrinsic != 0;
+        float* ecur = P.ecur + (size_t)b * L * 8;
+        run_stack<U, PT, C0, NC>(P.wpack, soff, 0xffffffffu, P.n_layer, smem, ACT, X, HS, tc, g, lane, ws, [&](int p, int f, float v) {
+            if (f < F) {
+                if (extrinsic) v -= X[tc.row[p] * kXW + 2 + f];
+                ecur[(size_t)tc.t[p] * 8 + f] = v;
+            }
+        });
+    } else {
+        float* xdec = P.out + (size_t)b * L;
+        run_stack<U, PT, C0, NC>(P.wpack, soff, 0xffffffffu, P.n_layer, smem, ACT, X, HS, tc, g, lane, ws, [&](int p, int f, float v) {
+            if (f == 0) xdec[P.perm[tc.t[p]]] = 1.0f / (1.0f + expf(-v));    // sigmoid(deinterleave), decoders.py:267
+        });
+    }
+}
+
 template <int U, int PT>
-__global__ __launch_bounds__(kThreads, 1) void seg_kernel(SegParams P) {
+__global__ __launch_bounds__(kThreads, 2) void seg_kernel(SegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = wave & (kGroups - 1), h = wave / kGroups;
     const int L = P.L, H = 2 * P.n_layer, NP = P.T + 2 * H;
     const int rows = NP + 4;
     float* ACT = reinterpret_cast<float*>(smem);
     float* X = ACT + (size_t)(rows + 1) * U;
+    float* HS = X + (size_t)(rows + 1) * kXW;
     int bid = blockIdx.x;
     int stack = P.stack;
     if (P.mode == 0) { stack = bid % 3; bid /= 3; }
@@ -556,8 +669,8 @@ __global__ __launch_bounds__(kThreads, 1) void seg_kernel(SegParams P) {
             xr[1] = rx[(size_t)t * 3 + (odd ? 2 : 1)];                              // r_par2 / r_par1
             if (stack > 0) {
                 // dec2 reads q[p[i]] (interleave, decoders.py:238); dec1 reads q2[inv[j]] (deinterleave, :249)
-                const int g = odd ? P.perm[t] : P.inv[t];
-                const float* e = P.eprev + ((size_t)b * L + g) * 8;
+                const int gi = odd ? P.perm[t] : P.inv[t];
+                const float* e = P.eprev + ((size_t)b * L + gi) * 8;
                 for (int f = 0; f < P.F; ++f) xr[2 + f] = e[f];
             }
         }
@@ -569,7 +682,7 @@ __global__ __launch_bounds__(kThreads, 1) void seg_kernel(SegParams P) {
         const int n = lane & 15;
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
-            const int m = (wave * PT + p) * 16 + n;
+            const int m = (g * PT + p) * 16 + n;
             const int t = s0 - H + m;
             const bool v = (m < NP) && (t >= 0) && (t < L);
             tc.valid[p] = v;
@@ -580,47 +693,10 @@ __global__ __launch_bounds__(kThreads, 1) void seg_kernel(SegParams P) {
             tc.row[p] = v ? 2 + m : 2;
         }
     }
-    WeightStream<U, PT> ws;
-    ws.init(P.wpack, P.wpack_bytes, lane);
-    const uint32_t soff = (uint32_t)stack * P.stack_stride * 4u;
-    ws.prefetch(soff);
-    if (P.mode == 0) {
-        const bool act_elu = P.act == 0;
-        double sum = 0.0, sumsq = 0.0;
-        float* xtx = P.out + (size_t)b * L * 3;
-        run_stack<U, PT>(P.wpack, soff, 0xffffffffu, P.n_layer, smem, ACT, X, tc, lane, ws, [&](int p, int f, float v) {
-            if (f == 0) {
-                if (act_elu) v = elu1(v);
-                xtx[(size_t)tc.t[p] * 3 + stack] = v;
-                sum += (double)v;
-                sumsq += (double)v * (double)v;
-            }
-        });
-        double* red = reinterpret_cast<double*>(smem);
-        red[tid] = sum;
-        red[kThreads + tid] = sumsq;
-        __syncthreads();
-        for (int off = kThreads / 2; off > 0; off >>= 1) {
-            if (tid < off) { red[tid] += red[tid + off]; red[kThreads + tid] += red[kThreads + tid + off]; }
-            __syncthreads();
-        }
-        if (tid == 0) { P.partials[2 * blockIdx.x] = red[0]; P.partials[2 * blockIdx.x + 1] = red[kThreads]; }
-    } else if (!P.last) {
-        const int F = P.F;
-        const bool extrinsic = P.extrinsic != 0;
-        float* ecur = P.ecur + (size_t)b * L * 8;
-        run_stack<U, PT>(P.wpack, soff, 0xffffffffu, P.n_layer, smem, ACT, X, tc, lane, ws, [&](int p, int f, float v) {
-            if (f < F) {
-                if (extrinsic) v -= X[tc.row[p] * kXW + 2 + f];
-                ecur[(size_t)tc.t[p] * 8 + f] = v;
-            }
-        });
-    } else {
-        float* xdec = P.out + (size_t)b * L;
-        run_stack<U, PT>(P.wpack, soff, 0xffffffffu, P.n_layer, smem, ACT, X, tc, lane, ws, [&](int p, int f, float v) {
-            if (f == 0) xdec[P.perm[tc.t[p]]] = 1.0f / (1.0f + expf(-v));    // sigmoid(deinterleave), decoders.py:267
-        });
-    }
+    double sum = 0.0, sumsq = 0.0;
+    if (__builtin_amdgcn_readfirstlane(h) == 0) seg_body<U, PT, 0, Split<U>::CTA>(P, smem, ACT, X, HS, tc, g, lane, stack, b, sum, sumsq);
+    else seg_body<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, ACT, X, HS, tc, g, lane, stack, b, sum, sumsq);
+    if (P.mode == 0) block_reduce_stats(smem, tid, sum, sumsq, P.partials);
 }
 
 // =============================================================================================
@@ -762,6 +838,7 @@ hipError_t launch_seg(int U, const SegParams& P, int grid, hipStream_t st) {
 int seg_lds_bytes(int U, int T, int n_layer) {
     const int rows = T + 4 * n_layer + 4;
     size_t b = (size_t)(rows + 1) * U * 4 + (size_t)(rows + 1) * kXW * 4;
+    b += (size_t)kHeadSlots * 8 * 4;     // head-combine scratch
     b = (b + 15) & ~(size_t)15;
     if (b < 2 * kThreads * sizeof(double)) b = 2 * kThreads * sizeof(double);
     return (int)b;
@@ -796,9 +873,11 @@ int fused_lds_bytes(int U, int L, int nb) {
     const int rows = nb * (L + 2) + 2;
     size_t b = (size_t)(rows + 1) * U * 4 + 2 * (size_t)(rows + 1) * kXW * 4 + 2 * (size_t)L * 4;
     b = (b + 15) & ~(size_t)15;
+    b += (size_t)kHeadSlots * 8 * 4;     // head-combine scratch
+    if (b < 2 * kThreads * sizeof(double)) b = 2 * kThreads * sizeof(double);
     return (int)b;
 }
 
-int fused_max_positions() { return kWaves * 5 * 16; }
+int fused_max_positions() { return kGroups * 5 * 16; }
 
 }  // namespace tae
