@@ -38,16 +38,19 @@ namespace tae {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
+using lds_cptr = const char __attribute__((address_space(3)))*;   // explicit LDS pointer (ds_* instructions)
 
-// ELU(alpha=1) = x > 0 ? x : expm1(x)  (F.elu, cnn_utils.py:26,43) as max(x, exp(min(x,0)) - 1):
-// 5 VALU ops, branch- and compare-free (on gfx950 every VALU op issued by a wave that is streaming
-// fp32 MFMAs costs ~5 matrix-pipe cycles, v_cmp / v_exp ~9: tools/probes/mfma_valu_probe.hip).
-// Absolute error <= 1.2e-7 for every x (one rounding of exp near 1, one of the subtraction); the
-// relative error for tiny negative x is not preserved (expm1 would return ~x), which is below the
-// rounding noise of the 500-term fp32 dot products that consume these activations.
+// ELU(alpha=1) = x > 0 ? x : expm1(x)  (F.elu, cnn_utils.py:26,43) as med3(x, exp(x) - 1, 0):
+// exp(x) - 1 >= x everywhere, so the median of {x, exp(x)-1, 0} is x for x > 0 and exp(x)-1 for x < 0
+// (large x: exp overflows to +inf, the median is still x).  4 VALU ops, branch- and compare-free -
+// on gfx950 every VALU op issued by a wave that is streaming fp32 MFMAs costs ~5 matrix-pipe cycles,
+// v_cmp / v_exp ~9 (tools/probes/mfma_valu_probe.hip).  Absolute error <= 1.2e-7 for every x (one
+// rounding of exp near 1, one of the subtraction); the relative error for tiny negative x is not
+// preserved (expm1 would return ~x), which is below the rounding noise of the 500-term fp32 dot
+// products that consume these activations.
 __device__ __forceinline__ float elu1(float x) {
-    const float e = __builtin_amdgcn_exp2f(fminf(x, 0.0f) * 1.44269504088896341f) - 1.0f;
-    return fmaxf(x, e);
+    const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f) - 1.0f;
+    return __builtin_amdgcn_fmed3f(x, e, 0.0f);
 }
 
 __device__ __forceinline__ f32x4 mfma16x16x4(float a, float b, f32x4 c) {
@@ -129,10 +132,13 @@ __device__ __forceinline__ void load_w(Ops<NC, PT>& o, __amdgpu_buffer_rsrc_t rs
 
 // Activation (B) fragments: one ds_read_b64 per position tile at running base + immediate.
 template <int NC, int PT, int OFF>
-__device__ __forceinline__ void load_x(Ops<NC, PT>& o, const char* lds, const uint32_t (&cur)[PT]) {
+__device__ __forceinline__ void load_x(Ops<NC, PT>& o, const lds_cptr (&cur)[PT]) {
     if (TAE_X & 16) return;
 #pragma unroll
-    for (int p = 0; p < PT; ++p) o.b[p] = *reinterpret_cast<const float2*>(lds + cur[p] + OFF);
+    for (int p = 0; p < PT; ++p) {
+        const f32x2 v = *reinterpret_cast<const f32x2 __attribute__((address_space(3)))*>(cur[p] + OFF);
+        o.b[p] = float2{v.x, v.y};
+    }
 }
 
 #ifndef TAE_SPREAD
@@ -187,25 +193,26 @@ __device__ __forceinline__ void conv_accumulate(f32x4 (&acc)[PT][NC], Ops<NC, PT
     constexpr uint32_t CSB = CTT * 512;   // bytes of A fragments per chunk
     constexpr int NV = n_wloads(CTT, C0, NC);
     Ops<NC, PT> o1;
-    uint32_t cur[PT];
+    lds_cptr cur[PT];        // loop-carried LDS pointers: one add per tile per 4 chunks, immediates otherwise
+    const lds_cptr lds3 = (lds_cptr)lds;
 #pragma unroll
-    for (int p = 0; p < PT; ++p) cur[p] = baddr[p];
-    load_x<NC, PT, 0>(o0, lds, cur);
+    for (int p = 0; p < PT; ++p) cur[p] = lds3 + baddr[p];
+    load_x<NC, PT, 0>(o0, cur);
     for (int it = 0; it < NCH / 4; ++it) {
         load_w<CTT, C0, NC, PT>(o1, rsrc, voff, soff + 1 * CSB);
-        load_x<NC, PT, 32>(o1, lds, cur);
+        load_x<NC, PT, 32>(o1, cur);
         mma_chunk<NC, PT>(acc, o0);
         spread_loads<NV, NC, PT>();
         load_w<CTT, C0, NC, PT>(o0, rsrc, voff, soff + 2 * CSB);
-        load_x<NC, PT, 64>(o0, lds, cur);
+        load_x<NC, PT, 64>(o0, cur);
         mma_chunk<NC, PT>(acc, o1);
         spread_loads<NV, NC, PT>();
         load_w<CTT, C0, NC, PT>(o1, rsrc, voff, soff + 3 * CSB);
-        load_x<NC, PT, 96>(o1, lds, cur);
+        load_x<NC, PT, 96>(o1, cur);
         mma_chunk<NC, PT>(acc, o0);
         spread_loads<NV, NC, PT>();
         load_w<CTT, C0, NC, PT>(o0, rsrc, voff, soff + 4 * CSB);
-        load_x<NC, PT, 128>(o0, lds, cur);
+        load_x<NC, PT, 128>(o0, cur);
         mma_chunk<NC, PT>(acc, o1);
         spread_loads<NV, NC, PT>();
         soff += 4 * CSB;
@@ -215,12 +222,12 @@ __device__ __forceinline__ void conv_accumulate(f32x4 (&acc)[PT][NC], Ops<NC, PT
     constexpr int TAIL = NCH % 4;     // o0 holds chunk NCH - TAIL
     if constexpr (TAIL >= 2) {
         load_w<CTT, C0, NC, PT>(o1, rsrc, voff, soff + 1 * CSB);
-        load_x<NC, PT, 32>(o1, lds, cur);
+        load_x<NC, PT, 32>(o1, cur);
     }
     if constexpr (TAIL >= 1) mma_chunk<NC, PT>(acc, o0);
     if constexpr (TAIL >= 3) {
         load_w<CTT, C0, NC, PT>(o0, rsrc, voff, soff + 2 * CSB);
-        load_x<NC, PT, 64>(o0, lds, cur);
+        load_x<NC, PT, 64>(o0, cur);
     }
     if constexpr (TAIL >= 2) mma_chunk<NC, PT>(acc, o1);
     if constexpr (TAIL >= 3) mma_chunk<NC, PT>(acc, o0);
