@@ -138,6 +138,13 @@ def main():
         dec_flops_per_launch = 2.0 * macs["dec"] * B * L
         achieved = dec_flops_per_launch / (dec_ms * 1e-3) / 1e12
         nb, lds = model.kernel_info()
+        # HBM-side traffic of the decoder kernel from the committed PMC passes (rocprofv3 cannot run inside
+        # this process): bytes per block measured at the same workload, scaled to this launch's blocks
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc", "traffic.json")
+        if os.path.isfile(tpath) and cfg.enc_num_layer == 2 and L == 100:
+            with open(tpath) as fh:
+                traffic = json.load(fh)["bytes_per_block"] * B / 1e9
         out = {
             "metric": "decoded info bits/sec @ block_len=100, 6-iter rate-1/3 CNN; BER match",
             "value": value, "unit": "bits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -153,7 +160,7 @@ def main():
             "ber": float(counts[0].item()) / bits_total, "bler": float(counts[1].item()) / (world * B * args.steps),
             "roofline": {"bound": "mfma", "kernel": "tae::dec_kernel<100,5> (fused 6-iteration decoder)",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc/traffic.json)",
                          "kernel_ms": dec_ms, "flops_per_launch": dec_flops_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -8,23 +8,27 @@ TAG=${1:-cur}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-B=${PMC_BATCH:-12288}
+B=${PMC_BATCH:-50000}
 run() {  # name, counters...
   name=$1; shift
   rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_${TAG}_$name -o pmc -- python $R/bench.py --steps 2 --warmup 1 --batch $B --no-cpu-baseline > $OUT/pmc_${TAG}_$name.log 2>&1
   f=$(find $OUT/pmc_${TAG}_$name -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python - "$f" <<'PY'
+  [ -n "$f" ] && python - "$f" $OUT/pmc_${TAG}_$name.txt $B <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
-    k = r["Kernel_Name"][:40]
-    agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
-    n[(k, r["Counter_Name"])] += 1
-for k in agg:
-    if "dec_kernel" in k:
-        print(k, {c: v / n[(k, c)] for c, v in agg[k].items()})
+    k = r["Kernel_Name"]; agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
+with open(sys.argv[2], "w") as fh:
+    fh.write(f"# rocprofv3 --pmc pass over `python bench.py --steps 2 --warmup 1 --batch {sys.argv[3]} --no-cpu-baseline`; mean counter value per dispatch\n")
+    for k in sorted(agg):
+        for c in sorted(agg[k]):
+            line = f"{k}\t{c}\t{agg[k][c]/n[(k,c)]:.6g}\t(dispatches={n[(k,c)]})"
+            fh.write(line + "\n")
+            if "dec_kernel" in k or "enc_kernel" in k: print(line)
 PY
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE
-run sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
-run sq3 SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAVES
+run sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES
+run tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
+run hbm_r FETCH_SIZE
+run hbm_w WRITE_SIZE
