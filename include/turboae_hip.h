@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAE_ABI_VERSION 1
+#define TAE_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define TAE_API __attribute__((visibility("default")))
@@ -60,6 +60,8 @@ typedef struct tae_config {
     int32_t extrinsic;        /* -extrinsic        get_args.py:83  */
     int32_t enc_act;          /* -enc_act: 0 = elu (default), 1 = linear   get_args.py:100 */
     int32_t max_batch;        /* blocks per call the workspace is sized for (grown by tae_reserve) */
+    int32_t dec_type;         /* -decoder: 0 = TurboAE_rate3_cnn (DEC_LargeCNN, decoders.py:157),
+                                 1 = TurboAE_rate3_rnn (DEC_LargeRNN with dec_rnn=gru, decoders.py:16; needs dec_num_unit=100)  main.py:75-88 */
 } tae_config;
 
 typedef struct tae_handle tae_handle;
@@ -103,7 +105,8 @@ TAE_API int tae_encode_prenorm(tae_handle* h, const float* u, float* x_tx, doubl
 TAE_API int tae_normalize(tae_handle* h, const float* x_tx, const double* stats3, const float* noise, float* codes,
                   float* received, int32_t B, void* stream);
 
-/* Replaces model.dec(received) = DEC_LargeCNN.forward (decoders.py:206-269). */
+/* Replaces model.dec(received) = DEC_LargeCNN.forward (decoders.py:206-269) or, with dec_type = 1,
+ * DEC_LargeRNN.forward (decoders.py:84-149). */
 TAE_API int tae_decode(tae_handle* h, const float* received, float* x_dec, int32_t B, void* stream);
 
 /* Replaces errors_ber / errors_bler (utils.py:6-18,49-66) as integer counts ACCUMULATED into

@@ -40,6 +40,9 @@ CASES = [
                                        extrinsic=0, dec_num_layer=3), 6, 11, 1.0, -1.5),
     ("fwd_u100_L1000_b2", dict(block_len=1000), 2, 12, 1.0, 2.0),
     ("fwd_u100_L150_b3_it2", dict(block_len=150, num_iteration=2), 3, 13, 1.0, 2.0),
+    # BASELINE configs[4]: DeepTurbo GRU decoder (DEC_LargeRNN) behind the CNN encoder
+    ("fwd_rnn_u100_L100_b4", dict(decoder="TurboAE_rate3_rnn"), 4, 14, 1.0, 2.0),
+    ("fwd_rnn_u100_L40_b3_it2_ft3", dict(decoder="TurboAE_rate3_rnn", block_len=40, num_iteration=2, num_iter_ft=3), 3, 15, 1.0, 1.0),
 ]
 
 

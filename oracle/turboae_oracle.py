@@ -127,6 +127,51 @@ def decode(received: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor, 
     return torch.sigmoid(logits)
 
 
+# decoders.py:16-149 (DEC_LargeRNN.forward) with dec_rnn='gru' (get_args.py:80), dec_act='linear'
+# (get_args.py:101) and dropout 0: the same turbo iteration as DEC_LargeCNN with each conv stack replaced
+# by torch.nn.GRU(2+F, H, num_layers=2, bidirectional=True, batch_first=True) + Linear(2H -> F | 1).
+# The GRU arithmetic is PyTorch's (third-party to the reference); its documented cell is
+#   r = sigmoid(W_ir x + b_ir + W_hr h + b_hr); z = sigmoid(W_iz x + b_iz + W_hz h + b_hz)
+#   n = tanh(W_in x + b_in + r * (W_hn h + b_hn)); h' = (1 - z) * n + z * h        (gate order r, z, n)
+def _gru_stack(x: torch.Tensor, w: Dict[str, torch.Tensor], prefix: str, hidden: int) -> torch.Tensor:
+    gru = torch.nn.GRU(x.shape[2], hidden, num_layers=2, bias=True, batch_first=True, dropout=0.0, bidirectional=True)
+    with torch.no_grad():
+        for name, _ in gru.named_parameters():
+            getattr(gru, name).copy_(w[f"{prefix}.{name}"])
+    gru.eval()
+    y, _ = gru(x)
+    return y
+
+
+def decode_rnn(received: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor, hidden: int, num_iteration: int,
+               num_iter_ft: int, extrinsic: int = 1, taps: Optional[dict] = None) -> torch.Tensor:
+    B, L, _ = received.shape
+    r_sys = received[:, :, 0:1]
+    r_sys_int = interleave(r_sys, p)
+    r_par1 = received[:, :, 1:2]
+    r_par2 = received[:, :, 2:3]
+    prior = torch.zeros((B, L, num_iter_ft), dtype=received.dtype)
+    x_plr = None
+    for it in range(num_iteration):
+        h = _gru_stack(torch.cat([r_sys, r_par1, prior], dim=2), w, f"dec.dec1_rnns.{it}", hidden)
+        x_plr = F.linear(h, w[f"dec.dec1_outputs.{it}.weight"], w[f"dec.dec1_outputs.{it}.bias"])
+        if extrinsic:
+            x_plr = x_plr - prior
+        x_plr_int = interleave(x_plr, p)
+        h = _gru_stack(torch.cat([r_sys_int, r_par2, x_plr_int], dim=2), w, f"dec.dec2_rnns.{it}", hidden)
+        x_plr = F.linear(h, w[f"dec.dec2_outputs.{it}.weight"], w[f"dec.dec2_outputs.{it}.bias"])
+        if it < num_iteration - 1:
+            if extrinsic:
+                x_plr = x_plr - x_plr_int
+            prior = deinterleave(x_plr, p)
+            if taps is not None:
+                taps[f"prior_{it}"] = prior.clone()
+    logits = deinterleave(x_plr, p)          # decoders.py:145-147: no extrinsic subtraction on the last half-iteration
+    if taps is not None:
+        taps["logits"] = logits.clone()
+    return torch.sigmoid(logits)
+
+
 # channel_ae.py:20-73 (Channel_AE.forward), AWGN branch (:41-42), rec_quantize off.
 def channel_ae_forward(u: torch.Tensor, fwd_noise: torch.Tensor, w: Dict[str, torch.Tensor], cfg: dict,
                        taps: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -139,8 +184,12 @@ def channel_ae_forward(u: torch.Tensor, fwd_noise: torch.Tensor, w: Dict[str, to
         x_tx = encode_prenorm(u, w, p, cfg["enc_num_layer"], cfg.get("enc_act", "elu"))
         codes, mean, std = power_constraint(x_tx)
         received = codes + fwd_noise
-        x_dec = decode(received, w, p, cfg["dec_num_layer"], cfg["num_iteration"], cfg["num_iter_ft"],
-                       cfg.get("extrinsic", 1), taps)
+        if cfg.get("decoder", "TurboAE_rate3_cnn") == "TurboAE_rate3_rnn":
+            x_dec = decode_rnn(received, w, p, cfg["dec_num_unit"], cfg["num_iteration"], cfg["num_iter_ft"],
+                               cfg.get("extrinsic", 1), taps)
+        else:
+            x_dec = decode(received, w, p, cfg["dec_num_layer"], cfg["num_iteration"], cfg["num_iter_ft"],
+                           cfg.get("extrinsic", 1), taps)
         if taps is not None:
             taps["x_tx"] = x_tx.clone()
             taps["mean"] = mean.clone()

@@ -32,19 +32,21 @@ def test_library_exports_every_declared_symbol():
 
 def test_num_weights_matches_python_side():
     lib = _lib.load()
-    for over in (dict(), dict(enc_num_layer=5), dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, num_iter_ft=3)):
+    for over in (dict(), dict(enc_num_layer=5), dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, num_iter_ft=3),
+                 dict(decoder="TurboAE_rate3_rnn"), dict(decoder="TurboAE_rate3_rnn", num_iteration=2, num_iter_ft=3)):
         cfg = TurboAEConfig(**over)
         c = _lib.TaeConfig(C.sizeof(_lib.TaeConfig), cfg.block_len, cfg.enc_num_layer, cfg.enc_num_unit, 5,
-                           cfg.dec_num_layer, cfg.dec_num_unit, 5, cfg.num_iteration, cfg.num_iter_ft, 1, 0, 1)
+                           cfg.dec_num_layer, cfg.dec_num_unit, 5, cfg.num_iteration, cfg.num_iter_ft, 1, 0, 1,
+                           1 if cfg.decoder == "TurboAE_rate3_rnn" else 0)
         assert lib.tae_num_weights(C.byref(c)) == W.num_params(cfg)
 
 
 def test_bad_config_is_rejected_with_message():
     lib = _lib.load()
-    c = _lib.TaeConfig(C.sizeof(_lib.TaeConfig), 100, 2, 48, 5, 5, 48, 5, 6, 5, 1, 0, 1)
+    c = _lib.TaeConfig(C.sizeof(_lib.TaeConfig), 100, 2, 48, 5, 5, 48, 5, 6, 5, 1, 0, 1, 0)
     assert lib.tae_num_weights(C.byref(c)) == 0
     assert b"channel width" in lib.tae_last_error()
-    c = _lib.TaeConfig(4, 100, 2, 100, 5, 5, 100, 5, 6, 5, 1, 0, 1)
+    c = _lib.TaeConfig(4, 100, 2, 100, 5, 5, 100, 5, 6, 5, 1, 0, 1, 0)
     assert lib.tae_num_weights(C.byref(c)) == 0
     assert b"struct_size" in lib.tae_last_error()
 

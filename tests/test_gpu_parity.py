@@ -272,3 +272,43 @@ def test_eval_sweep_matches_oracle_on_trained_weights(gpu_device, capsys):
         assert abs(res["ber"][si] - be_tot / (100.0 * L)) <= 1e-4
     assert res["ber"][0] > res["ber"][1] > 0.0          # BER falls with SNR on the trained model
     assert abs(res["enc_power"] - 1.0) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# DeepTurbo GRU decoder (BASELINE configs[4]): DEC_LargeRNN behind the CNN encoder
+ATOL_XDEC_RNN = 5e-5     # 24 two-layer bidirectional GRUs, 100 sequential steps each: fp32 recurrences drift a little more
+
+
+@pytest.mark.parametrize("name", [n for n in sorted(MANIFEST["cases"]) if "rnn" in n])
+def test_rnn_decoder_matches_reference_golden_and_oracle(gpu_device, name):
+    from turboae_amd import Channel_AE_HIP
+    meta = MANIFEST["cases"][name]
+    cfg = TurboAEConfig(**meta["config"])
+    assert cfg.decoder == "TurboAE_rate3_rnn"
+    sd = W.generate_state_dict(cfg, seed=meta["weight_seed"], gain=meta["gain"])
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=meta["B"])
+    xd, codes = model(torch.from_numpy(g["u"]).to(gpu_device), torch.from_numpy(g["noise"]).to(gpu_device))
+    assert np.abs(codes.cpu().numpy() - g["codes"]).max() <= ATOL_CODES
+    d = np.abs(xd.cpu().numpy() - g["x_dec"]).max()
+    assert d <= ATOL_XDEC_RNN, d
+    flips = (xd.cpu().numpy() > 0.5) != (g["x_dec"] > 0.5)
+    assert np.all(np.abs(g["logits"][flips]) < 2e-4)
+
+
+def test_rnn_decoder_batch_independent_and_chunked(gpu_device):
+    """Ragged batches (8 blocks per workgroup) and the internal 4096-block chunking must not change results."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", num_iteration=2)
+    sd = W.generate_state_dict(cfg, seed=14, gain=1.0)
+    B = 4101                      # crosses the 4096-block chunk boundary, not a multiple of 8
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    u, noise = model.generate_inputs(B, 2.0, seed=3)
+    rx = model.enc(u) + noise
+    full = model.dec(rx)
+    for lo, hi in ((0, 1), (3, 12), (4090, 4101)):
+        assert torch.equal(model.dec(rx[lo:hi].contiguous()), full[lo:hi]), (lo, hi)
+    u8, n8 = make_inputs(5, cfg.block_len, seed=77)
+    xd, _ = model(torch.from_numpy(u8).to(gpu_device), torch.from_numpy(n8).to(gpu_device))
+    xo, _ = O.channel_ae_forward(torch.from_numpy(u8), torch.from_numpy(n8), O.to_torch(sd), cfg.to_dict())
+    assert np.abs(xd.cpu().numpy() - xo.numpy()).max() <= ATOL_XDEC_RNN

@@ -24,6 +24,8 @@ class TurboAEConfig:
     num_iter_ft: int = 5          # get_args.py:84
     extrinsic: int = 1            # get_args.py:83
     enc_act: str = "elu"          # get_args.py:100 ("only elu works")
+    decoder: str = "TurboAE_rate3_cnn"   # get_args.py:26 / main.py:75-76,87-88: 'TurboAE_rate3_cnn' (DEC_LargeCNN) or
+                                         # 'TurboAE_rate3_rnn' (DEC_LargeRNN, 2-layer bidirectional GRU, dec_rnn='gru')
     interleaver_seed: int = 0     # channel_ae.py:33 (RandInterlv(block_len, 0))
 
     def validate(self) -> None:
@@ -43,6 +45,10 @@ class TurboAEConfig:
             raise ValueError("layer / iteration counts must be >= 1")
         if self.block_len < 1:
             raise ValueError("block_len must be >= 1")
+        if self.decoder not in ("TurboAE_rate3_cnn", "TurboAE_rate3_rnn"):
+            raise ValueError("decoder must be 'TurboAE_rate3_cnn' or 'TurboAE_rate3_rnn'")
+        if self.decoder == "TurboAE_rate3_rnn" and self.dec_num_unit != 100:
+            raise ValueError("the GRU decoder kernels are instantiated for dec_num_unit = 100")
 
     @staticmethod
     def from_args(args) -> "TurboAEConfig":
@@ -60,8 +66,13 @@ class TurboAEConfig:
         ke, kd = self.enc_kernel_size, self.dec_kernel_size
         ue, ud, f = self.enc_num_unit, self.dec_num_unit, self.num_iter_ft
         enc = 3 * (1 * ke * ue + (self.enc_num_layer - 1) * ue * ke * ue + ue)
-        stack = (2 + f) * kd * ud + (self.dec_num_layer - 1) * ud * kd * ud
-        dec = 2 * self.num_iteration * stack + (2 * self.num_iteration - 1) * ud * f + ud
+        if self.decoder == "TurboAE_rate3_rnn":
+            # 2-layer bidirectional GRU(2+F -> ud): per direction 3*ud*(in + ud) MAC per layer (244 200)
+            stack = 2 * (3 * ud * ((2 + f) + ud) + 3 * ud * (2 * ud + ud))
+            dec = 2 * self.num_iteration * stack + (2 * self.num_iteration - 1) * 2 * ud * f + 2 * ud
+        else:
+            stack = (2 + f) * kd * ud + (self.dec_num_layer - 1) * ud * kd * ud
+            dec = 2 * self.num_iteration * stack + (2 * self.num_iteration - 1) * ud * f + ud
         return {"enc": enc, "dec": dec, "total": enc + dec}
 
     def flops_per_bit(self) -> int:

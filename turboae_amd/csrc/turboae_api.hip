@@ -106,6 +106,15 @@ struct tae_handle {
     double* d_stats = nullptr;
     float* d_e0 = nullptr;   // long-block path: extrinsic exchange buffers (B, L, 8)
     float* d_e1 = nullptr;
+    // GRU decoder (dec_type = 1): canonical decoder weights uploaded as they are + per-chunk workspace
+    float* d_wrnn = nullptr;
+    int32_t rnn_chunk = 0;   // blocks per internal chunk (bounds the workspace)
+    float* d_gxa = nullptr;  // (chunk, L, 8) natural-order panel
+    float* d_gxb = nullptr;  // (chunk, L, 8) interleaved-order panel
+    float* d_gy0 = nullptr;  // (chunk, L, 2H) layer-0 outputs
+    float* d_gy1 = nullptr;  // (chunk, L, 2H) layer-1 outputs
+    float* d_ggi = nullptr;  // (chunk, L, 2, 3H) layer-1 input projections
+    float* d_gzero = nullptr;  // 6H zeros (b_ih already folded into the projections)
 };
 
 namespace {
@@ -121,7 +130,54 @@ int check_cfg(const tae_config* c) {
     if (c->num_iter_ft < 1 || c->num_iter_ft > 6) return fail(TAE_EINVAL, "num_iter_ft must be in 1..6");
     if (c->block_len < 1) return fail(TAE_EINVAL, "block_len must be >= 1");
     if (c->enc_act != 0 && c->enc_act != 1) return fail(TAE_EINVAL, "enc_act must be 0 (elu) or 1 (linear)");
+    if (c->dec_type != 0 && c->dec_type != 1) return fail(TAE_EINVAL, "dec_type must be 0 (cnn) or 1 (rnn/gru)");
+    if (c->dec_type == 1 && c->dec_num_unit != 100) return fail(TAE_EINVAL, "the GRU decoder kernels are instantiated for dec_num_unit = 100");
+    if (c->dec_type == 1 && c->block_len > tae::gru_max_rec_block_len()) return fail(TAE_EINVAL, "block_len too large for the GRU decoder's LDS-staged input panel");
     return TAE_OK;
+}
+
+// canonical GRU stack: per layer l and direction d: weight_ih (3H,cin) weight_hh (3H,H) bias_ih (3H) bias_hh (3H);
+// then Linear (nout,2H), bias (nout)   (turboae_amd/weights.py canonical_entries)
+size_t rnn_stack_floats(size_t H, size_t F, size_t nout) {
+    size_t n = 0;
+    for (int l = 0; l < 2; ++l) {
+        const size_t cin = l == 0 ? 2 + F : 2 * H;
+        n += 2 * (3 * H * cin + 3 * H * H + 3 * H + 3 * H);
+    }
+    return n + nout * 2 * H + nout;
+}
+
+// canonical GRU decoder -> per stack, per layer: w_ih (2,3H,cin) | w_hh (2,3H,H) | b_ih (2,3H) | b_hh (2,3H)
+// (both directions of one tensor contiguous), then Linear w | b.  Same total size as the canonical blob.
+void repack_rnn(const float* src, float* dst, size_t H, size_t F, int n_iter) {
+    for (int s = 0; s < 2 * n_iter; ++s) {
+        const size_t nout = (s == 2 * n_iter - 1) ? 1 : F;
+        for (int l = 0; l < 2; ++l) {
+            const size_t cin = l == 0 ? 2 + F : 2 * H;
+            const size_t n_ih = 3 * H * cin, n_hh = 3 * H * H, n_b = 3 * H, per = n_ih + n_hh + 2 * n_b;
+            for (int d = 0; d < 2; ++d) {
+                const float* p = src + d * per;
+                memcpy(dst + d * n_ih, p, n_ih * sizeof(float));
+                memcpy(dst + 2 * n_ih + d * n_hh, p + n_ih, n_hh * sizeof(float));
+                memcpy(dst + 2 * n_ih + 2 * n_hh + d * n_b, p + n_ih + n_hh, n_b * sizeof(float));
+                memcpy(dst + 2 * n_ih + 2 * n_hh + 2 * n_b + d * n_b, p + n_ih + n_hh + n_b, n_b * sizeof(float));
+            }
+            src += 2 * per;
+            dst += 2 * per;
+        }
+        memcpy(dst, src, (nout * 2 * H + nout) * sizeof(float));
+        src += nout * 2 * H + nout;
+        dst += (nout * 2 * H + nout + 3) / 4 * 4;        // keep every stack 16-byte aligned
+    }
+}
+
+size_t rnn_packed_floats(size_t H, size_t F, int n_iter) {
+    size_t n = 0;
+    for (int s = 0; s < 2 * n_iter; ++s) {
+        const size_t nout = (s == 2 * n_iter - 1) ? 1 : F;
+        n += rnn_stack_floats(H, F, nout) - (nout * 2 * H + nout) + (nout * 2 * H + nout + 3) / 4 * 4;
+    }
+    return n;
 }
 
 size_t num_weights(const tae_config* c) {
@@ -133,9 +189,13 @@ size_t num_weights(const tae_config* c) {
     }
     for (int it = 0; it < c->num_iteration; ++it)
         for (int half = 0; half < 2; ++half) {
-            for (int l = 0; l < c->dec_num_layer; ++l) n += U * (l == 0 ? 2 + F : U) * 5 + U;
             const size_t nout = (half == 1 && it == c->num_iteration - 1) ? 1 : F;
-            n += nout * U + nout;
+            if (c->dec_type == 1) {
+                n += rnn_stack_floats(U, F, nout);
+            } else {
+                for (int l = 0; l < c->dec_num_layer; ++l) n += U * (l == 0 ? 2 + F : U) * 5 + U;
+                n += nout * U + nout;
+            }
         }
     return n;
 }
@@ -258,7 +318,53 @@ int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_
     return TAE_OK;
 }
 
+// DEC_LargeRNN.forward (decoders.py:84-149): per half-iteration rec(layer 0) -> proj -> rec(layer 1) -> head
+int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st) {
+    const int L = h->cfg.block_len, F = h->cfg.num_iter_ft, H = 100, n_iter = h->cfg.num_iteration;
+    for (int32_t c0 = 0; c0 < B; c0 += h->rnn_chunk) {
+        const int32_t Bc = (B - c0 < h->rnn_chunk) ? B - c0 : h->rnn_chunk;
+        const size_t np = (size_t)Bc * L;
+        TAE_HIP(tae::launch_gru_prep(rx + (size_t)c0 * L * 3, h->d_perm, h->d_gxa, h->d_gxb, Bc, L, st));
+        const float* w = h->d_wrnn;
+        for (int s = 0; s < 2 * n_iter; ++s) {
+            const bool odd = (s & 1) != 0, last = (s == 2 * n_iter - 1);
+            const int nout = last ? 1 : F;
+            const float* xin = odd ? h->d_gxb : h->d_gxa;
+            // layer 0: (w_ih, w_hh, b_ih, b_hh) for fwd then reverse are interleaved in the canonical order
+            const size_t cin0 = 2 + F, cin1 = 2 * H;
+            const size_t per0 = 3 * H * cin0 + 3 * H * H + 6 * H, per1 = 3 * H * cin1 + 3 * H * H + 6 * H;
+            // gather the two directions into the (2, ...) layout the kernels expect: they are strided by per0 / per1;
+            // the kernels index dir * rows * cols contiguously, so use the repacked copy made at create time
+            tae::GruRecParams R0;
+            memset(&R0, 0, sizeof(R0));
+            R0.x = xin; R0.gi = nullptr; R0.B = Bc; R0.L = L; R0.cin = (int)cin0; R0.y = h->d_gy0;
+            R0.w_ih = w; R0.w_hh = w + 2 * 3 * H * cin0; R0.b_ih = R0.w_hh + 2 * 3 * H * H; R0.b_hh = R0.b_ih + 2 * 3 * H;
+            TAE_HIP(tae::launch_gru_rec(true, R0, st));
+            const float* w1 = w + 2 * per0;
+            tae::GruProjParams PP;
+            PP.yin = h->d_gy0; PP.w_ih = w1; PP.b_ih = w1 + 2 * 3 * H * cin1 + 2 * 3 * H * H; PP.gi = h->d_ggi; PP.npos = np;
+            TAE_HIP(tae::launch_gru_proj(PP, st));
+            tae::GruRecParams R1;
+            memset(&R1, 0, sizeof(R1));
+            R1.x = nullptr; R1.gi = h->d_ggi; R1.B = Bc; R1.L = L; R1.cin = 0; R1.y = h->d_gy1;
+            R1.w_ih = nullptr; R1.w_hh = w1 + 2 * 3 * H * cin1; R1.b_ih = h->d_gzero; R1.b_hh = PP.b_ih + 2 * 3 * H;
+            TAE_HIP(tae::launch_gru_rec(false, R1, st));
+            const float* wl = w + 2 * per0 + 2 * per1;
+            tae::GruHeadParams HP;
+            memset(&HP, 0, sizeof(HP));
+            HP.y = h->d_gy1; HP.w = wl; HP.b = wl + (size_t)nout * 2 * H; HP.xcur = xin;
+            HP.xnext = odd ? h->d_gxa : h->d_gxb; HP.xdec = xdec + (size_t)c0 * L;
+            HP.ptab = odd ? h->d_perm : h->d_inv;     // dec1 -> interleave (row inv[t]); dec2 -> deinterleave (row p[i])
+            HP.npos = np; HP.L = L; HP.F = F; HP.nout = nout; HP.extrinsic = h->cfg.extrinsic; HP.last = last ? 1 : 0;
+            TAE_HIP(tae::launch_gru_head(HP, st));
+            w += 2 * per0 + 2 * per1 + ((size_t)nout * 2 * H + nout + 3) / 4 * 4;
+        }
+    }
+    return TAE_OK;
+}
+
 int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st) {
+    if (h->cfg.dec_type == 1) return run_decoder_rnn(h, rx, xdec, B, st);
     if (h->nb < 1) return run_decoder_long(h, rx, xdec, B, st);
     tae::FusedParams P = base_params(h, B);
     P.wpack = h->d_wdec;
@@ -325,11 +431,16 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     h->dec_bytes = (uint32_t)(pdec.size() * sizeof(float));
     const float* src = weights;
     for (int s = 0; s < 3; ++s) src += pack_stack(src, lo, cfg->enc_num_layer, 1, 1, penc.data() + (size_t)s * h->enc_stride);
-    for (int it = 0; it < cfg->num_iteration; ++it)
-        for (int half = 0; half < 2; ++half) {
-            const int nout = (half == 1 && it == cfg->num_iteration - 1) ? 1 : F;
-            src += pack_stack(src, lo, cfg->dec_num_layer, 2 + F, nout, pdec.data() + (size_t)(2 * it + half) * h->dec_stride);
-        }
+    const float* dec_src = src;
+    if (cfg->dec_type == 1) {
+        src = weights + n_weights;          // canonical GRU weights are uploaded unchanged below
+    } else {
+        for (int it = 0; it < cfg->num_iteration; ++it)
+            for (int half = 0; half < 2; ++half) {
+                const int nout = (half == 1 && it == cfg->num_iteration - 1) ? 1 : F;
+                src += pack_stack(src, lo, cfg->dec_num_layer, 2 + F, nout, pdec.data() + (size_t)(2 * it + half) * h->dec_stride);
+            }
+    }
     if ((size_t)(src - weights) != n_weights) {
         delete h;
         return fail(TAE_EINVAL, "internal: weight walk mismatch");
@@ -349,6 +460,16 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     TAE_HIP_H(hipMalloc(&h->d_stats, 4 * sizeof(double)));
     TAE_HIP_H(hipMemcpy(h->d_wenc, penc.data(), penc.size() * sizeof(float), hipMemcpyHostToDevice));
     TAE_HIP_H(hipMemcpy(h->d_wdec, pdec.data(), pdec.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (cfg->dec_type == 1) {
+        const size_t nrnn = (size_t)(weights + n_weights - dec_src);
+        (void)nrnn;
+        std::vector<float> prnn(rnn_packed_floats(100, (size_t)F, cfg->num_iteration), 0.0f);
+        repack_rnn(dec_src, prnn.data(), 100, (size_t)F, cfg->num_iteration);
+        TAE_HIP_H(hipMalloc(&h->d_wrnn, prnn.size() * sizeof(float)));
+        TAE_HIP_H(hipMemcpy(h->d_wrnn, prnn.data(), prnn.size() * sizeof(float), hipMemcpyHostToDevice));
+        TAE_HIP_H(hipMalloc(&h->d_gzero, 6 * 100 * sizeof(float)));
+        TAE_HIP_H(hipMemset(h->d_gzero, 0, 6 * 100 * sizeof(float)));
+    }
     TAE_HIP_H(hipMemcpy(h->d_perm, ident.data(), L * sizeof(int32_t), hipMemcpyHostToDevice));
     TAE_HIP_H(hipMemcpy(h->d_inv, ident.data(), L * sizeof(int32_t), hipMemcpyHostToDevice));
 #undef TAE_HIP_H
@@ -363,6 +484,8 @@ int tae_destroy(tae_handle* h) {
     (void)hipFree(h->d_wenc); (void)hipFree(h->d_wdec); (void)hipFree(h->d_perm); (void)hipFree(h->d_inv);
     (void)hipFree(h->d_xtx); (void)hipFree(h->d_rx); (void)hipFree(h->d_partials); (void)hipFree(h->d_stats);
     (void)hipFree(h->d_e0); (void)hipFree(h->d_e1);
+    (void)hipFree(h->d_wrnn); (void)hipFree(h->d_gxa); (void)hipFree(h->d_gxb); (void)hipFree(h->d_gy0); (void)hipFree(h->d_gy1);
+    (void)hipFree(h->d_ggi); (void)hipFree(h->d_gzero);
     delete h;
     return TAE_OK;
 }
@@ -384,6 +507,17 @@ int tae_reserve(tae_handle* h, int32_t max_batch) {
     TAE_HIP(hipMalloc(&h->d_xtx, n3 * sizeof(float)));
     TAE_HIP(hipMalloc(&h->d_rx, n3 * sizeof(float)));
     TAE_HIP(hipMalloc(&h->d_partials, grid * 2 * sizeof(double)));
+    if (h->cfg.dec_type == 1) {
+        (void)hipFree(h->d_gxa); (void)hipFree(h->d_gxb); (void)hipFree(h->d_gy0); (void)hipFree(h->d_gy1); (void)hipFree(h->d_ggi);
+        h->d_gxa = h->d_gxb = h->d_gy0 = h->d_gy1 = h->d_ggi = nullptr;
+        h->rnn_chunk = max_batch < 4096 ? max_batch : 4096;
+        const size_t np = (size_t)h->rnn_chunk * h->cfg.block_len;
+        TAE_HIP(hipMalloc(&h->d_gxa, np * 8 * sizeof(float)));
+        TAE_HIP(hipMalloc(&h->d_gxb, np * 8 * sizeof(float)));
+        TAE_HIP(hipMalloc(&h->d_gy0, np * 200 * sizeof(float)));
+        TAE_HIP(hipMalloc(&h->d_gy1, np * 200 * sizeof(float)));
+        TAE_HIP(hipMalloc(&h->d_ggi, np * 600 * sizeof(float)));
+    }
     h->cap = max_batch;
     return TAE_OK;
 }

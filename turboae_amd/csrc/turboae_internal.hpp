@@ -46,6 +46,41 @@ struct SegParams {
     int32_t lds_bytes;
 };
 
+// ---- GRU decoder (turboae_gru.hip)
+struct GruRecParams {
+    const float* x;       // layer 0: input panel (B,L,8)
+    const float* gi;      // layer 1: input projections (B,L,2,3H)
+    const float* w_ih;    // layer 0: (2,3H,cin)
+    const float* b_ih;    // (2,3H)  (layer 1: already folded into gi -> pass zeros)
+    const float* w_hh;    // (2,3H,H)
+    const float* b_hh;    // (2,3H)
+    float* y;             // (B,L,2H)
+    int32_t B, L, cin;
+};
+struct GruProjParams {
+    const float* yin;     // (npos, 2H)
+    const float* w_ih;    // (2,3H,2H)
+    const float* b_ih;    // (2,3H)
+    float* gi;            // (npos,2,3H)
+    size_t npos;
+};
+struct GruHeadParams {
+    const float* y;       // (npos, 2H)
+    const float* w;       // (nout, 2H)
+    const float* b;       // (nout)
+    const float* xcur;    // this stack's input panel (extrinsic subtraction)
+    float* xnext;         // the other panel (scatter target), or nullptr when last
+    float* xdec;          // last: (B,L,1)
+    const int32_t* ptab;  // inv (after dec1) or perm (after dec2)
+    size_t npos;
+    int32_t L, F, nout, extrinsic, last;
+};
+hipError_t launch_gru_prep(const float* rx, const int32_t* perm, float* XA, float* XB, int B, int L, hipStream_t st);
+hipError_t launch_gru_rec(bool layer0, const GruRecParams& P, hipStream_t st);
+hipError_t launch_gru_proj(const GruProjParams& P, hipStream_t st);
+hipError_t launch_gru_head(const GruHeadParams& P, hipStream_t st);
+int gru_max_rec_block_len();
+
 hipError_t launch_seg(int U, const SegParams& P, int grid, hipStream_t st);
 int seg_lds_bytes(int U, int T, int n_layer);
 hipError_t launch_fused(int U, bool decoder, const FusedParams& P, int grid, hipStream_t st);

@@ -33,15 +33,28 @@ def canonical_entries(cfg: TurboAEConfig) -> List[Tuple[str, Tuple[int, ...]]]:
             out.append((f"enc.enc_cnn_{s}.cnns.{l}.bias", (ue,)))
         out.append((f"enc.enc_linear_{s}.weight", (1, ue)))
         out.append((f"enc.enc_linear_{s}.bias", (1,)))
+    rnn = cfg.decoder == "TurboAE_rate3_rnn"
     for it in range(cfg.num_iteration):
         for half in (1, 2):
-            for l in range(cfg.dec_num_layer):
-                cin = 2 + f if l == 0 else ud
-                out.append((f"dec.dec{half}_cnns.{it}.cnns.{l}.weight", (ud, cin, kd)))
-                out.append((f"dec.dec{half}_cnns.{it}.cnns.{l}.bias", (ud,)))
             nout = 1 if (half == 2 and it == cfg.num_iteration - 1) else f
-            out.append((f"dec.dec{half}_outputs.{it}.weight", (nout, ud)))
-            out.append((f"dec.dec{half}_outputs.{it}.bias", (nout,)))
+            if rnn:
+                # torch.nn.GRU(2+F, ud, num_layers=2, bidirectional=True) parameter names (decoders.py:41-49)
+                for l in (0, 1):
+                    cin = 2 + f if l == 0 else 2 * ud
+                    for sfx in ("", "_reverse"):
+                        out.append((f"dec.dec{half}_rnns.{it}.weight_ih_l{l}{sfx}", (3 * ud, cin)))
+                        out.append((f"dec.dec{half}_rnns.{it}.weight_hh_l{l}{sfx}", (3 * ud, ud)))
+                        out.append((f"dec.dec{half}_rnns.{it}.bias_ih_l{l}{sfx}", (3 * ud,)))
+                        out.append((f"dec.dec{half}_rnns.{it}.bias_hh_l{l}{sfx}", (3 * ud,)))
+                out.append((f"dec.dec{half}_outputs.{it}.weight", (nout, 2 * ud)))
+                out.append((f"dec.dec{half}_outputs.{it}.bias", (nout,)))
+            else:
+                for l in range(cfg.dec_num_layer):
+                    cin = 2 + f if l == 0 else ud
+                    out.append((f"dec.dec{half}_cnns.{it}.cnns.{l}.weight", (ud, cin, kd)))
+                    out.append((f"dec.dec{half}_cnns.{it}.cnns.{l}.bias", (ud,)))
+                out.append((f"dec.dec{half}_outputs.{it}.weight", (nout, ud)))
+                out.append((f"dec.dec{half}_outputs.{it}.bias", (nout,)))
     return out
 
 
@@ -61,7 +74,7 @@ def add_module(state_dict: Dict[str, object]) -> Dict[str, object]:
     """Inverse of :func:`strip_module`: keys as the reference produces with ``-is_parallel 1``."""
     out = {}
     for k, v in state_dict.items():
-        k2 = re.sub(r"^(enc\.enc_cnn_\d|enc\.enc_linear_\d|dec\.dec\d_cnns\.\d+|dec\.dec\d_outputs\.\d+)\.",
+        k2 = re.sub(r"^(enc\.enc_cnn_\d|enc\.enc_linear_\d|dec\.dec\d_cnns\.\d+|dec\.dec\d_rnns\.\d+|dec\.dec\d_outputs\.\d+)\.",
                     r"\1.module.", k)
         out[k2] = v
     return out
@@ -126,7 +139,7 @@ def generate_state_dict(cfg: TurboAEConfig, seed: int = 20190001, gain: float = 
         n = int(np.prod(shape))
         u = philox.random_uniform_pm1(seed, off, n, philox.STREAM_WEIGHTS)
         off += n
-        if key.endswith(".weight"):
+        if key.rsplit(".", 1)[-1].startswith("weight"):     # "...weight", "weight_ih_l0", "weight_hh_l1_reverse", ...
             fan_in = int(np.prod(shape[1:]))
             bound = gain * np.sqrt(3.0 / fan_in)
         else:
