@@ -30,7 +30,8 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kGruH = 100;          // hidden units per direction (dec_num_unit)
 constexpr int kGruRows = 3 * kGruH; // gate rows per direction
-constexpr int kGruThreads = 320;    // 5 waves: 300 gate rows + 20 idle lanes
+constexpr int kGruThreads = 300;    // one thread per gate row (5 waves, the last one partially filled): no per-row predicates,
+                                    // which would let the compiler sink the FMAs below the LDS reads and spill all of h
 constexpr int kGruNBK = 8;          // blocks per workgroup in gru_rec
 constexpr int kGruPT = 32;          // positions per workgroup in gru_proj
 constexpr int kXWg = 8;             // floats per row of the XA / XB panels
@@ -64,15 +65,14 @@ __global__ __launch_bounds__(kGruThreads) void gru_rec_kernel(GruRecParams P) {
     constexpr int H = kGruH, NBK = kGruNBK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* hbuf = reinterpret_cast<float*>(smem);            // [NBK][H]
-    float* gates = hbuf + NBK * H;                           // [NBK][4][H]: r, z, n_i, n_h
-    float* xs = gates + NBK * 4 * H;                         // LAYER0: [NBK][L][8]
+    float* gates = hbuf + NBK * H;                           // [NBK][5][H]: r, z, n_i, n_h, (unused)
+    float* xs = gates + NBK * 5 * H;                         // LAYER0: [NBK][L][8]
     const int tid = threadIdx.x, j = tid;
     const int dir = blockIdx.y;
     const int L = P.L;
     const int b0 = blockIdx.x * NBK;
     const int nblk = min(NBK, P.B - b0);
-    const bool row = j < kGruRows;
-    const int jj = row ? j : 0;
+    const int jj = j;
 
     // this thread's recurrent weights stay in registers for the whole sequence
     float wh[H];
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kGruThreads) void gru_rec_kernel(GruRecParams P) {
                 a = fmaf(wi[4], x1.x, a); a = fmaf(wi[5], x1.y, a); a = fmaf(wi[6], x1.z, a); a = fmaf(wi[7], x1.w, a);
                 gi[b] = a;
             } else {
-                gi[b] = (row && b < nblk) ? GI[((size_t)b * L + t) * 2 * kGruRows] : 0.0f;
+                gi[b] = (b < nblk) ? GI[((size_t)b * L + t) * 2 * kGruRows] : 0.0f;
             }
             gh[b] = bh;
         }
@@ -128,19 +128,23 @@ __global__ __launch_bounds__(kGruThreads) void gru_rec_kernel(GruRecParams P) {
                 a = fmaf(wh[k], hv.x, a); a = fmaf(wh[k + 1], hv.y, a); a = fmaf(wh[k + 2], hv.z, a); a = fmaf(wh[k + 3], hv.w, a);
                 gh[b] = a;
             }
+            // keep the scheduler from hoisting all NBK*H broadcast reads above the FMAs (it spills otherwise)
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (row) {
+        // branch-free stores (a per-thread `if (gate < 2)` lets the compiler sink the FMA chains below all
+        // the LDS reads, which then spill): slot = gate holds sigmoid(pre) for r/z and gi for n; the n rows
+        // park gh in slot 3, the r/z rows in the unused slot 4
 #pragma unroll
-            for (int b = 0; b < NBK; ++b) {
-                if (gate < 2) gates[(b * 4 + gate) * H + u] = sigmoidf_(gi[b] + gh[b]);
-                else { gates[(b * 4 + 2) * H + u] = gi[b]; gates[(b * 4 + 3) * H + u] = gh[b]; }
-            }
+        for (int b = 0; b < NBK; ++b) {
+            const float sg = sigmoidf_(gi[b] + gh[b]);
+            gates[(b * 5 + gate) * H + u] = gate < 2 ? sg : gi[b];
+            gates[(b * 5 + (gate < 2 ? 4 : 3)) * H + u] = gh[b];
         }
         __syncthreads();
         for (int e = tid; e < nblk * H; e += kGruThreads) {
             const int b = e / H, uu = e - b * H;
-            const float r = gates[(b * 4 + 0) * H + uu], z = gates[(b * 4 + 1) * H + uu];
-            const float n = tanhf(gates[(b * 4 + 2) * H + uu] + r * gates[(b * 4 + 3) * H + uu]);
+            const float r = gates[(b * 5 + 0) * H + uu], z = gates[(b * 5 + 1) * H + uu];
+            const float n = tanhf(gates[(b * 5 + 2) * H + uu] + r * gates[(b * 5 + 3) * H + uu]);
             const float hn = (1.0f - z) * n + z * hbuf[b * H + uu];
             hbuf[b * H + uu] = hn;
             Y[((size_t)b * L + t) * 2 * H + uu] = hn;
@@ -155,8 +159,7 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_proj_kernel(GruProjParams 
     __shared__ __attribute__((aligned(16))) float ys[PT * K];
     const int tid = threadIdx.x;
     const int dir = blockIdx.y;
-    const bool row = tid < kGruRows;
-    const int jj = row ? tid : 0;
+    const int jj = tid;
     float w[K];
     {
         const float* wp = P.w_ih + ((size_t)dir * kGruRows + jj) * K;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_proj_kernel(GruProjParams 
             const f32x4 yv = *reinterpret_cast<const f32x4*>(ys + p * K + k);
             a = fmaf(w[k], yv.x, a); a = fmaf(w[k + 1], yv.y, a); a = fmaf(w[k + 2], yv.z, a); a = fmaf(w[k + 3], yv.w, a);
         }
-        if (row) P.gi[((p0 + p) * 2 + dir) * kGruRows + jj] = a;
+        P.gi[((p0 + p) * 2 + dir) * kGruRows + jj] = a;
     }
 }
 
@@ -228,7 +231,7 @@ hipError_t launch_gru_prep(const float* rx, const int32_t* perm, float* XA, floa
 }
 
 int gru_rec_lds_bytes(int L, bool layer0) {
-    size_t b = (size_t)kGruNBK * kGruH * 4 + (size_t)kGruNBK * 4 * kGruH * 4;
+    size_t b = (size_t)kGruNBK * kGruH * 4 + (size_t)kGruNBK * 5 * kGruH * 4;
     if (layer0) b += (size_t)kGruNBK * L * kXWg * 4;
     return (int)((b + 15) & ~(size_t)15);
 }
@@ -258,6 +261,6 @@ hipError_t launch_gru_head(const GruHeadParams& P, hipStream_t st) {
     return hipGetLastError();
 }
 
-int gru_max_rec_block_len() { return (160 * 1024 - kGruNBK * 5 * kGruH * 4) / (kGruNBK * kXWg * 4); }
+int gru_max_rec_block_len() { return (160 * 1024 - kGruNBK * 6 * kGruH * 4) / (kGruNBK * kXWg * 4); }
 
 }  // namespace tae
