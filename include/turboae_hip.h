@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAE_ABI_VERSION 2
+#define TAE_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define TAE_API __attribute__((visibility("default")))
@@ -64,6 +64,24 @@ typedef struct tae_config {
                                  1 = TurboAE_rate3_rnn (DEC_LargeRNN with dec_rnn=gru, decoders.py:16; needs dec_num_unit=100)  main.py:75-88 */
 } tae_config;
 
+/* Encoder-output / channel variants of the same kernels (reference flags in parentheses).  Defaults
+ * (all zero except the limits) are the reference defaults: batch power normalisation, AWGN add. */
+typedef struct tae_channel_opts {
+    int32_t struct_size;          /* = sizeof(tae_channel_opts) */
+    int32_t norm_mode;            /* 0: batch mean/std (encoders.py:107-116); 1: none (--no_code_norm, :104-105);
+                                     2: fixed mean/std below (--precompute_norm_stats, :110-114 - the caller keeps the running averages) */
+    float   mean, std;            /* norm_mode 2 */
+    int32_t ste;                  /* 1: -train_channel_mode block_norm_ste: STEQuantize.forward on the normalised codes (encoders.py:20-36,118-120) */
+    float   enc_value_limit;      /* -enc_value_limit (get_args.py:168) */
+    float   enc_quantize_level;   /* -enc_quantize_level (get_args.py:167); 2 = sign */
+    float   enc_truncate_limit;   /* -enc_truncate_limit > 0: clamp (encoders.py:122-123) */
+    int32_t channel;              /* 0: received = codes + noise (awgn, t-dist, radar, ge_awgn; channel_ae.py:41-42);
+                                     1: codes * noise (bec, :44-45); 2: codes * (2*noise - 1) (bsc, ge; :47-49) */
+    int32_t rec_quantize;         /* 1: --rec_quantize: STEQuantize.forward(received, limit, level) (channel_ae.py:67-69, ste.py:9-23) */
+    float   rec_quantize_limit;   /* the reference passes rec_quantize_level as the limit too (channel_ae.py:69) */
+    float   rec_quantize_level;
+} tae_channel_opts;
+
 typedef struct tae_handle tae_handle;
 
 /* Number of fp32 values tae_create expects in `weights` for this configuration (canonical order:
@@ -85,6 +103,10 @@ TAE_API int tae_reserve(tae_handle* h, int32_t max_batch);
  * decoders.py:202-204).  `p` is a HOST array with p[i] in [0,L), a permutation; L must equal
  * block_len.  out[:, i, :] = in[:, p[i], :] (interleavers.py:15-21). */
 TAE_API int tae_set_interleaver(tae_handle* h, const int32_t* p, int32_t L);
+
+/* Selects the encoder-output / channel variant used by tae_forward, tae_encode and tae_normalize from now on
+ * (NULL restores the defaults).  Replaces reading args.* inside power_constraint / Channel_AE.forward. */
+TAE_API int tae_set_channel_opts(tae_handle* h, const tae_channel_opts* opts);
 
 /* Replaces Channel_AE.forward (channel_ae.py:20-73, AWGN branch :41-42):
  *   codes = enc(u) ; received = codes + noise ; x_dec = dec(received).

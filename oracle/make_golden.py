@@ -43,30 +43,52 @@ CASES = [
     # BASELINE configs[4]: DeepTurbo GRU decoder (DEC_LargeRNN) behind the CNN encoder
     ("fwd_rnn_u100_L100_b4", dict(decoder="TurboAE_rate3_rnn"), 4, 14, 1.0, 2.0),
     ("fwd_rnn_u100_L40_b3_it2_ft3", dict(decoder="TurboAE_rate3_rnn", block_len=40, num_iteration=2, num_iter_ft=3), 3, 15, 1.0, 1.0),
+    # encoder-output / channel variants on the same kernels; small nets keep them cheap
+    ("var_ste2_bsc", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, train_channel_mode="block_norm_ste", channel="bsc"), 5, 16, 1.0, 0.1),
+    ("var_ste4_trunc_recq", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, train_channel_mode="block_norm_ste",
+                                 enc_quantize_level=4.0, enc_value_limit=1.5, enc_truncate_limit=1.2, rec_quantize=True,
+                                 rec_quantize_level=4), 5, 17, 1.0, 2.0),
+    ("var_nonorm_bec", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, no_code_norm=True, channel="bec"), 5, 18, 1.0, 0.2),
+    ("var_precomp_trunc", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, precompute_norm_stats=True,
+                               enc_truncate_limit=1.5), 5, 19, 1.0, 2.0),
 ]
 
 
-def make_inputs(B, L, snr_db, seed):
-    u = philox.random_bits(seed, 0, B * L).reshape(B, L, 1)
-    noise = (np.float32(O.snr_db2sigma(snr_db)) * philox.random_normal(seed, 0, B * L * 3)).reshape(B, L, 3).astype(np.float32)
+def make_inputs(B, L, snr_db, seed, channel="awgn", offset=0):
+    """bits + channel 'noise': Gaussian for the additive channels; for bec / bsc the 0/1 keep-mask of
+    channels.py:48-54 with erase / flip probability `snr_db` (reused as the channel parameter)."""
+    u = philox.random_bits(seed, offset * L, B * L).reshape(B, L, 1)
+    if channel in ("bec", "bsc", "ge"):
+        w = philox.random_u32(seed, philox.STREAM_NOISE, offset * L * 3, B * L * 3).astype(np.float64) / 2.0 ** 32
+        noise = (w >= snr_db).astype(np.float32).reshape(B, L, 3)
+    else:
+        noise = (np.float32(O.snr_db2sigma(snr_db)) * philox.random_normal(seed, offset * L * 3, B * L * 3)).reshape(B, L, 3).astype(np.float32)
     return u, noise
 
 
 def run_case(name, over, B, wseed, gain, snr_db, manifest):
     cfg = TurboAEConfig(**over)
     sd = W.generate_state_dict(cfg, seed=wseed, gain=gain)
-    u, noise = make_inputs(B, cfg.block_len, snr_db, seed=100 + wseed)
+    u, noise = make_inputs(B, cfg.block_len, snr_db, seed=100 + wseed, channel=cfg.channel)
     model, _ = R.build_reference_model(cfg.to_dict(), B)
     R.load_weights(model, sd)
     x_ref, c_ref = R.reference_forward(model, u, noise)
-    taps = {}
-    x_or, c_or = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict(), taps)
+    taps, state = {}, {}
+    x_or, c_or = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict(), taps, state)
     dx = float(np.abs(x_ref - x_or.numpy()).max())
     dc = float(np.abs(c_ref - c_or.numpy()).max())
     assert dc <= 2e-6 and dx <= 5e-6, (name, dc, dx)
+    extra = {}
+    if cfg.precompute_norm_stats:
+        # running statistics: a second call on a different batch must use the averaged mean / std (encoders.py:110-114)
+        u2, noise2 = make_inputs(B, cfg.block_len, snr_db, seed=100 + wseed, channel=cfg.channel, offset=B)
+        x2_ref, c2_ref = R.reference_forward(model, u2, noise2)
+        x2_or, c2_or = O.channel_ae_forward(torch.from_numpy(u2), torch.from_numpy(noise2), O.to_torch(sd), cfg.to_dict(), None, state)
+        assert np.abs(c2_ref - c2_or.numpy()).max() <= 2e-6 and np.abs(x2_ref - x2_or.numpy()).max() <= 5e-6
+        extra = dict(u2=u2, noise2=noise2, x_dec2=x2_ref, codes2=c2_ref)
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), u=u, noise=noise, x_dec=x_ref, codes=c_ref,
                         logits=taps["logits"].numpy(), x_tx=taps["x_tx"].numpy(),
-                        mean=taps["mean"].numpy(), std=taps["std"].numpy())
+                        mean=taps["mean"].numpy(), std=taps["std"].numpy(), **extra)
     manifest["cases"][name] = {"config": cfg.to_dict(), "B": B, "weight_seed": wseed, "gain": gain, "snr_db": snr_db,
                                "input_seed": 100 + wseed, "oracle_vs_reference_max_abs": {"x_dec": dx, "codes": dc},
                                "ber_reference": O.errors_ber(torch.from_numpy(u), torch.from_numpy(x_ref))}

@@ -47,7 +47,18 @@ def build_reference_model(cfg: dict, batch_size: int, is_parallel: int = 1):
             "-num_iteration", str(cfg["num_iteration"]), "-num_iter_ft", str(cfg["num_iter_ft"]),
             "-extrinsic", str(cfg.get("extrinsic", 1)), "-enc_act", cfg.get("enc_act", "elu"),
             "-is_parallel", str(is_parallel), "-batch_size", str(batch_size),
-            "-block_len", str(cfg["block_len"]), "--no-cuda"]
+            "-block_len", str(cfg["block_len"]), "--no-cuda",
+            "-channel", cfg.get("channel", "awgn"), "-train_channel_mode", cfg.get("train_channel_mode", "block_norm"),
+            "-enc_truncate_limit", str(cfg.get("enc_truncate_limit", 0.0)),
+            "-enc_value_limit", str(cfg.get("enc_value_limit", 1.0)),
+            "-enc_quantize_level", str(cfg.get("enc_quantize_level", 2.0)),
+            "-rec_quantize_level", str(cfg.get("rec_quantize_level", 2))]
+    if cfg.get("no_code_norm", False):
+        argv.append("--no_code_norm")
+    if cfg.get("precompute_norm_stats", False):
+        argv.append("--precompute_norm_stats")
+    if cfg.get("rec_quantize", False):
+        argv.append("--rec_quantize")
     old = sys.argv
     sys.argv = argv
     try:

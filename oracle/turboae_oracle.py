@@ -55,12 +55,51 @@ def same_shape_conv1d(x: torch.Tensor, w: Dict[str, torch.Tensor], prefix: str, 
     return h.transpose(1, 2)
 
 
-# encoders.py:102-125 (power_constraint, block_norm branch): (x - mean(x)) * 1.0 / std(x), mean and
-# unbiased std over ALL B*L*3 elements.
-def power_constraint(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+# encoders.py:20-36 / ste.py:9-23 (STEQuantize.forward): clamp to +-limit then sign (level 2) or a uniform grid
+def ste_quantize(x: torch.Tensor, limit: float, level: float) -> torch.Tensor:
+    rng = 2.0 * limit
+    c = torch.clamp(x, -limit, limit)
+    if level == 2:
+        return torch.sign(c)
+    return torch.round((c + limit) * ((level - 1.0) / rng)) * rng / (level - 1.0) - limit
+
+
+# encoders.py:102-125 (power_constraint): (x - mean(x)) * 1.0 / std(x), mean and unbiased std over ALL B*L*3
+# elements; variants --no_code_norm (:104-105), --precompute_norm_stats (:110-114, `state` carries the running
+# mean_scalar / std_scalar / num_test_block), block_norm_ste (:118-120), enc_truncate_limit (:122-123).
+def power_constraint(x: torch.Tensor, cfg: Optional[dict] = None, state: Optional[dict] = None):
+    cfg = cfg or {}
     mean = torch.mean(x)
     std = torch.std(x)
-    return (x - mean) * 1.0 / std, mean, std
+    if cfg.get("no_code_norm", False):
+        return x, mean, std
+    if cfg.get("precompute_norm_stats", False):
+        state["num_test_block"] = state.get("num_test_block", 0.0) + 1.0
+        n = state["num_test_block"]
+        state["mean_scalar"] = (state.get("mean_scalar", torch.zeros(1)) * (n - 1) + mean) / n
+        state["std_scalar"] = (state.get("std_scalar", torch.ones(1)) * (n - 1) + std) / n
+        y = (x - state["mean_scalar"]) / state["std_scalar"]
+    else:
+        y = (x - mean) * 1.0 / std
+    if cfg.get("train_channel_mode", "block_norm") == "block_norm_ste":
+        y = ste_quantize(y, cfg.get("enc_value_limit", 1.0), cfg.get("enc_quantize_level", 2.0))
+    if cfg.get("enc_truncate_limit", 0.0) > 0:
+        y = torch.clamp(y, -cfg["enc_truncate_limit"], cfg["enc_truncate_limit"])
+    return y, mean, std
+
+
+# channel_ae.py:41-49,67-69: the channel applied to the codes and the optional receive quantiser
+def apply_channel(codes: torch.Tensor, fwd_noise: torch.Tensor, cfg: dict) -> torch.Tensor:
+    ch = cfg.get("channel", "awgn")
+    if ch == "bec":
+        rx = codes * fwd_noise
+    elif ch in ("bsc", "ge"):
+        rx = codes * (2.0 * fwd_noise - 1.0)
+    else:
+        rx = codes + fwd_noise
+    if cfg.get("rec_quantize", False):
+        rx = ste_quantize(rx, cfg.get("rec_quantize_level", 2), cfg.get("rec_quantize_level", 2))
+    return rx
 
 
 def _enc_act(x: torch.Tensor, enc_act: str) -> torch.Tensor:
@@ -85,8 +124,8 @@ def encode_prenorm(u: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor,
     return torch.cat([b1, b2, b3], dim=2)
 
 
-def encode(u, w, p, enc_num_layer, enc_act="elu"):
-    codes, _, _ = power_constraint(encode_prenorm(u, w, p, enc_num_layer, enc_act))
+def encode(u, w, p, enc_num_layer, enc_act="elu", cfg=None, state=None):
+    codes, _, _ = power_constraint(encode_prenorm(u, w, p, enc_num_layer, enc_act), cfg, state)
     return codes
 
 
@@ -174,16 +213,17 @@ def decode_rnn(received: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tens
 
 # channel_ae.py:20-73 (Channel_AE.forward), AWGN branch (:41-42), rec_quantize off.
 def channel_ae_forward(u: torch.Tensor, fwd_noise: torch.Tensor, w: Dict[str, torch.Tensor], cfg: dict,
-                       taps: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """cfg keys: block_len, enc_num_layer, dec_num_layer, num_iteration, num_iter_ft, extrinsic, enc_act."""
+                       taps: Optional[dict] = None, state: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cfg keys: block_len, enc_num_layer, dec_num_layer, num_iteration, num_iter_ft, extrinsic, enc_act (+ the
+    variant flags of power_constraint / apply_channel).  `state` = running norm statistics across calls."""
     with torch.no_grad():
         if cfg.get("p_array") is not None:      # enc/dec.set_interleaver(p) (channel_ae.py:35-36)
             p = torch.from_numpy(np.asarray(cfg["p_array"], dtype=np.int64))
         else:
             p = torch.from_numpy(rand_interleaver(u.shape[1], cfg.get("interleaver_seed", 0)))
         x_tx = encode_prenorm(u, w, p, cfg["enc_num_layer"], cfg.get("enc_act", "elu"))
-        codes, mean, std = power_constraint(x_tx)
-        received = codes + fwd_noise
+        codes, mean, std = power_constraint(x_tx, cfg, state if state is not None else {})
+        received = apply_channel(codes, fwd_noise, cfg)
         if cfg.get("decoder", "TurboAE_rate3_cnn") == "TurboAE_rate3_rnn":
             x_dec = decode_rnn(received, w, p, cfg["dec_num_unit"], cfg["num_iteration"], cfg["num_iter_ft"],
                                cfg.get("extrinsic", 1), taps)

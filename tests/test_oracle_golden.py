@@ -24,14 +24,18 @@ def test_oracle_matches_reference_fixture(name):
     cfg = TurboAEConfig(**meta["config"])
     sd = W.generate_state_dict(cfg, seed=meta["weight_seed"], gain=meta["gain"])
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    taps = {}
-    x, c = O.channel_ae_forward(torch.from_numpy(g["u"]), torch.from_numpy(g["noise"]), O.to_torch(sd), cfg.to_dict(), taps)
+    taps, state = {}, {}
+    x, c = O.channel_ae_forward(torch.from_numpy(g["u"]), torch.from_numpy(g["noise"]), O.to_torch(sd), cfg.to_dict(), taps, state)
     # the reference itself is not bit-deterministic across thread counts: <= 5e-7 / 6e-8
     assert np.abs(c.numpy() - g["codes"]).max() <= 2e-6
     assert np.abs(x.numpy() - g["x_dec"]).max() <= 5e-6
     assert np.abs(taps["x_tx"].numpy() - g["x_tx"]).max() <= 2e-6
     assert abs(float(taps["mean"]) - float(g["mean"])) <= 1e-6
     assert abs(float(taps["std"]) - float(g["std"])) <= 1e-6
+    if "u2" in g.files:      # --precompute_norm_stats: the second call uses the running averages
+        x2, c2 = O.channel_ae_forward(torch.from_numpy(g["u2"]), torch.from_numpy(g["noise2"]), O.to_torch(sd), cfg.to_dict(), None, state)
+        assert np.abs(c2.numpy() - g["codes2"]).max() <= 2e-6
+        assert np.abs(x2.numpy() - g["x_dec2"]).max() <= 5e-6
 
 
 @pytest.mark.parametrize("L", [40, 64, 100, 150, 1000])

@@ -12,7 +12,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TAE_LIB", os.path.join(_HERE, "lib", "libturboae_hip.so"))   # TAE_LIB: kernel-variant experiments
 
-TAE_ABI_VERSION = 2
+TAE_ABI_VERSION = 3
 
 
 class TaeConfig(C.Structure):
@@ -20,6 +20,13 @@ class TaeConfig(C.Structure):
         "struct_size", "block_len", "enc_num_layer", "enc_num_unit", "enc_kernel_size",
         "dec_num_layer", "dec_num_unit", "dec_kernel_size", "num_iteration", "num_iter_ft",
         "extrinsic", "enc_act", "max_batch", "dec_type")]
+
+
+class TaeChannelOpts(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("norm_mode", C.c_int32), ("mean", C.c_float), ("std", C.c_float),
+                ("ste", C.c_int32), ("enc_value_limit", C.c_float), ("enc_quantize_level", C.c_float),
+                ("enc_truncate_limit", C.c_float), ("channel", C.c_int32), ("rec_quantize", C.c_int32),
+                ("rec_quantize_limit", C.c_float), ("rec_quantize_level", C.c_float)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/turboae_hip.h
@@ -32,6 +39,7 @@ SIGNATURES = {
     "tae_destroy": (C.c_int, [_P]),
     "tae_reserve": (C.c_int, [_P, C.c_int32]),
     "tae_set_interleaver": (C.c_int, [_P, _P, C.c_int32]),
+    "tae_set_channel_opts": (C.c_int, [_P, C.POINTER(TaeChannelOpts)]),
     "tae_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, _P]),
     "tae_encode": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "tae_encode_prenorm": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P]),

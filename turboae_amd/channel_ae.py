@@ -71,6 +71,39 @@ class _Engine:
         self.cap = max_batch
         self.p_array: Optional[np.ndarray] = None
         self.set_interleaver(rand_interleaver(cfg.block_len, cfg.interleaver_seed))
+        self.reset_precomp()
+        self.apply_channel_opts()
+
+    # -- encoder-output / channel variants -------------------------------------------------------
+    def reset_precomp(self) -> None:               # ENCBase.reset_precomp, encoders.py:84-87
+        self.mean_scalar, self.std_scalar, self.num_test_block = 0.0, 1.0, 0.0
+
+    def apply_channel_opts(self, fixed: Optional[Tuple[float, float]] = None) -> None:
+        cfg = self.cfg
+        o = _lib.TaeChannelOpts()
+        o.struct_size = C.sizeof(_lib.TaeChannelOpts)
+        o.norm_mode = 1 if cfg.no_code_norm else (2 if fixed is not None else 0)
+        o.mean, o.std = (fixed if fixed is not None else (0.0, 1.0))
+        o.ste = 1 if cfg.train_channel_mode == "block_norm_ste" else 0
+        o.enc_value_limit, o.enc_quantize_level = cfg.enc_value_limit, cfg.enc_quantize_level
+        o.enc_truncate_limit = cfg.enc_truncate_limit
+        o.channel = {"bec": 1, "bsc": 2, "ge": 2}.get(cfg.channel, 0)
+        o.rec_quantize = 1 if cfg.rec_quantize else 0
+        # channel_ae.py:69 passes rec_quantize_level for BOTH the limit and the level
+        o.rec_quantize_limit = float(cfg.rec_quantize_level)
+        o.rec_quantize_level = float(cfg.rec_quantize_level)
+        _lib.check(self.lib.tae_set_channel_opts(self.h, C.byref(o)))
+
+    def update_precomp(self, stats: torch.Tensor) -> None:
+        """--precompute_norm_stats (encoders.py:110-114): running averages of the per-call mean / std."""
+        from .distributed import mean_std_from_stats
+        this_mean, this_std = mean_std_from_stats(stats)
+        f32 = np.float32
+        self.num_test_block += 1.0
+        n = f32(self.num_test_block)
+        self.mean_scalar = float((f32(self.mean_scalar) * (n - f32(1.0)) + f32(this_mean)) / n)
+        self.std_scalar = float((f32(self.std_scalar) * (n - f32(1.0)) + f32(this_std)) / n)
+        self.apply_channel_opts(fixed=(self.mean_scalar, self.std_scalar))
 
     def close(self) -> None:
         if getattr(self, "h", None) is not None and self.h:
@@ -134,7 +167,14 @@ class _EncView:
         e.reserve(B)
         codes = e._out(B, 3)
         with torch.cuda.device(e.device):
-            _lib.check(e.lib.tae_encode(e.h, _ptr(u), _ptr(codes), B, _stream()))
+            if e.cfg.precompute_norm_stats and not e.cfg.no_code_norm:
+                x_tx = e._out(B, 3)
+                stats = torch.empty(3, dtype=torch.float64, device=e.device)
+                _lib.check(e.lib.tae_encode_prenorm(e.h, _ptr(u), _ptr(x_tx), _ptr(stats), B, _stream()))
+                e.update_precomp(stats)
+                _lib.check(e.lib.tae_normalize(e.h, _ptr(x_tx), _ptr(stats), None, _ptr(codes), None, B, _stream()))
+            else:
+                _lib.check(e.lib.tae_encode(e.h, _ptr(u), _ptr(codes), B, _stream()))
         return codes
 
     forward = __call__
@@ -196,6 +236,7 @@ class Channel_AE_HIP:
         old = self._eng
         self._eng = _Engine(self.cfg, state_dict, old.device, old.cap)
         self._eng.set_interleaver(old.p_array)
+        self._eng.mean_scalar, self._eng.std_scalar, self._eng.num_test_block = old.mean_scalar, old.std_scalar, old.num_test_block
         self.enc._e = self._eng
         self.dec._e = self._eng
         old.close()
@@ -216,7 +257,15 @@ class Channel_AE_HIP:
         e.reserve(B)
         x_dec, codes = e._out(B, 1), e._out(B, 3)
         with torch.cuda.device(e.device):
-            _lib.check(e.lib.tae_forward(e.h, _ptr(u), _ptr(noise), _ptr(x_dec), _ptr(codes), B, _stream()))
+            if e.cfg.precompute_norm_stats and not e.cfg.no_code_norm:
+                x_tx, rx = e._out(B, 3), e._out(B, 3)
+                stats = torch.empty(3, dtype=torch.float64, device=e.device)
+                _lib.check(e.lib.tae_encode_prenorm(e.h, _ptr(u), _ptr(x_tx), _ptr(stats), B, _stream()))
+                e.update_precomp(stats)
+                _lib.check(e.lib.tae_normalize(e.h, _ptr(x_tx), _ptr(stats), _ptr(noise), _ptr(codes), _ptr(rx), B, _stream()))
+                _lib.check(e.lib.tae_decode(e.h, _ptr(rx), _ptr(x_dec), B, _stream()))
+            else:
+                _lib.check(e.lib.tae_forward(e.h, _ptr(u), _ptr(noise), _ptr(x_dec), _ptr(codes), B, _stream()))
         return x_dec, codes
 
     __call__ = forward

@@ -27,6 +27,16 @@ class TurboAEConfig:
     decoder: str = "TurboAE_rate3_cnn"   # get_args.py:26 / main.py:75-76,87-88: 'TurboAE_rate3_cnn' (DEC_LargeCNN) or
                                          # 'TurboAE_rate3_rnn' (DEC_LargeRNN, 2-layer bidirectional GRU, dec_rnn='gru')
     interleaver_seed: int = 0     # channel_ae.py:33 (RandInterlv(block_len, 0))
+    # ---- encoder-output / channel variants on the same kernels
+    channel: str = "awgn"                 # get_args.py:43; channel_ae.py:41-49 ('fading' draws its own RNG: not supported)
+    no_code_norm: bool = False            # get_args.py:159; encoders.py:104-105
+    precompute_norm_stats: bool = False   # get_args.py:218; encoders.py:110-114 (running mean/std over calls)
+    train_channel_mode: str = "block_norm"   # get_args.py:135; 'block_norm_ste' quantises the codes (encoders.py:118-120)
+    enc_truncate_limit: float = 0.0       # get_args.py:138; encoders.py:122-123
+    enc_value_limit: float = 1.0          # get_args.py:168
+    enc_quantize_level: float = 2.0       # get_args.py:167
+    rec_quantize: bool = False            # get_args.py:205; channel_ae.py:67-69
+    rec_quantize_level: int = 2           # get_args.py:207 (the reference also passes it as the clamp limit)
 
     def validate(self) -> None:
         if self.code_rate_k != 1 or self.code_rate_n != 3:
@@ -45,6 +55,8 @@ class TurboAEConfig:
             raise ValueError("layer / iteration counts must be >= 1")
         if self.block_len < 1:
             raise ValueError("block_len must be >= 1")
+        if self.channel not in ("awgn", "t-dist", "radar", "ge_awgn", "bec", "bsc", "ge"):
+            raise ValueError("channel must be one of awgn, t-dist, radar, ge_awgn, bec, bsc, ge")
         if self.decoder not in ("TurboAE_rate3_cnn", "TurboAE_rate3_rnn"):
             raise ValueError("decoder must be 'TurboAE_rate3_cnn' or 'TurboAE_rate3_rnn'")
         if self.decoder == "TurboAE_rate3_rnn" and self.dec_num_unit != 100:

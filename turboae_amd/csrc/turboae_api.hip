@@ -115,6 +115,7 @@ struct tae_handle {
     float* d_gy1 = nullptr;  // (chunk, L, 2H) layer-1 outputs
     float* d_ggi = nullptr;  // (chunk, L, 2, 3H) layer-1 input projections
     float* d_gzero = nullptr;  // 6H zeros (b_ih already folded into the projections)
+    tae::NormOpts nopts;       // encoder-output / channel variant (tae_set_channel_opts)
 };
 
 namespace {
@@ -228,6 +229,17 @@ int check_batch(tae_handle* h, int32_t B) {
     if (B < 1) return fail(TAE_EINVAL, "batch must be >= 1");
     if (B > h->cap) return fail(TAE_ESTATE, "batch exceeds reserved workspace; call tae_reserve first");
     return TAE_OK;
+}
+
+tae::NormOpts default_norm_opts() {
+    tae::NormOpts o;
+    memset(&o, 0, sizeof(o));
+    o.std = 1.0f;
+    o.enc_value_limit = 1.0f;
+    o.enc_quantize_level = 2.0f;
+    o.rec_quantize_limit = 1.0f;
+    o.rec_quantize_level = 2.0f;
+    return o;
 }
 
 tae::FusedParams base_params(const tae_handle* h, int32_t B) {
@@ -407,6 +419,7 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         return fail(TAE_EHIP, "no HIP device available: libturboae_hip needs an AMD GPU (no CPU fallback)");
     tae_handle* h = new tae_handle();
     h->cfg = *cfg;
+    h->nopts = default_norm_opts();
     h->U = cfg->enc_num_unit;
     (void)hipGetDevice(&h->device);
     h->nb = choose_nb(h->U, cfg->block_len, &h->lds_bytes);
@@ -536,6 +549,25 @@ int tae_set_interleaver(tae_handle* h, const int32_t* p, int32_t L) {
     return TAE_OK;
 }
 
+int tae_set_channel_opts(tae_handle* h, const tae_channel_opts* o) {
+    if (!h) return fail(TAE_EINVAL, "handle is NULL");
+    if (!o) { h->nopts = default_norm_opts(); return TAE_OK; }
+    if (o->struct_size != (int32_t)sizeof(tae_channel_opts)) return fail(TAE_EINVAL, "tae_channel_opts.struct_size mismatch (ABI)");
+    if (o->norm_mode < 0 || o->norm_mode > 2) return fail(TAE_EINVAL, "norm_mode must be 0, 1 or 2");
+    if (o->norm_mode == 2 && !(o->std > 0.0f)) return fail(TAE_EINVAL, "fixed std must be > 0");
+    if (o->channel < 0 || o->channel > 2) return fail(TAE_EINVAL, "channel must be 0 (additive), 1 (bec) or 2 (bsc/ge)");
+    if (o->ste && (!(o->enc_value_limit > 0.0f) || o->enc_quantize_level < 2.0f)) return fail(TAE_EINVAL, "bad STE quantiser parameters");
+    if (o->rec_quantize && (!(o->rec_quantize_limit > 0.0f) || o->rec_quantize_level < 2.0f)) return fail(TAE_EINVAL, "bad receive quantiser parameters");
+    tae::NormOpts n;
+    n.norm_mode = o->norm_mode; n.mean = o->mean; n.std = o->std;
+    n.ste = o->ste; n.enc_value_limit = o->enc_value_limit; n.enc_quantize_level = o->enc_quantize_level;
+    n.enc_truncate_limit = o->enc_truncate_limit;
+    n.channel = o->channel; n.rec_quantize = o->rec_quantize;
+    n.rec_quantize_limit = o->rec_quantize_limit; n.rec_quantize_level = o->rec_quantize_level;
+    h->nopts = n;
+    return TAE_OK;
+}
+
 int tae_encode_prenorm(tae_handle* h, const float* u, float* x_tx, double* stats3, int32_t B, void* stream) {
     int rc = check_batch(h, B);
     if (rc != TAE_OK) return rc;
@@ -550,7 +582,7 @@ int tae_normalize(tae_handle* h, const float* x_tx, const double* stats3, const 
     if (!x_tx || !stats3) return fail(TAE_EINVAL, "NULL tensor");
     if ((received != nullptr) != (noise != nullptr)) return fail(TAE_EINVAL, "noise and received must be given together");
     if (!codes && !received) return fail(TAE_EINVAL, "nothing to write");
-    TAE_HIP(tae::launch_normalize(x_tx, stats3, noise, codes, received, (size_t)B * h->cfg.block_len * 3, (hipStream_t)stream));
+    TAE_HIP(tae::launch_normalize(x_tx, stats3, noise, codes, received, (size_t)B * h->cfg.block_len * 3, h->nopts, (hipStream_t)stream));
     return TAE_OK;
 }
 

@@ -85,8 +85,13 @@ hipError_t launch_seg(int U, const SegParams& P, int grid, hipStream_t st);
 int seg_lds_bytes(int U, int T, int n_layer);
 hipError_t launch_fused(int U, bool decoder, const FusedParams& P, int grid, hipStream_t st);
 hipError_t launch_reduce_partials(const double* partials, int n, double count, double* stats, hipStream_t st);
+struct NormOpts {          // device-side view of tae_channel_opts
+    int32_t norm_mode; float mean, std;
+    int32_t ste; float enc_value_limit, enc_quantize_level, enc_truncate_limit;
+    int32_t channel, rec_quantize; float rec_quantize_limit, rec_quantize_level;
+};
 hipError_t launch_normalize(const float* xtx, const double* stats, const float* noise, float* codes, float* rx, size_t n,
-                            hipStream_t st);
+                            const NormOpts& o, hipStream_t st);
 hipError_t launch_count_errors(const float* xdec, const float* u, int B, int L, unsigned long long* counts, hipStream_t st);
 hipError_t launch_gen_inputs(float* u, float* noise, size_t n_bits, size_t bit_offset, unsigned long long seed_bits,
                              unsigned long long seed_noise, float sigma, hipStream_t st);

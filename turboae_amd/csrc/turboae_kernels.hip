@@ -721,21 +721,45 @@ __global__ void reduce_partials_kernel(const double* __restrict__ partials, int 
     if (threadIdx.x == 0) { stats[0] = red[0]; stats[1] = red[256]; stats[2] = count; }
 }
 
-// power_constraint (encoders.py:107-116): codes = (x - mean) * 1.0 / std, unbiased std, fp32 arithmetic
-// on fp32 mean/std; channel_ae.py:42: received = codes + noise.
+// STEQuantize.forward (encoders.py:20-36 / ste.py:9-23): clamp to +-limit, then sign (level 2) or a uniform
+// `level`-point grid; torch.round is round-half-to-even (rintf), the fp32 operation order is the reference's.
+__device__ __forceinline__ float ste_quantize(float x, float lim, float level) {
+    const float range = 2.0f * lim;
+    const float c = fminf(fmaxf(x, -lim), lim);
+    if (level == 2.0f) return c > 0.0f ? 1.0f : (c < 0.0f ? -1.0f : 0.0f);
+    const float k = (float)(((double)level - 1.0) / (double)range);
+    return __fdiv_rn(rintf((c + lim) * k) * range, level - 1.0f) - lim;
+}
+
+// power_constraint (encoders.py:102-125): codes = (x - mean) * 1.0 / std with the batch's mean / unbiased std
+// (fp32 arithmetic on fp32 mean/std), or no normalisation, or fixed statistics; optional STE quantisation and
+// truncation; then the channel of Channel_AE.forward (channel_ae.py:41-49) and the optional receive quantiser (:67-69).
 __global__ void normalize_kernel(const float* __restrict__ xtx, const double* __restrict__ stats,
                                  const float* __restrict__ noise, float* __restrict__ codes, float* __restrict__ rx,
-                                 size_t n) {
-    const double sum = stats[0], sumsq = stats[1], cnt = stats[2];
-    const double mean_d = sum / cnt;
-    double var_d = (sumsq - sum * mean_d) / (cnt - 1.0);
-    if (var_d < 0.0) var_d = 0.0;
-    const float mean = (float)mean_d;
-    const float sd = (float)sqrt(var_d);
+                                 size_t n, NormOpts o) {
+    float mean = o.mean, sd = o.std;
+    if (o.norm_mode == 0) {
+        const double sum = stats[0], sumsq = stats[1], cnt = stats[2];
+        const double mean_d = sum / cnt;
+        double var_d = (sumsq - sum * mean_d) / (cnt - 1.0);
+        if (var_d < 0.0) var_d = 0.0;
+        mean = (float)mean_d;
+        sd = (float)sqrt(var_d);
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float c = __fdiv_rn(xtx[i] - mean, sd);
+        float c = xtx[i];
+        if (o.norm_mode != 1) {
+            c = __fdiv_rn(c - mean, sd);
+            if (o.ste) c = ste_quantize(c, o.enc_value_limit, o.enc_quantize_level);
+            if (o.enc_truncate_limit > 0.0f) c = fminf(fmaxf(c, -o.enc_truncate_limit), o.enc_truncate_limit);
+        }
         if (codes) codes[i] = c;
-        if (rx) rx[i] = c + noise[i];
+        if (rx) {
+            const float nz = noise[i];
+            float r = o.channel == 0 ? c + nz : (o.channel == 1 ? c * nz : c * (2.0f * nz - 1.0f));
+            if (o.rec_quantize) r = ste_quantize(r, o.rec_quantize_limit, o.rec_quantize_level);
+            rx[i] = r;
+        }
     }
 }
 
@@ -857,9 +881,9 @@ hipError_t launch_reduce_partials(const double* partials, int n, double count, d
 }
 
 hipError_t launch_normalize(const float* xtx, const double* stats, const float* noise, float* codes, float* rx, size_t n,
-                            hipStream_t st) {
+                            const NormOpts& o, hipStream_t st) {
     const int grid = (int)std::min<size_t>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(normalize_kernel, dim3(grid), dim3(256), 0, st, xtx, stats, noise, codes, rx, n);
+    hipLaunchKernelGGL(normalize_kernel, dim3(grid), dim3(256), 0, st, xtx, stats, noise, codes, rx, n, o);
     return hipGetLastError();
 }
 
