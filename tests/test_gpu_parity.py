@@ -332,3 +332,22 @@ def test_rnn_decoder_batch_independent_and_chunked(gpu_device):
     xd, _ = model(torch.from_numpy(u8).to(gpu_device), torch.from_numpy(n8).to(gpu_device))
     xo, _ = O.channel_ae_forward(torch.from_numpy(u8), torch.from_numpy(n8), O.to_torch(sd), cfg.to_dict())
     assert np.abs(xd.cpu().numpy() - xo.numpy()).max() <= ATOL_XDEC_RNN
+
+
+def test_variable_block_length(gpu_device):
+    """--is_variable_block_len: the same weights on other block lengths (seed-0 permutation of that length)."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(enc_num_unit=32, dec_num_unit=32, num_iteration=2)
+    sd = W.generate_state_dict(cfg, seed=21, gain=1.0)
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4, is_variable_block_len=True)
+    for L in (100, 37, 160):
+        u, noise = make_inputs(4, L, seed=60 + L)
+        xd, codes = model(torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device))
+        ocfg = cfg.to_dict()
+        ocfg["block_len"] = L
+        xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), ocfg)
+        assert np.abs(codes.cpu().numpy() - co.numpy()).max() <= ATOL_CODES
+        assert np.abs(xd.cpu().numpy() - xo.numpy()).max() <= ATOL_XDEC
+    strict = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4)
+    with pytest.raises(ValueError):
+        strict(torch.zeros(2, 50, 1, device=gpu_device), torch.zeros(2, 50, 3, device=gpu_device))

@@ -209,8 +209,14 @@ class Channel_AE_HIP:
     """Drop-in for ``Channel_AE(args, enc, dec)`` on the AWGN / rate-1/3 CNN eval path."""
 
     def __init__(self, args_or_cfg, state_dict: Dict[str, object], device: Optional[torch.device] = None,
-                 max_batch: int = 500, is_same_interleaver: int = 1):
+                 max_batch: int = 500, is_same_interleaver: int = 1, is_variable_block_len: Optional[bool] = None):
         cfg = _as_cfg(args_or_cfg)
+        # --is_variable_block_len (get_args.py:125; encoders.py:353-360, decoders.py:208-215): the fully convolutional
+        # model runs on any block length with the seed-0 permutation of that length; one engine per length
+        if is_variable_block_len is None:
+            is_variable_block_len = bool(getattr(args_or_cfg, "is_variable_block_len", False))
+        self.is_variable_block_len = is_variable_block_len
+        self._by_len: Dict[int, _Engine] = {}
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         self.cfg = cfg
@@ -245,10 +251,21 @@ class Channel_AE_HIP:
     def kernel_info(self):
         return self._eng.kernel_info()
 
+    def _engine_for(self, L: int) -> _Engine:
+        if L == self.cfg.block_len:
+            return self._eng
+        if not self.is_variable_block_len:
+            raise ValueError(f"input block length {L} != configured block_len {self.cfg.block_len} "
+                             "(pass is_variable_block_len=True to allow other lengths)")
+        if L not in self._by_len:
+            from dataclasses import replace
+            self._by_len[L] = _Engine(replace(self.cfg, block_len=L), self._eng._state, self._eng.device, self._eng.cap)
+        return self._by_len[L]
+
     def forward(self, input: torch.Tensor, fwd_noise: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        e = self._eng
+        e = self._engine_for(input.shape[1]) if input.dim() == 3 else self._eng
         if self.is_same_interleaver:   # channel_ae.py:32-36: RandInterlv(block_len, 0) on every call
-            e.set_interleaver(rand_interleaver(self.cfg.block_len, 0))
+            e.set_interleaver(rand_interleaver(e.cfg.block_len, 0))
         u = e._in(input, 1, "input")
         noise = e._in(fwd_noise, 3, "fwd_noise")
         B = u.shape[0]
