@@ -27,6 +27,12 @@
 namespace tae {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// two independent fp32 FMAs in one v_pk_fma_f32: dot products run as two interleaved chains (even / odd k)
+// that are added at the end; the weight pair (w[k], w[k+1]) is a natural register pair (a broadcast {w, w}
+// operand would be materialised per weight and double the register footprint)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 w, f32x2 x, f32x2 acc) { return __builtin_elementwise_fma(w, x, acc); }
 
 constexpr int kGruH = 100;          // hidden units per direction (dec_num_unit)
 constexpr int kGruRows = 3 * kGruH; // gate rows per direction
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(kGruThreads) void gru_rec_kernel(GruRecParams P) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) wi[c] = (LAYER0 && c < P.cin) ? P.w_ih[((size_t)dir * kGruRows + jj) * P.cin + c] : 0.0f;
 
-    for (int i = tid; i < NBK * H; i += kGruThreads) hbuf[i] = 0.0f;     // h_0 = 0
+    for (int i = tid; i < NBK * H; i += kGruThreads) hbuf[i] = 0.0f;     // h_0 = 0; layout hbuf[b][k]
     if (LAYER0) {
         const float* X = P.x + (size_t)b0 * L * kXWg;
         for (int i = tid; i < nblk * L * 2; i += kGruThreads)
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(kGruThreads) void gru_rec_kernel(GruRecParams P) {
     float* Y = P.y + (size_t)b0 * L * 2 * H + (size_t)dir * H;
     for (int s = 0; s < L; ++s) {
         const int t = dir == 0 ? s : L - 1 - s;
-        float gi[NBK], gh[NBK];
+        float gi[NBK];
 #pragma unroll
         for (int b = 0; b < NBK; ++b) {
             if (LAYER0) {
@@ -116,19 +122,20 @@ __global__ __launch_bounds__(kGruThreads) void gru_rec_kernel(GruRecParams P) {
             } else {
                 gi[b] = (b < nblk) ? GI[((size_t)b * L + t) * 2 * kGruRows] : 0.0f;
             }
-            gh[b] = bh;
         }
-        // gh[b] += W_hh[j,:] . h_t[b,:]   (h broadcast from LDS)
+        // gh[b] = b_hh[j] + W_hh[j,:] . h_t[b,:]: h broadcast from LDS, two k per v_pk_fma_f32
+        f32x2 gh2[NBK];
+#pragma unroll
+        for (int b = 0; b < NBK; ++b) gh2[b] = f32x2{bh, 0.0f};
 #pragma unroll
         for (int k = 0; k < H; k += 4) {
 #pragma unroll
             for (int b = 0; b < NBK; ++b) {
                 const f32x4 hv = *reinterpret_cast<const f32x4*>(hbuf + b * H + k);
-                float a = gh[b];
-                a = fmaf(wh[k], hv.x, a); a = fmaf(wh[k + 1], hv.y, a); a = fmaf(wh[k + 2], hv.z, a); a = fmaf(wh[k + 3], hv.w, a);
-                gh[b] = a;
+                gh2[b] = pk_fma(f32x2{wh[k], wh[k + 1]}, f32x2{hv.x, hv.y}, gh2[b]);
+                gh2[b] = pk_fma(f32x2{wh[k + 2], wh[k + 3]}, f32x2{hv.z, hv.w}, gh2[b]);
             }
-            // keep the scheduler from hoisting all NBK*H broadcast reads above the FMAs (it spills otherwise)
+            // keep the scheduler from hoisting all the broadcast reads above the FMAs (it spills otherwise)
             __builtin_amdgcn_sched_barrier(0);
         }
         // branch-free stores (a per-thread `if (gate < 2)` lets the compiler sink the FMA chains below all
@@ -136,9 +143,10 @@ __global__ __launch_bounds__(kGruThreads) void gru_rec_kernel(GruRecParams P) {
         // park gh in slot 3, the r/z rows in the unused slot 4
 #pragma unroll
         for (int b = 0; b < NBK; ++b) {
-            const float sg = sigmoidf_(gi[b] + gh[b]);
+            const float ghb = gh2[b].x + gh2[b].y;
+            const float sg = sigmoidf_(gi[b] + ghb);
             gates[(b * 5 + gate) * H + u] = gate < 2 ? sg : gi[b];
-            gates[(b * 5 + (gate < 2 ? 4 : 3)) * H + u] = gh[b];
+            gates[(b * 5 + (gate < 2 ? 4 : 3)) * H + u] = ghb;
         }
         __syncthreads();
         for (int e = tid; e < nblk * H; e += kGruThreads) {
@@ -153,7 +161,8 @@ __global__ __launch_bounds__(kGruThreads) void gru_rec_kernel(GruRecParams P) {
     }
 }
 
-// GI[p][dir][j] = b_ih[dir][j] + sum_k W_ih[dir][j][k] * Yin[p][k], K = 2H (layer-1 input projections)
+// GI[p][dir][j] = b_ih[dir][j] + sum_k W_ih[dir][j][k] * Yin[p][k], K = 2H (layer-1 input projections).
+// Thread j owns W_ih row j (2H registers); the position tile is staged in LDS and broadcast.
 __global__ __launch_bounds__(kGruThreads, 2) void gru_proj_kernel(GruProjParams P) {
     constexpr int K = 2 * kGruH, PT = kGruPT;
     __shared__ __attribute__((aligned(16))) float ys[PT * K];
@@ -175,14 +184,22 @@ __global__ __launch_bounds__(kGruThreads, 2) void gru_proj_kernel(GruProjParams 
     for (int i = tid; i < np * K / 4; i += kGruThreads)
         reinterpret_cast<f32x4*>(ys)[i] = reinterpret_cast<const f32x4*>(P.yin + p0 * K)[i];
     __syncthreads();
-    for (int p = 0; p < np; ++p) {
-        float a = bias;
+#pragma unroll 1
+    for (int p = 0; p < np; p += 2) {
+        f32x2 a0 = {bias, 0.0f}, a1 = {bias, 0.0f};
+        const float* y0 = ys + p * K;
+        const float* y1 = ys + (p + 1 < np ? p + 1 : p) * K;
 #pragma unroll
         for (int k = 0; k < K; k += 4) {
-            const f32x4 yv = *reinterpret_cast<const f32x4*>(ys + p * K + k);
-            a = fmaf(w[k], yv.x, a); a = fmaf(w[k + 1], yv.y, a); a = fmaf(w[k + 2], yv.z, a); a = fmaf(w[k + 3], yv.w, a);
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(y0 + k);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(y1 + k);
+            a0 = pk_fma(f32x2{w[k], w[k + 1]}, f32x2{v0.x, v0.y}, a0);
+            a1 = pk_fma(f32x2{w[k], w[k + 1]}, f32x2{v1.x, v1.y}, a1);
+            a0 = pk_fma(f32x2{w[k + 2], w[k + 3]}, f32x2{v0.z, v0.w}, a0);
+            a1 = pk_fma(f32x2{w[k + 2], w[k + 3]}, f32x2{v1.z, v1.w}, a1);
         }
-        P.gi[((p0 + p) * 2 + dir) * kGruRows + jj] = a;
+        P.gi[((p0 + p) * 2 + dir) * kGruRows + jj] = a0.x + a0.y;
+        if (p + 1 < np) P.gi[((p0 + p + 1) * 2 + dir) * kGruRows + jj] = a1.x + a1.y;
     }
 }
 
