@@ -29,15 +29,20 @@ int fail(int code, const std::string& msg) {
     } while (0)
 
 struct Layout {   // must mirror tae::Geo<U> in turboae_kernels.hip
-    int U, CT, CP, nch_mid, midf, l0f;
+    int U, CT, CP, nch_mid, midf, l0f, sup, sfm, sf0;
     explicit Layout(int u) : U(u) {
         CT = (U + 15) / 16;
         CP = CT * 16;
         nch_mid = (5 * U + 7) / 8;
         midf = nch_mid * CT * 128;
         l0f = 5 * CT * 128;
+        sup = (U % 16) == 4;
+        sfm = sup ? U * 128 : 0;       // super-tile A fragments of a U->U layer: K' = 8 shifts x U -> U chunks of 8
+        sf0 = sup ? 8 * 128 : 0;       // first layer: 8 shifts x 8 padded inputs
     }
-    size_t stack_stride(int n_layer) const { return (size_t)l0f + CP + (size_t)(n_layer - 1) * (midf + CP) + 8 * CP + 8; }
+    size_t stack_stride(int n_layer) const {
+        return (size_t)l0f + CP + sf0 + (size_t)(n_layer - 1) * (midf + CP + sfm) + 8 * CP + 8;
+    }
 };
 
 // im2col-flattened weight W'[co][k], k = tap * cin_pad + ci (tap-major), zero outside the real tensor.
@@ -62,6 +67,22 @@ void pack_conv(const float* W, int U, int cin, int cin_pad, int nch, int CT, flo
                 }
 }
 
+// Super-tile A fragments for the remainder channels (see tae::super_accumulate): row r = 4*s + c is channel
+// crem + c at position shift s, K' = u * cin_pad + ci, A[r][K'] = W[crem + c][ci][u - s] for 0 <= u - s <= 4.
+// Stored per chunk PAIR as [pair][lane][even chunk: k-step 0, 1 | odd chunk: k-step 0, 1].
+void pack_super(const float* W, int U, int cin, int cin_pad, int nch, int crem, float* dst) {
+    for (int c = 0; c < nch; ++c)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int st = 0; st < 2; ++st) {
+                const int r = lane & 15, sh = r / 4, ch = r % 4;
+                const int kp = 8 * c + 2 * (lane >> 4) + st;
+                const int u = kp / cin_pad, ci = kp % cin_pad, j = u - sh;
+                float v = 0.0f;
+                if (u < 8 && j >= 0 && j <= 4 && ci < cin && crem + ch < U) v = W[((size_t)(crem + ch) * cin + ci) * 5 + j];
+                dst[((size_t)(c / 2) * 64 + lane) * 4 + (c % 2) * 2 + st] = v;
+            }
+}
+
 // canonical stack (conv layers then Linear head) -> packed stack; returns floats consumed from src
 size_t pack_stack(const float* src, const Layout& lo, int n_layer, int cin0, int nout, float* dst) {
     const float* s = src;
@@ -70,10 +91,14 @@ size_t pack_stack(const float* src, const Layout& lo, int n_layer, int cin0, int
         const int cin = l == 0 ? cin0 : lo.U;
         pack_conv(s, lo.U, cin, l == 0 ? 8 : lo.U, l == 0 ? 5 : lo.nch_mid, lo.CT, d);
         d += l == 0 ? lo.l0f : lo.midf;
-        s += (size_t)lo.U * cin * 5;
-        for (int c = 0; c < lo.CP; ++c) d[c] = c < lo.U ? s[c] : 0.0f;
+        const float* b = s + (size_t)lo.U * cin * 5;
+        for (int c = 0; c < lo.CP; ++c) d[c] = c < lo.U ? b[c] : 0.0f;
         d += lo.CP;
-        s += lo.U;
+        if (lo.sup) {
+            pack_super(s, lo.U, cin, l == 0 ? 8 : lo.U, l == 0 ? 8 : lo.U, 16 * (lo.CT - 1), d);
+            d += l == 0 ? lo.sf0 : lo.sfm;
+        }
+        s = b + lo.U;
     }
     for (int f = 0; f < 8; ++f)
         for (int c = 0; c < lo.CP; ++c) d[f * lo.CP + c] = (f < nout && c < lo.U) ? s[(size_t)f * lo.U + c] : 0.0f;
@@ -94,6 +119,7 @@ struct tae_handle {
     int enc_T = 0, enc_nseg = 0, enc_lds = 0, dec_T = 0, dec_nseg = 0, dec_lds = 0;
     uint32_t enc_stride = 0, dec_stride = 0;
     uint32_t enc_bytes = 0, dec_bytes = 0;
+    int super = 0;           // remainder channels via super-tiles (U % 16 == 4 and block_len % 4 == 0)
     float* d_wenc = nullptr;
     float* d_wdec = nullptr;
     int32_t* d_perm = nullptr;
@@ -213,7 +239,7 @@ int choose_nb(int U, int L, int* lds_out) {
 // Segment geometry of the long-block path: T centre positions + 2*H halo positions <= max positions.
 bool choose_seg(int U, int L, int n_layer, int* T, int* nseg, int* lds) {
     const int H = 2 * n_layer;
-    int tmax = tae::fused_max_positions() - 2 * H;
+    int tmax = tae::fused_max_positions() - 2 * H - 3;    // 3 alignment rows: panel origin floored to a multiple of 4
     while (tmax >= 16 && tae::seg_lds_bytes(U, tmax, n_layer) > 160 * 1024) tmax -= 16;
     if (tmax < 16) return false;
     const char* cap = getenv("TAE_SEG_T");
@@ -255,6 +281,7 @@ tae::FusedParams base_params(const tae_handle* h, int32_t B) {
     P.extrinsic = h->cfg.extrinsic;
     P.act = h->cfg.enc_act;
     P.lds_bytes = h->lds_bytes;
+    P.super = h->super;
     return P;
 }
 
@@ -268,6 +295,7 @@ tae::SegParams seg_params(const tae_handle* h, int32_t B) {
     P.F = h->cfg.num_iter_ft;
     P.extrinsic = h->cfg.extrinsic;
     P.act = h->cfg.enc_act;
+    P.super = h->super;
     return P;
 }
 
@@ -437,6 +465,8 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     }
     const Layout lo(h->U);
     const int F = cfg->num_iter_ft;
+    const char* nosup = getenv("TAE_NO_SUPER");     // testing knob: force the padded-tile path
+    h->super = (lo.sup && cfg->block_len % 4 == 0 && !(nosup && nosup[0] == '1')) ? 1 : 0;
     h->enc_stride = (uint32_t)lo.stack_stride(cfg->enc_num_layer);
     h->dec_stride = (uint32_t)lo.stack_stride(cfg->dec_num_layer);
     std::vector<float> penc((size_t)3 * h->enc_stride, 0.0f), pdec((size_t)2 * cfg->num_iteration * h->dec_stride, 0.0f);

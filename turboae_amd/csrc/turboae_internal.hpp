@@ -24,6 +24,7 @@ struct FusedParams {
     uint32_t stack_stride;  // floats between consecutive stacks in wpack
     uint32_t wpack_bytes;   // size of the packed weight buffer (buffer-resource bound)
     int32_t lds_bytes;
+    int32_t super;          // 1: remainder channels via super-tiles (needs U % 16 == 4 and block_len % 4 == 0)
 };
 
 // Arguments of the per-stack segmented kernel used when a block does not fit one workgroup.
@@ -44,6 +45,7 @@ struct SegParams {
     uint32_t stack_stride;
     uint32_t wpack_bytes;
     int32_t lds_bytes;
+    int32_t super;
 };
 
 // ---- GRU decoder (turboae_gru.hip)

@@ -70,6 +70,13 @@ struct Geo {
     static constexpr int CS = CT * 128;              // floats of A fragments per chunk
     static constexpr int MIDF = NCH_MID * CS;        // floats of A fragments per U->U layer
     static constexpr int L0F = NCH_L0 * CS;
+    // "super-tile" for the 4 remainder channels when U % 16 == 4 (see super_accumulate): A fragments with
+    // rows = 4 position shifts x 4 channels over K' = 8 shifts x C_in, stored after the bias of every layer
+    static constexpr bool SUP = (U % 16) == 4;
+    static constexpr int SCH_MID = SUP ? U : 0;      // K' / 8 chunks of a U->U layer
+    static constexpr int SCH_L0 = SUP ? 8 : 0;       // first layer: 8 shifts x 8 padded inputs
+    static constexpr int SFM = SCH_MID * 128;        // floats of super A fragments per U->U layer
+    static constexpr int SF0 = SCH_L0 * 128;
 };
 
 // Workgroup shape: 8 waves = 2 per SIMD.  Wave w = g + 4h: g selects the position group (PT
@@ -148,10 +155,9 @@ __device__ __forceinline__ void load_x(Ops<NC, PT>& o, const lds_cptr (&cur)[PT]
 // spread the vector-memory loads evenly through the MFMA stream.  The waves of a workgroup fetch the
 // same fragments at nearly the same time; issued back to back the 1 KB loads saturate the CU's
 // 64 B/clk texture-address path and the MFMAs queued behind them in program order wait.
-template <int NV, int NC, int PT>
+template <int NV, int ND, int NM>
 __device__ __forceinline__ void spread_loads() {
 #if TAE_SPREAD
-    constexpr int NM = 2 * PT * NC, ND = PT;
     constexpr int GV = NM / (2 * NV);          // MFMAs between vector-memory loads (first half of the chunk)
     constexpr int GD = (NM - NV * GV) / ND;    // MFMAs between LDS reads (second half)
 #pragma unroll
@@ -180,57 +186,130 @@ __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[PT][NC], const Ops<NC, PT
         for (int ct = 0; ct < NC; ++ct) acc[p][ct] = mfma16x16x4(o.a[ct].y, o.b[p].y, acc[p][ct]);
 }
 
+// ---- "super-tile" for the remainder channels --------------------------------------------------------
+// U = 100 leaves 4 channels (96..99) in a 7th 16-row tile that is 75 % padding.  Instead of M = 16
+// channels x N = 16 positions, the remainder uses M = 4 position shifts x 4 channels and N = 16 position
+// QUADS: row r = 4s + c of A is channel 96 + c of the (s)-th position of a quad, column n is quad n, and the
+// contraction runs over K' = 8 shifts x C_in, K' = u * C_in + ci, with A[(s,c)][(u,ci)] = W[96+c][ci][u - s]
+// for 0 <= u - s <= 4 and 0 otherwise, B[(u,ci)][n] = X[row(quad n) - 2 + u][ci] - again one contiguous run of
+// panel floats per column, so B fragments are single ds_read_b64s.  One tile thus produces 64 positions x 4
+// channels in 2 * (K'/8) MFMAs (200 for a U->U layer) where the padded tile needs 4 * 126 = 504.  The two
+// waves of a SIMD take one super-tile each (quads 0..15 / 16..19 of their position group's 20) and three
+// regular channel tiles each, which balances them exactly.  Every
+// position is computed by the same chain whatever its place in the batch (shift s = index-in-block mod 4),
+// so results stay bitwise independent of batching.  Lane (n, q) receives D rows 4q..4q+3 = the 4 channels
+// of position 4n + q of its quads.  Requires quads not to straddle blocks (block_len % 4 == 0).
+struct SuperCtx {      // this wave's super-tile (lower channel half: quads 0..15, upper half: quads 16..19)
+    int row0;         // panel row of the first position of this lane's quad
+    int slot;         // workgroup-wide position slot (head scratch row) of this lane's position
+    bool valid;       // this lane's position is a real in-block position (its activations are written back)
+    bool center;      // ... whose stack output this workgroup owns
+};
+
+struct SOps {
+    f32x4 a;          // A fragments of a chunk pair: even chunk (k-step x, y), odd chunk (x, y)
+    float2 b[2];      // B fragments of the two chunks
+};
+
+// chunk pair `PAIR` relative to the loop-carried bases (ssoff: SGPR byte offset of the super A fragments,
+// scur: LDS pointer of this lane's quad column); everything else is an immediate
+template <int PAIR>
+__device__ __forceinline__ void sload(SOps& o, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t ssoff, lds_cptr scur) {
+    o.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, ssoff + PAIR * 1024u, 0));
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const f32x2 v = *reinterpret_cast<const f32x2 __attribute__((address_space(3)))*>(scur + PAIR * 64 + c * 32);
+        o.b[c] = float2{v.x, v.y};
+    }
+}
+
+// two independent accumulation chains (k-step parity) so consecutive MFMAs never wait on each other
+__device__ __forceinline__ void smma(f32x4 (&accS)[2], const SOps& o) {
+    accS[0] = mfma16x16x4(o.a.x, o.b[0].x, accS[0]);
+    accS[1] = mfma16x16x4(o.a.y, o.b[0].y, accS[1]);
+    accS[0] = mfma16x16x4(o.a.z, o.b[1].x, accS[0]);
+    accS[1] = mfma16x16x4(o.a.w, o.b[1].y, accS[1]);
+}
+
 // acc += W (16*NC x 8*NCH) * im2col (8*NCH x PT*16), software-pipelined one chunk ahead, four chunks
 // per loop iteration so that every address is a loop-carried base plus an immediate.
 // `o0` arrives with the chunk-0 WEIGHT fragments already loaded (prefetched across the previous
 // layer's epilogue and barriers).  The prefetch of chunk NCH (one past the end) is a harmless
 // over-read: weights continue into the bias block, LDS rows into the panel's slack row.
+// With NPAIR > 0 the wave also accumulates its super-tile (accS): three
+// chunk pairs of the K' = 8-shift contraction ride along with every four main chunks, on a 3-stage
+// register ring (each pair is fetched a whole loop iteration before it is used).
 // soff : wave-uniform byte offset of this layer's A fragments inside the packed weight buffer
 // baddr: per position tile, LDS byte address of (row-2)*stride + 8*kq for this lane
-template <int CTT, int C0, int NC, int PT, int NCH>
-__device__ __forceinline__ void conv_accumulate(f32x4 (&acc)[PT][NC], Ops<NC, PT>& o0, __amdgpu_buffer_rsrc_t rsrc,
-                                                uint32_t voff, uint32_t soff, const char* lds, const uint32_t (&baddr)[PT]) {
+template <int CTT, int C0, int NC, int PT, int NCH, int NPAIR>
+__device__ __forceinline__ void conv_accumulate(f32x4 (&acc)[PT][NC], f32x4 (&accS)[2], Ops<NC, PT>& o0,
+                                                __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, uint32_t ssoff,
+                                                const char* lds, const uint32_t (&baddr)[PT], uint32_t sbase) {
     constexpr uint32_t CSB = CTT * 512;   // bytes of A fragments per chunk
-    constexpr int NV = n_wloads(CTT, C0, NC);
+    constexpr bool SUP = NPAIR > 0;
+    constexpr int NV = n_wloads(CTT, C0, NC), NM = 2 * PT * NC;
     Ops<NC, PT> o1;
-    lds_cptr cur[PT];        // loop-carried LDS pointers: one add per tile per 4 chunks, immediates otherwise
     const lds_cptr lds3 = (lds_cptr)lds;
+    lds_cptr cur[PT];        // loop-carried LDS pointers: one add per tile per 4 chunks, immediates otherwise
 #pragma unroll
     for (int p = 0; p < PT; ++p) cur[p] = lds3 + baddr[p];
+    lds_cptr scur = lds3 + sbase;
+    SOps s0, s1, s2;
+    if constexpr (SUP) {
+        sload<0>(s0, rsrc, voff, ssoff, scur);
+        sload<1>(s1, rsrc, voff, ssoff, scur);
+        sload<2>(s2, rsrc, voff, ssoff, scur);
+    }
     load_x<NC, PT, 0>(o0, cur);
     for (int it = 0; it < NCH / 4; ++it) {
         load_w<CTT, C0, NC, PT>(o1, rsrc, voff, soff + 1 * CSB);
         load_x<NC, PT, 32>(o1, cur);
         mma_chunk<NC, PT>(acc, o0);
-        spread_loads<NV, NC, PT>();
+        if constexpr (SUP) { smma(accS, s0); sload<3>(s0, rsrc, voff, ssoff, scur); }
+        spread_loads<NV + (SUP ? 1 : 0), PT + (SUP ? 2 : 0), NM + (SUP ? 4 : 0)>();
         load_w<CTT, C0, NC, PT>(o0, rsrc, voff, soff + 2 * CSB);
         load_x<NC, PT, 64>(o0, cur);
         mma_chunk<NC, PT>(acc, o1);
-        spread_loads<NV, NC, PT>();
+        if constexpr (SUP) { smma(accS, s1); sload<4>(s1, rsrc, voff, ssoff, scur); }
+        spread_loads<NV + (SUP ? 1 : 0), PT + (SUP ? 2 : 0), NM + (SUP ? 4 : 0)>();
         load_w<CTT, C0, NC, PT>(o1, rsrc, voff, soff + 3 * CSB);
         load_x<NC, PT, 96>(o1, cur);
         mma_chunk<NC, PT>(acc, o0);
-        spread_loads<NV, NC, PT>();
+        if constexpr (SUP) { smma(accS, s2); sload<5>(s2, rsrc, voff, ssoff, scur); }
+        spread_loads<NV + (SUP ? 1 : 0), PT + (SUP ? 2 : 0), NM + (SUP ? 4 : 0)>();
         load_w<CTT, C0, NC, PT>(o0, rsrc, voff, soff + 4 * CSB);
         load_x<NC, PT, 128>(o0, cur);
         mma_chunk<NC, PT>(acc, o1);
-        spread_loads<NV, NC, PT>();
+        spread_loads<NV, PT, NM>();
         soff += 4 * CSB;
 #pragma unroll
         for (int p = 0; p < PT; ++p) cur[p] += 128;
+        if constexpr (SUP) {
+            ssoff += 3 * 1024u;
+            scur += 3 * 64;
+        }
     }
-    constexpr int TAIL = NCH % 4;     // o0 holds chunk NCH - TAIL
+    constexpr int TAIL = NCH % 4;     // o0 holds chunk NCH - TAIL; the ring holds pairs 3*(NCH/4) + {0,1,2}
+    constexpr int DONE = 3 * (NCH / 4);
     if constexpr (TAIL >= 2) {
         load_w<CTT, C0, NC, PT>(o1, rsrc, voff, soff + 1 * CSB);
         load_x<NC, PT, 32>(o1, cur);
     }
     if constexpr (TAIL >= 1) mma_chunk<NC, PT>(acc, o0);
+    if constexpr (SUP && DONE + 0 < NPAIR) { smma(accS, s0); if constexpr (DONE + 3 < NPAIR) sload<3>(s0, rsrc, voff, ssoff, scur); }
     if constexpr (TAIL >= 3) {
         load_w<CTT, C0, NC, PT>(o0, rsrc, voff, soff + 2 * CSB);
         load_x<NC, PT, 64>(o0, cur);
     }
     if constexpr (TAIL >= 2) mma_chunk<NC, PT>(acc, o1);
+    if constexpr (SUP && DONE + 1 < NPAIR) { smma(accS, s1); if constexpr (DONE + 4 < NPAIR) sload<4>(s1, rsrc, voff, ssoff, scur); }
     if constexpr (TAIL >= 3) mma_chunk<NC, PT>(acc, o0);
+    if constexpr (SUP && DONE + 2 < NPAIR) { smma(accS, s2); if constexpr (DONE + 5 < NPAIR) sload<5>(s2, rsrc, voff, ssoff, scur); }
+    // drain the pairs the main chunks did not cover (2 for a U->U layer of U = 100)
+    if constexpr (SUP && DONE + 3 < NPAIR) smma(accS, s0);
+    if constexpr (SUP && DONE + 4 < NPAIR) smma(accS, s1);
+    if constexpr (SUP && DONE + 5 < NPAIR) smma(accS, s2);
+    static_assert(!SUP || NPAIR <= DONE + 6, "super-tile pairs must fit the main loop plus one drain round");
 }
 
 // Per-lane view of the position tiles a wave owns.
@@ -288,14 +367,19 @@ struct WeightStream {
 //
 // Packed stack layout (floats), written by turboae_api.hip::pack_stack:
 //   per layer: A fragments [chunk][...] (see load_w) | bias [CP];  then Linear weights [8][CP] | bias [8]
-template <int U, int PT, int C0, int NC, class Epi>
+// SUPER: this (upper-half) wave additionally computes the 4 remainder channels of its position group with
+// two super-tiles (see super_accumulate); its NC then excludes the padded last channel tile.
+template <int U, int PT, int C0, int NC, bool SUPER, class Epi>
 __device__ __forceinline__ void run_stack(const float* __restrict__ wpack, uint32_t soff, uint32_t snext, int n_layer,
                                           char* smem, float* ACT, const float* Xin, float* HS, const TileCtx<PT>& tc,
-                                          int g, int lane, WeightStream<U, PT, C0, NC>& ws, Epi epi) {
+                                          const SuperCtx& sc, int g, int lane, WeightStream<U, PT, C0, NC>& ws, Epi epi) {
     using G = Geo<U>;
     constexpr int CTT = G::CT;
+    constexpr int CREM = 16 * (CTT - 1);      // first remainder channel (96 for U = 100)
+    static_assert(!SUPER || (G::SUP && C0 + NC <= CTT - 1), "with super-tiles the padded last channel tile is not computed");
     const int q = lane >> 4;
     f32x4 acc[PT][NC];
+    f32x4 accS[2];
     uint32_t lo = soff;      // byte offset of the current layer
     for (int l = 0; l < n_layer; ++l) {
         const bool first = (l == 0);
@@ -310,15 +394,22 @@ __device__ __forceinline__ void run_stack(const float* __restrict__ wpack, uint3
             for (int p = 0; p < PT; ++p)
 #pragma unroll
                 for (int i = 0; i < NC; ++i) acc[p][i] = b4[i];
+            if constexpr (SUPER) {
+                accS[0] = *reinterpret_cast<const f32x4*>(bias + CREM);   // rows (s, c): bias[96 + c]
+                accS[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         uint32_t baddr[PT];
         const uint32_t stride = first ? (uint32_t)(kXW * 4) : (uint32_t)(U * 4);
         const uint32_t poff = (uint32_t)(reinterpret_cast<const char*>(first ? Xin : ACT) - smem);
 #pragma unroll
         for (int p = 0; p < PT; ++p) baddr[p] = poff + (uint32_t)(tc.row[p] - 2) * stride + 8u * q;
-        if (first) conv_accumulate<CTT, C0, NC, PT, G::NCH_L0>(acc, ws.o, ws.rsrc, ws.voff, lo, smem, baddr);
-        else conv_accumulate<CTT, C0, NC, PT, G::NCH_MID>(acc, ws.o, ws.rsrc, ws.voff, lo, smem, baddr);
-        lo += fragb + G::CP * 4u;
+        uint32_t sb = 0u;
+        if constexpr (SUPER) sb = poff + (uint32_t)(sc.row0 - 2) * stride + 8u * q;
+        const uint32_t so = lo + fragb + G::CP * 4u;     // super A fragments follow the bias
+        if (first) conv_accumulate<CTT, C0, NC, PT, G::NCH_L0, SUPER ? G::SCH_L0 / 2 : 0>(acc, accS, ws.o, ws.rsrc, ws.voff, lo, so, smem, baddr, sb);
+        else conv_accumulate<CTT, C0, NC, PT, G::NCH_MID, SUPER ? G::SCH_MID / 2 : 0>(acc, accS, ws.o, ws.rsrc, ws.voff, lo, so, smem, baddr, sb);
+        lo += fragb + G::CP * 4u + (first ? G::SF0 : G::SFM) * 4u;
         // prefetch the next conv layer's chunk-0 weights (this stack's next layer, or the next stack's first)
         {
             const uint32_t nxt = (l + 1 < n_layer) ? lo : snext;
@@ -337,6 +428,11 @@ __device__ __forceinline__ void run_stack(const float* __restrict__ wpack, uint3
                     if (TAE_X & 2) asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
                     else if (tc.valid[p] && ch < U) *reinterpret_cast<f32x4*>(ACT + tc.row[p] * U + ch) = v;
                 }
+            }
+            if constexpr (SUPER) {
+                f32x4 v = accS[0] + accS[1];
+                v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
+                if (sc.valid) *reinterpret_cast<f32x4*>(ACT + (sc.row0 + q) * U + CREM) = v;
             }
             if (!(TAE_X & 1)) __syncthreads();
         }
@@ -373,12 +469,35 @@ __device__ __forceinline__ void run_stack(const float* __restrict__ wpack, uint3
     for (int p = 0; p < PT; ++p) butterfly8(part[p], hi32, hi16, k2[p]);
     // combine the two channel halves: upper half parks its partials, lower half adds them
     const int n = lane & 15;
+    // remainder channels (super-tile): this lane holds all 4 of them for its quad position; their Linear
+    // contribution is added to that position's parked partial sums (one wave: LDS operations are in order).
+    // The sum parked for a position is always  k2(upper half) + c_super, whichever wave computed c_super.
+    auto add_super = [&]() {
+        f32x4 e = accS[0] + accS[1];
+        e.x = elu1(e.x); e.y = elu1(e.y); e.z = elu1(e.z); e.w = elu1(e.w);
+        float* hs = HS + sc.slot * 8;
+        f32x4 h0 = *reinterpret_cast<const f32x4*>(hs), h1 = *reinterpret_cast<const f32x4*>(hs + 4);
+        float c8[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wl + f * G::CP + CREM);
+            c8[f] = fmaf(e.w, w.w, fmaf(e.z, w.z, fmaf(e.y, w.y, e.x * w.x)));
+        }
+        h0 += f32x4{c8[0], c8[1], c8[2], c8[3]};
+        h1 += f32x4{c8[4], c8[5], c8[6], c8[7]};
+        if (sc.center) {
+            *reinterpret_cast<f32x4*>(hs) = h0;
+            *reinterpret_cast<f32x4*>(hs + 4) = h1;
+        }
+    };
     if constexpr (C0 != 0) {
 #pragma unroll
         for (int p = 0; p < PT; ++p)
             *reinterpret_cast<float2*>(HS + ((g * PT + p) * 16 + n) * 8 + 2 * q) = float2{k2[p][0], k2[p][1]};
+        if constexpr (SUPER) add_super();
     }
     __syncthreads();
+    if constexpr (C0 == 0 && SUPER) add_super();       // the lower half's super-tile (quads 0..15), after the upper half parked
     if constexpr (C0 == 0) {
         const float* lb = wl + 8 * G::CP;
         const float bq0 = lb[2 * q], bq1 = lb[2 * q + 1];
@@ -414,6 +533,22 @@ __device__ __forceinline__ void make_tiles(TileCtx<PT>& tc, int g, int lane, int
     }
 }
 
+// super-tile view of position group g (whole-block layout): the lower channel half (h = 0) takes quads 0..15,
+// the upper half (h = 1) quads 16..19 of the group's 20 (its lanes n >= 4 duplicate them and never write back)
+template <int PT>
+__device__ __forceinline__ void make_super(SuperCtx& sc, int g, int h, int lane, int L, int npos) {
+    const int n = lane & 15, q = lane >> 4;
+    const int Q = h == 0 ? n : 16 + (n & 3);
+    const int m0 = g * PT * 16 + 4 * Q;
+    const bool ok = (h == 0 || n < 4) && (m0 + q < npos);
+    const int mm0 = m0 < npos ? m0 : 0;
+    const int b = mm0 / L, t0 = mm0 - b * L;
+    sc.row0 = b * (L + 2) + 2 + t0;
+    sc.slot = mm0 + q;
+    sc.valid = ok;
+    sc.center = ok;
+}
+
 struct Panels {
     float* ACT;
     float* XA;
@@ -447,13 +582,16 @@ struct Split {
     static constexpr int CTA = CT >= 3 ? 2 * ((CT + 2) / 4) : 1;   // even when possible, so 16-byte pair loads stay whole
     static constexpr int CTB = CT - CTA;
     static_assert(CTB >= 1, "both channel halves need at least one tile");
+    // with super-tiles the padded last tile disappears and each half takes one super-tile: split CT - 1 evenly
+    static constexpr int SA = (CT - 1 + 1) / 2;
+    static constexpr int SB = CT - 1 - SA;
 };
 
 // =============================================================================================
 // Decoder: DEC_LargeCNN.forward (decoders.py:206-269) for nb blocks per workgroup.
-template <int U, int PT, int C0, int NC>
+template <int U, int PT, int C0, int NC, bool SUPER>
 __device__ __forceinline__ void dec_body(const FusedParams& P, char* smem, const Panels& pn, const TileCtx<PT>& tc,
-                                         int g, int lane, int blk0) {
+                                         const SuperCtx& sc, int g, int lane, int blk0) {
     const int L = P.L;
     const int n_stack = 2 * P.n_iter;
     const int F = P.F;
@@ -470,7 +608,7 @@ __device__ __forceinline__ void dec_body(const FusedParams& P, char* smem, const
         // dec2 output q2[i] becomes prior[p[i]] (deinterleave, decoders.py:249)
         const int* ptab = (s & 1) ? pn.PERM : pn.INV;
         if (s + 1 < n_stack) {
-            run_stack<U, PT, C0, NC>(P.wpack, s * sstride, (s + 1) * sstride, P.n_layer, smem, pn.ACT, Xin, pn.HS, tc, g, lane, ws,
+            run_stack<U, PT, C0, NC, SUPER>(P.wpack, s * sstride, (s + 1) * sstride, P.n_layer, smem, pn.ACT, Xin, pn.HS, tc, sc, g, lane, ws,
                                      [&](int p, int f, float v) {
                 if (f < F) {
                     if (extrinsic) v -= Xin[tc.row[p] * kXW + 2 + f];   // decoders.py:235-236,246-247
@@ -479,7 +617,7 @@ __device__ __forceinline__ void dec_body(const FusedParams& P, char* smem, const
             });
         } else {
             // last half-iteration: Linear(U->1), no extrinsic subtraction, sigmoid(deinterleave) (decoders.py:262-267)
-            run_stack<U, PT, C0, NC>(P.wpack, s * sstride, 0xffffffffu, P.n_layer, smem, pn.ACT, Xin, pn.HS, tc, g, lane, ws,
+            run_stack<U, PT, C0, NC, SUPER>(P.wpack, s * sstride, 0xffffffffu, P.n_layer, smem, pn.ACT, Xin, pn.HS, tc, sc, g, lane, ws,
                                      [&](int p, int f, float v) {
                 if (f == 0) xdec[tc.blk[p] * L + ptab[tc.t[p]]] = 1.0f / (1.0f + expf(-v));
             });
@@ -518,16 +656,26 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel(FusedParams P) {
 
     TileCtx<PT> tc;
     make_tiles<PT>(tc, g, lane, L, npos);
-    if (__builtin_amdgcn_readfirstlane(h) == 0) dec_body<U, PT, 0, Split<U>::CTA>(P, smem, pn, tc, g, lane, blk0);
-    else dec_body<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, g, lane, blk0);
+    SuperCtx sc;
+    make_super<PT>(sc, g, h, lane, L, npos);
+    const bool upper = __builtin_amdgcn_readfirstlane(h) != 0;
+    if constexpr (Geo<U>::SUP) {
+        if (P.super) {
+            if (!upper) dec_body<U, PT, 0, Split<U>::SA, true>(P, smem, pn, tc, sc, g, lane, blk0);
+            else dec_body<U, PT, Split<U>::SA, Split<U>::SB, true>(P, smem, pn, tc, sc, g, lane, blk0);
+            return;
+        }
+    }
+    if (!upper) dec_body<U, PT, 0, Split<U>::CTA, false>(P, smem, pn, tc, sc, g, lane, blk0);
+    else dec_body<U, PT, Split<U>::CTA, Split<U>::CTB, false>(P, smem, pn, tc, sc, g, lane, blk0);
 }
 
 // =============================================================================================
 // Encoder before power normalisation: ENC_interCNN.forward (encoders.py:362-373) + per-workgroup
 // partial sums for power_constraint (encoders.py:107-108).
-template <int U, int PT, int C0, int NC>
+template <int U, int PT, int C0, int NC, bool SUPER>
 __device__ __forceinline__ void enc_body(const FusedParams& P, char* smem, const Panels& pn, const TileCtx<PT>& tc,
-                                         int g, int lane, int blk0, double& sum, double& sumsq) {
+                                         const SuperCtx& sc, int g, int lane, int blk0, double& sum, double& sumsq) {
     const int L = P.L;
     float* xtx = P.out + (size_t)blk0 * L * 3;
     const bool act_elu = P.act == 0;
@@ -537,8 +685,8 @@ __device__ __forceinline__ void enc_body(const FusedParams& P, char* smem, const
     const uint32_t sstride = P.stack_stride * 4u;
     for (int s = 0; s < 3; ++s) {
         const float* Xin = (s == 2) ? pn.XB : pn.XA;
-        run_stack<U, PT, C0, NC>(P.wpack, s * sstride, s < 2 ? (s + 1) * sstride : 0xffffffffu, P.n_layer, smem, pn.ACT, Xin,
-                                 pn.HS, tc, g, lane, ws, [&](int p, int f, float v) {
+        run_stack<U, PT, C0, NC, SUPER>(P.wpack, s * sstride, s < 2 ? (s + 1) * sstride : 0xffffffffu, P.n_layer, smem, pn.ACT,
+                                        Xin, pn.HS, tc, sc, g, lane, ws, [&](int p, int f, float v) {
             if (f == 0) {
                 if (act_elu) v = elu1(v);                      // enc_act (encoders.py:364)
                 xtx[(size_t)(tc.blk[p] * L + tc.t[p]) * 3 + s] = v;   // x_p2 stays in interleaved order (encoders.py:371-373)
@@ -592,8 +740,21 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel(FusedParams P) {
     TileCtx<PT> tc;
     make_tiles<PT>(tc, g, lane, L, npos);
     double sum = 0.0, sumsq = 0.0;
-    if (__builtin_amdgcn_readfirstlane(h) == 0) enc_body<U, PT, 0, Split<U>::CTA>(P, smem, pn, tc, g, lane, blk0, sum, sumsq);
-    else enc_body<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, g, lane, blk0, sum, sumsq);
+    SuperCtx sc;
+    make_super<PT>(sc, g, h, lane, L, npos);
+    const bool upper = __builtin_amdgcn_readfirstlane(h) != 0;
+    bool done = false;
+    if constexpr (Geo<U>::SUP) {
+        if (P.super) {
+            if (!upper) enc_body<U, PT, 0, Split<U>::SA, true>(P, smem, pn, tc, sc, g, lane, blk0, sum, sumsq);
+            else enc_body<U, PT, Split<U>::SA, Split<U>::SB, true>(P, smem, pn, tc, sc, g, lane, blk0, sum, sumsq);
+            done = true;
+        }
+    }
+    if (!done) {
+        if (!upper) enc_body<U, PT, 0, Split<U>::CTA, false>(P, smem, pn, tc, sc, g, lane, blk0, sum, sumsq);
+        else enc_body<U, PT, Split<U>::CTA, Split<U>::CTB, false>(P, smem, pn, tc, sc, g, lane, blk0, sum, sumsq);
+    }
     block_reduce_stats(smem, tid, sum, sumsq, P.partials);
 }
 
@@ -606,9 +767,9 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel(FusedParams P) {
 // padding), and garbage from the panel edges creeps inwards 2 rows per layer, never reaching the
 // centre.  The F extrinsic values per position travel between stacks through the (B, L, 8) fp32
 // exchange buffers in HBM; (de)interleaving is the gather on the read side.
-template <int U, int PT, int C0, int NC>
-__device__ __forceinline__ void seg_body(const SegParams& P, char* smem, float* ACT, float* X, float* HS,
-                                         const TileCtx<PT>& tc, int g, int lane, int stack, int b, double& sum, double& sumsq) {
+template <int U, int PT, int C0, int NC, bool SUPER>
+__device__ __forceinline__ void seg_body(const SegParams& P, char* smem, float* ACT, float* X, float* HS, const TileCtx<PT>& tc,
+                                         const SuperCtx& sc, int g, int lane, int stack, int b, double& sum, double& sumsq) {
     const int L = P.L;
     WeightStream<U, PT, C0, NC> ws;
     ws.init(P.wpack, P.wpack_bytes, lane);
@@ -617,7 +778,7 @@ __device__ __forceinline__ void seg_body(const SegParams& P, char* smem, float* 
     if (P.mode == 0) {
         const bool act_elu = P.act == 0;
         float* xtx = P.out + (size_t)b * L * 3;
-        run_stack<U, PT, C0, NC>(P.wpack, soff, 0xffffffffu, P.n_layer, smem, ACT, X, HS, tc, g, lane, ws, [&](int p, int f, float v) {
+        run_stack<U, PT, C0, NC, SUPER>(P.wpack, soff, 0xffffffffu, P.n_layer, smem, ACT, X, HS, tc, sc, g, lane, ws, [&](int p, int f, float v) {
             if (f == 0) {
                 if (act_elu) v = elu1(v);
                 xtx[(size_t)tc.t[p] * 3 + stack] = v;
@@ -629,7 +790,7 @@ __device__ __forceinline__ void seg_body(const SegParams& P, char* smem, float* 
         const int F = P.F;
         const bool extrinsic = P.extrinsic != 0;
         float* ecur = P.ecur + (size_t)b * L * 8;
-        run_stack<U, PT, C0, NC>(P.wpack, soff, 0xffffffffu, P.n_layer, smem, ACT, X, HS, tc, g, lane, ws, [&](int p, int f, float v) {
+        run_stack<U, PT, C0, NC, SUPER>(P.wpack, soff, 0xffffffffu, P.n_layer, smem, ACT, X, HS, tc, sc, g, lane, ws, [&](int p, int f, float v) {
             if (f < F) {
                 if (extrinsic) v -= X[tc.row[p] * kXW + 2 + f];
                 ecur[(size_t)tc.t[p] * 8 + f] = v;
@@ -637,7 +798,7 @@ __device__ __forceinline__ void seg_body(const SegParams& P, char* smem, float* 
         });
     } else {
         float* xdec = P.out + (size_t)b * L;
-        run_stack<U, PT, C0, NC>(P.wpack, soff, 0xffffffffu, P.n_layer, smem, ACT, X, HS, tc, g, lane, ws, [&](int p, int f, float v) {
+        run_stack<U, PT, C0, NC, SUPER>(P.wpack, soff, 0xffffffffu, P.n_layer, smem, ACT, X, HS, tc, sc, g, lane, ws, [&](int p, int f, float v) {
             if (f == 0) xdec[P.perm[tc.t[p]]] = 1.0f / (1.0f + expf(-v));    // sigmoid(deinterleave), decoders.py:267
         });
     }
@@ -648,23 +809,27 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel(SegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = wave & (kGroups - 1), h = wave / kGroups;
-    const int L = P.L, H = 2 * P.n_layer, NP = P.T + 2 * H;
-    const int rows = NP + 4;
-    float* ACT = reinterpret_cast<float*>(smem);
-    float* X = ACT + (size_t)(rows + 1) * U;
-    float* HS = X + (size_t)(rows + 1) * kXW;
+    const int L = P.L, H = 2 * P.n_layer;
     int bid = blockIdx.x;
     int stack = P.stack;
     if (P.mode == 0) { stack = bid % 3; bid /= 3; }
     const int seg = bid % P.nseg, b = bid / P.nseg;
     const int s0 = seg * P.T;
     const int tlen = min(P.T, L - s0);
+    // panel position m <-> block index t = tstart + m; tstart is floored to a multiple of 4 so that the
+    // super-tile's shift index (m mod 4) equals t mod 4, exactly as in the whole-block kernels
+    const int tstart = (s0 - H) - ((s0 - H) & 3);
+    const int NP = s0 + P.T + H - tstart;              // <= T + 2H + 3
+    const int rows = P.T + 2 * H + 3 + 4;              // allocation-independent of the segment
+    float* ACT = reinterpret_cast<float*>(smem);
+    float* X = ACT + (size_t)(rows + 1) * U;
+    float* HS = X + (size_t)(rows + 1) * kXW;
     const bool odd = (stack & 1) != 0;
 
     zero_lds(smem, P.lds_bytes, tid);
     __syncthreads();
     for (int m = tid; m < NP; m += kThreads) {
-        const int t = s0 - H + m;
+        const int t = tstart + m;
         if (t < 0 || t >= L) continue;
         float* xr = X + (size_t)(2 + m) * kXW;
         if (P.mode == 0) {
@@ -685,12 +850,13 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel(SegParams P) {
     __syncthreads();
 
     TileCtx<PT> tc;
+    SuperCtx sc;
     {
-        const int n = lane & 15;
+        const int n = lane & 15, q = lane >> 4;
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
             const int m = (g * PT + p) * 16 + n;
-            const int t = s0 - H + m;
+            const int t = tstart + m;
             const bool v = (m < NP) && (t >= 0) && (t < L);
             tc.valid[p] = v;
             tc.center[p] = v && (t >= s0) && (t < s0 + tlen);
@@ -699,10 +865,32 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel(SegParams P) {
             tc.rowbase[p] = 2;
             tc.row[p] = v ? 2 + m : 2;
         }
+        {
+            const int Q = h == 0 ? n : 16 + (n & 3);
+            const int m0 = g * PT * 16 + 4 * Q;
+            const int t = tstart + m0 + q;
+            const bool ok = (h == 0 || n < 4) && (m0 + q < NP) && (t >= 0) && (t < L);
+            const int mm0 = m0 < NP ? m0 : 0;
+            sc.row0 = 2 + mm0;
+            sc.slot = mm0 + q;
+            sc.valid = ok;
+            sc.center = ok && (t >= s0) && (t < s0 + tlen);
+        }
     }
     double sum = 0.0, sumsq = 0.0;
-    if (__builtin_amdgcn_readfirstlane(h) == 0) seg_body<U, PT, 0, Split<U>::CTA>(P, smem, ACT, X, HS, tc, g, lane, stack, b, sum, sumsq);
-    else seg_body<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, ACT, X, HS, tc, g, lane, stack, b, sum, sumsq);
+    const bool upper = __builtin_amdgcn_readfirstlane(h) != 0;
+    bool done = false;
+    if constexpr (Geo<U>::SUP) {
+        if (P.super) {
+            if (!upper) seg_body<U, PT, 0, Split<U>::SA, true>(P, smem, ACT, X, HS, tc, sc, g, lane, stack, b, sum, sumsq);
+            else seg_body<U, PT, Split<U>::SA, Split<U>::SB, true>(P, smem, ACT, X, HS, tc, sc, g, lane, stack, b, sum, sumsq);
+            done = true;
+        }
+    }
+    if (!done) {
+        if (!upper) seg_body<U, PT, 0, Split<U>::CTA, false>(P, smem, ACT, X, HS, tc, sc, g, lane, stack, b, sum, sumsq);
+        else seg_body<U, PT, Split<U>::CTA, Split<U>::CTB, false>(P, smem, ACT, X, HS, tc, sc, g, lane, stack, b, sum, sumsq);
+    }
     if (P.mode == 0) block_reduce_stats(smem, tid, sum, sumsq, P.partials);
 }
 
@@ -867,7 +1055,7 @@ hipError_t launch_seg(int U, const SegParams& P, int grid, hipStream_t st) {
 }
 
 int seg_lds_bytes(int U, int T, int n_layer) {
-    const int rows = T + 4 * n_layer + 4;
+    const int rows = T + 4 * n_layer + 3 + 4;     // + up to 3 alignment rows (panel origin floored to a multiple of 4)
     size_t b = (size_t)(rows + 1) * U * 4 + (size_t)(rows + 1) * kXW * 4;
     b += (size_t)kHeadSlots * 8 * 4;     // head-combine scratch
     b = (b + 15) & ~(size_t)15;
