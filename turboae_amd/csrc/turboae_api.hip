@@ -139,7 +139,7 @@ struct tae_handle {
     float* d_gxb = nullptr;  // (chunk, L, 8) interleaved-order panel
     float* d_gy0 = nullptr;  // (chunk, L, 2H) layer-0 outputs
     float* d_gy1 = nullptr;  // (chunk, L, 2H) layer-1 outputs
-    float* d_ggi = nullptr;  // (chunk, L, 2, 3H) layer-1 input projections
+    float* d_ggi = nullptr;  // (chunk, L, 2, 19, 16) layer-1 input projections in gate-tile order
     float* d_gzero = nullptr;  // 6H zeros (b_ih already folded into the projections)
     tae::NormOpts nopts;       // encoder-output / channel variant (tae_set_channel_opts)
 };
@@ -159,7 +159,6 @@ int check_cfg(const tae_config* c) {
     if (c->enc_act != 0 && c->enc_act != 1) return fail(TAE_EINVAL, "enc_act must be 0 (elu) or 1 (linear)");
     if (c->dec_type != 0 && c->dec_type != 1) return fail(TAE_EINVAL, "dec_type must be 0 (cnn) or 1 (rnn/gru)");
     if (c->dec_type == 1 && c->dec_num_unit != 100) return fail(TAE_EINVAL, "the GRU decoder kernels are instantiated for dec_num_unit = 100");
-    if (c->dec_type == 1 && c->block_len > tae::gru_max_rec_block_len()) return fail(TAE_EINVAL, "block_len too large for the GRU decoder's LDS-staged input panel");
     return TAE_OK;
 }
 
@@ -174,24 +173,111 @@ size_t rnn_stack_floats(size_t H, size_t F, size_t nout) {
     return n + nout * 2 * H + nout;
 }
 
-// canonical GRU decoder -> per stack, per layer: w_ih (2,3H,cin) | w_hh (2,3H,H) | b_ih (2,3H) | b_hh (2,3H)
-// (both directions of one tensor contiguous), then Linear w | b.  Same total size as the canonical blob.
+// ---- GRU decoder packing (kernel-side layout: turboae_gru.hip) ------------------------------------------
+// Gate rows of one direction in 19 MFMA row tiles: tile 3*ut + g = gate g (r, z, n) of units 16*ut + m;
+// remainder tile 18, row 4*qq + i = gate i of unit 96 + qq.  `slot3` says what the remainder's 4th row holds:
+// nothing (-1) or the n gate again (layer-0 input projection), in which case row i = 2 is empty instead.
+constexpr int kGH = 100, kGRT = 19, kGKP = 13;
+constexpr size_t kGRecF = (size_t)kGRT * kGKP * 128, kGXF = (size_t)kGRT * 128, kGB0 = 25 * 16, kGB1 = 7 * 16;
+constexpr size_t kGProjF = 2 * 25 * (size_t)kGRT * 128, kGPB = 2 * (size_t)kGRT * 16;
+constexpr size_t kGL0Dir = kGRecF + kGXF + kGB0, kGL1Dir = kGRecF + kGB1;
+
+inline int gru_row(int T, int m, bool n_in_slot3) {
+    if (T < 18) return (T % 3) * kGH + 16 * (T / 3) + m;
+    const int qq = m >> 2, i = m & 3;
+    if (n_in_slot3) return i < 2 ? i * kGH + 96 + qq : (i == 3 ? 2 * kGH + 96 + qq : -1);
+    return i < 3 ? i * kGH + 96 + qq : -1;
+}
+// unit contracted by lane group kq in k-step s of the recurrent product
+inline int gru_kunit(int s, int kq) { return s < 24 ? 16 * (s / 4) + 4 * kq + (s % 4) : 96 + kq; }
+
+// W_hh (3H,H) -> [tile][k-step pair][lane][2]
+void pack_gru_rec(const float* Whh, float* dst) {
+    for (int T = 0; T < kGRT; ++T)
+        for (int kp = 0; kp < kGKP; ++kp)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int st = 0; st < 2; ++st) {
+                    const int s = 2 * kp + st, row = gru_row(T, lane & 15, false);
+                    dst[(((size_t)T * kGKP + kp) * 64 + lane) * 2 + st] = (s <= 24 && row >= 0) ? Whh[(size_t)row * kGH + gru_kunit(s, lane >> 4)] : 0.0f;
+                }
+}
+// layer-0 W_ih (3H,cin) -> [tile][lane][2]: k-step 0 = panel columns 0..3, k-step 1 = columns 4..7
+void pack_gru_x(const float* Wih, int cin, float* dst) {
+    for (int T = 0; T < kGRT; ++T)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int st = 0; st < 2; ++st) {
+                const int k = 4 * st + (lane >> 4), row = gru_row(T, lane & 15, true);
+                dst[((size_t)T * 64 + lane) * 2 + st] = (row >= 0 && k < cin) ? Wih[(size_t)row * cin + k] : 0.0f;
+            }
+}
+// layer-0 accumulator-init rows: 19 tiles (r, z: b_ih + b_hh; n: b_hn; remainder (r, z, b_hn, b_in)) + 6 n-input tiles (b_in)
+void pack_gru_bias0(const float* bih, const float* bhh, float* dst) {
+    for (int T = 0; T < kGRT; ++T)
+        for (int m = 0; m < 16; ++m) {
+            float v;
+            if (T < 18) { const int r = gru_row(T, m, false); v = (T % 3 < 2) ? bih[r] + bhh[r] : bhh[r]; }
+            else { const int qq = m >> 2, i = m & 3, u = 96 + qq;
+                   v = i < 2 ? bih[i * kGH + u] + bhh[i * kGH + u] : (i == 2 ? bhh[2 * kGH + u] : bih[2 * kGH + u]); }
+            dst[T * 16 + m] = v;
+        }
+    for (int ut = 0; ut < 6; ++ut)
+        for (int m = 0; m < 16; ++m) dst[(kGRT + ut) * 16 + m] = bih[2 * kGH + 16 * ut + m];
+}
+// layer-1 b_hn rows: 6 unit tiles + remainder (0, 0, b_hn, 0)
+void pack_gru_bias1(const float* bhh, float* dst) {
+    for (int ut = 0; ut < 6; ++ut)
+        for (int m = 0; m < 16; ++m) dst[ut * 16 + m] = bhh[2 * kGH + 16 * ut + m];
+    for (int m = 0; m < 16; ++m) dst[6 * 16 + m] = (m & 3) == 2 ? bhh[2 * kGH + 96 + (m >> 2)] : 0.0f;
+}
+// layer-1 W_ih (3H,2H) of one direction -> conv_accumulate's chunk-major pair layout over 19 tiles (see pack_conv)
+void pack_gru_proj(const float* Wih, float* dst) {
+    for (int c = 0; c < 25; ++c)
+        for (int ct = 0; ct < kGRT; ++ct)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int st = 0; st < 2; ++st) {
+                    size_t idx = (size_t)c * kGRT * 128;
+                    if (ct < 18) idx += (size_t)(ct / 2) * 256 + lane * 4 + (ct % 2) * 2 + st;
+                    else idx += (size_t)9 * 256 + lane * 2 + st;
+                    const int row = gru_row(ct, lane & 15, false);
+                    dst[idx] = row >= 0 ? Wih[(size_t)row * 2 * kGH + 8 * c + 2 * (lane >> 4) + st] : 0.0f;
+                }
+}
+// projection bias rows: b_ih, plus b_hh for the r and z gates (b_hn stays inside r * (...))
+void pack_gru_pbias(const float* bih, const float* bhh, float* dst) {
+    for (int T = 0; T < kGRT; ++T)
+        for (int m = 0; m < 16; ++m) {
+            const int r = gru_row(T, m, false);
+            dst[T * 16 + m] = r < 0 ? 0.0f : (r < 2 * kGH ? bih[r] + bhh[r] : bih[r]);
+        }
+}
+
+size_t rnn_packed_stack_floats(size_t nout) { return 2 * kGL0Dir + kGProjF + kGPB + 2 * kGL1Dir + (nout * 2 * kGH + nout + 3) / 4 * 4; }
+
+// canonical GRU decoder -> per stack: L0 {dir: REC | XF | BIAS0} | L1 {PROJ (2 dirs) | PBIAS (2 dirs) | dir: REC | BIAS1} | Linear w | b
 void repack_rnn(const float* src, float* dst, size_t H, size_t F, int n_iter) {
     for (int s = 0; s < 2 * n_iter; ++s) {
         const size_t nout = (s == 2 * n_iter - 1) ? 1 : F;
-        for (int l = 0; l < 2; ++l) {
-            const size_t cin = l == 0 ? 2 + F : 2 * H;
-            const size_t n_ih = 3 * H * cin, n_hh = 3 * H * H, n_b = 3 * H, per = n_ih + n_hh + 2 * n_b;
-            for (int d = 0; d < 2; ++d) {
-                const float* p = src + d * per;
-                memcpy(dst + d * n_ih, p, n_ih * sizeof(float));
-                memcpy(dst + 2 * n_ih + d * n_hh, p + n_ih, n_hh * sizeof(float));
-                memcpy(dst + 2 * n_ih + 2 * n_hh + d * n_b, p + n_ih + n_hh, n_b * sizeof(float));
-                memcpy(dst + 2 * n_ih + 2 * n_hh + 2 * n_b + d * n_b, p + n_ih + n_hh + n_b, n_b * sizeof(float));
-            }
-            src += 2 * per;
-            dst += 2 * per;
+        const size_t cin0 = 2 + F, cin1 = 2 * H;
+        const size_t per0 = 3 * H * cin0 + 3 * H * H + 6 * H, per1 = 3 * H * cin1 + 3 * H * H + 6 * H;
+        for (int d = 0; d < 2; ++d) {
+            const float* p = src + d * per0;           // weight_ih | weight_hh | bias_ih | bias_hh
+            float* o = dst + d * kGL0Dir;
+            pack_gru_rec(p + 3 * H * cin0, o);
+            pack_gru_x(p, (int)cin0, o + kGRecF);
+            pack_gru_bias0(p + 3 * H * cin0 + 3 * H * H, p + 3 * H * cin0 + 3 * H * H + 3 * H, o + kGRecF + kGXF);
         }
+        src += 2 * per0;
+        dst += 2 * kGL0Dir;
+        for (int d = 0; d < 2; ++d) {
+            const float* p = src + d * per1;
+            pack_gru_proj(p, dst + d * (kGProjF / 2));
+            pack_gru_pbias(p + 3 * H * cin1 + 3 * H * H, p + 3 * H * cin1 + 3 * H * H + 3 * H, dst + kGProjF + d * (kGPB / 2));
+            float* o = dst + kGProjF + kGPB + d * kGL1Dir;
+            pack_gru_rec(p + 3 * H * cin1, o);
+            pack_gru_bias1(p + 3 * H * cin1 + 3 * H * H + 3 * H, o + kGRecF);
+        }
+        src += 2 * per1;
+        dst += kGProjF + kGPB + 2 * kGL1Dir;
         memcpy(dst, src, (nout * 2 * H + nout) * sizeof(float));
         src += nout * 2 * H + nout;
         dst += (nout * 2 * H + nout + 3) / 4 * 4;        // keep every stack 16-byte aligned
@@ -199,11 +285,9 @@ void repack_rnn(const float* src, float* dst, size_t H, size_t F, int n_iter) {
 }
 
 size_t rnn_packed_floats(size_t H, size_t F, int n_iter) {
+    (void)H;
     size_t n = 0;
-    for (int s = 0; s < 2 * n_iter; ++s) {
-        const size_t nout = (s == 2 * n_iter - 1) ? 1 : F;
-        n += rnn_stack_floats(H, F, nout) - (nout * 2 * H + nout) + (nout * 2 * H + nout + 3) / 4 * 4;
-    }
+    for (int s = 0; s < 2 * n_iter; ++s) n += rnn_packed_stack_floats((s == 2 * n_iter - 1) ? 1 : F);
     return n;
 }
 
@@ -370,26 +454,19 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
             const bool odd = (s & 1) != 0, last = (s == 2 * n_iter - 1);
             const int nout = last ? 1 : F;
             const float* xin = odd ? h->d_gxb : h->d_gxa;
-            // layer 0: (w_ih, w_hh, b_ih, b_hh) for fwd then reverse are interleaved in the canonical order
-            const size_t cin0 = 2 + F, cin1 = 2 * H;
-            const size_t per0 = 3 * H * cin0 + 3 * H * H + 6 * H, per1 = 3 * H * cin1 + 3 * H * H + 6 * H;
-            // gather the two directions into the (2, ...) layout the kernels expect: they are strided by per0 / per1;
-            // the kernels index dir * rows * cols contiguously, so use the repacked copy made at create time
             tae::GruRecParams R0;
             memset(&R0, 0, sizeof(R0));
-            R0.x = xin; R0.gi = nullptr; R0.B = Bc; R0.L = L; R0.cin = (int)cin0; R0.y = h->d_gy0;
-            R0.w_ih = w; R0.w_hh = w + 2 * 3 * H * cin0; R0.b_ih = R0.w_hh + 2 * 3 * H * H; R0.b_hh = R0.b_ih + 2 * 3 * H;
+            R0.w = w; R0.w_dir_stride = (uint32_t)kGL0Dir; R0.x = xin; R0.B = Bc; R0.L = L; R0.y = h->d_gy0;
             TAE_HIP(tae::launch_gru_rec(true, R0, st));
-            const float* w1 = w + 2 * per0;
+            const float* w1 = w + 2 * kGL0Dir;
             tae::GruProjParams PP;
-            PP.yin = h->d_gy0; PP.w_ih = w1; PP.b_ih = w1 + 2 * 3 * H * cin1 + 2 * 3 * H * H; PP.gi = h->d_ggi; PP.npos = np;
+            PP.yin = h->d_gy0; PP.w = w1; PP.gi = h->d_ggi; PP.npos = np;
             TAE_HIP(tae::launch_gru_proj(PP, st));
             tae::GruRecParams R1;
             memset(&R1, 0, sizeof(R1));
-            R1.x = nullptr; R1.gi = h->d_ggi; R1.B = Bc; R1.L = L; R1.cin = 0; R1.y = h->d_gy1;
-            R1.w_ih = nullptr; R1.w_hh = w1 + 2 * 3 * H * cin1; R1.b_ih = h->d_gzero; R1.b_hh = PP.b_ih + 2 * 3 * H;
+            R1.w = w1 + kGProjF + kGPB; R1.w_dir_stride = (uint32_t)kGL1Dir; R1.gi = h->d_ggi; R1.B = Bc; R1.L = L; R1.y = h->d_gy1;
             TAE_HIP(tae::launch_gru_rec(false, R1, st));
-            const float* wl = w + 2 * per0 + 2 * per1;
+            const float* wl = w1 + kGProjF + kGPB + 2 * kGL1Dir;
             tae::GruHeadParams HP;
             memset(&HP, 0, sizeof(HP));
             HP.y = h->d_gy1; HP.w = wl; HP.b = wl + (size_t)nout * 2 * H; HP.xcur = xin;
@@ -397,7 +474,7 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
             HP.ptab = odd ? h->d_perm : h->d_inv;     // dec1 -> interleave (row inv[t]); dec2 -> deinterleave (row p[i])
             HP.npos = np; HP.L = L; HP.F = F; HP.nout = nout; HP.extrinsic = h->cfg.extrinsic; HP.last = last ? 1 : 0;
             TAE_HIP(tae::launch_gru_head(HP, st));
-            w += 2 * per0 + 2 * per1 + ((size_t)nout * 2 * H + nout + 3) / 4 * 4;
+            w += rnn_packed_stack_floats((size_t)nout);
         }
     }
     return TAE_OK;
@@ -553,13 +630,16 @@ int tae_reserve(tae_handle* h, int32_t max_batch) {
     if (h->cfg.dec_type == 1) {
         (void)hipFree(h->d_gxa); (void)hipFree(h->d_gxb); (void)hipFree(h->d_gy0); (void)hipFree(h->d_gy1); (void)hipFree(h->d_ggi);
         h->d_gxa = h->d_gxb = h->d_gy0 = h->d_gy1 = h->d_ggi = nullptr;
-        h->rnn_chunk = max_batch < 4096 ? max_batch : 4096;
+        // one full wave of recurrent workgroups = 256 CUs x 128 blocks / 2 directions; bound the workspace for long blocks
+        int32_t chunk = 16384;
+        while (chunk > 128 && (size_t)chunk * h->cfg.block_len > (size_t)16384 * 100) chunk -= 128;
+        h->rnn_chunk = max_batch < chunk ? max_batch : chunk;
         const size_t np = (size_t)h->rnn_chunk * h->cfg.block_len;
         TAE_HIP(hipMalloc(&h->d_gxa, np * 8 * sizeof(float)));
         TAE_HIP(hipMalloc(&h->d_gxb, np * 8 * sizeof(float)));
         TAE_HIP(hipMalloc(&h->d_gy0, np * 200 * sizeof(float)));
         TAE_HIP(hipMalloc(&h->d_gy1, np * 200 * sizeof(float)));
-        TAE_HIP(hipMalloc(&h->d_ggi, np * 600 * sizeof(float)));
+        TAE_HIP(hipMalloc(&h->d_ggi, np * 608 * sizeof(float)));
     }
     h->cap = max_batch;
     return TAE_OK;

@@ -50,20 +50,17 @@ struct SegParams {
 
 // ---- GRU decoder (turboae_gru.hip)
 struct GruRecParams {
-    const float* x;       // layer 0: input panel (B,L,8)
-    const float* gi;      // layer 1: input projections (B,L,2,3H)
-    const float* w_ih;    // layer 0: (2,3H,cin)
-    const float* b_ih;    // (2,3H)  (layer 1: already folded into gi -> pass zeros)
-    const float* w_hh;    // (2,3H,H)
-    const float* b_hh;    // (2,3H)
-    float* y;             // (B,L,2H)
-    int32_t B, L, cin;
+    const float* w;        // per direction: recurrent A fragments | (layer 0: input A fragments | bias rows) or (layer 1: b_hn rows)
+    uint32_t w_dir_stride; // floats between the two directions' blocks
+    const float* x;        // layer 0: input panel (B,L,8)
+    const float* gi;       // layer 1: input projections (B,L,2,19,16) in gate-tile order
+    float* y;              // (B,L,2H)
+    int32_t B, L;
 };
 struct GruProjParams {
     const float* yin;     // (npos, 2H)
-    const float* w_ih;    // (2,3H,2H)
-    const float* b_ih;    // (2,3H)
-    float* gi;            // (npos,2,3H)
+    const float* w;       // A fragments (2 dirs x 25 chunks x 19 tiles) followed by the bias rows (2 x 19 x 16)
+    float* gi;            // (npos,2,19,16)
     size_t npos;
 };
 struct GruHeadParams {
@@ -81,7 +78,6 @@ hipError_t launch_gru_prep(const float* rx, const int32_t* perm, float* XA, floa
 hipError_t launch_gru_rec(bool layer0, const GruRecParams& P, hipStream_t st);
 hipError_t launch_gru_proj(const GruProjParams& P, hipStream_t st);
 hipError_t launch_gru_head(const GruHeadParams& P, hipStream_t st);
-int gru_max_rec_block_len();
 
 hipError_t launch_seg(int U, const SegParams& P, int grid, hipStream_t st);
 int seg_lds_bytes(int U, int T, int n_layer);
