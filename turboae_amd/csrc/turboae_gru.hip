@@ -120,10 +120,10 @@ __global__ __launch_bounds__(512) void gru_rec_kernel(GruRecParams P) {
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(P.w + (size_t)dir * P.w_dir_stride);
         constexpr int NV = (kRecFragF + (LAYER0 ? kXFragF + kBias0F : kBias1F)) / 4;
-        for (int i = tid; i < NV; i += 512) reinterpret_cast<f32x4*>(smem)[i] = src[i];
+        for (int i = tid; i < NV; i += (int)blockDim.x) reinterpret_cast<f32x4*>(smem)[i] = src[i];
     }
     __syncthreads();
-    const int b0 = (blockIdx.x * 8 + wave) * 16;
+    const int b0 = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * 16;
     if (b0 >= P.B) return;                                  // no barrier below: waves are independent
     const int nb = min(16, P.B - b0);
     const bool valid = n < nb;
@@ -261,7 +261,7 @@ __device__ __forceinline__ void proj_half(const GruProjParams& P, const char* sm
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const size_t pos = p0 + (g * 2 + p) * 16 + n;
-            if (pos < P.npos) {
+            if (pos < P.npos && !(TAE_X & 32)) {
                 float* dst = P.gi + pos * kGiRowF + dir * (kRT * 16) + C0 * 16 + 4 * kq;
 #pragma unroll
                 for (int ct = 0; ct < NC; ++ct) *reinterpret_cast<f32x4*>(dst + ct * 16) = acc[p][ct];
@@ -350,12 +350,16 @@ int gru_rec_lds_bytes(bool layer0) { return (kRecFragF + (layer0 ? kXFragF + kBi
 
 hipError_t launch_gru_rec(bool layer0, const GruRecParams& P, hipStream_t st) {
     const int lds = gru_rec_lds_bytes(layer0);
-    const dim3 grid((P.B + 127) / 128, 2);
+    // 8 waves (128 blocks) per workgroup when that still fills the 256 CUs (one workgroup per CU: W_hh takes
+    // most of the LDS); fewer waves for small batches - a step costs the same whether a SIMD carries 1 or 2 waves' MFMAs
+    int nw = 8;
+    while (nw > 1 && 2 * ((P.B + 16 * nw - 1) / (16 * nw)) < 256) nw >>= 1;
+    const dim3 grid((P.B + 16 * nw - 1) / (16 * nw), 2);
     const void* fn = layer0 ? reinterpret_cast<const void*>(gru_rec_kernel<true>) : reinterpret_cast<const void*>(gru_rec_kernel<false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    if (layer0) hipLaunchKernelGGL(gru_rec_kernel<true>, grid, dim3(512), lds, st, P);
-    else hipLaunchKernelGGL(gru_rec_kernel<false>, grid, dim3(512), lds, st, P);
+    if (layer0) hipLaunchKernelGGL(gru_rec_kernel<true>, grid, dim3(64 * nw), lds, st, P);
+    else hipLaunchKernelGGL(gru_rec_kernel<false>, grid, dim3(64 * nw), lds, st, P);
     return hipGetLastError();
 }
 
