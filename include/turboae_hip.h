@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAE_ABI_VERSION 3
+#define TAE_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define TAE_API __attribute__((visibility("default")))
@@ -62,7 +62,14 @@ typedef struct tae_config {
     int32_t max_batch;        /* blocks per call the workspace is sized for (grown by tae_reserve) */
     int32_t dec_type;         /* -decoder: 0 = TurboAE_rate3_cnn (DEC_LargeCNN, decoders.py:157),
                                  1 = TurboAE_rate3_rnn (DEC_LargeRNN with dec_rnn=gru, decoders.py:16; needs dec_num_unit=100)  main.py:75-88 */
+    int32_t precision;        /* arithmetic of the conv contractions (no reference counterpart; the reference is fp32 on CPU/CUDA):
+                                 TAE_PREC_AUTO = 0: fp32 operands carried as two fp16 halves, three v_mfma_f32_16x16x32_f16 products,
+                                 fp32 accumulation - fp32-grade results - where the whole-block kernels apply,
+                                 TAE_PREC_F32 otherwise; TAE_PREC_F32 = 1: v_mfma_f32_16x16x4_f32 on the fp32 operands everywhere */
 } tae_config;
+
+#define TAE_PREC_AUTO 0
+#define TAE_PREC_F32 1
 
 /* Encoder-output / channel variants of the same kernels (reference flags in parentheses).  Defaults
  * (all zero except the limits) are the reference defaults: batch power normalisation, AWGN add. */
@@ -144,6 +151,12 @@ TAE_API int tae_generate_inputs(tae_handle* h, float* u, float* noise, int32_t B
 
 /* Blocks per workgroup and dynamic LDS bytes of the fused kernels (for DESIGN / bench reporting). */
 TAE_API int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_t* lds_bytes);
+
+/* Arithmetic actually in use (*precision = 0: fp32 MFMA, 1: fp16-split MFMA) and its sticky range flag:
+ * *overflow = 1 if, since the last call, an activation exceeded the fp16 range (65504) in the fp16-split
+ * kernels, which clamp there - results of those launches are not trustworthy; recreate the handle with
+ * TAE_PREC_F32.  Synchronises the device (reads one word back) and clears the flag. */
+TAE_API int tae_range_status(tae_handle* h, int32_t* precision, int32_t* overflow);
 
 TAE_API const char* tae_last_error(void);
 TAE_API int tae_abi_version(void);

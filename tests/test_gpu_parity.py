@@ -200,12 +200,56 @@ def test_rejects_bad_shapes(gpu_device):
         model(torch.zeros(2, 100, 1, device=gpu_device), torch.zeros(3, 100, 3, device=gpu_device))
 
 
+def test_precision_modes_against_fp64_oracle(gpu_device):
+    """The default fp16-split contraction (hi/lo halves, 3 MFMA products, fp32 accumulate) must be fp32-grade:
+    measured against the oracle run in FLOAT64 it may not be worse than the exact-fp32 MFMA kernels
+    (beyond a small slack), and both stay inside the parity tolerances."""
+    from turboae_amd import Channel_AE_HIP
+    B = 12
+    u, noise = make_inputs(B, 100, seed=61)
+    ud, nd = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
+    base = TurboAEConfig()
+    sd = W.generate_state_dict(base, seed=7, gain=1.0)
+    sd64 = {k: torch.from_numpy(np.asarray(v, dtype=np.float64)) for k, v in sd.items()}
+    x64, c64 = O.channel_ae_forward(torch.from_numpy(u).double(), torch.from_numpy(noise).double(), sd64, base.to_dict())
+    err = {}
+    for prec in ("auto", "f32"):
+        model = Channel_AE_HIP(TurboAEConfig(precision=prec), sd, device=gpu_device, max_batch=B)
+        xd, codes = model(ud, nd)
+        mode, ovf = model.range_status()
+        assert mode == ("f16x2" if prec == "auto" else "f32") and not ovf
+        err[prec] = (float((codes.cpu().double() - c64).abs().max()), float((xd.cpu().double() - x64).abs().max()))
+    print("max |err| vs fp64 oracle (codes, x_dec):", err)
+    for k in (0, 1):
+        assert err["auto"][k] <= 2.0 * err["f32"][k] + 5e-7, err
+    assert err["auto"][0] <= ATOL_CODES and err["auto"][1] <= ATOL_XDEC
+
+
+def test_fp16_split_reports_out_of_range_activations(gpu_device):
+    """Weights scaled so that activations exceed 65504: the fp16-split kernels clamp and raise the sticky flag
+    (check_range() raises); precision='f32' handles the same model."""
+    from turboae_amd import Channel_AE_HIP, _lib
+    cfg = TurboAEConfig(num_iteration=1)
+    sd = W.generate_state_dict(cfg, seed=5, gain=40.0)
+    u, noise = make_inputs(4, cfg.block_len, seed=62)
+    ud, nd = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4)
+    model(ud, nd)
+    with pytest.raises(_lib.TurboAEError):
+        model.check_range()
+    model.check_range()          # the flag is cleared by the read
+    exact = Channel_AE_HIP(TurboAEConfig(num_iteration=1, precision="f32"), sd, device=gpu_device, max_batch=4)
+    xd, codes = exact(ud, nd)
+    exact.check_range()
+    assert torch.isfinite(codes).all()
+
+
 @pytest.mark.parametrize("seg_t", [None, "37", "16"])
 def test_segmented_path_is_bit_identical_to_fused(gpu_device, monkeypatch, seg_t):
     """The long-block (segmented, halo-recompute) kernels sum every dot product in the same order as
     the whole-block kernels, so on a short block both paths must agree bit for bit."""
     from turboae_amd import Channel_AE_HIP
-    cfg = TurboAEConfig(num_iteration=2)
+    cfg = TurboAEConfig(num_iteration=2, precision="f32")     # the long-block kernels are fp32-MFMA: compare like with like
     sd = W.generate_state_dict(cfg, seed=7, gain=1.0)
     u, noise = make_inputs(7, cfg.block_len, seed=51)
     ud, nd = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)

@@ -1,0 +1,150 @@
+// Micro-probe for the fp16-split contraction (fp32 operands as hi + lo halves, 3 MFMA products):
+//   A. operand layout of v_mfma_f32_16x16x32_f16, fp16-denormal handling, accuracy of the 3-product
+//      emulation vs the exact-fp32 v_mfma_f32_16x16x4_f32 chain (both against an fp64 host reference);
+//   B. issue rate of v_mfma_f32_16x16x32_f16 with 1 and 2 waves per SIMD, and the price of filler
+//      instructions beside it.
+// Build: hipcc --offload-arch=gfx950 -O3 -o probe f16_split_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <random>
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+
+constexpr int K = 512;
+
+// D[16][16] = A[16][K] * B[K][16]; one wave.  mode 0: fp32 MFMA chain; mode 1: f16 split, 3 products;
+// mode 2: f16 hi only (1 product); mode 3: 4 products (adds lo*lo)
+__global__ void gemm_probe(const float* A, const float* B, float* D, int mode, float wscale) {
+    const int lane = threadIdx.x, i = lane & 15, kq = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (mode == 0) {
+        for (int k0 = 0; k0 < K; k0 += 4)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i * K + k0 + kq], B[(k0 + kq) * 16 + i], acc, 0, 0, 0);
+    } else {
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            h8 ah, al, bh, bl;
+            for (int j = 0; j < 8; ++j) {
+                const float a = A[i * K + k0 + 8 * kq + j] * wscale;
+                const float b = B[(k0 + 8 * kq + j) * 16 + i];
+                ah[j] = (_Float16)a; al[j] = (_Float16)(a - (float)ah[j]);
+                bh[j] = (_Float16)b; bl[j] = (_Float16)(b - (float)bh[j]);
+            }
+            if (mode == 3) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bl, acc, 0, 0, 0);
+            if (mode != 2) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+        }
+    }
+    for (int r = 0; r < 4; ++r) D[(4 * kq + r) * 16 + i] = acc[r] / wscale;
+}
+
+template <int KIND, int NF, int NT>
+__global__ __launch_bounds__(NT) void rate_probe(float* out, int iters, float seed) {
+    f32x4 acc[30];
+    for (int i = 0; i < 30; ++i) acc[i] = f32x4{seed, seed, seed, seed};
+    h8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(seed + threadIdx.x + j); b[j] = (_Float16)(seed * 0.5f + j); }
+    float f[8];
+    for (int i = 0; i < 8; ++i) f[i] = seed + i;
+    float g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    __shared__ float lds[2048];
+    lds[threadIdx.x] = seed;
+    __syncthreads();
+    unsigned ldsaddr = (threadIdx.x & 63) * 8;
+    const float* gptr = out + (threadIdx.x & 63) * 4;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 60; ++m) {
+            acc[m % 30] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[m % 30], 0, 0, 0);
+            if (m < NF) {
+                float& x = f[m % 8];
+                if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x) : "v"(f[(m + 1) % 8]));
+                if (KIND == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(x));
+                if (KIND == 2) asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(x) : "v"(f[(m + 1) % 8]));
+                if (KIND == 3) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(x));
+                if (KIND == 4) asm volatile("ds_read_b64 %0, %1" : "=v"(*(double*)&g[(m % 4) * 2]) : "v"(ldsaddr));
+                if (KIND == 5) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(*(f32x4*)&g[(m % 2) * 4]) : "v"(gptr));
+                if (KIND == 6) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(*(double*)&f[(m % 4) * 2]) : "v"(*(double*)&f[((m + 1) % 4) * 2]));
+                if (KIND == 7) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(f[(m + 1) % 8]), "v"(f[(m + 2) % 8]));
+                if (KIND == 8) asm volatile("ds_write_b64 %0, %1" :: "v"(ldsaddr), "v"(*(double*)&f[(m % 4) * 2]) : "memory");
+            }
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 30; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    for (int i = 0; i < 8; ++i) s += f[i] + g[i];
+    out[blockIdx.x * NT + threadIdx.x] = s;
+}
+
+template <int KIND, int NF, int NT>
+void rate(float* d, const char* name) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = 20000;
+    rate_probe<KIND, NF, NT><<<256, NT>>>(d, 10, 0.0f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    rate_probe<KIND, NF, NT><<<256, NT>>>(d, iters, 0.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double wavesPerSimd = NT / 256.0;
+    const double nsPerMfma = ms * 1e6 / ((double)iters * 60 * wavesPerSimd);
+    const double tf = 256.0 * 4 * wavesPerSimd * iters * 60 * 16384.0 / (ms * 1e-3) / 1e12;
+    printf("%-14s NF=%2d threads=%d: %.2f ms  %.2f ns per MFMA per SIMD (%.1f cyc @2.4GHz)  %.0f TFLOP/s\n", name, NF, NT, ms, nsPerMfma, nsPerMfma * 2.4, tf);
+}
+
+int main() {
+    std::mt19937 rng(1);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    std::uniform_real_distribution<float> ud(-0.0775f, 0.0775f);     // U(+-sqrt(3/500)): the conv weights' range
+    std::vector<float> A(16 * K), B(K * 16), D(256);
+    float *dA, *dB, *dD;
+    hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dD, 4 * 256 * 512);
+    auto run = [&](int mode, float ws, const char* what) {
+        hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
+        gemm_probe<<<1, 64>>>(dA, dB, dD, mode, ws);
+        hipMemcpy(D.data(), dD, 256 * 4, hipMemcpyDeviceToHost);
+        double maxe = 0, maxref = 0, rms = 0;
+        for (int i = 0; i < 16; ++i)
+            for (int n = 0; n < 16; ++n) {
+                double r = 0;
+                for (int k = 0; k < K; ++k) r += (double)A[i * K + k] * (double)B[k * 16 + n];
+                const double e = fabs(D[i * 16 + n] - r);
+                maxe = fmax(maxe, e); maxref = fmax(maxref, fabs(r)); rms += e * e;
+            }
+        printf("%-44s mode %d wscale %6g: max|err| %.3e  rms %.3e  (max|ref| %.3f)\n", what, mode, ws, maxe, sqrt(rms / 256), maxref);
+    };
+    // 1. layout: small integers (exact in every mode)
+    for (auto& v : A) v = (float)((int)(rng() % 7) - 3);
+    for (auto& v : B) v = (float)((int)(rng() % 5) - 2);
+    run(0, 1.f, "layout check, small integers"); run(2, 1.f, "layout check, small integers");
+    // 2. fp16 denormal inputs: A = 2^-20 (fp16 denormal), B = 1 -> K * 2^-20
+    for (auto& v : A) v = ldexpf(1.f, -20);
+    for (auto& v : B) v = 1.f;
+    run(2, 1.f, "fp16 denormal A (expect 0 error if kept)");
+    // 3. accuracy on layer-like data: weights U(+-0.0775), activations ELU(N(0,1))
+    for (int rep = 0; rep < 2; ++rep) {
+        for (auto& v : A) v = ud(rng);
+        for (auto& v : B) { const float x = nd(rng) * (rep ? 3.f : 1.f); v = x > 0 ? x : expm1f(x); }
+        run(0, 1.f, rep ? "layer-like (act x3), fp32 MFMA chain" : "layer-like, fp32 MFMA chain");
+        run(2, 1.f, "  f16 hi only");
+        run(1, 1.f, "  f16 split 3 products, unscaled weights");
+        run(1, 1024.f, "  f16 split 3 products, weights x 2^10");
+        run(3, 1024.f, "  f16 split 4 products, weights x 2^10");
+    }
+    // B. issue rates
+    rate<0, 0, 256>(dD, "bare"); rate<0, 0, 512>(dD, "bare");
+    rate<0, 30, 512>(dD, "v_fma"); rate<1, 30, 512>(dD, "v_exp"); rate<2, 30, 512>(dD, "cvt_pkrtz"); rate<3, 30, 512>(dD, "cvt_f32_f16");
+    rate<4, 30, 512>(dD, "ds_read_b64"); rate<4, 60, 512>(dD, "ds_read_b64"); rate<5, 15, 512>(dD, "global_b128"); rate<5, 30, 512>(dD, "global_b128");
+    rate<6, 30, 512>(dD, "v_pk_add_f32"); rate<7, 30, 512>(dD, "v_med3"); rate<8, 15, 512>(dD, "ds_write_b64");
+    rate<0, 60, 512>(dD, "v_fma"); rate<0, 60, 256>(dD, "v_fma");
+    return 0;
+}

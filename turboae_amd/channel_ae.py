@@ -60,7 +60,7 @@ class _Engine:
         c = _lib.TaeConfig(C.sizeof(_lib.TaeConfig), cfg.block_len, cfg.enc_num_layer, cfg.enc_num_unit,
                            cfg.enc_kernel_size, cfg.dec_num_layer, cfg.dec_num_unit, cfg.dec_kernel_size,
                            cfg.num_iteration, cfg.num_iter_ft, cfg.extrinsic, _ENC_ACT[cfg.enc_act], max_batch,
-                           1 if cfg.decoder == "TurboAE_rate3_rnn" else 0)
+                           1 if cfg.decoder == "TurboAE_rate3_rnn" else 0, 1 if cfg.precision == "f32" else 0)
         n = self.lib.tae_num_weights(C.byref(c))
         if n != blob.size:
             raise _lib.TurboAEError(f"weight count mismatch: library wants {n}, blob has {blob.size}")
@@ -134,6 +134,20 @@ class _Engine:
         nb, lds = C.c_int32(), C.c_int32()
         _lib.check(self.lib.tae_kernel_info(self.h, C.byref(nb), C.byref(lds)))
         return nb.value, lds.value
+
+    def range_status(self) -> Tuple[str, bool]:
+        """('f16x2' | 'f32', overflow): the arithmetic in use and whether an activation left the fp16 range since
+        the last call (the f16x2 kernels clamp at 65504 and report).  Synchronises the device."""
+        prec, ovf = C.c_int32(), C.c_int32()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.tae_range_status(self.h, C.byref(prec), C.byref(ovf)))
+        return ("f16x2" if prec.value == 1 else "f32"), bool(ovf.value)
+
+    def check_range(self) -> None:
+        prec, ovf = self.range_status()
+        if ovf:
+            raise _lib.TurboAEError("an activation exceeded the fp16 range in the fp16-split kernels (clamped at 65504); "
+                                    "results are not trustworthy - use TurboAEConfig(precision='f32')")
 
     # ---- tensor helpers
     def _in(self, t: torch.Tensor, last: int, name: str) -> torch.Tensor:
@@ -250,6 +264,13 @@ class Channel_AE_HIP:
 
     def kernel_info(self):
         return self._eng.kernel_info()
+
+    def range_status(self):
+        return self._eng.range_status()
+
+    def check_range(self) -> None:
+        """Raises TurboAEError if the fp16-split kernels saw an out-of-range activation (call after a batch of forwards)."""
+        self._eng.check_range()
 
     def _engine_for(self, L: int) -> _Engine:
         if L == self.cfg.block_len:

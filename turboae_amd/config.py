@@ -27,6 +27,8 @@ class TurboAEConfig:
     decoder: str = "TurboAE_rate3_cnn"   # get_args.py:26 / main.py:75-76,87-88: 'TurboAE_rate3_cnn' (DEC_LargeCNN) or
                                          # 'TurboAE_rate3_rnn' (DEC_LargeRNN, 2-layer bidirectional GRU, dec_rnn='gru')
     interleaver_seed: int = 0     # channel_ae.py:33 (RandInterlv(block_len, 0))
+    precision: str = "auto"       # no reference counterpart: 'auto' = fp16-split MFMA contraction (fp32-grade)
+                                  # where the whole-block kernels apply; 'f32' = fp32 MFMA everywhere
     # ---- encoder-output / channel variants on the same kernels
     channel: str = "awgn"                 # get_args.py:43; channel_ae.py:41-49 ('fading' draws its own RNG: not supported)
     no_code_norm: bool = False            # get_args.py:159; encoders.py:104-105
@@ -43,6 +45,8 @@ class TurboAEConfig:
             raise ValueError("only the rate-1/3 code (code_rate_k=1, code_rate_n=3) is on the hot path")
         if self.enc_kernel_size != 5 or self.dec_kernel_size != 5:
             raise ValueError("HIP path implements kernel_size=5 (the reference default and all BASELINE configs)")
+        if self.precision not in ("auto", "f32"):
+            raise ValueError("precision must be 'auto' or 'f32'")
         if self.enc_act not in ("elu", "linear"):
             raise ValueError("enc_act must be 'elu' (reference default) or 'linear'")
         if self.enc_num_unit != self.dec_num_unit:

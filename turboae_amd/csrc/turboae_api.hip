@@ -109,6 +109,102 @@ size_t pack_stack(const float* src, const Layout& lo, int n_layer, int cin0, int
     return (size_t)(s - src);
 }
 
+// ---- f16x2 representation (turboae_h2.hip) -----------------------------------------------------------------
+struct LayoutH {   // must mirror tae::GeoH<U>
+    int U, CT, CP, nsl_mid;
+    uint32_t slb, midb, l0b, tailb;
+    explicit LayoutH(int u) : U(u) {
+        CT = (U + 15) / 16;
+        CP = CT * 16;
+        nsl_mid = (5 * U + 31) / 32;
+        slb = (uint32_t)CT * 2048u;
+        midb = (uint32_t)nsl_mid * slb;
+        l0b = 2u * slb;
+        tailb = (uint32_t)CP * 4u + 16u;
+    }
+    size_t stack_bytes(int n_layer) const {
+        return (size_t)l0b + (size_t)(n_layer - 1) * midb + (size_t)n_layer * tailb + (size_t)8 * CP * 4 + 32;
+    }
+};
+
+// fp32 -> fp16 bits, round to nearest even, denormals kept (the device side uses v_cvt_f16_f32 in the default mode)
+inline uint16_t f2h(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                 // rounds to >= 65520 -> inf
+    if (x < 0x33000001u) return (uint16_t)sign;                               // <= 2^-25 -> 0 (ties to even)
+    int e = (int)(x >> 23) - 127;
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    int shift = e >= -14 ? 13 : 13 + (-14 - e);                               // denormal: more bits dropped
+    const uint32_t half = 1u << (shift - 1), rest = m & ((1u << shift) - 1);
+    uint32_t r = m >> shift;
+    if (rest > half || (rest == half && (r & 1u))) ++r;
+    if (e >= -14) return (uint16_t)(sign | (uint32_t)(((e + 15) << 10) + (r - 0x400u)));   // carry propagates into the exponent
+    return (uint16_t)(sign | r);
+}
+inline float h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const int e = (h >> 10) & 0x1f;
+    const uint32_t m = h & 0x3ffu;
+    float v;
+    if (e == 0) v = ldexpf((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = ldexpf((float)(m | 0x400u), e - 25);
+    return sign ? -v : v;
+}
+
+// Conv1d weight (U, cin, 5) -> [slab][channel tile][hi | lo][lane][8 halves]: lane (i = lane & 15, kq = lane >> 4) holds
+// W'[co = 16 ct + i][k = 32 slab + 8 kq + j] * scale, split into hi = f16(w), lo = f16(w - hi)
+void pack_conv_h(const float* W, int U, int cin, int cin_pad, int nslab, int CT, float scale, uint16_t* dst) {
+    for (int sl = 0; sl < nslab; ++sl)
+        for (int ct = 0; ct < CT; ++ct)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const float w = wflat(W, U, cin, cin_pad, ct * 16 + (lane & 15), 32 * sl + 8 * (lane >> 4) + j) * scale;
+                    const uint16_t hi = f2h(w), lo = f2h(w - h2f(hi));
+                    const size_t base = ((size_t)(sl * CT + ct) * 2) * 512 + (size_t)lane * 8 + j;
+                    dst[base] = hi;
+                    dst[base + 512] = lo;
+                }
+}
+
+// canonical stack -> f16x2 packed stack (bytes at dst); returns floats consumed from src
+size_t pack_stack_h(const float* src, const LayoutH& lo, int n_layer, int cin0, int nout, char* dst) {
+    const float* s = src;
+    char* d = dst;
+    for (int l = 0; l < n_layer; ++l) {
+        const int cin = l == 0 ? cin0 : lo.U;
+        const size_t nw = (size_t)lo.U * cin * 5;
+        float maxabs = 0.0f;
+        for (size_t i = 0; i < nw; ++i) maxabs = fmaxf(maxabs, fabsf(s[i]));
+        int e = 0;
+        if (maxabs > 0.0f && std::isfinite(maxabs)) (void)frexpf(maxabs, &e);    // maxabs in [2^(e-1), 2^e)
+        int S = (maxabs > 0.0f) ? 14 - e : 0;                                    // scaled max in [2^13, 2^14)
+        if (S > 60) S = 60;
+        if (S < -60) S = -60;
+        const float scale = ldexpf(1.0f, S), inv = ldexpf(1.0f, -S);
+        pack_conv_h(s, lo.U, cin, l == 0 ? 8 : lo.U, l == 0 ? 2 : lo.nsl_mid, lo.CT, scale, reinterpret_cast<uint16_t*>(d));
+        d += l == 0 ? lo.l0b : lo.midb;
+        const float* b = s + nw;
+        float* t = reinterpret_cast<float*>(d);
+        for (int c = 0; c < lo.CP; ++c) t[c] = c < lo.U ? b[c] * scale : 0.0f;
+        for (int c = 0; c < 4; ++c) t[lo.CP + c] = inv;
+        d += lo.tailb;
+        s = b + lo.U;
+    }
+    float* t = reinterpret_cast<float*>(d);
+    for (int f = 0; f < 8; ++f)
+        for (int c = 0; c < lo.CP; ++c) t[f * lo.CP + c] = (f < nout && c < lo.U) ? s[(size_t)f * lo.U + c] : 0.0f;
+    t += 8 * lo.CP;
+    s += (size_t)nout * lo.U;
+    for (int f = 0; f < 8; ++f) t[f] = f < nout ? s[f] : 0.0f;
+    s += nout;
+    return (size_t)(s - src);
+}
+
 }  // namespace
 
 struct tae_handle {
@@ -120,6 +216,13 @@ struct tae_handle {
     uint32_t enc_stride = 0, dec_stride = 0;
     uint32_t enc_bytes = 0, dec_bytes = 0;
     int super = 0;           // remainder channels via super-tiles (U % 16 == 4 and block_len % 4 == 0)
+    // f16x2 representation of the whole-block kernels (prec == 1); the fp32 packs above stay resident for the long-block path
+    int prec = 0;            // 0: v_mfma_f32_16x16x4_f32 on fp32 operands; 1: 3 x v_mfma_f32_16x16x32_f16 on hi/lo halves
+    int lds_bytes_h = 0;
+    uint32_t enc_stride_h = 0, dec_stride_h = 0, enc_bytes_h = 0, dec_bytes_h = 0;
+    char* d_wenc_h = nullptr;
+    char* d_wdec_h = nullptr;
+    uint32_t* d_flags = nullptr;   // bit 0: an activation left the fp16 range (f16x2 kernels clamp and report)
     float* d_wenc = nullptr;
     float* d_wdec = nullptr;
     int32_t* d_perm = nullptr;
@@ -158,6 +261,7 @@ int check_cfg(const tae_config* c) {
     if (c->block_len < 1) return fail(TAE_EINVAL, "block_len must be >= 1");
     if (c->enc_act != 0 && c->enc_act != 1) return fail(TAE_EINVAL, "enc_act must be 0 (elu) or 1 (linear)");
     if (c->dec_type != 0 && c->dec_type != 1) return fail(TAE_EINVAL, "dec_type must be 0 (cnn) or 1 (rnn/gru)");
+    if (c->precision != TAE_PREC_AUTO && c->precision != TAE_PREC_F32) return fail(TAE_EINVAL, "precision must be TAE_PREC_AUTO (0) or TAE_PREC_F32 (1)");
     if (c->dec_type == 1 && c->dec_num_unit != 100) return fail(TAE_EINVAL, "the GRU decoder kernels are instantiated for dec_num_unit = 100");
     return TAE_OK;
 }
@@ -437,6 +541,14 @@ int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_
     P.stack_stride = h->enc_stride;
     P.wpack_bytes = h->enc_bytes;
     const int grid = (B + h->nb - 1) / h->nb;
+    if (h->prec == 1) {
+        P.wpack = reinterpret_cast<const float*>(h->d_wenc_h);
+        P.stack_stride = h->enc_stride_h;
+        P.wpack_bytes = h->enc_bytes_h;
+        P.lds_bytes = h->lds_bytes_h;
+        P.flags = h->d_flags;
+        TAE_HIP(tae::launch_fused_h(h->U, false, P, grid, st));
+    } else
     TAE_HIP(tae::launch_fused(h->U, false, P, grid, st));
     TAE_HIP(tae::launch_reduce_partials(h->d_partials, grid, (double)B * h->cfg.block_len * 3.0, stats, st));
     return TAE_OK;
@@ -491,6 +603,15 @@ int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStrea
     P.stack_stride = h->dec_stride;
     P.wpack_bytes = h->dec_bytes;
     const int grid = (B + h->nb - 1) / h->nb;
+    if (h->prec == 1) {
+        P.wpack = reinterpret_cast<const float*>(h->d_wdec_h);
+        P.stack_stride = h->dec_stride_h;
+        P.wpack_bytes = h->dec_bytes_h;
+        P.lds_bytes = h->lds_bytes_h;
+        P.flags = h->d_flags;
+        TAE_HIP(tae::launch_fused_h(h->U, true, P, grid, st));
+        return TAE_OK;
+    }
     TAE_HIP(tae::launch_fused(h->U, true, P, grid, st));
     return TAE_OK;
 }
@@ -565,6 +686,33 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         delete h;
         return fail(TAE_EINVAL, "internal: weight walk mismatch");
     }
+    // precision of the whole-block kernels: config field, overridden by env TAE_PRECISION=f32|f16x2 (testing knob)
+    int want_h2 = cfg->precision == TAE_PREC_F32 ? 0 : 1;
+    if (const char* pe = getenv("TAE_PRECISION")) {
+        if (!strcmp(pe, "f32")) want_h2 = 0;
+        else if (!strcmp(pe, "f16x2")) want_h2 = 1;
+    }
+    std::vector<char> penc_h, pdec_h;
+    if (want_h2 && h->nb >= 1 && tae::fused_lds_bytes_h(h->U, cfg->block_len, h->nb) <= 160 * 1024) {
+        h->prec = 1;
+        h->lds_bytes_h = tae::fused_lds_bytes_h(h->U, cfg->block_len, h->nb);
+        const LayoutH lh(h->U);
+        h->enc_stride_h = (uint32_t)lh.stack_bytes(cfg->enc_num_layer);
+        h->dec_stride_h = (uint32_t)lh.stack_bytes(cfg->dec_num_layer);
+        penc_h.assign((size_t)3 * h->enc_stride_h, 0);
+        h->enc_bytes_h = (uint32_t)penc_h.size();
+        const float* s2 = weights;
+        for (int s = 0; s < 3; ++s) s2 += pack_stack_h(s2, lh, cfg->enc_num_layer, 1, 1, penc_h.data() + (size_t)s * h->enc_stride_h);
+        if (cfg->dec_type == 0) {
+            pdec_h.assign((size_t)2 * cfg->num_iteration * h->dec_stride_h, 0);
+            h->dec_bytes_h = (uint32_t)pdec_h.size();
+            for (int it = 0; it < cfg->num_iteration; ++it)
+                for (int half = 0; half < 2; ++half) {
+                    const int nout = (half == 1 && it == cfg->num_iteration - 1) ? 1 : F;
+                    s2 += pack_stack_h(s2, lh, cfg->dec_num_layer, 2 + F, nout, pdec_h.data() + (size_t)(2 * it + half) * h->dec_stride_h);
+                }
+        }
+    }
     const int L = cfg->block_len;
     std::vector<int32_t> ident(L);
     for (int i = 0; i < L; ++i) ident[i] = i;
@@ -578,6 +726,16 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     TAE_HIP_H(hipMalloc(&h->d_perm, L * sizeof(int32_t)));
     TAE_HIP_H(hipMalloc(&h->d_inv, L * sizeof(int32_t)));
     TAE_HIP_H(hipMalloc(&h->d_stats, 4 * sizeof(double)));
+    TAE_HIP_H(hipMalloc(&h->d_flags, 4 * sizeof(uint32_t)));
+    TAE_HIP_H(hipMemset(h->d_flags, 0, 4 * sizeof(uint32_t)));
+    if (h->prec == 1) {
+        TAE_HIP_H(hipMalloc(&h->d_wenc_h, penc_h.size()));
+        TAE_HIP_H(hipMemcpy(h->d_wenc_h, penc_h.data(), penc_h.size(), hipMemcpyHostToDevice));
+        if (!pdec_h.empty()) {
+            TAE_HIP_H(hipMalloc(&h->d_wdec_h, pdec_h.size()));
+            TAE_HIP_H(hipMemcpy(h->d_wdec_h, pdec_h.data(), pdec_h.size(), hipMemcpyHostToDevice));
+        }
+    }
     TAE_HIP_H(hipMemcpy(h->d_wenc, penc.data(), penc.size() * sizeof(float), hipMemcpyHostToDevice));
     TAE_HIP_H(hipMemcpy(h->d_wdec, pdec.data(), pdec.size() * sizeof(float), hipMemcpyHostToDevice));
     if (cfg->dec_type == 1) {
@@ -606,6 +764,7 @@ int tae_destroy(tae_handle* h) {
     (void)hipFree(h->d_e0); (void)hipFree(h->d_e1);
     (void)hipFree(h->d_wrnn); (void)hipFree(h->d_gxa); (void)hipFree(h->d_gxb); (void)hipFree(h->d_gy0); (void)hipFree(h->d_gy1);
     (void)hipFree(h->d_ggi); (void)hipFree(h->d_gzero);
+    (void)hipFree(h->d_wenc_h); (void)hipFree(h->d_wdec_h); (void)hipFree(h->d_flags);
     delete h;
     return TAE_OK;
 }
@@ -746,6 +905,18 @@ int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_t* lds_b
     if (!h) return fail(TAE_EINVAL, "handle is NULL");
     if (blocks_per_workgroup) *blocks_per_workgroup = h->nb;
     if (lds_bytes) *lds_bytes = h->nb >= 1 ? h->lds_bytes : h->dec_lds;
+    return TAE_OK;
+}
+
+int tae_range_status(tae_handle* h, int32_t* precision, int32_t* overflow) {
+    if (!h) return fail(TAE_EINVAL, "handle is NULL");
+    if (precision) *precision = h->prec;
+    if (overflow) {
+        uint32_t f = 0;
+        TAE_HIP(hipMemcpy(&f, h->d_flags, sizeof(f), hipMemcpyDeviceToHost));
+        if (f) TAE_HIP(hipMemset(h->d_flags, 0, sizeof(f)));
+        *overflow = (int32_t)(f & 1u);
+    }
     return TAE_OK;
 }
 

@@ -265,4 +265,233 @@ __device__ __forceinline__ void conv_accumulate(f32x4 (&acc)[PT][NC], f32x4 (&ac
 }
 
 
+// ---- workgroup geometry and helpers shared by the fp32 and the f16x2 kernels ---------------------------
+template <int U>
+struct Geo {
+    static constexpr int CT = (U + 15) / 16;         // 16-wide output-channel tiles
+    static constexpr int CP = CT * 16;               // padded channel count
+    static constexpr int NCH_MID = (5 * U + 7) / 8;  // K chunks (8 k each) of a U->U layer
+    static constexpr int NCH_L0 = 5;                 // K chunks of the first layer (5 taps x 8 padded inputs)
+    static constexpr int CS = CT * 128;              // floats of A fragments per chunk
+    static constexpr int MIDF = NCH_MID * CS;        // floats of A fragments per U->U layer
+    static constexpr int L0F = NCH_L0 * CS;
+    // "super-tile" for the 4 remainder channels when U % 16 == 4 (see super_accumulate): A fragments with
+    // rows = 4 position shifts x 4 channels over K' = 8 shifts x C_in, stored after the bias of every layer
+    static constexpr bool SUP = (U % 16) == 4;
+    static constexpr int SCH_MID = SUP ? U : 0;      // K' / 8 chunks of a U->U layer
+    static constexpr int SCH_L0 = SUP ? 8 : 0;       // first layer: 8 shifts x 8 padded inputs
+    static constexpr int SFM = SCH_MID * 128;        // floats of super A fragments per U->U layer
+    static constexpr int SF0 = SCH_L0 * 128;
+};
+
+// Per-lane view of the position tiles a wave owns.
+template <int PT>
+struct TileCtx {
+    int row[PT];      // panel row of this lane's position in tile p
+    int rowbase[PT];  // panel row of position 0 of the same block
+    int t[PT];        // index inside the block
+    int blk[PT];      // block index inside the workgroup
+    bool valid[PT];   // in-block row of the panel: its activations are written back
+    bool center[PT];  // position whose stack output this workgroup owns (== valid for whole blocks)
+};
+
+// Reduce 8 per-lane partial outputs over the 4 lane groups (q = lane >> 4) of a position with a
+// reduce-scatter butterfly: afterwards lane group q holds outputs f = 2q (k2[0]) and f = 2q + 1 (k2[1]).
+__device__ __forceinline__ void butterfly8(const float (&part)[8], bool hi32, bool hi16, float (&k2)[2]) {
+    float k4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float keep = hi32 ? part[4 + j] : part[j];
+        const float send = hi32 ? part[j] : part[4 + j];
+        k4[j] = keep + __shfl_xor(send, 32);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float keep = hi16 ? k4[2 + j] : k4[j];
+        const float send = hi16 ? k4[j] : k4[2 + j];
+        k2[j] = keep + __shfl_xor(send, 16);
+    }
+}
+
+template <int PT>
+__device__ __forceinline__ void make_tiles(TileCtx<PT>& tc, int g, int lane, int L, int npos) {
+    const int n = lane & 15;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int m = (g * PT + p) * 16 + n;
+        const bool v = m < npos;
+        const int mm = v ? m : 0;
+        const int b = mm / L;
+        const int t = mm - b * L;
+        tc.valid[p] = v;
+        tc.center[p] = v;
+        tc.blk[p] = b;
+        tc.t[p] = t;
+        tc.rowbase[p] = b * (L + 2) + 2;
+        tc.row[p] = tc.rowbase[p] + t;
+    }
+}
+
+__device__ __forceinline__ void zero_lds(char* smem, int bytes, int tid) {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < bytes / 16; i += kThreads) reinterpret_cast<f32x4*>(smem)[i] = z;
+}
+
+// channel-tile split between the two waves of a SIMD: lower half [0, CTA), upper half [CTA, CT)
+template <int U>
+struct Split {
+    static constexpr int CT = Geo<U>::CT;
+    static constexpr int CTA = CT >= 3 ? 2 * ((CT + 2) / 4) : 1;   // even when possible, so 16-byte pair loads stay whole
+    static constexpr int CTB = CT - CTA;
+    static_assert(CTB >= 1, "both channel halves need at least one tile");
+    // with super-tiles the padded last tile disappears and each half takes one super-tile: split CT - 1 evenly
+    static constexpr int SA = (CT - 1 + 1) / 2;
+    static constexpr int SB = CT - 1 - SA;
+};
+
+__device__ __forceinline__ void block_reduce_stats(char* smem, int tid, double sum, double sumsq, double* partials) {
+    // deterministic fixed-order tree; the panels are dead after the last stack's closing barrier, so the
+    // reduction scratch aliases them (no static LDS: guide G17)
+    double* red = reinterpret_cast<double*>(smem);
+    red[tid] = sum;
+    red[kThreads + tid] = sumsq;
+    __syncthreads();
+    for (int off = kThreads / 2; off > 0; off >>= 1) {
+        if (tid < off) { red[tid] += red[tid + off]; red[kThreads + tid] += red[kThreads + tid + off]; }
+        __syncthreads();
+    }
+    if (tid == 0) { partials[2 * blockIdx.x] = red[0]; partials[2 * blockIdx.x + 1] = red[kThreads]; }
+}
+
+
+// =====================================================================================================
+// fp16-split contraction ("f16x2"): every fp32 operand x is carried as hi = f16(x), lo = f16(x - hi)
+// (both round-to-nearest; fp16 denormals are kept by the matrix pipe, measured in
+// tools/probes/f16_split_probe.hip), and a product is the sum of three v_mfma_f32_16x16x32_f16:
+// hi*lo + lo*hi + hi*hi, accumulated in fp32.  hi + lo represents x to 2^-22 relative (absolute floor
+// 2^-25); the dropped lo*lo term is 2^-22 of the product.  Against an fp64 reference the 500-term dot
+// products of this network come out with rms error 2.0e-7 vs 3.2e-7 for the v_mfma_f32_16x16x4_f32
+// chain (fewer fp32 roundings: 48 accumulations instead of 125), i.e. the result is fp32-grade while the
+// matrix pipe runs 16x32-deep f16 instructions in 16 cycles instead of 16x4-deep f32 ones in 32:
+// 3 MFMAs / 16 cycles per 32 k  vs  8 MFMAs / 32 cycles  ->  5.3x fewer pipe cycles.
+// Weights are pre-scaled per layer by a power of two (max |w| -> [2^13, 2^14)) so that their lo halves
+// stay normal; the accumulators carry that scale (bias pre-scaled) and the epilogue multiplies it out.
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+using h4 = __attribute__((ext_vector_type(4))) _Float16;
+using u32x2v = __attribute__((ext_vector_type(2))) uint32_t;
+using u32x4w = __attribute__((ext_vector_type(4))) uint32_t;
+
+__device__ __forceinline__ f32x4 mfma16x16x32h(h8 a, h8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+constexpr float kH2Limit = 65504.0f;     // activations are clamped to the fp16 range before the split
+
+// 4 fp32 values -> 4 hi halves + 4 lo halves
+__device__ __forceinline__ void split4(f32x4 v, h4& hi, h4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (_Float16)v[i];
+        lo[i] = (_Float16)(v[i] - (float)hi[i]);
+    }
+}
+
+// A fragments of one 32-k slab for NC channel tiles: hi and lo halves, 16 bytes per lane each
+template <int NC>
+struct OpsHA {
+    h8 hi[NC], lo[NC];
+};
+
+// packed slab layout: [channel tile][hi | lo][lane][8 halves] = 2 KB per tile
+template <int CTT, int C0, int NC>
+__device__ __forceinline__ void load_wh(OpsHA<NC>& o, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+    if (TAE_X & 8) { asm volatile("" :: "s"(soff)); return; }
+    // hi halves first: the first product of a tile (hi * lo) needs them, the lo halves one product later
+#pragma unroll
+    for (int i = 0; i < NC; ++i) o.hi[i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (C0 + i) * 2048, soff, 0));
+#pragma unroll
+    for (int i = 0; i < NC; ++i) o.lo[i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (C0 + i) * 2048 + 1024, soff, 0));
+}
+
+struct OpsHB {
+    h8 hi, lo;
+};
+
+// B fragments of one position tile: 8 consecutive halves of the im2col row from each plane (8-byte aligned)
+template <int OFF>
+__device__ __forceinline__ void load_xh(OpsHB& o, lds_cptr ph, lds_cptr pl) {
+    using lds_u2 = const u32x2v __attribute__((address_space(3)));
+    if (TAE_X & 16) return;
+    const u32x2v a0 = *reinterpret_cast<lds_u2*>(ph + OFF), a1 = *reinterpret_cast<lds_u2*>(ph + OFF + 8);
+    const u32x2v b0 = *reinterpret_cast<lds_u2*>(pl + OFF), b1 = *reinterpret_cast<lds_u2*>(pl + OFF + 8);
+    o.hi = __builtin_bit_cast(h8, u32x4w{a0.x, a0.y, a1.x, a1.y});
+    o.lo = __builtin_bit_cast(h8, u32x4w{b0.x, b0.y, b1.x, b1.y});
+}
+
+template <int NC>
+__device__ __forceinline__ void mma_tile_h(f32x4 (&acc)[NC], const OpsHA<NC>& a, const OpsHB& b) {
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma16x16x32h(a.hi[ct], b.lo, acc[ct]);
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma16x16x32h(a.lo[ct], b.hi, acc[ct]);
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma16x16x32h(a.hi[ct], b.hi, acc[ct]);
+}
+
+// acc += W (16*NC x 32*NSLAB) * im2col (32*NSLAB x PT*16) in the f16x2 representation.
+// `a0` arrives with slab 0's A fragments loaded.  Slabs are processed in pairs (A fragments ping-pong
+// between two register sets, fetched one slab = ~1000 cycles ahead); within a slab the position tiles are
+// walked one at a time, their B fragments fetched two tiles ahead from LDS.
+// soff  : wave-uniform byte offset of this layer's A fragments
+// bh/bl : per position tile, LDS byte address of (row-2)*stride + 16*kq in the hi / lo plane
+template <int CTT, int C0, int NC, int PT, int NSLAB>
+__device__ __forceinline__ void conv_accumulate_h(f32x4 (&acc)[PT][NC], OpsHA<NC>& a0, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff,
+                                                  uint32_t soff, const char* lds, const uint32_t (&bh)[PT], const uint32_t (&bl)[PT]) {
+    constexpr uint32_t SB = CTT * 2048;       // bytes of A fragments per slab
+    const lds_cptr lds3 = (lds_cptr)lds;
+    lds_cptr ch[PT], cl[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) { ch[p] = lds3 + bh[p]; cl[p] = lds3 + bl[p]; }
+    OpsHA<NC> a1;
+    OpsHB b[2];                                // ring: tile j of the running (slab, tile) sequence sits in b[j % 2]
+    load_xh<0>(b[0], ch[0], cl[0]);
+    // One slab.  Tile p uses ring slot (RB + p) % 2 and prefetches the next tile (of this slab at OFF, or tile 0 of
+    // the next slab at OFF + 64): one tile = 3 * NC MFMAs (>= 150 cycles) of cover for the LDS latency.  The issue
+    // order is pinned with sched_group_barriers - left alone, the scheduler sinks every load to just before its
+    // first use (LDS reads then wait with lgkmcnt(0) in front of each tile, weight loads lose their one-slab lead):
+    // per tile {LDS reads of the next tile} first, then this tile's MFMAs with the slab's 2 * NC weight loads (for
+    // the NEXT slab) dealt out one per three MFMAs.
+    constexpr int NVS = PT < 3 ? PT : 3;               // the weight loads go out during the first NVS tiles of a slab (lead >= 2 tiles)
+    constexpr int NVT = (2 * NC + NVS - 1) / NVS;      // weight loads threaded through one of those tiles' MFMAs
+#define TAE_H_SLAB(ACUR, OFF, RB)                                                                          \
+    _Pragma("unroll") for (int p = 0; p < PT; ++p) {                                                       \
+        if (p + 1 < PT) load_xh<(OFF)>(b[((RB) + p + 1) % 2], ch[p + 1 < PT ? p + 1 : 0], cl[p + 1 < PT ? p + 1 : 0]);   \
+        else load_xh<(OFF) + 64>(b[((RB) + p + 1) % 2], ch[0], cl[0]);                                     \
+        mma_tile_h<NC>(acc[p], ACUR, b[((RB) + p) % 2]);                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                 \
+        if (p < NVS) {                                                                                     \
+            _Pragma("unroll") for (int v = 0; v < NVT; ++v) {                                              \
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NC / NVT, 0);                              \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                         \
+            }                                                                                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NC - NVT * (3 * NC / NVT), 0);                 \
+        } else {                                                                                           \
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NC, 0);                                        \
+        }                                                                                                  \
+    }
+    int s = 0;
+#pragma unroll 1
+    for (; s + 1 < NSLAB; s += 2) {
+        load_wh<CTT, C0, NC>(a1, rsrc, voff, soff + SB);
+        TAE_H_SLAB(a0, 0, 0)
+        load_wh<CTT, C0, NC>(a0, rsrc, voff, soff + 2 * SB);
+        TAE_H_SLAB(a1, 64, PT % 2)
+        soff += 2 * SB;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) { ch[p] += 128; cl[p] += 128; }
+    }
+    if constexpr (NSLAB % 2 == 1) { TAE_H_SLAB(a0, 0, 0) }
+#undef TAE_H_SLAB
+}
+
 }  // namespace tae

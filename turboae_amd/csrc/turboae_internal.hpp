@@ -25,6 +25,7 @@ struct FusedParams {
     uint32_t wpack_bytes;   // size of the packed weight buffer (buffer-resource bound)
     int32_t lds_bytes;
     int32_t super;          // 1: remainder channels via super-tiles (needs U % 16 == 4 and block_len % 4 == 0)
+    uint32_t* flags;        // f16x2 kernels: bit 0 set when an activation left the fp16 range (stack_stride is in BYTES there)
 };
 
 // Arguments of the per-stack segmented kernel used when a block does not fit one workgroup.
@@ -82,6 +83,8 @@ hipError_t launch_gru_head(const GruHeadParams& P, hipStream_t st);
 hipError_t launch_seg(int U, const SegParams& P, int grid, hipStream_t st);
 int seg_lds_bytes(int U, int T, int n_layer);
 hipError_t launch_fused(int U, bool decoder, const FusedParams& P, int grid, hipStream_t st);
+hipError_t launch_fused_h(int U, bool decoder, const FusedParams& P, int grid, hipStream_t st);
+int fused_lds_bytes_h(int U, int L, int nb);
 hipError_t launch_reduce_partials(const double* partials, int n, double count, double* stats, hipStream_t st);
 struct NormOpts {          // device-side view of tae_channel_opts
     int32_t norm_mode; float mean, std;

@@ -37,53 +37,6 @@
 
 namespace tae {
 
-template <int U>
-struct Geo {
-    static constexpr int CT = (U + 15) / 16;         // 16-wide output-channel tiles
-    static constexpr int CP = CT * 16;               // padded channel count
-    static constexpr int NCH_MID = (5 * U + 7) / 8;  // K chunks (8 k each) of a U->U layer
-    static constexpr int NCH_L0 = 5;                 // K chunks of the first layer (5 taps x 8 padded inputs)
-    static constexpr int CS = CT * 128;              // floats of A fragments per chunk
-    static constexpr int MIDF = NCH_MID * CS;        // floats of A fragments per U->U layer
-    static constexpr int L0F = NCH_L0 * CS;
-    // "super-tile" for the 4 remainder channels when U % 16 == 4 (see super_accumulate): A fragments with
-    // rows = 4 position shifts x 4 channels over K' = 8 shifts x C_in, stored after the bias of every layer
-    static constexpr bool SUP = (U % 16) == 4;
-    static constexpr int SCH_MID = SUP ? U : 0;      // K' / 8 chunks of a U->U layer
-    static constexpr int SCH_L0 = SUP ? 8 : 0;       // first layer: 8 shifts x 8 padded inputs
-    static constexpr int SFM = SCH_MID * 128;        // floats of super A fragments per U->U layer
-    static constexpr int SF0 = SCH_L0 * 128;
-};
-
-// Per-lane view of the position tiles a wave owns.
-template <int PT>
-struct TileCtx {
-    int row[PT];      // panel row of this lane's position in tile p
-    int rowbase[PT];  // panel row of position 0 of the same block
-    int t[PT];        // index inside the block
-    int blk[PT];      // block index inside the workgroup
-    bool valid[PT];   // in-block row of the panel: its activations are written back
-    bool center[PT];  // position whose stack output this workgroup owns (== valid for whole blocks)
-};
-
-// Reduce 8 per-lane partial outputs over the 4 lane groups (q = lane >> 4) of a position with a
-// reduce-scatter butterfly: afterwards lane group q holds outputs f = 2q (k2[0]) and f = 2q + 1 (k2[1]).
-__device__ __forceinline__ void butterfly8(const float (&part)[8], bool hi32, bool hi16, float (&k2)[2]) {
-    float k4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float keep = hi32 ? part[4 + j] : part[j];
-        const float send = hi32 ? part[j] : part[4 + j];
-        k4[j] = keep + __shfl_xor(send, 32);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float keep = hi16 ? k4[2 + j] : k4[j];
-        const float send = hi16 ? k4[j] : k4[2 + j];
-        k2[j] = keep + __shfl_xor(send, 16);
-    }
-}
-
 // Weight-side state shared by the stacks of one kernel: the buffer resource over the packed
 // weights and the chunk-0 A fragments of the NEXT conv layer, fetched before the current layer's
 // epilogue so that their L2 latency hides behind it.
@@ -257,25 +210,6 @@ __device__ __forceinline__ void run_stack(const float* __restrict__ wpack, uint3
     __syncthreads();
 }
 
-template <int PT>
-__device__ __forceinline__ void make_tiles(TileCtx<PT>& tc, int g, int lane, int L, int npos) {
-    const int n = lane & 15;
-#pragma unroll
-    for (int p = 0; p < PT; ++p) {
-        const int m = (g * PT + p) * 16 + n;
-        const bool v = m < npos;
-        const int mm = v ? m : 0;
-        const int b = mm / L;
-        const int t = mm - b * L;
-        tc.valid[p] = v;
-        tc.center[p] = v;
-        tc.blk[p] = b;
-        tc.t[p] = t;
-        tc.rowbase[p] = b * (L + 2) + 2;
-        tc.row[p] = tc.rowbase[p] + t;
-    }
-}
-
 // super-tile view of position group g (whole-block layout): the lower channel half (h = 0) takes quads 0..15,
 // the upper half (h = 1) quads 16..19 of the group's 20 (its lanes n >= 4 duplicate them and never write back)
 template <int PT>
@@ -312,23 +246,6 @@ __device__ __forceinline__ Panels carve(char* smem, int rows, int L) {
     pn.HS = reinterpret_cast<float*>(smem + (((reinterpret_cast<char*>(pn.INV + L) - smem) + 15) & ~15));
     return pn;
 }
-
-__device__ __forceinline__ void zero_lds(char* smem, int bytes, int tid) {
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < bytes / 16; i += kThreads) reinterpret_cast<f32x4*>(smem)[i] = z;
-}
-
-// channel-tile split between the two waves of a SIMD: lower half [0, CTA), upper half [CTA, CT)
-template <int U>
-struct Split {
-    static constexpr int CT = Geo<U>::CT;
-    static constexpr int CTA = CT >= 3 ? 2 * ((CT + 2) / 4) : 1;   // even when possible, so 16-byte pair loads stay whole
-    static constexpr int CTB = CT - CTA;
-    static_assert(CTB >= 1, "both channel halves need at least one tile");
-    // with super-tiles the padded last tile disappears and each half takes one super-tile: split CT - 1 evenly
-    static constexpr int SA = (CT - 1 + 1) / 2;
-    static constexpr int SB = CT - 1 - SA;
-};
 
 // =============================================================================================
 // Decoder: DEC_LargeCNN.forward (decoders.py:206-269) for nb blocks per workgroup.
@@ -438,20 +355,6 @@ __device__ __forceinline__ void enc_body(const FusedParams& P, char* smem, const
             }
         });
     }
-}
-
-__device__ __forceinline__ void block_reduce_stats(char* smem, int tid, double sum, double sumsq, double* partials) {
-    // deterministic fixed-order tree; the panels are dead after the last stack's closing barrier, so the
-    // reduction scratch aliases them (no static LDS: guide G17)
-    double* red = reinterpret_cast<double*>(smem);
-    red[tid] = sum;
-    red[kThreads + tid] = sumsq;
-    __syncthreads();
-    for (int off = kThreads / 2; off > 0; off >>= 1) {
-        if (tid < off) { red[tid] += red[tid + off]; red[kThreads + tid] += red[kThreads + tid + off]; }
-        __syncthreads();
-    }
-    if (tid == 0) { partials[2 * blockIdx.x] = red[0]; partials[2 * blockIdx.x + 1] = red[kThreads]; }
 }
 
 template <int U, int PT>

@@ -80,6 +80,7 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
         t = tot.cpu().tolist()
         bit_res.append(int(t[0]))
         blk_res.append(int(t[1]))
+        model.check_range()          # fp16-split kernels: fail loudly if an activation left the fp16 range
     say("final results on SNRs ", snrs)
     say("BER", ber_res)
     say("BLER", bler_res)
