@@ -484,7 +484,7 @@ __device__ __forceinline__ void conv_accumulate_h(f32x4 (&acc)[PT][NC], OpsHA<NC
     for (; s + 1 < NSLAB; s += 2) {
         load_wh<CTT, C0, NC>(a1, rsrc, voff, soff + SB);
         TAE_H_SLAB(a0, 0, 0)
-        load_wh<CTT, C0, NC>(a0, rsrc, voff, soff + 2 * SB);
+        if (s + 2 < NSLAB) load_wh<CTT, C0, NC>(a0, rsrc, voff, soff + 2 * SB);   // no fetch past the layer: the caller refills a0
         TAE_H_SLAB(a1, 64, PT % 2)
         soff += 2 * SB;
 #pragma unroll

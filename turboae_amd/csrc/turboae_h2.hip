@@ -53,18 +53,21 @@ struct XPlane {
 };
 
 struct PanelsH {
+    int dump;        // write-only row after the slack row (index rows + 1): where padding lanes / padding channels store
     char* AH;
     char* AL;
     XPlane XA, XB;
     int* PERM;
     int* INV;
+    int* ROWT;       // [kHeadSlots] panel row of every position slot of the workgroup
     float* HS;
 };
 
 template <int U>
 __device__ __forceinline__ PanelsH carve_h(char* smem, int rows, int L) {
     PanelsH pn;
-    const size_t ab = (size_t)(rows + 1) * U * 2, xb = (size_t)(rows + 1 + kXSlack) * kXRowB;
+    pn.dump = rows + 1;
+    const size_t ab = (size_t)(rows + 2) * U * 2, xb = (size_t)(rows + 1 + kXSlack) * kXRowB;
     pn.AH = smem;
     pn.AL = pn.AH + ab;
     pn.XA.h = pn.AL + ab;
@@ -73,8 +76,48 @@ __device__ __forceinline__ PanelsH carve_h(char* smem, int rows, int L) {
     pn.XB.l = pn.XB.h + xb;
     pn.PERM = reinterpret_cast<int*>(pn.XB.l + xb);
     pn.INV = pn.PERM + L;
-    pn.HS = reinterpret_cast<float*>(smem + (((reinterpret_cast<char*>(pn.INV + L) - smem) + 15) & ~15));
+    pn.ROWT = pn.INV + L;
+    pn.HS = reinterpret_cast<float*>(smem + (((reinterpret_cast<char*>(pn.ROWT + kHeadSlots) - smem) + 15) & ~15));
     return pn;
+}
+
+// Per-lane view of the position tiles a wave owns, kept small (the accumulators, two A-fragment sets and the
+// B ring leave few registers): everything else is recomputed where it is needed (once per stack).
+template <int PT>
+struct TileH {
+    const int* rowtab;  // LDS table [PT][16] of this wave's group: panel row of tile p's position n (padding lanes: row 2, real
+                        // finite data).  Read on demand (twice per layer) instead of living in - and being spilled from - VGPRs.
+    uint32_t valid;     // bit p: in-block position of this workgroup (its stack output is owned here)
+    int m0;             // workgroup-relative position of tile 0 (tile p: m0 + 16 p)
+    int L;
+    __device__ __forceinline__ int row(int p) const {
+        const int* t = rowtab;
+        asm volatile("" : "+v"(t));          // keep the load where it is used (it is loop-invariant: hoisted, it would be spilled)
+        return t[p * 16];
+    }
+    __device__ __forceinline__ bool ok(int p) const { return (valid >> p) & 1u; }
+    __device__ __forceinline__ int blk(int p) const { return (m0 + 16 * p) / L; }
+    __device__ __forceinline__ int t(int p) const { const int m = m0 + 16 * p; return m - (m / L) * L; }
+    __device__ __forceinline__ int rowbase(int p) const { return blk(p) * (L + 2) + 2; }
+};
+
+// Padding lanes (positions past the workgroup's blocks) compute on row 2 and store to the write-only dump row, so
+// the epilogue needs no per-tile branches.
+template <int PT>
+__device__ __forceinline__ void make_tiles_h(TileH<PT>& tc, int* rowtab, int g, int lane, int L, int npos) {
+    const int n = lane & 15;
+    tc.valid = 0u;
+    tc.m0 = g * PT * 16 + n;
+    tc.L = L;
+    tc.rowtab = rowtab + g * PT * 16 + n;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int m = tc.m0 + 16 * p;
+        const bool v = m < npos;
+        const int b = (v ? m : 0) / L;
+        if (lane < 16) rowtab[(g * PT + p) * 16 + n] = v ? b * (L + 2) + 2 + (m - b * L) : 2;    // both channel halves write the same values
+        tc.valid |= (v ? 1u : 0u) << p;
+    }
 }
 
 template <int U, int C0, int NC>
@@ -89,15 +132,27 @@ struct WeightStreamH {
     __device__ __forceinline__ void prefetch(uint32_t soff) { load_wh<GeoH<U>::CT, C0, NC>(a, rsrc, voff, soff); }
 };
 
+// Layer epilogue for 4 accumulator values: x = acc * 2^-S, ELU, running max (range report), split into fp16
+// halves.  Scalar fp32 ops on purpose: the packed forms (v_pk_mul_f32 / v_pk_add_f32) measured 6 % slower
+// here.  No clamp: an out-of-range activation turns into inf / NaN halves and `vmax` reports it
+// (tae_range_status).
+__device__ __forceinline__ void elu_split4(f32x4 a, float inv_scale, float& vmax, h4& hi, h4& lo) {
+    f32x4 v = a * inv_scale;
+    if (!(TAE_X & 4)) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
+    vmax = fmaxf(fmaxf(vmax, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));   // ELU output >= -1: only the upper side can overflow
+    split4(v, hi, lo);
+}
+
 // One SameShapeConv1d stack (cnn_utils.py:36-46) + Linear head; same contract as run_stack in
 // turboae_kernels.hip.  `vmax` collects max |activation| before the fp16-range clamp (overflow report).
 template <int U, int PT, int C0, int NC, class Epi>
 __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint32_t soff, uint32_t snext, int n_layer, char* smem,
-                                            const PanelsH& pn, const XPlane& xin, const TileCtx<PT>& tc, int g, int lane,
+                                            const PanelsH& pn, const XPlane& xin, const TileH<PT>& tc, int g, int lane,
                                             WeightStreamH<U, C0, NC>& ws, float& vmax, Epi epi) {
     using G = GeoH<U>;
     constexpr int CTT = G::CT;
     const int q = lane >> 4;
+    const int dump_row = pn.dump;
     f32x4 acc[PT][NC];
     uint32_t lo = soff;
     float inv_scale = 1.0f;
@@ -120,7 +175,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
         const uint32_t ph = (uint32_t)((first ? xin.h : pn.AH) - smem), pl = (uint32_t)((first ? xin.l : pn.AL) - smem);
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
-            const uint32_t o = (uint32_t)(tc.row[p] - 2) * stride + 16u * q;
+            const uint32_t o = (uint32_t)(tc.row(p) - 2) * stride + 16u * q;
             bh[p] = ph + o;
             bl[p] = pl + o;
         }
@@ -133,22 +188,24 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
         }
         if (l + 1 < n_layer) {
             if (!first && !(TAE_X & 1)) __syncthreads();
+            int wrow[PT];
+#pragma unroll
+            for (int p = 0; p < PT; ++p) wrow[p] = tc.row(p);
 #pragma unroll
             for (int p = 0; p < PT; ++p) {
 #pragma unroll
                 for (int i = 0; i < NC; ++i) {
-                    f32x4 v = acc[p][i] * inv_scale;
-                    if (!(TAE_X & 4)) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
-                    // ELU output is >= -1: only the upper side can leave the fp16 range
-                    vmax = fmaxf(fmaxf(vmax, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
-                    v.x = fminf(v.x, kH2Limit); v.y = fminf(v.y, kH2Limit); v.z = fminf(v.z, kH2Limit); v.w = fminf(v.w, kH2Limit);
                     h4 hi, lw;
-                    split4(v, hi, lw);
+                    elu_split4(acc[p][i], inv_scale, vmax, hi, lw);
+                    // channels >= U exist only in the last channel tile (zero weights, zero bias -> ELU(0) = 0): they are
+                    // steered to the dump row instead of branching
                     const int ch = (C0 + i) * 16 + 4 * q;
+                    const bool inb = (((C0 + i) * 16 + 16 <= U) || (ch < U)) && tc.ok(p);
+                    const int off = inb ? (wrow[p] * U + ch) * 2 : (dump_row * U + 4 * q) * 2;
                     if (TAE_X & 2) asm volatile("" :: "v"(hi), "v"(lw));
-                    else if (tc.valid[p] && ch < U) {
-                        *reinterpret_cast<h4*>(pn.AH + (size_t)(tc.row[p] * U + ch) * 2) = hi;
-                        *reinterpret_cast<h4*>(pn.AL + (size_t)(tc.row[p] * U + ch) * 2) = lw;
+                    else {
+                        *reinterpret_cast<h4*>(pn.AH + off) = hi;
+                        *reinterpret_cast<h4*>(pn.AL + off) = lw;
                     }
                 }
             }
@@ -199,7 +256,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
         for (int p = 0; p < PT; ++p) {
             float2 other = float2{0.0f, 0.0f};
             if constexpr (NC < CTT) other = *reinterpret_cast<const float2*>(HS + ((g * PT + p) * 16 + n) * 8 + 2 * q);
-            if (tc.center[p]) {
+            if (tc.ok(p)) {
                 epi(p, 2 * q, (k2[p][0] + other.x) + bq0);
                 epi(p, 2 * q + 1, (k2[p][1] + other.y) + bq1);
             }
@@ -215,7 +272,7 @@ __device__ __forceinline__ void report_range(float vmax, uint32_t* flags) {
 // =============================================================================================
 // Decoder: DEC_LargeCNN.forward (decoders.py:206-269)
 template <int U, int PT, int C0, int NC>
-__device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, const PanelsH& pn, const TileCtx<PT>& tc, int g, int lane, int blk0) {
+__device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, const PanelsH& pn, const TileH<PT>& tc, int g, int lane, int blk0) {
     const int L = P.L;
     const int n_stack = 2 * P.n_iter;
     const int F = P.F;
@@ -235,15 +292,15 @@ __device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, con
             run_stack_h<U, PT, C0, NC>(wpack, s * sstride, (s + 1) * sstride, P.n_layer, smem, pn, Xin, tc, g, lane, ws, vmax,
                                        [&](int p, int f, float v) {
                 if (f < F) {
-                    if (extrinsic) v -= Xin.read(tc.row[p], 2 + f);            // decoders.py:235-236,246-247
+                    if (extrinsic) v -= Xin.read(tc.row(p), 2 + f);            // decoders.py:235-236,246-247
                     vmax = fmaxf(vmax, fabsf(v));
-                    Xout.write(tc.rowbase[p] + ptab[tc.t[p]], 2 + f, v);       // interleave / deinterleave (decoders.py:238,249)
+                    Xout.write(tc.rowbase(p) + ptab[tc.t(p)], 2 + f, v);       // interleave / deinterleave (decoders.py:238,249)
                 }
             });
         } else {
             run_stack_h<U, PT, C0, NC>(wpack, s * sstride, 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, vmax,
                                        [&](int p, int f, float v) {
-                if (f == 0) xdec[tc.blk[p] * L + ptab[tc.t[p]]] = 1.0f / (1.0f + expf(-v));   // decoders.py:262-267
+                if (f == 0) xdec[tc.blk(p) * L + ptab[tc.t(p)]] = 1.0f / (1.0f + expf(-v));   // decoders.py:262-267
             });
         }
     }
@@ -283,8 +340,9 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
     report_range(vmax, P.flags);
     __syncthreads();
 
-    TileCtx<PT> tc;
-    make_tiles<PT>(tc, g, lane, L, npos);
+    TileH<PT> tc;
+    make_tiles_h<PT>(tc, pn.ROWT, g, lane, L, npos);
+    __syncthreads();
     const bool upper = __builtin_amdgcn_readfirstlane(h) != 0;
     if (!upper) dec_body_h<U, PT, 0, Split<U>::CTA>(P, smem, pn, tc, g, lane, blk0);
     else dec_body_h<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, g, lane, blk0);
@@ -293,7 +351,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
 // =============================================================================================
 // Encoder before power normalisation: ENC_interCNN.forward (encoders.py:362-373)
 template <int U, int PT, int C0, int NC>
-__device__ __forceinline__ void enc_body_h(const FusedParams& P, char* smem, const PanelsH& pn, const TileCtx<PT>& tc, int g, int lane,
+__device__ __forceinline__ void enc_body_h(const FusedParams& P, char* smem, const PanelsH& pn, const TileH<PT>& tc, int g, int lane,
                                            int blk0, double& sum, double& sumsq) {
     const int L = P.L;
     float* xtx = P.out + (size_t)blk0 * L * 3;
@@ -310,7 +368,7 @@ __device__ __forceinline__ void enc_body_h(const FusedParams& P, char* smem, con
                                    [&](int p, int f, float v) {
             if (f == 0) {
                 if (act_elu) v = elu1(v);                                  // enc_act (encoders.py:364)
-                xtx[(size_t)(tc.blk[p] * L + tc.t[p]) * 3 + s] = v;        // x_p2 stays in interleaved order (encoders.py:371-373)
+                xtx[(size_t)(tc.blk(p) * L + tc.t(p)) * 3 + s] = v;        // x_p2 stays in interleaved order (encoders.py:371-373)
                 sum += (double)v;
                 sumsq += (double)v * (double)v;
             }
@@ -345,8 +403,9 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
     }
     __syncthreads();
 
-    TileCtx<PT> tc;
-    make_tiles<PT>(tc, g, lane, L, npos);
+    TileH<PT> tc;
+    make_tiles_h<PT>(tc, pn.ROWT, g, lane, L, npos);
+    __syncthreads();
     double sum = 0.0, sumsq = 0.0;
     const bool upper = __builtin_amdgcn_readfirstlane(h) != 0;
     if (!upper) enc_body_h<U, PT, 0, Split<U>::CTA>(P, smem, pn, tc, g, lane, blk0, sum, sumsq);
@@ -379,7 +438,7 @@ hipError_t launch_fused_h(int U, bool decoder, const FusedParams& P, int grid, h
 
 int fused_lds_bytes_h(int U, int L, int nb) {
     const int rows = nb * (L + 2) + 2;
-    size_t b = 2 * (size_t)(rows + 1) * U * 2 + 4 * (size_t)(rows + 1 + kXSlack) * kXRowB + 2 * (size_t)L * 4;
+    size_t b = 2 * (size_t)(rows + 2) * U * 2 + 4 * (size_t)(rows + 1 + kXSlack) * kXRowB + 2 * (size_t)L * 4 + (size_t)kHeadSlots * 4;
     b = (b + 15) & ~(size_t)15;
     b += (size_t)kHeadSlots * 8 * 4;
     if (b < 2 * kThreads * sizeof(double)) b = 2 * kThreads * sizeof(double);
