@@ -35,6 +35,8 @@ if ROOT not in sys.path:
 from turboae_amd import TurboAEConfig, Channel_AE_HIP, weights as W   # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_F16_MFMA_TFLOPS = 2500.0     # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+F16X2_PRODUCTS = 3                # MFMA products per fp32-equivalent multiply-accumulate in the fp16-split contraction
 
 
 def cpu_baseline(cfg: TurboAEConfig, sd, budget_s: float = 12.0):
@@ -68,6 +70,8 @@ def main():
     ap.add_argument("--snr", type=float, default=2.0)
     ap.add_argument("--enc-layers", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=("auto", "f32"), default="auto",
+                    help="auto: fp16-split MFMA contraction (fp32-grade, DESIGN.md 3.7); f32: v_mfma_f32_16x16x4_f32")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,7 +91,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
 
-    cfg = TurboAEConfig(enc_num_layer=args.enc_layers)
+    cfg = TurboAEConfig(enc_num_layer=args.enc_layers, precision=args.precision)
     sd = W.generate_state_dict(cfg, seed=20190001, gain=1.0)
     B, L = args.batch, cfg.block_len
     model = Channel_AE_HIP(cfg, sd, device=dev, max_batch=B)
@@ -138,10 +142,20 @@ def main():
         dec_flops_per_launch = 2.0 * macs["dec"] * B * L
         achieved = dec_flops_per_launch / (dec_ms * 1e-3) / 1e12
         nb, lds = model.kernel_info()
+        mode, overflow = model.range_status()
+        if overflow:
+            raise SystemExit("activation range overflow reported by the fp16-split kernels: results invalid")
+        f16x2 = mode == "f16x2"
+        # Roofline of the dominant kernel (the fused decoder).  fp32 mode: algorithmic FLOPs against the fp32 MFMA peak.
+        # fp16-split mode: every fp32-equivalent MAC costs 3 fp16 MFMA MACs, so the ceiling for ALGORITHMIC FLOPs is the
+        # dense fp16 MFMA peak / 3; `mfma_tflops_executed` = 3 x achieved is what the matrix pipes actually ran.
+        peak = PEAK_F16_MFMA_TFLOPS / F16X2_PRODUCTS if f16x2 else PEAK_FP32_MFMA_TFLOPS
+        kname = "tae::dec_kernel_h<100,5> (fused 6-iteration decoder, fp16-split MFMA)" if f16x2 else "tae::dec_kernel<100,5> (fused 6-iteration decoder, fp32 MFMA)"
+        pmc_dir = "r01_pmc_f16x2" if f16x2 else "r01_pmc"
         # HBM-side traffic of the decoder kernel from the committed PMC passes (rocprofv3 cannot run inside
         # this process): bytes per block measured at the same workload, scaled to this launch's blocks
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc", "traffic.json")
+        tpath = os.path.join(ROOT, "profiles", pmc_dir, "traffic.json")
         if os.path.isfile(tpath) and cfg.enc_num_layer == 2 and L == 100:
             with open(tpath) as fh:
                 traffic = json.load(fh)["bytes_per_block"] * B / 1e9
@@ -149,7 +163,9 @@ def main():
             "metric": "decoded info bits/sec @ block_len=100, 6-iter rate-1/3 CNN; BER match",
             "value": value, "unit": "bits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": ("f16x2: fp32 operands as fp16 hi+lo halves, 3 x v_mfma_f32_16x16x32_f16 per 32 k, fp32 accumulate (fp32-grade, "
+                      "DESIGN.md 3.7)") if f16x2 else "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: TurboAE_rate3_cnn enc{cfg.enc_num_layer}/dec{cfg.dec_num_layer}, "
                                    f"block_len={L}, batch={B} blocks per GPU, {cfg.num_iteration} iters, AWGN SNR={args.snr} dB, "
                                    "random-init weights (portable generator), inputs resident in HBM",
@@ -158,9 +174,14 @@ def main():
                        "blocks_per_workgroup": nb, "lds_bytes_per_workgroup": lds},
             "total_tflops": value * cfg.flops_per_bit() / 1e12,
             "ber": float(counts[0].item()) / bits_total, "bler": float(counts[1].item()) / (world * B * args.steps),
-            "roofline": {"bound": "mfma", "kernel": "tae::dec_kernel<100,5> (fused 6-iteration decoder)",
-                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc/traffic.json)",
+            "roofline": {"bound": "mfma", "kernel": kname,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
+                         "traffic_unit": f"GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{pmc_dir}/traffic.json)",
+                         "peak_basis": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 products per fp32-equivalent MAC" if f16x2
+                                        else "dense fp32 MFMA peak"),
+                         "mfma_tflops_executed": achieved * (F16X2_PRODUCTS if f16x2 else 1),
+                         "vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "kernel_ms": dec_ms, "flops_per_launch": dec_flops_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
