@@ -244,12 +244,13 @@ def test_fp16_split_reports_out_of_range_activations(gpu_device):
     assert torch.isfinite(codes).all()
 
 
+@pytest.mark.parametrize("prec", ["auto", "f32"])
 @pytest.mark.parametrize("seg_t", [None, "37", "16"])
-def test_segmented_path_is_bit_identical_to_fused(gpu_device, monkeypatch, seg_t):
+def test_segmented_path_is_bit_identical_to_fused(gpu_device, monkeypatch, seg_t, prec):
     """The long-block (segmented, halo-recompute) kernels sum every dot product in the same order as
     the whole-block kernels, so on a short block both paths must agree bit for bit."""
     from turboae_amd import Channel_AE_HIP
-    cfg = TurboAEConfig(num_iteration=2, precision="f32")     # the long-block kernels are fp32-MFMA: compare like with like
+    cfg = TurboAEConfig(num_iteration=2, precision=prec)
     sd = W.generate_state_dict(cfg, seed=7, gain=1.0)
     u, noise = make_inputs(7, cfg.block_len, seed=51)
     ud, nd = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)

@@ -218,7 +218,7 @@ struct tae_handle {
     int super = 0;           // remainder channels via super-tiles (U % 16 == 4 and block_len % 4 == 0)
     // f16x2 representation of the whole-block kernels (prec == 1); the fp32 packs above stay resident for the long-block path
     int prec = 0;            // 0: v_mfma_f32_16x16x4_f32 on fp32 operands; 1: 3 x v_mfma_f32_16x16x32_f16 on hi/lo halves
-    int lds_bytes_h = 0;
+    int lds_bytes_h = 0, enc_lds_h = 0, dec_lds_h = 0;
     uint32_t enc_stride_h = 0, dec_stride_h = 0, enc_bytes_h = 0, dec_bytes_h = 0;
     char* d_wenc_h = nullptr;
     char* d_wdec_h = nullptr;
@@ -501,6 +501,14 @@ int run_encoder_long(tae_handle* h, const float* u, float* xtx, double* stats, i
     P.wpack_bytes = h->enc_bytes;
     P.lds_bytes = h->enc_lds;
     const int grid = 3 * B * h->enc_nseg;
+    if (h->prec == 1) {
+        P.wpack = reinterpret_cast<const float*>(h->d_wenc_h);
+        P.stack_stride = h->enc_stride_h;
+        P.wpack_bytes = h->enc_bytes_h;
+        P.lds_bytes = h->enc_lds_h;
+        P.flags = h->d_flags;
+        TAE_HIP(tae::launch_seg_h(h->U, P, grid, st));
+    } else
     TAE_HIP(tae::launch_seg(h->U, P, grid, st));
     TAE_HIP(tae::launch_reduce_partials(h->d_partials, grid, (double)B * h->cfg.block_len * 3.0, stats, st));
     return TAE_OK;
@@ -520,12 +528,20 @@ int run_decoder_long(tae_handle* h, const float* rx, float* xdec, int32_t B, hip
     P.lds_bytes = h->dec_lds;
     const int n_stack = 2 * h->cfg.num_iteration;
     const int grid = B * h->dec_nseg;
+    if (h->prec == 1) {
+        P.wpack = reinterpret_cast<const float*>(h->d_wdec_h);
+        P.stack_stride = h->dec_stride_h;
+        P.wpack_bytes = h->dec_bytes_h;
+        P.lds_bytes = h->dec_lds_h;
+        P.flags = h->d_flags;
+    }
     for (int s = 0; s < n_stack; ++s) {
         P.stack = s;
         P.last = (s == n_stack - 1);
         P.eprev = (s & 1) ? h->d_e0 : h->d_e1;
         P.ecur = (s & 1) ? h->d_e1 : h->d_e0;
-        TAE_HIP(tae::launch_seg(h->U, P, grid, st));
+        if (h->prec == 1) TAE_HIP(tae::launch_seg_h(h->U, P, grid, st));
+        else TAE_HIP(tae::launch_seg(h->U, P, grid, st));
     }
     return TAE_OK;
 }
@@ -693,9 +709,17 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         else if (!strcmp(pe, "f16x2")) want_h2 = 1;
     }
     std::vector<char> penc_h, pdec_h;
-    if (want_h2 && h->nb >= 1 && tae::fused_lds_bytes_h(h->U, cfg->block_len, h->nb) <= 160 * 1024) {
-        h->prec = 1;
+    bool h2_ok = false;
+    if (want_h2 && h->nb >= 1) {
         h->lds_bytes_h = tae::fused_lds_bytes_h(h->U, cfg->block_len, h->nb);
+        h2_ok = h->lds_bytes_h <= 160 * 1024;
+    } else if (want_h2) {               // long-block path: same segment geometry, f16x2 panels
+        h->enc_lds_h = tae::seg_lds_bytes_h(h->U, h->enc_T, cfg->enc_num_layer);
+        h->dec_lds_h = tae::seg_lds_bytes_h(h->U, h->dec_T, cfg->dec_num_layer);
+        h2_ok = h->enc_lds_h <= 160 * 1024 && h->dec_lds_h <= 160 * 1024;
+    }
+    if (h2_ok) {
+        h->prec = 1;
         const LayoutH lh(h->U);
         h->enc_stride_h = (uint32_t)lh.stack_bytes(cfg->enc_num_layer);
         h->dec_stride_h = (uint32_t)lh.stack_bytes(cfg->dec_num_layer);
@@ -904,7 +928,7 @@ int tae_generate_inputs(tae_handle* h, float* u, float* noise, int32_t B, int64_
 int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_t* lds_bytes) {
     if (!h) return fail(TAE_EINVAL, "handle is NULL");
     if (blocks_per_workgroup) *blocks_per_workgroup = h->nb;
-    if (lds_bytes) *lds_bytes = h->nb >= 1 ? h->lds_bytes : h->dec_lds;
+    if (lds_bytes) *lds_bytes = h->nb >= 1 ? (h->prec == 1 ? h->lds_bytes_h : h->lds_bytes) : (h->prec == 1 ? h->dec_lds_h : h->dec_lds);
     return TAE_OK;
 }
 

@@ -87,7 +87,8 @@ template <int PT>
 struct TileH {
     const int* rowtab;  // LDS table [PT][16] of this wave's group: panel row of tile p's position n (padding lanes: row 2, real
                         // finite data).  Read on demand (twice per layer) instead of living in - and being spilled from - VGPRs.
-    uint32_t valid;     // bit p: in-block position of this workgroup (its stack output is owned here)
+    uint32_t valid;     // bit p: in-block position held in this workgroup's panel (its activations are written back)
+    uint32_t center;    // bit p: position whose stack output this workgroup owns (== valid for whole blocks)
     int m0;             // workgroup-relative position of tile 0 (tile p: m0 + 16 p)
     int L;
     __device__ __forceinline__ int row(int p) const {
@@ -96,6 +97,7 @@ struct TileH {
         return t[p * 16];
     }
     __device__ __forceinline__ bool ok(int p) const { return (valid >> p) & 1u; }
+    __device__ __forceinline__ bool own(int p) const { return (center >> p) & 1u; }
     __device__ __forceinline__ int blk(int p) const { return (m0 + 16 * p) / L; }
     __device__ __forceinline__ int t(int p) const { const int m = m0 + 16 * p; return m - (m / L) * L; }
     __device__ __forceinline__ int rowbase(int p) const { return blk(p) * (L + 2) + 2; }
@@ -118,6 +120,7 @@ __device__ __forceinline__ void make_tiles_h(TileH<PT>& tc, int* rowtab, int g, 
         if (lane < 16) rowtab[(g * PT + p) * 16 + n] = v ? b * (L + 2) + 2 + (m - b * L) : 2;    // both channel halves write the same values
         tc.valid |= (v ? 1u : 0u) << p;
     }
+    tc.center = tc.valid;
 }
 
 template <int U, int C0, int NC>
@@ -256,7 +259,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
         for (int p = 0; p < PT; ++p) {
             float2 other = float2{0.0f, 0.0f};
             if constexpr (NC < CTT) other = *reinterpret_cast<const float2*>(HS + ((g * PT + p) * 16 + n) * 8 + 2 * q);
-            if (tc.ok(p)) {
+            if (tc.own(p)) {
                 epi(p, 2 * q, (k2[p][0] + other.x) + bq0);
                 epi(p, 2 * q + 1, (k2[p][1] + other.y) + bq1);
             }
@@ -413,6 +416,141 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
     block_reduce_stats(smem, tid, sum, sumsq, P.partials);
 }
 
+
+// =============================================================================================
+// Long blocks (block_len > 320): one stack per launch over (block, segment) workgroups with halo recompute -
+// the f16x2 twin of seg_kernel in turboae_kernels.hip (same segment geometry, same exchange buffers; the
+// fp32 extrinsic values are split into halves when they are staged into the X planes).
+template <int U, int PT, int C0, int NC>
+__device__ __forceinline__ void seg_body_h(const SegParams& P, char* smem, const PanelsH& pn, const TileH<PT>& tc, int g, int lane,
+                                           int stack, int b, int tstart, double& sum, double& sumsq) {
+    const int L = P.L;
+    const char* wpack = reinterpret_cast<const char*>(P.wpack);
+    WeightStreamH<U, C0, NC> ws;
+    ws.init(wpack, P.wpack_bytes, lane);
+    const uint32_t soff = (uint32_t)stack * P.stack_stride;
+    ws.prefetch(soff);
+    const XPlane X = pn.XA;
+    float vmax = 0.0f;
+    if (P.mode == 0) {
+        const bool act_elu = P.act == 0;
+        float* xtx = P.out + (size_t)b * L * 3;
+        run_stack_h<U, PT, C0, NC>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, vmax, [&](int p, int f, float v) {
+            if (f == 0) {
+                if (act_elu) v = elu1(v);
+                xtx[(size_t)(tstart + tc.m0 + 16 * p) * 3 + stack] = v;
+                sum += (double)v;
+                sumsq += (double)v * (double)v;
+            }
+        });
+    } else if (!P.last) {
+        const int F = P.F;
+        const bool extrinsic = P.extrinsic != 0;
+        float* ecur = P.ecur + (size_t)b * L * 8;
+        run_stack_h<U, PT, C0, NC>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, vmax, [&](int p, int f, float v) {
+            if (f < F) {
+                if (extrinsic) v -= X.read(tc.row(p), 2 + f);
+                vmax = fmaxf(vmax, fabsf(v));
+                ecur[(size_t)(tstart + tc.m0 + 16 * p) * 8 + f] = v;
+            }
+        });
+    } else {
+        float* xdec = P.out + (size_t)b * L;
+        run_stack_h<U, PT, C0, NC>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, vmax, [&](int p, int f, float v) {
+            if (f == 0) xdec[P.perm[tstart + tc.m0 + 16 * p]] = 1.0f / (1.0f + expf(-v));    // sigmoid(deinterleave), decoders.py:267
+        });
+    }
+    report_range(vmax, P.flags);
+}
+
+template <int U>
+__device__ __forceinline__ PanelsH carve_seg_h(char* smem, int rows) {
+    PanelsH pn;
+    pn.dump = rows + 1;
+    const size_t ab = (size_t)(rows + 2) * U * 2, xb = (size_t)(rows + 1 + kXSlack) * kXRowB;
+    pn.AH = smem;
+    pn.AL = pn.AH + ab;
+    pn.XA.h = pn.AL + ab;
+    pn.XA.l = pn.XA.h + xb;
+    pn.XB = pn.XA;
+    pn.PERM = nullptr;
+    pn.INV = nullptr;
+    pn.ROWT = reinterpret_cast<int*>(pn.XA.l + xb);
+    pn.HS = reinterpret_cast<float*>(smem + (((reinterpret_cast<char*>(pn.ROWT + kHeadSlots) - smem) + 15) & ~15));
+    return pn;
+}
+
+template <int U, int PT>
+__global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = wave & (kGroups - 1), h = wave / kGroups;
+    const int L = P.L, H = 2 * P.n_layer;
+    int bid = blockIdx.x;
+    int stack = P.stack;
+    if (P.mode == 0) { stack = bid % 3; bid /= 3; }
+    const int seg = bid % P.nseg, b = bid / P.nseg;
+    const int s0 = seg * P.T;
+    const int tlen = min(P.T, L - s0);
+    const int tstart = (s0 - H) - ((s0 - H) & 3);      // same panel origin as the fp32 kernel (floored to a multiple of 4)
+    const int NP = s0 + P.T + H - tstart;
+    const int rows = P.T + 2 * H + 3 + 4;
+    const PanelsH pn = carve_seg_h<U>(smem, rows);
+    const bool odd = (stack & 1) != 0;
+
+    zero_lds(smem, P.lds_bytes, tid);
+    __syncthreads();
+    float vmax = 0.0f;
+    for (int m = tid; m < NP; m += kThreads) {
+        const int t = tstart + m;
+        if (t < 0 || t >= L) continue;
+        const int row = 2 + m;
+        if (P.mode == 0) {
+            const int src = (stack == 2) ? P.perm[t] : t;                           // encoders.py:369
+            pn.XA.write(row, 0, 2.0f * P.in[(size_t)b * L + src] - 1.0f);           // encoders.py:362
+        } else {
+            const float* rx = P.in + (size_t)b * L * 3;
+            const float r0 = odd ? rx[(size_t)P.perm[t] * 3] : rx[(size_t)t * 3];   // r_sys_int / r_sys
+            const float r1 = rx[(size_t)t * 3 + (odd ? 2 : 1)];                     // r_par2 / r_par1
+            vmax = fmaxf(vmax, fmaxf(fabsf(r0), fabsf(r1)));
+            pn.XA.write(row, 0, r0);
+            pn.XA.write(row, 1, r1);
+            if (stack > 0) {
+                // dec2 reads q[p[i]] (interleave, decoders.py:238); dec1 reads q2[inv[j]] (deinterleave, :249)
+                const int gi = odd ? P.perm[t] : P.inv[t];
+                const float* e = P.eprev + ((size_t)b * L + gi) * 8;
+                for (int f = 0; f < P.F; ++f) pn.XA.write(row, 2 + f, e[f]);
+            }
+        }
+    }
+    report_range(vmax, P.flags);
+
+    TileH<PT> tc;
+    {
+        const int n = lane & 15;
+        tc.valid = 0u;
+        tc.center = 0u;
+        tc.m0 = g * PT * 16 + n;
+        tc.L = L;
+        tc.rowtab = pn.ROWT + g * PT * 16 + n;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int m = tc.m0 + 16 * p;
+            const int t = tstart + m;
+            const bool v = (m < NP) && (t >= 0) && (t < L);
+            if (lane < 16) pn.ROWT[(g * PT + p) * 16 + n] = v ? 2 + m : 2;
+            tc.valid |= (v ? 1u : 0u) << p;
+            tc.center |= ((v && t >= s0 && t < s0 + tlen) ? 1u : 0u) << p;
+        }
+    }
+    __syncthreads();
+    double sum = 0.0, sumsq = 0.0;
+    const bool upper = __builtin_amdgcn_readfirstlane(h) != 0;
+    if (!upper) seg_body_h<U, PT, 0, Split<U>::CTA>(P, smem, pn, tc, g, lane, stack, b, tstart, sum, sumsq);
+    else seg_body_h<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, g, lane, stack, b, tstart, sum, sumsq);
+    if (P.mode == 0) block_reduce_stats(smem, tid, sum, sumsq, P.partials);
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int U>
 static hipError_t launch_fused_h_u(bool decoder, const FusedParams& P, int grid, hipStream_t st) {
@@ -434,6 +572,34 @@ hipError_t launch_fused_h(int U, bool decoder, const FusedParams& P, int grid, h
         case 32: return launch_fused_h_u<32>(decoder, P, grid, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+template <int U>
+static hipError_t launch_seg_h_u(const SegParams& P, int grid, hipStream_t st) {
+    constexpr int PT = 5;
+    auto k = seg_kernel_h<U, PT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_h(int U, const SegParams& P, int grid, hipStream_t st) {
+    switch (U) {
+        case 100: return launch_seg_h_u<100>(P, grid, st);
+        case 64: return launch_seg_h_u<64>(P, grid, st);
+        case 32: return launch_seg_h_u<32>(P, grid, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+int seg_lds_bytes_h(int U, int T, int n_layer) {
+    const int rows = T + 4 * n_layer + 3 + 4;
+    size_t b = 2 * (size_t)(rows + 2) * U * 2 + 2 * (size_t)(rows + 1 + kXSlack) * kXRowB + (size_t)kHeadSlots * 4;
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)kHeadSlots * 8 * 4;
+    if (b < 2 * kThreads * sizeof(double)) b = 2 * kThreads * sizeof(double);
+    return (int)b;
 }
 
 int fused_lds_bytes_h(int U, int L, int nb) {
