@@ -237,6 +237,7 @@ struct tae_handle {
     float* d_e1 = nullptr;
     // GRU decoder (dec_type = 1): canonical decoder weights uploaded as they are + per-chunk workspace
     float* d_wrnn = nullptr;
+    char* d_wrnn_h = nullptr;   // f16x2 packing of the same (prec == 1)
     int32_t rnn_chunk = 0;   // blocks per internal chunk (bounds the workspace)
     float* d_gxa = nullptr;  // (chunk, L, 8) natural-order panel
     float* d_gxb = nullptr;  // (chunk, L, 8) interleaved-order panel
@@ -393,6 +394,141 @@ size_t rnn_packed_floats(size_t H, size_t F, int n_iter) {
     size_t n = 0;
     for (int s = 0; s < 2 * n_iter; ++s) n += rnn_packed_stack_floats((s == 2 * n_iter - 1) ? 1 : F);
     return n;
+}
+
+// ---- GRU decoder, f16x2 representation (turboae_gru_h2.hip) -----------------------------------------------
+constexpr size_t kGHTileB = 3 * 2048 + 1024, kGHFragB = 19 * kGHTileB, kGHNiB = 6 * 1024;
+constexpr size_t kGHRec0B = kGHFragB + kGHNiB + 25 * 64 + 16, kGHRec1B = kGHFragB + 7 * 64 + 16;
+constexpr size_t kGHProjDirB = 7 * 19 * 2048, kGHProjB = 2 * kGHProjDirB + 2 * 19 * 64 + 16;
+
+inline void put_split(char* dst, size_t hi_off, size_t lo_off, float w) {
+    const uint16_t hi = f2h(w), lo = f2h(w - h2f(hi));
+    memcpy(dst + hi_off, &hi, 2);
+    memcpy(dst + lo_off, &lo, 2);
+}
+inline float pow2_scale(float maxabs) {       // power of two that brings maxabs into [2^13, 2^14)
+    if (!(maxabs > 0.0f) || !std::isfinite(maxabs)) return 1.0f;
+    int e = 0;
+    (void)frexpf(maxabs, &e);
+    int S = 14 - e;
+    if (S > 60) S = 60;
+    if (S < -60) S = -60;
+    return ldexpf(1.0f, S);
+}
+inline float max_abs(const float* p, size_t n) {
+    float m = 0.0f;
+    for (size_t i = 0; i < n; ++i) m = fmaxf(m, fabsf(p[i]));
+    return m;
+}
+
+// W_hh (3H,H) [+ layer-0 W_ih (3H,cin)] -> per gate tile: 3 slabs x (hi | lo) x [lane][8 halves], then the K = 16 remainder
+// (hi | lo) x [lane][4 halves]: k0 = unit 96 + kq, k1..3 = stack inputs 3kq .. 3kq+2 (layer 0)
+void pack_gru_rec_h(const float* Whh, const float* Wih0, int cin, float scale, char* dst) {
+    for (int T = 0; T < kGRT; ++T)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int m = lane & 15, kq = lane >> 4;
+            const int rowh = gru_row(T, m, false) >= 0 && !(Wih0 && T == 18 && (m & 3) == 3) ? gru_row(T, m, false) : -1;
+            for (int sl = 0; sl < 3; ++sl)
+                for (int j = 0; j < 8; ++j) {
+                    const int unit = j < 4 ? 16 * (2 * sl) + 4 * kq + j : 16 * (2 * sl + 1) + 4 * kq + (j - 4);
+                    const float w = rowh >= 0 ? Whh[(size_t)rowh * kGH + unit] * scale : 0.0f;
+                    const size_t o = (size_t)T * kGHTileB + sl * 2048 + lane * 16 + j * 2;
+                    put_split(dst, o, o + 1024, w);
+                }
+            for (int j = 0; j < 4; ++j) {
+                float w = 0.0f;
+                if (j == 0) w = rowh >= 0 ? Whh[(size_t)rowh * kGH + 96 + kq] * scale : 0.0f;
+                else if (Wih0) {
+                    const int xi = 3 * kq + j - 1;
+                    int rowx;
+                    if (T < 18) rowx = (T % 3 < 2) ? (T % 3) * kGH + 16 * (T / 3) + m : -1;      // the n-gate input part has its own tiles
+                    else { const int qq = m >> 2, i = m & 3; rowx = i < 2 ? i * kGH + 96 + qq : (i == 3 ? 2 * kGH + 96 + qq : -1); }
+                    if (rowx >= 0 && xi < cin) w = Wih0[(size_t)rowx * cin + xi] * scale;
+                }
+                const size_t o = (size_t)T * kGHTileB + 6144 + lane * 8 + j * 2;
+                put_split(dst, o, o + 512, w);
+            }
+        }
+}
+// layer 0: n-gate input tiles (K = 16 fragments, x only)
+void pack_gru_ni_h(const float* Wih0, int cin, float scale, char* dst) {
+    for (int ut = 0; ut < 6; ++ut)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 4; ++j) {
+                const int m = lane & 15, kq = lane >> 4, xi = 3 * kq + j - 1;
+                const float w = (j >= 1 && xi < cin) ? Wih0[(size_t)(2 * kGH + 16 * ut + m) * cin + xi] * scale : 0.0f;
+                const size_t o = (size_t)ut * 1024 + lane * 8 + j * 2;
+                put_split(dst, o, o + 512, w);
+            }
+}
+// layer-1 W_ih (3H,2H) of one direction -> [slab 7][gate tile 19][hi | lo][lane][8 halves]
+void pack_gru_proj_h(const float* Wih, float scale, char* dst) {
+    for (int sl = 0; sl < 7; ++sl)
+        for (int ct = 0; ct < kGRT; ++ct)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int row = gru_row(ct, lane & 15, false), k = 32 * sl + 8 * (lane >> 4) + j;
+                    const float w = (row >= 0 && k < 2 * kGH) ? Wih[(size_t)row * 2 * kGH + k] * scale : 0.0f;
+                    const size_t o = ((size_t)(sl * kGRT + ct) * 2) * 1024 + lane * 16 + j * 2;
+                    put_split(dst, o, o + 1024, w);
+                }
+}
+
+size_t rnn_h_stack_bytes(size_t nout) { return 2 * kGHRec0B + kGHProjB + 2 * kGHRec1B + ((nout * 2 * kGH + nout) * 4 + 15) / 16 * 16; }
+size_t rnn_h_packed_bytes(size_t F, int n_iter) {
+    size_t n = 0;
+    for (int s = 0; s < 2 * n_iter; ++s) n += rnn_h_stack_bytes((s == 2 * n_iter - 1) ? 1 : F);
+    return n;
+}
+
+// canonical GRU decoder -> per stack: L0 {dir: REC | NI | BIAS0 * 2^S | 2^-S} | L1 {PROJ (2 dirs) | PBIAS * 2^Sp | 2^-Sp | dir: REC | BN1 * 2^S | 2^-S} | Linear
+void repack_rnn_h(const float* src, char* dst, size_t F, int n_iter) {
+    const size_t H = kGH;
+    for (int s = 0; s < 2 * n_iter; ++s) {
+        const size_t nout = (s == 2 * n_iter - 1) ? 1 : F;
+        const size_t cin0 = 2 + F, cin1 = 2 * H;
+        const size_t per0 = 3 * H * cin0 + 3 * H * H + 6 * H, per1 = 3 * H * cin1 + 3 * H * H + 6 * H;
+        for (int d = 0; d < 2; ++d) {
+            const float* p = src + d * per0;           // weight_ih | weight_hh | bias_ih | bias_hh
+            const float scale = pow2_scale(fmaxf(max_abs(p, 3 * H * cin0), max_abs(p + 3 * H * cin0, 3 * H * H)));
+            char* o = dst + d * kGHRec0B;
+            pack_gru_rec_h(p + 3 * H * cin0, p, (int)cin0, scale, o);
+            pack_gru_ni_h(p, (int)cin0, scale, o + kGHFragB);
+            float* b = reinterpret_cast<float*>(o + kGHFragB + kGHNiB);
+            pack_gru_bias0(p + 3 * H * cin0 + 3 * H * H, p + 3 * H * cin0 + 3 * H * H + 3 * H, b);
+            for (int i = 0; i < 25 * 16; ++i) b[i] *= scale;
+            for (int i = 0; i < 4; ++i) b[25 * 16 + i] = 1.0f / scale;
+        }
+        src += 2 * per0;
+        dst += 2 * kGHRec0B;
+        {
+            const float scale = pow2_scale(fmaxf(max_abs(src, 3 * H * cin1), max_abs(src + per1, 3 * H * cin1)));
+            float* pb = reinterpret_cast<float*>(dst + 2 * kGHProjDirB);
+            for (int d = 0; d < 2; ++d) {
+                const float* p = src + d * per1;
+                pack_gru_proj_h(p, scale, dst + d * kGHProjDirB);
+                pack_gru_pbias(p + 3 * H * cin1 + 3 * H * H, p + 3 * H * cin1 + 3 * H * H + 3 * H, pb + d * (kGRT * 16));
+            }
+            for (int i = 0; i < 2 * kGRT * 16; ++i) pb[i] *= scale;
+            for (int i = 0; i < 4; ++i) pb[2 * kGRT * 16 + i] = 1.0f / scale;
+        }
+        dst += kGHProjB;
+        for (int d = 0; d < 2; ++d) {
+            const float* p = src + d * per1;
+            const float scale = pow2_scale(max_abs(p + 3 * H * cin1, 3 * H * H));
+            char* o = dst + d * kGHRec1B;
+            pack_gru_rec_h(p + 3 * H * cin1, nullptr, 0, scale, o);
+            float* b = reinterpret_cast<float*>(o + kGHFragB);
+            pack_gru_bias1(p + 3 * H * cin1 + 3 * H * H + 3 * H, b);
+            for (int i = 0; i < 7 * 16; ++i) b[i] *= scale;
+            for (int i = 0; i < 4; ++i) b[7 * 16 + i] = 1.0f / scale;
+        }
+        src += 2 * per1;
+        dst += 2 * kGHRec1B;
+        memcpy(dst, src, (nout * 2 * H + nout) * sizeof(float));
+        src += nout * 2 * H + nout;
+        dst += ((nout * 2 * H + nout) * 4 + 15) / 16 * 16;
+    }
 }
 
 size_t num_weights(const tae_config* c) {
@@ -577,6 +713,37 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
         const int32_t Bc = (B - c0 < h->rnn_chunk) ? B - c0 : h->rnn_chunk;
         const size_t np = (size_t)Bc * L;
         TAE_HIP(tae::launch_gru_prep(rx + (size_t)c0 * L * 3, h->d_perm, h->d_gxa, h->d_gxb, Bc, L, st));
+        if (h->prec == 1) {
+            // f16x2 kernels: layer 0 writes Y0 as halves straight into the projection's operand layout
+            const char* wb = h->d_wrnn_h;
+            for (int s = 0; s < 2 * n_iter; ++s) {
+                const bool odd = (s & 1) != 0, last = (s == 2 * n_iter - 1);
+                const int nout = last ? 1 : F;
+                const float* xin = odd ? h->d_gxb : h->d_gxa;
+                tae::GruRecParams R0;
+                memset(&R0, 0, sizeof(R0));
+                R0.w = reinterpret_cast<const float*>(wb); R0.w_dir_stride = (uint32_t)kGHRec0B; R0.x = xin; R0.B = Bc; R0.L = L; R0.y = h->d_gy0;
+                TAE_HIP(tae::launch_gru_rec_h(true, R0, st));
+                const char* w1 = wb + 2 * kGHRec0B;
+                tae::GruProjParams PP;
+                PP.yin = h->d_gy0; PP.w = reinterpret_cast<const float*>(w1); PP.gi = h->d_ggi; PP.npos = np; PP.B = Bc; PP.L = L;
+                TAE_HIP(tae::launch_gru_proj_h(PP, st));
+                tae::GruRecParams R1;
+                memset(&R1, 0, sizeof(R1));
+                R1.w = reinterpret_cast<const float*>(w1 + kGHProjB); R1.w_dir_stride = (uint32_t)kGHRec1B; R1.gi = h->d_ggi; R1.B = Bc; R1.L = L; R1.y = h->d_gy1;
+                TAE_HIP(tae::launch_gru_rec_h(false, R1, st));
+                const float* wl = reinterpret_cast<const float*>(w1 + kGHProjB + 2 * kGHRec1B);
+                tae::GruHeadParams HP;
+                memset(&HP, 0, sizeof(HP));
+                HP.y = h->d_gy1; HP.w = wl; HP.b = wl + (size_t)nout * 2 * H; HP.xcur = xin;
+                HP.xnext = odd ? h->d_gxa : h->d_gxb; HP.xdec = xdec + (size_t)c0 * L;
+                HP.ptab = odd ? h->d_perm : h->d_inv;
+                HP.npos = np; HP.L = L; HP.F = F; HP.nout = nout; HP.extrinsic = h->cfg.extrinsic; HP.last = last ? 1 : 0;
+                TAE_HIP(tae::launch_gru_head(HP, st));
+                wb += rnn_h_stack_bytes((size_t)nout);
+            }
+            continue;
+        }
         const float* w = h->d_wrnn;
         for (int s = 0; s < 2 * n_iter; ++s) {
             const bool odd = (s & 1) != 0, last = (s == 2 * n_iter - 1);
@@ -588,7 +755,7 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
             TAE_HIP(tae::launch_gru_rec(true, R0, st));
             const float* w1 = w + 2 * kGL0Dir;
             tae::GruProjParams PP;
-            PP.yin = h->d_gy0; PP.w = w1; PP.gi = h->d_ggi; PP.npos = np;
+            PP.yin = h->d_gy0; PP.w = w1; PP.gi = h->d_ggi; PP.npos = np; PP.B = Bc; PP.L = L;
             TAE_HIP(tae::launch_gru_proj(PP, st));
             tae::GruRecParams R1;
             memset(&R1, 0, sizeof(R1));
@@ -769,6 +936,12 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         repack_rnn(dec_src, prnn.data(), 100, (size_t)F, cfg->num_iteration);
         TAE_HIP_H(hipMalloc(&h->d_wrnn, prnn.size() * sizeof(float)));
         TAE_HIP_H(hipMemcpy(h->d_wrnn, prnn.data(), prnn.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (h->prec == 1) {
+            std::vector<char> prnn_h(rnn_h_packed_bytes((size_t)F, cfg->num_iteration), 0);
+            repack_rnn_h(dec_src, prnn_h.data(), (size_t)F, cfg->num_iteration);
+            TAE_HIP_H(hipMalloc(&h->d_wrnn_h, prnn_h.size()));
+            TAE_HIP_H(hipMemcpy(h->d_wrnn_h, prnn_h.data(), prnn_h.size(), hipMemcpyHostToDevice));
+        }
         TAE_HIP_H(hipMalloc(&h->d_gzero, 6 * 100 * sizeof(float)));
         TAE_HIP_H(hipMemset(h->d_gzero, 0, 6 * 100 * sizeof(float)));
     }
@@ -788,7 +961,7 @@ int tae_destroy(tae_handle* h) {
     (void)hipFree(h->d_e0); (void)hipFree(h->d_e1);
     (void)hipFree(h->d_wrnn); (void)hipFree(h->d_gxa); (void)hipFree(h->d_gxb); (void)hipFree(h->d_gy0); (void)hipFree(h->d_gy1);
     (void)hipFree(h->d_ggi); (void)hipFree(h->d_gzero);
-    (void)hipFree(h->d_wenc_h); (void)hipFree(h->d_wdec_h); (void)hipFree(h->d_flags);
+    (void)hipFree(h->d_wenc_h); (void)hipFree(h->d_wdec_h); (void)hipFree(h->d_flags); (void)hipFree(h->d_wrnn_h);
     delete h;
     return TAE_OK;
 }

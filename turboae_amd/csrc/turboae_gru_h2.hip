@@ -1,0 +1,342 @@
+// DeepTurbo GRU decoder (DEC_LargeRNN, decoders.py:84-149) in the f16x2 representation: the kernels of
+// turboae_gru.hip with every fp32 operand of the two big contractions (W_hh * h_t in the recurrence,
+// W_ih1 * y0 in the layer-1 input projection) carried as fp16 hi + lo halves and three f16 MFMA products
+// per 32 k (see turboae_device.hpp, "fp16-split contraction").  Gate arithmetic, state update, biases and
+// the Linear head stay fp32.
+//
+// gru_rec_h: as gru_rec (one wave = 16 blocks x one direction, h_t never leaves the registers, W_hh
+// fragments resident in LDS, no barriers), with
+//   * k-slab s (32 k) of the recurrent product = unit tiles 2s and 2s+1: lane (n, kq) supplies the units
+//     16(2s) + 4kq + j (j < 4) and 16(2s+1) + 4kq + (j-4) - exactly the 8 state values that lane holds in the
+//     D layout of those two unit tiles, re-split into halves after every step;
+//   * the 4 remainder units (96..99) as one K = 16 MFMA (v_mfma_f32_16x16x16_f16): lane kq supplies unit
+//     96 + kq in k = 4kq, and - layer 0 - its three spare k slots carry the stack inputs x_t[3kq .. 3kq+2], so
+//     the K = 7 input projection costs no extra MFMAs for the r / z rows (the n-gate input part needs its own
+//     accumulators: 6 extra K = 16 tiles);
+//   * unit-tile-major order: the r, z, n tiles of one unit tile (+ remainder slab) are finished together and
+//     their gate arithmetic overlaps the next unit tile's MFMAs.
+// gru_proj_h: GI = W_ih1 * Y0 + b on conv_accumulate_h (K = 200 -> 7 slabs), 160 positions per workgroup
+// staged in LDS as hi / lo planes; the layer-0 recurrence writes Y0 directly as halves
+// [pos][hi 200 | lo 200], so staging is a copy.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "turboae_internal.hpp"
+#include "turboae_device.hpp"
+
+namespace tae {
+
+using u32x4v = __attribute__((ext_vector_type(4))) uint32_t;
+using h2v = __attribute__((ext_vector_type(2))) _Float16;
+
+constexpr int kGH = 100;
+constexpr int kGXW = 8;
+constexpr int kRecTileB = 3 * 2048 + 1024;                 // bytes of A fragments per gate-row tile: 3 slabs (hi | lo) + K=16 remainder (hi | lo)
+constexpr int kRecFragB = 19 * kRecTileB;                   // 136 192
+constexpr int kNiFragB = 6 * 1024;                          // layer 0: n-gate input tiles (K = 16, hi | lo)
+constexpr int kRec0B = kRecFragB + kNiFragB + 25 * 64 + 16; // + accumulator-init rows + 2^-S
+constexpr int kRec1B = kRecFragB + 7 * 64 + 16;             // + b_hn rows + 2^-S
+constexpr int kGiRowF = 2 * 19 * 16;
+
+__device__ __forceinline__ f32x4 mfma16x16x16h(h4 a, h4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float sigm_h(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float tanh_h(float x) {
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)), 1.0f);
+}
+
+using lds_q4 = const u32x4v __attribute__((address_space(3)));
+using lds_q2 = const u32x2v __attribute__((address_space(3)));
+using lds_f4c = const f32x4 __attribute__((address_space(3)));
+
+// 3 products of one 32-k slab for the NG gate tiles of a unit tile
+template <int NG>
+__device__ __forceinline__ void slab_mma(f32x4 (&acc)[NG], lds_cptr fr, h8 bh, h8 bl) {
+    h8 ah[NG], al[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        ah[g] = __builtin_bit_cast(h8, *reinterpret_cast<lds_q4*>(fr + g * kRecTileB));
+        al[g] = __builtin_bit_cast(h8, *reinterpret_cast<lds_q4*>(fr + g * kRecTileB + 1024));
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(ah[g], bl, acc[g]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(al[g], bh, acc[g]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(ah[g], bh, acc[g]);
+}
+// the K = 16 remainder slab (fragments at `fr + g * STRIDE`, hi then lo 512 bytes apart)
+template <int NG, int STRIDE>
+__device__ __forceinline__ void rem_mma(f32x4 (&acc)[NG], lds_cptr fr, h4 bh, h4 bl) {
+    h4 ah[NG], al[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        ah[g] = __builtin_bit_cast(h4, *reinterpret_cast<lds_q2*>(fr + g * STRIDE));
+        al[g] = __builtin_bit_cast(h4, *reinterpret_cast<lds_q2*>(fr + g * STRIDE + 512));
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x16h(ah[g], bl, acc[g]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x16h(al[g], bh, acc[g]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x16h(ah[g], bh, acc[g]);
+}
+
+template <bool LAYER0>
+__global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y, L = P.L;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(P.w) + (size_t)dir * P.w_dir_stride);
+        constexpr int NV = (LAYER0 ? kRec0B : kRec1B) / 16;
+        for (int i = tid; i < NV; i += (int)blockDim.x) reinterpret_cast<f32x4*>(smem)[i] = src[i];
+    }
+    __syncthreads();
+    const int b0 = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * 16;
+    if (b0 >= P.B) return;                                  // no barrier below: waves are independent
+    const int nb = min(16, P.B - b0);
+    const bool valid = n < nb;
+    const int nc = valid ? n : nb - 1;
+    const lds_cptr lds3 = (lds_cptr)smem;
+    const lds_cptr bias = lds3 + kRecFragB + (LAYER0 ? kNiFragB : 0) + q * 16;
+    const float inv = *reinterpret_cast<const float*>(smem + kRecFragB + (LAYER0 ? kNiFragB + 25 * 64 : 7 * 64));
+
+    const __amdgpu_buffer_rsrc_t rs_in = LAYER0
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x + (size_t)b0 * L * kGXW), 0, nb * L * kGXW * 4, 0x00020000)
+        // GI is time-major [t][dir][block][19 tiles x 16]: at step t the 16 blocks of a wave read one contiguous 19 KB run
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.gi), 0, -1, 0x00020000);
+    const uint32_t v_in = LAYER0 ? (uint32_t)(nc * L * kGXW * 4) : (uint32_t)((b0 + nc) * (19 * 64) + q * 16);
+    // outputs: layer 0 -> Y0 as halves [pos][hi 200 | lo 200] (the projection kernel's operand), layer 1 -> Y1 fp32 [pos][200]
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y + (size_t)b0 * L * 2 * kGH, 0, nb * L * 2 * kGH * 4, 0x00020000);
+    const uint32_t v_y = !valid ? 0x80000000u
+        : (LAYER0 ? (uint32_t)(n * L * 800 + (dir * kGH + 4 * q) * 2) : (uint32_t)(n * L * 800 + dir * kGH * 4 + q * 16));
+    const uint32_t v_yr = !valid ? 0x80000000u
+        : (LAYER0 ? (uint32_t)(n * L * 800 + (dir * kGH + 96 + q) * 2) : (uint32_t)(n * L * 800 + (dir * kGH + 96 + q) * 4));
+
+    f32x4 h[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) h[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float hr = 0.0f;
+    h8 bh[3], bl[3];                        // B operands of the three 32-k slabs = halves of h (unit tiles 2s, 2s+1)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { bh[s] = h8{0, 0, 0, 0, 0, 0, 0, 0}; bl[s] = bh[s]; }
+    h4 rh = {0, 0, 0, 0}, rl = {0, 0, 0, 0};   // remainder slab: k0 = h of unit 96 + q, k1..3 = this lane's share of x_t (layer 0)
+
+    // x_t (layer 0): lane group q carries x[3q .. 3q+2] (q = 2: x[6] only; q = 3: nothing)
+    auto load_x = [&](int t, f32x4& xa, f32x4& xb) {
+        const uint32_t so = (uint32_t)t * kGXW * 4;
+        xa = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_in, so, 0));
+        xb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_in + 16, so, 0));
+    };
+    auto set_x = [&](const f32x4& xa, const f32x4& xb) {
+        const float x0 = q == 0 ? xa.x : (q == 1 ? xa.w : (q == 2 ? xb.z : 0.0f));
+        const float x1 = q == 0 ? xa.y : (q == 1 ? xb.x : 0.0f);
+        const float x2 = q == 0 ? xa.z : (q == 1 ? xb.y : 0.0f);
+        const float xs[3] = {x0, x1, x2};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const _Float16 hi = (_Float16)xs[j];
+            rh[j + 1] = hi;
+            rl[j + 1] = (_Float16)(xs[j] - (float)hi);
+        }
+    };
+    f32x4 xa = {0.f, 0.f, 0.f, 0.f}, xb = xa;
+    if (LAYER0) {
+        load_x(dir ? L - 1 : 0, xa, xb);
+        set_x(xa, xb);
+    }
+#pragma unroll 1
+    for (int s = 0; s < L; ++s) {
+        const int t = dir ? L - 1 - s : s;
+        f32x4 g[19];
+        if (LAYER0) {
+            const int tn = dir ? (t > 0 ? t - 1 : 0) : (t + 1 < L ? t + 1 : t);
+            load_x(tn, xa, xb);
+        } else {
+            const uint32_t so = (uint32_t)(t * 2 + dir) * (uint32_t)P.B * (19 * 64);
+#pragma unroll
+            for (int T = 0; T < 19; ++T)
+                g[T] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_in + T * 64, so, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);     // keep this step's loads up here (they are consumed by the gate arithmetic / next step)
+        h4 nhi[6], nlo[6];
+        const uint32_t yo = (uint32_t)t * 800u;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            constexpr int NG = LAYER0 ? 4 : 3;
+            f32x4 acc[NG];
+            if (LAYER0) {
+#pragma unroll
+                for (int gI = 0; gI < 3; ++gI) acc[gI] = *reinterpret_cast<lds_f4c*>(bias + (3 * u + gI) * 64);
+                acc[NG - 1] = *reinterpret_cast<lds_f4c*>(bias + (19 + u) * 64);
+            } else {
+                acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[1] = acc[0];
+                acc[2] = *reinterpret_cast<lds_f4c*>(bias + u * 64);
+            }
+            const lds_cptr fr = lds3 + (3 * u) * kRecTileB + lane * 16;
+            f32x4 a3[3] = {acc[0], acc[1], acc[2]};
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) slab_mma<3>(a3, fr + sl * 2048, bh[sl], bl[sl]);
+            rem_mma<3, kRecTileB>(a3, lds3 + (3 * u) * kRecTileB + 6144 + lane * 8, rh, rl);
+            f32x4 ani = {0.f, 0.f, 0.f, 0.f};
+            if (LAYER0) {
+                f32x4 a1[1] = {acc[NG - 1]};
+                rem_mma<1, 1024>(a1, lds3 + kRecFragB + u * 1024 + lane * 8, rh, rl);
+                ani = a1[0];
+            }
+            f32x4 hn;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float r = sigm_h(LAYER0 ? a3[0][i] * inv : fmaf(a3[0][i], inv, g[3 * u][i]));
+                const float z = sigm_h(LAYER0 ? a3[1][i] * inv : fmaf(a3[1][i], inv, g[3 * u + 1][i]));
+                const float nn = tanh_h(fmaf(r, a3[2][i] * inv, LAYER0 ? ani[i] * inv : g[3 * u + 2][i]));
+                hn[i] = fmaf(z, h[u][i] - nn, nn);
+            }
+            h[u] = hn;
+            split4(hn, nhi[u], nlo[u]);
+            if (LAYER0) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nhi[u]), rs_y, v_y + u * 32, yo, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nlo[u]), rs_y, v_y + u * 32 + 400, yo, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, hn), rs_y, v_y + u * 64, yo, 0);
+            }
+        }
+        // remainder tile: rows 4qq + i = gate i of unit 96 + qq (i = 3: layer-0 n-gate input part)
+        {
+            f32x4 a1[1];
+            a1[0] = *reinterpret_cast<lds_f4c*>(bias + (LAYER0 ? 18 : 6) * 64);
+            const lds_cptr fr = lds3 + 18 * kRecTileB + lane * 16;
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) slab_mma<1>(a1, fr + sl * 2048, bh[sl], bl[sl]);
+            rem_mma<1, kRecTileB>(a1, lds3 + 18 * kRecTileB + 6144 + lane * 8, rh, rl);
+            const f32x4 a = a1[0];
+            const float r = sigm_h(LAYER0 ? a[0] * inv : fmaf(a[0], inv, g[18][0]));
+            const float z = sigm_h(LAYER0 ? a[1] * inv : fmaf(a[1], inv, g[18][1]));
+            const float nn = tanh_h(fmaf(r, a[2] * inv, LAYER0 ? a[3] * inv : g[18][2]));
+            hr = fmaf(z, hr - nn, nn);
+        }
+        // next step's B operands
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            bh[sl] = h8{nhi[2 * sl][0], nhi[2 * sl][1], nhi[2 * sl][2], nhi[2 * sl][3], nhi[2 * sl + 1][0], nhi[2 * sl + 1][1], nhi[2 * sl + 1][2], nhi[2 * sl + 1][3]};
+            bl[sl] = h8{nlo[2 * sl][0], nlo[2 * sl][1], nlo[2 * sl][2], nlo[2 * sl][3], nlo[2 * sl + 1][0], nlo[2 * sl + 1][1], nlo[2 * sl + 1][2], nlo[2 * sl + 1][3]};
+        }
+        {
+            const _Float16 hi = (_Float16)hr;
+            const _Float16 lo = (_Float16)(hr - (float)hi);
+            rh[0] = hi;
+            rl[0] = lo;
+            if (LAYER0) {
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, hi), rs_y, v_yr, yo, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, lo), rs_y, v_yr + 400, yo, 0);
+                set_x(xa, xb);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, hr), rs_y, v_yr, yo, 0);
+            }
+        }
+    }
+}
+
+// ---- layer-1 input projections, f16x2 GEMM ---------------------------------------------------------------
+// Workgroup = 8 waves, 160 positions staged in LDS (hi plane | lo plane, rows of 200 halves); wave (pg, rq):
+// position group pg (5 tiles), row quarter rq = (direction, half): gate tiles [0, 10) or [10, 19) of that
+// direction in two passes of <= 5 tiles (accumulators 5 x 5 tiles).
+constexpr int kProjHPos = 160;
+constexpr int kProjHPlaneB = kProjHPos * 400 + 512;          // + slack for the K padding over-read of the last row
+constexpr int kProjHLds = 2 * kProjHPlaneB;
+constexpr int kProjHSlabs = 7;                                // K = 200 -> 224
+constexpr uint32_t kProjHDirB = kProjHSlabs * 19 * 2048u;     // A fragments of one direction
+
+template <int C0, int NC>
+__device__ __forceinline__ void proj_pass_h(const GruProjParams& P, const char* smem, int pg, int dir, int lane, size_t p0) {
+    const int n = lane & 15, kq = lane >> 4;
+    const char* wb = reinterpret_cast<const char*>(P.w);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wb), 0, (int)(2 * kProjHDirB + 2 * 19 * 64 + 16), 0x00020000);
+    const uint32_t voff = (uint32_t)lane * 16u;
+    const uint32_t soff = (uint32_t)dir * kProjHDirB;
+    const float* bias = reinterpret_cast<const float*>(wb + 2 * kProjHDirB) + dir * (19 * 16);
+    const float inv = reinterpret_cast<const float*>(wb + 2 * kProjHDirB)[2 * 19 * 16];
+    uint32_t bh[5], bl[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        bh[p] = (uint32_t)(((pg * 5 + p) * 16 + n) * 400 + 16 * kq);
+        bl[p] = bh[p] + (uint32_t)kProjHPlaneB;
+    }
+    OpsHA<NC> a0;
+    load_wh<19, C0, NC>(a0, rsrc, voff, soff);
+    f32x4 acc[5][NC];
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + (C0 + ct) * 16 + 4 * kq);
+#pragma unroll
+        for (int p = 0; p < 5; ++p) acc[p][ct] = bv;
+    }
+    conv_accumulate_h<19, C0, NC, 5, kProjHSlabs>(acc, a0, rsrc, voff, soff, smem, bh, bl);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const size_t pos = p0 + (pg * 5 + p) * 16 + n;
+        if (pos < P.npos) {
+            const size_t b = pos / (size_t)P.L, t = pos - b * (size_t)P.L;
+            float* dst = P.gi + ((t * 2 + dir) * (size_t)P.B + b) * (19 * 16) + C0 * 16 + 4 * kq;
+#pragma unroll
+            for (int ct = 0; ct < NC; ++ct) *reinterpret_cast<f32x4*>(dst + ct * 16) = acc[p][ct] * inv;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void gru_proj_h_kernel(GruProjParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t p0 = (size_t)blockIdx.x * kProjHPos;
+    const int np = (int)min((size_t)kProjHPos, P.npos - p0);
+    {
+        // Y0 arrives as halves [pos][hi 200 | lo 200]: 50 16-byte pieces per position, 25 per plane
+        const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(P.yin) + p0 * 800);
+        for (int i = tid; i < kProjHLds / 16; i += 512) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        for (int i = tid; i < np * 50; i += 512) {
+            const int pos = i / 50, c = i - pos * 50, plane = c >= 25 ? 1 : 0, cc = c - plane * 25;
+            *reinterpret_cast<f32x4*>(smem + plane * kProjHPlaneB + pos * 400 + cc * 16) = src[i];
+        }
+    }
+    __syncthreads();
+    const int pg = wave & 1, rq = wave >> 1, dir = rq >> 1;
+    if ((rq & 1) == 0) {
+        proj_pass_h<0, 5>(P, smem, pg, dir, lane, p0);
+        proj_pass_h<5, 5>(P, smem, pg, dir, lane, p0);
+    } else {
+        proj_pass_h<10, 5>(P, smem, pg, dir, lane, p0);
+        proj_pass_h<15, 4>(P, smem, pg, dir, lane, p0);
+    }
+}
+
+int gru_rec_h_lds_bytes(bool layer0) { return layer0 ? kRec0B : kRec1B; }
+
+hipError_t launch_gru_rec_h(bool layer0, const GruRecParams& P, hipStream_t st) {
+    const int lds = gru_rec_h_lds_bytes(layer0);
+    int nw = 8;
+    while (nw > 1 && 2 * ((P.B + 16 * nw - 1) / (16 * nw)) < 256) nw >>= 1;
+    const dim3 grid((P.B + 16 * nw - 1) / (16 * nw), 2);
+    const void* fn = layer0 ? reinterpret_cast<const void*>(gru_rec_h_kernel<true>) : reinterpret_cast<const void*>(gru_rec_h_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    if (layer0) hipLaunchKernelGGL(gru_rec_h_kernel<true>, grid, dim3(64 * nw), lds, st, P);
+    else hipLaunchKernelGGL(gru_rec_h_kernel<false>, grid, dim3(64 * nw), lds, st, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_gru_proj_h(const GruProjParams& P, hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_proj_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kProjHLds);
+    if (e != hipSuccess) return e;
+    const dim3 grid((unsigned)((P.npos + kProjHPos - 1) / kProjHPos));
+    hipLaunchKernelGGL(gru_proj_h_kernel, grid, dim3(512), kProjHLds, st, P);
+    return hipGetLastError();
+}
+
+}  // namespace tae

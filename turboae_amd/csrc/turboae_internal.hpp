@@ -62,8 +62,9 @@ struct GruRecParams {
 struct GruProjParams {
     const float* yin;     // (npos, 2H)
     const float* w;       // A fragments (2 dirs x 25 chunks x 19 tiles) followed by the bias rows (2 x 19 x 16)
-    float* gi;            // (npos,2,19,16)
+    float* gi;            // (npos,2,19,16); f16x2 kernels: time-major (L,2,B,19,16)
     size_t npos;
+    int32_t B, L;         // f16x2 kernels: blocks in this chunk and block length (npos = B * L)
 };
 struct GruHeadParams {
     const float* y;       // (npos, 2H)
@@ -79,6 +80,8 @@ struct GruHeadParams {
 hipError_t launch_gru_prep(const float* rx, const int32_t* perm, float* XA, float* XB, int B, int L, hipStream_t st);
 hipError_t launch_gru_rec(bool layer0, const GruRecParams& P, hipStream_t st);
 hipError_t launch_gru_proj(const GruProjParams& P, hipStream_t st);
+hipError_t launch_gru_rec_h(bool layer0, const GruRecParams& P, hipStream_t st);      // f16x2: w / w_dir_stride in BYTES, layer-0 y as halves
+hipError_t launch_gru_proj_h(const GruProjParams& P, hipStream_t st);
 hipError_t launch_gru_head(const GruHeadParams& P, hipStream_t st);
 
 hipError_t launch_seg(int U, const SegParams& P, int grid, hipStream_t st);
