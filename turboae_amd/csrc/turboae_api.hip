@@ -244,7 +244,6 @@ struct tae_handle {
     float* d_gy0 = nullptr;  // (chunk, L, 2H) layer-0 outputs
     float* d_gy1 = nullptr;  // (chunk, L, 2H) layer-1 outputs
     float* d_ggi = nullptr;  // (chunk, L, 2, 19, 16) layer-1 input projections in gate-tile order
-    float* d_gzero = nullptr;  // 6H zeros (b_ih already folded into the projections)
     tae::NormOpts nopts;       // encoder-output / channel variant (tae_set_channel_opts)
 };
 
@@ -942,8 +941,6 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
             TAE_HIP_H(hipMalloc(&h->d_wrnn_h, prnn_h.size()));
             TAE_HIP_H(hipMemcpy(h->d_wrnn_h, prnn_h.data(), prnn_h.size(), hipMemcpyHostToDevice));
         }
-        TAE_HIP_H(hipMalloc(&h->d_gzero, 6 * 100 * sizeof(float)));
-        TAE_HIP_H(hipMemset(h->d_gzero, 0, 6 * 100 * sizeof(float)));
     }
     TAE_HIP_H(hipMemcpy(h->d_perm, ident.data(), L * sizeof(int32_t), hipMemcpyHostToDevice));
     TAE_HIP_H(hipMemcpy(h->d_inv, ident.data(), L * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -960,7 +957,7 @@ int tae_destroy(tae_handle* h) {
     (void)hipFree(h->d_xtx); (void)hipFree(h->d_rx); (void)hipFree(h->d_partials); (void)hipFree(h->d_stats);
     (void)hipFree(h->d_e0); (void)hipFree(h->d_e1);
     (void)hipFree(h->d_wrnn); (void)hipFree(h->d_gxa); (void)hipFree(h->d_gxb); (void)hipFree(h->d_gy0); (void)hipFree(h->d_gy1);
-    (void)hipFree(h->d_ggi); (void)hipFree(h->d_gzero);
+    (void)hipFree(h->d_ggi);
     (void)hipFree(h->d_wenc_h); (void)hipFree(h->d_wdec_h); (void)hipFree(h->d_flags); (void)hipFree(h->d_wrnn_h);
     delete h;
     return TAE_OK;
