@@ -83,7 +83,9 @@ typedef struct tae_channel_opts {
     float   enc_quantize_level;   /* -enc_quantize_level (get_args.py:167); 2 = sign */
     float   enc_truncate_limit;   /* -enc_truncate_limit > 0: clamp (encoders.py:122-123) */
     int32_t channel;              /* 0: received = codes + noise (awgn, t-dist, radar, ge_awgn; channel_ae.py:41-42);
-                                     1: codes * noise (bec, :44-45); 2: codes * (2*noise - 1) (bsc, ge; :47-49) */
+                                     1: codes * noise (bec, :44-45); 2: codes * (2*noise - 1) (bsc, ge; :47-49);
+                                     3: fading_h * codes + noise (fading, :51-56) - the reference draws fading_h inside forward; here
+                                        the caller supplies it: `noise` then points to 2*B*L*3 floats, fading_h followed by the noise */
     int32_t rec_quantize;         /* 1: --rec_quantize: STEQuantize.forward(received, limit, level) (channel_ae.py:67-69, ste.py:9-23) */
     float   rec_quantize_limit;   /* the reference passes rec_quantize_level as the limit too (channel_ae.py:69) */
     float   rec_quantize_level;

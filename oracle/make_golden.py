@@ -51,7 +51,12 @@ CASES = [
     ("var_nonorm_bec", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, no_code_norm=True, channel="bec"), 5, 18, 1.0, 0.2),
     ("var_precomp_trunc", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, precompute_norm_stats=True,
                                enc_truncate_limit=1.5), 5, 19, 1.0, 2.0),
+    # -channel fading: the reference draws fading_h from the torch global stream inside forward (channel_ae.py:51-56);
+    # seeded here and reproduced draw for draw, the coefficients travel in the fixture
+    ("var_fading", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, channel="fading"), 5, 20, 1.0, 3.0),
 ]
+
+FADING_SEED = 20190020
 
 
 def make_inputs(B, L, snr_db, seed, channel="awgn", offset=0):
@@ -72,20 +77,28 @@ def run_case(name, over, B, wseed, gain, snr_db, manifest):
     u, noise = make_inputs(B, cfg.block_len, snr_db, seed=100 + wseed, channel=cfg.channel)
     model, _ = R.build_reference_model(cfg.to_dict(), B)
     R.load_weights(model, sd)
+    fading = None
+    if cfg.channel == "fading":
+        torch.manual_seed(FADING_SEED)
+        a, b = torch.randn(noise.shape), torch.randn(noise.shape)          # the two draws of channel_ae.py:53, in order
+        fading = (torch.sqrt(a ** 2 + b ** 2) / torch.sqrt(torch.tensor(3.14 / 2.0))).type(torch.FloatTensor)
+        torch.manual_seed(FADING_SEED)                                      # the reference now makes the same draws
     x_ref, c_ref = R.reference_forward(model, u, noise)
     taps, state = {}, {}
-    x_or, c_or = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict(), taps, state)
+    x_or, c_or = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict(), taps, state, fading)
     dx = float(np.abs(x_ref - x_or.numpy()).max())
     dc = float(np.abs(c_ref - c_or.numpy()).max())
     assert dc <= 2e-6 and dx <= 5e-6, (name, dc, dx)
     extra = {}
+    if fading is not None:
+        extra["fading"] = fading.numpy()
     if cfg.precompute_norm_stats:
         # running statistics: a second call on a different batch must use the averaged mean / std (encoders.py:110-114)
         u2, noise2 = make_inputs(B, cfg.block_len, snr_db, seed=100 + wseed, channel=cfg.channel, offset=B)
         x2_ref, c2_ref = R.reference_forward(model, u2, noise2)
         x2_or, c2_or = O.channel_ae_forward(torch.from_numpy(u2), torch.from_numpy(noise2), O.to_torch(sd), cfg.to_dict(), None, state)
         assert np.abs(c2_ref - c2_or.numpy()).max() <= 2e-6 and np.abs(x2_ref - x2_or.numpy()).max() <= 5e-6
-        extra = dict(u2=u2, noise2=noise2, x_dec2=x2_ref, codes2=c2_ref)
+        extra.update(dict(u2=u2, noise2=noise2, x_dec2=x2_ref, codes2=c2_ref))
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), u=u, noise=noise, x_dec=x_ref, codes=c_ref,
                         logits=taps["logits"].numpy(), x_tx=taps["x_tx"].numpy(),
                         mean=taps["mean"].numpy(), std=taps["std"].numpy(), **extra)

@@ -89,9 +89,13 @@ def power_constraint(x: torch.Tensor, cfg: Optional[dict] = None, state: Optiona
 
 
 # channel_ae.py:41-49,67-69: the channel applied to the codes and the optional receive quantiser
-def apply_channel(codes: torch.Tensor, fwd_noise: torch.Tensor, cfg: dict) -> torch.Tensor:
+def apply_channel(codes: torch.Tensor, fwd_noise: torch.Tensor, cfg: dict, fading: Optional[torch.Tensor] = None) -> torch.Tensor:
     ch = cfg.get("channel", "awgn")
-    if ch == "bec":
+    if ch == "fading":
+        # channel_ae.py:51-56: the reference draws fading_h = sqrt(randn^2 + randn^2) / sqrt(3.14 / 2) here; the draw is
+        # made explicit (oracle/make_golden.py reproduces it from the torch seed)
+        rx = fading * codes + fwd_noise
+    elif ch == "bec":
         rx = codes * fwd_noise
     elif ch in ("bsc", "ge"):
         rx = codes * (2.0 * fwd_noise - 1.0)
@@ -213,7 +217,8 @@ def decode_rnn(received: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tens
 
 # channel_ae.py:20-73 (Channel_AE.forward), AWGN branch (:41-42), rec_quantize off.
 def channel_ae_forward(u: torch.Tensor, fwd_noise: torch.Tensor, w: Dict[str, torch.Tensor], cfg: dict,
-                       taps: Optional[dict] = None, state: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                       taps: Optional[dict] = None, state: Optional[dict] = None,
+                       fading: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """cfg keys: block_len, enc_num_layer, dec_num_layer, num_iteration, num_iter_ft, extrinsic, enc_act (+ the
     variant flags of power_constraint / apply_channel).  `state` = running norm statistics across calls."""
     with torch.no_grad():
@@ -223,7 +228,7 @@ def channel_ae_forward(u: torch.Tensor, fwd_noise: torch.Tensor, w: Dict[str, to
             p = torch.from_numpy(rand_interleaver(u.shape[1], cfg.get("interleaver_seed", 0)))
         x_tx = encode_prenorm(u, w, p, cfg["enc_num_layer"], cfg.get("enc_act", "elu"))
         codes, mean, std = power_constraint(x_tx, cfg, state if state is not None else {})
-        received = apply_channel(codes, fwd_noise, cfg)
+        received = apply_channel(codes, fwd_noise, cfg, fading)
         if cfg.get("decoder", "TurboAE_rate3_cnn") == "TurboAE_rate3_rnn":
             x_dec = decode_rnn(received, w, p, cfg["dec_num_unit"], cfg["num_iteration"], cfg["num_iter_ft"],
                                cfg.get("extrinsic", 1), taps)

@@ -93,7 +93,8 @@ def test_forward_matches_reference_golden(gpu_device, name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=meta["B"])
     quantised = cfg.train_channel_mode == "block_norm_ste"
-    xd, codes = model(torch.from_numpy(g["u"]).to(gpu_device), torch.from_numpy(g["noise"]).to(gpu_device))
+    fading = torch.from_numpy(g["fading"]).to(gpu_device) if "fading" in g.files else None
+    xd, codes = model(torch.from_numpy(g["u"]).to(gpu_device), torch.from_numpy(g["noise"]).to(gpu_device), fading)
     _check_against_golden(xd, codes, g["codes"], g["x_dec"], g["logits"], quantised)
     if "u2" in g.files:      # --precompute_norm_stats: second call normalises with the running averages
         xd2, codes2 = model(torch.from_numpy(g["u2"]).to(gpu_device), torch.from_numpy(g["noise2"]).to(gpu_device))
@@ -337,6 +338,24 @@ def test_eval_sweep_matches_oracle_on_trained_weights(gpu_device, capsys):
         assert abs(res["ber"][si] - be_tot / (100.0 * L)) <= 1e-4
     assert res["ber"][0] > res["ber"][1] > 0.0          # BER falls with SNR on the trained model
     assert abs(res["enc_power"] - 1.0) < 1e-4
+
+
+@pytest.mark.parametrize("channel,lo,hi,benign", [("bec", 0.0, 0.4, 0.02), ("radar", 6.0, -2.0, 0.05), ("fading", 8.0, 0.0, 0.02),
+                                                  ("ge_awgn", 6.0, -2.0, 0.02), ("t-dist", 6.0, -2.0, 0.02)])
+def test_eval_sweep_other_channels(gpu_device, channel, lo, hi, benign):
+    """The sweep on the reference's other channels (noise from turboae_amd/channels.py): the short-trained model must be
+    near error-free at the benign end and clearly worse at the harsh end (`lo`, `hi` are SNR dB or the erase probability)."""
+    from dataclasses import replace
+    from turboae_amd import Channel_AE_HIP, evaluate
+    g = np.load(os.path.join(GOLD, "trained_enc2dec5_u100.npz"))
+    cfg = replace(TurboAEConfig(**MANIFEST["trained"]["config"]), channel=channel)
+    sd = W.unpack_blob(cfg, g["weights_fp16"].astype(np.float32))
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=100)
+    res = evaluate.test(model, snr_test_start=lo, snr_test_end=hi, snr_points=2, num_block=200, batch_size=100, seed=5,
+                        verbose=False, enc_power_epilogue=False)
+    assert res["ber"][0] < res["ber"][1]
+    assert res["ber"][0] < benign and res["ber"][1] > benign      # (5 % power-25 impulses leave ~3 % errors even at 6 dB)
+    model.check_range()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -87,7 +87,7 @@ class _Engine:
         o.ste = 1 if cfg.train_channel_mode == "block_norm_ste" else 0
         o.enc_value_limit, o.enc_quantize_level = cfg.enc_value_limit, cfg.enc_quantize_level
         o.enc_truncate_limit = cfg.enc_truncate_limit
-        o.channel = {"bec": 1, "bsc": 2, "ge": 2}.get(cfg.channel, 0)
+        o.channel = {"bec": 1, "bsc": 2, "ge": 2, "fading": 3}.get(cfg.channel, 0)
         o.rec_quantize = 1 if cfg.rec_quantize else 0
         # channel_ae.py:69 passes rec_quantize_level for BOTH the limit and the level
         o.rec_quantize_limit = float(cfg.rec_quantize_level)
@@ -283,15 +283,31 @@ class Channel_AE_HIP:
             self._by_len[L] = _Engine(replace(self.cfg, block_len=L), self._eng._state, self._eng.device, self._eng.cap)
         return self._by_len[L]
 
-    def forward(self, input: torch.Tensor, fwd_noise: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def _channel_input(self, e, fwd_noise: torch.Tensor, fading: Optional[torch.Tensor]) -> torch.Tensor:
+        """The tensor handed to the library as `noise`: for channel='fading' the fading coefficients followed by the
+        additive noise (include/turboae_hip.h, tae_channel_opts.channel = 3); otherwise the noise itself."""
+        noise = e._in(fwd_noise, 3, "fwd_noise")
+        if e.cfg.channel != "fading":
+            if fading is not None:
+                raise ValueError("fading coefficients given but the configured channel is not 'fading'")
+            return noise
+        if fading is None:
+            raise ValueError("channel='fading' needs the fading coefficients (the reference draws them inside forward, "
+                             "channel_ae.py:51-56; turboae_amd.channels.rayleigh_fading generates them)")
+        fh = e._in(fading, 3, "fading")
+        if fh.shape != noise.shape:
+            raise ValueError("fading and fwd_noise shapes differ")
+        return torch.cat([fh.reshape(-1), noise.reshape(-1)])
+
+    def forward(self, input: torch.Tensor, fwd_noise: torch.Tensor, fading: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         e = self._engine_for(input.shape[1]) if input.dim() == 3 else self._eng
         if self.is_same_interleaver:   # channel_ae.py:32-36: RandInterlv(block_len, 0) on every call
             e.set_interleaver(rand_interleaver(e.cfg.block_len, 0))
         u = e._in(input, 1, "input")
-        noise = e._in(fwd_noise, 3, "fwd_noise")
         B = u.shape[0]
-        if noise.shape[0] != B:
+        if fwd_noise.shape[0] != B:
             raise ValueError("input and fwd_noise batch sizes differ")
+        noise = self._channel_input(e, fwd_noise, fading)
         e.reserve(B)
         x_dec, codes = e._out(B, 1), e._out(B, 3)
         with torch.cuda.device(e.device):
@@ -321,11 +337,11 @@ class Channel_AE_HIP:
         return x_tx, stats
 
     def normalize(self, x_tx: torch.Tensor, stats: torch.Tensor, fwd_noise: Optional[torch.Tensor] = None,
-                  want_codes: bool = True):
+                  want_codes: bool = True, fading: Optional[torch.Tensor] = None):
         e = self._eng
         x = e._in(x_tx, 3, "x_tx")
         B = x.shape[0]
-        noise = None if fwd_noise is None else e._in(fwd_noise, 3, "fwd_noise")
+        noise = None if fwd_noise is None else self._channel_input(e, fwd_noise, fading)
         codes = e._out(B, 3) if want_codes else None
         rx = e._out(B, 3) if noise is not None else None
         st = stats.to(device=e.device, dtype=torch.float64).contiguous()

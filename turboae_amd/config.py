@@ -30,7 +30,11 @@ class TurboAEConfig:
     precision: str = "auto"       # no reference counterpart: 'auto' = fp16-split MFMA contraction (fp32-grade)
                                   # where the whole-block kernels apply; 'f32' = fp32 MFMA everywhere
     # ---- encoder-output / channel variants on the same kernels
-    channel: str = "awgn"                 # get_args.py:43; channel_ae.py:41-49 ('fading' draws its own RNG: not supported)
+    channel: str = "awgn"                 # get_args.py:43; channel_ae.py:41-56 ('fading': the caller supplies fading_h, which the
+                                          # reference draws inside forward)
+    vv: float = 5.0                       # get_args.py:53, t-dist degrees of freedom (noise generation only, channels.py:40-41)
+    radar_prob: float = 0.05              # get_args.py:55 (channels.py:43-49)
+    radar_power: float = 5.0              # get_args.py:56
     no_code_norm: bool = False            # get_args.py:159; encoders.py:104-105
     precompute_norm_stats: bool = False   # get_args.py:218; encoders.py:110-114 (running mean/std over calls)
     train_channel_mode: str = "block_norm"   # get_args.py:135; 'block_norm_ste' quantises the codes (encoders.py:118-120)
@@ -59,8 +63,8 @@ class TurboAEConfig:
             raise ValueError("layer / iteration counts must be >= 1")
         if self.block_len < 1:
             raise ValueError("block_len must be >= 1")
-        if self.channel not in ("awgn", "t-dist", "radar", "ge_awgn", "bec", "bsc", "ge"):
-            raise ValueError("channel must be one of awgn, t-dist, radar, ge_awgn, bec, bsc, ge")
+        if self.channel not in ("awgn", "t-dist", "radar", "ge_awgn", "bec", "bsc", "ge", "fading"):
+            raise ValueError("channel must be one of awgn, t-dist, radar, ge_awgn, bec, bsc, ge, fading")
         if self.decoder not in ("TurboAE_rate3_cnn", "TurboAE_rate3_rnn"):
             raise ValueError("decoder must be 'TurboAE_rate3_cnn' or 'TurboAE_rate3_rnn'")
         if self.decoder == "TurboAE_rate3_rnn" and self.dec_num_unit != 100:

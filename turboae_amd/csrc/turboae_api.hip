@@ -1018,7 +1018,7 @@ int tae_set_channel_opts(tae_handle* h, const tae_channel_opts* o) {
     if (o->struct_size != (int32_t)sizeof(tae_channel_opts)) return fail(TAE_EINVAL, "tae_channel_opts.struct_size mismatch (ABI)");
     if (o->norm_mode < 0 || o->norm_mode > 2) return fail(TAE_EINVAL, "norm_mode must be 0, 1 or 2");
     if (o->norm_mode == 2 && !(o->std > 0.0f)) return fail(TAE_EINVAL, "fixed std must be > 0");
-    if (o->channel < 0 || o->channel > 2) return fail(TAE_EINVAL, "channel must be 0 (additive), 1 (bec) or 2 (bsc/ge)");
+    if (o->channel < 0 || o->channel > 3) return fail(TAE_EINVAL, "channel must be 0 (additive), 1 (bec), 2 (bsc/ge) or 3 (fading)");
     if (o->ste && (!(o->enc_value_limit > 0.0f) || o->enc_quantize_level < 2.0f)) return fail(TAE_EINVAL, "bad STE quantiser parameters");
     if (o->rec_quantize && (!(o->rec_quantize_limit > 0.0f) || o->rec_quantize_level < 2.0f)) return fail(TAE_EINVAL, "bad receive quantiser parameters");
     tae::NormOpts n;

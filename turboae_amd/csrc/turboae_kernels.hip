@@ -591,6 +591,7 @@ __global__ void normalize_kernel(const float* __restrict__ xtx, const double* __
         if (rx) {
             const float nz = noise[i];
             float r = o.channel == 0 ? c + nz : (o.channel == 1 ? c * nz : c * (2.0f * nz - 1.0f));
+            if (o.channel == 3) r = nz * c + noise[n + i];      // fading: `noise` = [fading_h | additive noise] (channel_ae.py:51-56)
             if (o.rec_quantize) r = ste_quantize(r, o.rec_quantize_limit, o.rec_quantize_level);
             rx[i] = r;
         }

@@ -20,6 +20,7 @@ from typing import Dict, List, Optional
 
 import torch
 
+from . import channels
 from .distributed import all_reduce_sum_, shard_bounds
 
 
@@ -57,14 +58,23 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
         for batch_idx in range(num_test_batch):
             first = (si * num_test_batch + batch_idx) * batch_size + lo       # global block index of this shard
             counts = torch.zeros(2, dtype=torch.int64, device=dev)
+            fading = None
             if nloc > 0:
                 u, noise = model.generate_inputs(nloc, snr, seed=seed, first_block=first)
+                if model.cfg.channel != "awgn":
+                    # other channels: generate_noise restated on the device (turboae_amd/channels.py), one generator per
+                    # (seed, global first block of the shard): shards of any world size draw independent streams
+                    gen = torch.Generator(device=dev)
+                    gen.manual_seed((seed * 1000003 + first) & 0x7FFFFFFFFFFFFFFF)
+                    noise = channels.generate_noise((nloc, L, 3), model.cfg, snr, device=dev, generator=gen)
+                    if model.cfg.channel == "fading":
+                        fading = channels.rayleigh_fading((nloc, L, 3), device=dev, generator=gen)
                 x_tx, stats = model.encode_prenorm(u)
             else:
                 stats = torch.zeros(3, dtype=torch.float64, device=dev)
             all_reduce_sum_(stats)                                            # batch-global mean/std (encoders.py:107-108)
             if nloc > 0:
-                _, rx = model.normalize(x_tx, stats, noise, want_codes=False)
+                _, rx = model.normalize(x_tx, stats, noise, want_codes=False, fading=fading)
                 x_dec = model.dec(rx)
                 model.count_errors(x_dec, u, counts)
             all_reduce_sum_(counts)
