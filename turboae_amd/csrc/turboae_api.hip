@@ -725,7 +725,8 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
                 TAE_HIP(tae::launch_gru_rec_h(true, R0, st));
                 const char* w1 = wb + 2 * kGHRec0B;
                 tae::GruProjParams PP;
-                PP.yin = h->d_gy0; PP.w = reinterpret_cast<const float*>(w1); PP.gi = h->d_ggi; PP.npos = np; PP.B = Bc; PP.L = L;
+                const size_t npg = (size_t)((Bc + 15) / 16) * 16 * L;       // block-group-major rows incl. the padding blocks of the last group
+                PP.yin = h->d_gy0; PP.w = reinterpret_cast<const float*>(w1); PP.gi = h->d_ggi; PP.npos = npg; PP.B = Bc; PP.L = L;
                 TAE_HIP(tae::launch_gru_proj_h(PP, st));
                 tae::GruRecParams R1;
                 memset(&R1, 0, sizeof(R1));
@@ -737,7 +738,8 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
                 HP.y = h->d_gy1; HP.w = wl; HP.b = wl + (size_t)nout * 2 * H; HP.xcur = xin;
                 HP.xnext = odd ? h->d_gxa : h->d_gxb; HP.xdec = xdec + (size_t)c0 * L;
                 HP.ptab = odd ? h->d_perm : h->d_inv;
-                HP.npos = np; HP.L = L; HP.F = F; HP.nout = nout; HP.extrinsic = h->cfg.extrinsic; HP.last = last ? 1 : 0;
+                HP.npos = npg; HP.L = L; HP.F = F; HP.nout = nout; HP.extrinsic = h->cfg.extrinsic; HP.last = last ? 1 : 0;
+                HP.grouped = 1; HP.B = Bc;
                 TAE_HIP(tae::launch_gru_head(HP, st));
                 wb += rnn_h_stack_bytes((size_t)nout);
             }
@@ -987,12 +989,17 @@ int tae_reserve(tae_handle* h, int32_t max_batch) {
         int32_t chunk = 16384;
         while (chunk > 128 && (size_t)chunk * h->cfg.block_len > (size_t)16384 * 100) chunk -= 128;
         h->rnn_chunk = max_batch < chunk ? max_batch : chunk;
-        const size_t np = (size_t)h->rnn_chunk * h->cfg.block_len;
+        const size_t np = (size_t)((h->rnn_chunk + 15) / 16 * 16) * h->cfg.block_len;     // whole block groups (f16x2 path layout)
         TAE_HIP(hipMalloc(&h->d_gxa, np * 8 * sizeof(float)));
         TAE_HIP(hipMalloc(&h->d_gxb, np * 8 * sizeof(float)));
         TAE_HIP(hipMalloc(&h->d_gy0, np * 200 * sizeof(float)));
         TAE_HIP(hipMalloc(&h->d_gy1, np * 200 * sizeof(float)));
         TAE_HIP(hipMalloc(&h->d_ggi, np * 608 * sizeof(float)));
+        // rows of padding blocks (last block group) are never written; they are read next to valid rows by the K-padding
+        // over-read of the projection GEMM (x zero weights), so they must hold finite values
+        TAE_HIP(hipMemset(h->d_gy0, 0, np * 200 * sizeof(float)));
+        TAE_HIP(hipMemset(h->d_gy1, 0, np * 200 * sizeof(float)));
+        TAE_HIP(hipMemset(h->d_ggi, 0, np * 608 * sizeof(float)));
     }
     h->cap = max_batch;
     return TAE_OK;

@@ -307,8 +307,8 @@ __global__ __launch_bounds__(64 * kHeadWaves) void gru_head_kernel(GruHeadParams
     for (int i = 0; i < 4; ++i) bias[i] = (4 * kq + i) < P.nout ? P.b[4 * kq + i] : 0.0f;
     const size_t ntile = (P.npos + 15) / 16;
     for (size_t tile = (size_t)blockIdx.x * kHeadWaves + (threadIdx.x >> 6); tile < ntile; tile += (size_t)gridDim.x * kHeadWaves) {
-        const size_t pos = tile * 16 + n;
-        const size_t pc = pos < P.npos ? pos : P.npos - 1;
+        const size_t posy = tile * 16 + n;      // row of Y1
+        const size_t pc = posy < P.npos ? posy : P.npos - 1;
         const float* y = P.y + pc * K + 4 * kq;
         f32x4 v[12];
 #pragma unroll
@@ -322,9 +322,20 @@ __global__ __launch_bounds__(64 * kHeadWaves) void gru_head_kernel(GruHeadParams
         acc[0] = mfma16x16x4(a[48], vl.x, acc[0]);
         acc[1] = mfma16x16x4(a[49], vl.y, acc[1]);
         const f32x4 o = (acc[0] + acc[1]) + (acc[2] + acc[3]);       // rows 4*kq + i = outputs f of position n
-        if (pos >= P.npos || kq >= 2) continue;
-        const size_t b = pos / P.L;
-        const int t = (int)(pos - b * P.L);
+        if (posy >= P.npos || kq >= 2) continue;
+        size_t b;
+        int t;
+        if (P.grouped) {            // f16x2 path: pos' = ((b / 16) * L + t) * 16 + b % 16
+            const size_t row = posy >> 4;
+            const size_t grp = row / P.L;
+            t = (int)(row - grp * P.L);
+            b = grp * 16 + (posy & 15);
+            if (b >= (size_t)P.B) continue;
+        } else {
+            b = posy / P.L;
+            t = (int)(posy - b * P.L);
+        }
+        const size_t pos = b * P.L + t;      // (block, t) order of the X panels
         if (!P.last) {
             const float* xc = P.xcur + pos * kXWg + 2;
             float* xn = P.xnext + (b * P.L + P.ptab[t]) * kXWg + 2;

@@ -51,37 +51,52 @@ using lds_q4 = const u32x4v __attribute__((address_space(3)));
 using lds_q2 = const u32x2v __attribute__((address_space(3)));
 using lds_f4c = const f32x4 __attribute__((address_space(3)));
 
-// 3 products of one 32-k slab for the NG gate tiles of a unit tile
+// A fragments of one k-slab for NG gate tiles (tile stride STRIDE bytes): 32-k slabs as 8 halves per lane, the K = 16
+// remainder slab as 4 halves per lane; hi then lo, 1024 / 512 bytes apart.  Loads and MFMAs are separate calls so the
+// caller can issue the next slab's LDS reads before the current slab's MFMAs (pinned with sched_group_barrier: left to
+// the scheduler every read ends up right in front of its first use and the LDS latency is exposed 28 times per step).
+template <int NG> struct FragS { h8 ah[NG], al[NG]; };
+template <int NG> struct FragR { h4 ah[NG], al[NG]; };
+
 template <int NG>
-__device__ __forceinline__ void slab_mma(f32x4 (&acc)[NG], lds_cptr fr, h8 bh, h8 bl) {
-    h8 ah[NG], al[NG];
+__device__ __forceinline__ void load_slab(FragS<NG>& f, lds_cptr fr) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        ah[g] = __builtin_bit_cast(h8, *reinterpret_cast<lds_q4*>(fr + g * kRecTileB));
-        al[g] = __builtin_bit_cast(h8, *reinterpret_cast<lds_q4*>(fr + g * kRecTileB + 1024));
+        f.ah[g] = __builtin_bit_cast(h8, *reinterpret_cast<lds_q4*>(fr + g * kRecTileB));
+        f.al[g] = __builtin_bit_cast(h8, *reinterpret_cast<lds_q4*>(fr + g * kRecTileB + 1024));
     }
-#pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(ah[g], bl, acc[g]);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(al[g], bh, acc[g]);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(ah[g], bh, acc[g]);
 }
-// the K = 16 remainder slab (fragments at `fr + g * STRIDE`, hi then lo 512 bytes apart)
+template <int NG>
+__device__ __forceinline__ void mma_slab(f32x4 (&acc)[NG], const FragS<NG>& f, h8 bh, h8 bl) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(f.ah[g], bl, acc[g]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(f.al[g], bh, acc[g]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(f.ah[g], bh, acc[g]);
+}
 template <int NG, int STRIDE>
-__device__ __forceinline__ void rem_mma(f32x4 (&acc)[NG], lds_cptr fr, h4 bh, h4 bl) {
-    h4 ah[NG], al[NG];
+__device__ __forceinline__ void load_rem(FragR<NG>& f, lds_cptr fr) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        ah[g] = __builtin_bit_cast(h4, *reinterpret_cast<lds_q2*>(fr + g * STRIDE));
-        al[g] = __builtin_bit_cast(h4, *reinterpret_cast<lds_q2*>(fr + g * STRIDE + 512));
+        f.ah[g] = __builtin_bit_cast(h4, *reinterpret_cast<lds_q2*>(fr + g * STRIDE));
+        f.al[g] = __builtin_bit_cast(h4, *reinterpret_cast<lds_q2*>(fr + g * STRIDE + 512));
     }
+}
+template <int NG>
+__device__ __forceinline__ void mma_rem(f32x4 (&acc)[NG], const FragR<NG>& f, h4 bh, h4 bl) {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x16h(ah[g], bl, acc[g]);
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x16h(f.ah[g], bl, acc[g]);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x16h(al[g], bh, acc[g]);
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x16h(f.al[g], bh, acc[g]);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x16h(ah[g], bh, acc[g]);
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x16h(f.ah[g], bh, acc[g]);
+}
+// {ND LDS reads, then NM MFMAs}: the reads (for a LATER slab) go first, the MFMAs of the current slab cover their latency
+template <int ND, int NM>
+__device__ __forceinline__ void pin_ds_mma() {
+    __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
 }
 
 template <bool LAYER0>
@@ -107,15 +122,15 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
 
     const __amdgpu_buffer_rsrc_t rs_in = LAYER0
         ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x + (size_t)b0 * L * kGXW), 0, nb * L * kGXW * 4, 0x00020000)
-        // GI is time-major [t][dir][block][19 tiles x 16]: at step t the 16 blocks of a wave read one contiguous 19 KB run
         : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.gi), 0, -1, 0x00020000);
-    const uint32_t v_in = LAYER0 ? (uint32_t)(nc * L * kGXW * 4) : (uint32_t)((b0 + nc) * (19 * 64) + q * 16);
+    const uint32_t v_in = LAYER0 ? (uint32_t)(nc * L * kGXW * 4) : (uint32_t)((n * 4 + q) * 16);
+    const uint32_t gi_wave = (uint32_t)(b0 / 16) * (uint32_t)L * (2 * 19 * 1024u) + (uint32_t)dir * (19 * 1024u);
     // outputs: layer 0 -> Y0 as halves [pos][hi 200 | lo 200] (the projection kernel's operand), layer 1 -> Y1 fp32 [pos][200]
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y + (size_t)b0 * L * 2 * kGH, 0, nb * L * 2 * kGH * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y + (size_t)b0 * L * 2 * kGH, 0, 16 * L * 2 * kGH * 4, 0x00020000);
     const uint32_t v_y = !valid ? 0x80000000u
-        : (LAYER0 ? (uint32_t)(n * L * 800 + (dir * kGH + 4 * q) * 2) : (uint32_t)(n * L * 800 + dir * kGH * 4 + q * 16));
+        : (LAYER0 ? (uint32_t)(n * 800 + (dir * kGH + 4 * q) * 2) : (uint32_t)(n * 800 + dir * kGH * 4 + q * 16));
     const uint32_t v_yr = !valid ? 0x80000000u
-        : (LAYER0 ? (uint32_t)(n * L * 800 + (dir * kGH + 96 + q) * 2) : (uint32_t)(n * L * 800 + (dir * kGH + 96 + q) * 4));
+        : (LAYER0 ? (uint32_t)(n * 800 + (dir * kGH + 96 + q) * 2) : (uint32_t)(n * 800 + (dir * kGH + 96 + q) * 4));
 
     f32x4 h[6];
 #pragma unroll
@@ -149,6 +164,9 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
         load_x(dir ? L - 1 : 0, xa, xb);
         set_x(xa, xb);
     }
+    FragS<3> fa, fb;       // A-fragment ping-pong of the unit tiles
+    FragS<1> f1;           // ... of the remainder tile
+    load_slab<3>(fa, lds3 + lane * 16);
 #pragma unroll 1
     for (int s = 0; s < L; ++s) {
         const int t = dir ? L - 1 - s : s;
@@ -157,14 +175,14 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
             const int tn = dir ? (t > 0 ? t - 1 : 0) : (t + 1 < L ? t + 1 : t);
             load_x(tn, xa, xb);
         } else {
-            const uint32_t so = (uint32_t)(t * 2 + dir) * (uint32_t)P.B * (19 * 64);
+            const uint32_t so = gi_wave + (uint32_t)t * (2 * 19 * 1024u);
 #pragma unroll
             for (int T = 0; T < 19; ++T)
-                g[T] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_in + T * 64, so, 0));
+                g[T] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_in, so + T * 1024u, 0));
         }
         __builtin_amdgcn_sched_barrier(0);     // keep this step's loads up here (they are consumed by the gate arithmetic / next step)
         h4 nhi[6], nlo[6];
-        const uint32_t yo = (uint32_t)t * 800u;
+        const uint32_t yo = (uint32_t)t * (16 * 800u);
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
             constexpr int NG = LAYER0 ? 4 : 3;
@@ -178,17 +196,32 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
                 acc[1] = acc[0];
                 acc[2] = *reinterpret_cast<lds_f4c*>(bias + u * 64);
             }
-            const lds_cptr fr = lds3 + (3 * u) * kRecTileB + lane * 16;
             f32x4 a3[3] = {acc[0], acc[1], acc[2]};
-#pragma unroll
-            for (int sl = 0; sl < 3; ++sl) slab_mma<3>(a3, fr + sl * 2048, bh[sl], bl[sl]);
-            rem_mma<3, kRecTileB>(a3, lds3 + (3 * u) * kRecTileB + 6144 + lane * 8, rh, rl);
+            // slabs 0..2 + remainder of this unit tile; fa arrives with slab 0 loaded (end of the previous unit tile / step)
+            const lds_cptr fr = lds3 + (3 * u) * kRecTileB + lane * 16;
+            const lds_cptr frn = lds3 + (3 * (u + 1)) * kRecTileB + lane * 16;      // next unit tile (u = 5: the remainder tile 18)
+            FragR<3> fq;
+            load_slab<3>(fb, fr + 2048);
+            mma_slab<3>(a3, fa, bh[0], bl[0]);
+            pin_ds_mma<6, 9>();
+            load_slab<3>(fa, fr + 4096);
+            mma_slab<3>(a3, fb, bh[1], bl[1]);
+            pin_ds_mma<6, 9>();
+            load_rem<3, kRecTileB>(fq, lds3 + (3 * u) * kRecTileB + 6144 + lane * 8);
+            FragR<1> fn;
+            if (LAYER0) load_rem<1, 1024>(fn, lds3 + kRecFragB + u * 1024 + lane * 8);
+            mma_slab<3>(a3, fa, bh[2], bl[2]);
+            pin_ds_mma<LAYER0 ? 8 : 6, 9>();
+            if (u < 5) load_slab<3>(fa, frn);
+            else load_slab<1>(f1, frn);
+            mma_rem<3>(a3, fq, rh, rl);
             f32x4 ani = {0.f, 0.f, 0.f, 0.f};
             if (LAYER0) {
                 f32x4 a1[1] = {acc[NG - 1]};
-                rem_mma<1, 1024>(a1, lds3 + kRecFragB + u * 1024 + lane * 8, rh, rl);
+                mma_rem<1>(a1, fn, rh, rl);
                 ani = a1[0];
             }
+            pin_ds_mma<6, LAYER0 ? 12 : 9>();
             f32x4 hn;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -211,9 +244,16 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
             f32x4 a1[1];
             a1[0] = *reinterpret_cast<lds_f4c*>(bias + (LAYER0 ? 18 : 6) * 64);
             const lds_cptr fr = lds3 + 18 * kRecTileB + lane * 16;
-#pragma unroll
-            for (int sl = 0; sl < 3; ++sl) slab_mma<1>(a1, fr + sl * 2048, bh[sl], bl[sl]);
-            rem_mma<1, kRecTileB>(a1, lds3 + 18 * kRecTileB + 6144 + lane * 8, rh, rl);
+            FragS<1> f2;
+            FragR<1> fq;
+            load_slab<1>(f2, fr + 2048);
+            mma_slab<1>(a1, f1, bh[0], bl[0]);
+            load_slab<1>(f1, fr + 4096);
+            mma_slab<1>(a1, f2, bh[1], bl[1]);
+            load_rem<1, kRecTileB>(fq, lds3 + 18 * kRecTileB + 6144 + lane * 8);
+            mma_slab<1>(a1, f1, bh[2], bl[2]);
+            load_slab<3>(fa, lds3 + lane * 16);          // slab 0 of unit tile 0 for the next step
+            mma_rem<1>(a1, fq, rh, rl);
             const f32x4 a = a1[0];
             const float r = sigm_h(LAYER0 ? a[0] * inv : fmaf(a[0], inv, g[18][0]));
             const float z = sigm_h(LAYER0 ? a[1] * inv : fmaf(a[1], inv, g[18][1]));
@@ -281,10 +321,9 @@ __device__ __forceinline__ void proj_pass_h(const GruProjParams& P, const char* 
     for (int p = 0; p < 5; ++p) {
         const size_t pos = p0 + (pg * 5 + p) * 16 + n;
         if (pos < P.npos) {
-            const size_t b = pos / (size_t)P.L, t = pos - b * (size_t)P.L;
-            float* dst = P.gi + ((t * 2 + dir) * (size_t)P.B + b) * (19 * 16) + C0 * 16 + 4 * kq;
+            float* dst = P.gi + ((pos >> 4) * 2 + dir) * (size_t)(19 * 256) + (size_t)C0 * 256 + (n * 4 + kq) * 4;
 #pragma unroll
-            for (int ct = 0; ct < NC; ++ct) *reinterpret_cast<f32x4*>(dst + ct * 16) = acc[p][ct] * inv;
+            for (int ct = 0; ct < NC; ++ct) *reinterpret_cast<f32x4*>(dst + ct * 256) = acc[p][ct] * inv;
         }
     }
 }

@@ -76,6 +76,7 @@ struct GruHeadParams {
     const int32_t* ptab;  // inv (after dec1) or perm (after dec2)
     size_t npos;
     int32_t L, F, nout, extrinsic, last;
+    int32_t grouped, B;   // grouped = 1: rows of y are in block-group-major order (f16x2 GRU path), B = blocks
 };
 hipError_t launch_gru_prep(const float* rx, const int32_t* perm, float* XA, float* XB, int B, int L, hipStream_t st);
 hipError_t launch_gru_rec(bool layer0, const GruRecParams& P, hipStream_t st);
