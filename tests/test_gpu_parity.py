@@ -363,11 +363,13 @@ def test_eval_sweep_other_channels(gpu_device, channel, lo, hi, benign):
 ATOL_XDEC_RNN = 5e-5     # 24 two-layer bidirectional GRUs, 100 sequential steps each: fp32 recurrences drift a little more
 
 
+@pytest.mark.parametrize("prec", ["auto", "f32"])
 @pytest.mark.parametrize("name", [n for n in sorted(MANIFEST["cases"]) if "rnn" in n])
-def test_rnn_decoder_matches_reference_golden_and_oracle(gpu_device, name):
+def test_rnn_decoder_matches_reference_golden_and_oracle(gpu_device, name, prec):
+    from dataclasses import replace
     from turboae_amd import Channel_AE_HIP
     meta = MANIFEST["cases"][name]
-    cfg = TurboAEConfig(**meta["config"])
+    cfg = replace(TurboAEConfig(**meta["config"]), precision=prec)      # f16x2 kernels (default) and the fp32-MFMA kernels
     assert cfg.decoder == "TurboAE_rate3_rnn"
     sd = W.generate_state_dict(cfg, seed=meta["weight_seed"], gain=meta["gain"])
     g = np.load(os.path.join(GOLD, name + ".npz"))
@@ -381,7 +383,7 @@ def test_rnn_decoder_matches_reference_golden_and_oracle(gpu_device, name):
 
 
 def test_rnn_decoder_batch_independent_and_chunked(gpu_device):
-    """Ragged batches (8 blocks per workgroup) and the internal 4096-block chunking must not change results."""
+    """Ragged batches (partial 16-block groups) and the internal chunking must not change results."""
     from turboae_amd import Channel_AE_HIP
     cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", num_iteration=2)
     sd = W.generate_state_dict(cfg, seed=14, gain=1.0)
