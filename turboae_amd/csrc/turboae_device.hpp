@@ -387,13 +387,19 @@ __device__ __forceinline__ f32x4 mfma16x16x32h(h8 a, h8 b, f32x4 c) {
 
 constexpr float kH2Limit = 65504.0f;     // activations are clamped to the fp16 range before the split
 
-// 4 fp32 values -> 4 hi halves + 4 lo halves
+// 4 fp32 values -> 4 hi halves + 4 lo halves.  Three instructions per value pair: v_cvt_pk_f16_f32 (both hi halves,
+// round to nearest), then v_fma_mixlo_f16 / v_fma_mixhi_f16, which read the f16 hi half as fp32, compute v - hi exactly
+// in fp32 and round once to f16.  (Left to the compiler the same arithmetic takes eight: it converts hi twice and back.)
 __device__ __forceinline__ void split4(f32x4 v, h4& hi, h4& lo) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        hi[i] = (_Float16)v[i];
-        lo[i] = (_Float16)(v[i] - (float)hi[i]);
-    }
+    uint32_t h01, h23, l01, l23;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h01) : "v"(v.x), "v"(v.y));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h23) : "v"(v.z), "v"(v.w));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(h01), "v"(v.x));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h23), "v"(v.z));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(v.y));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(v.w));
+    hi = __builtin_bit_cast(h4, u32x2v{h01, h23});
+    lo = __builtin_bit_cast(h4, u32x2v{l01, l23});
 }
 
 // A fragments of one 32-k slab for NC channel tiles: hi and lo halves, 16 bytes per lane each
