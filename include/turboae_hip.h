@@ -160,6 +160,10 @@ TAE_API int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_
  * TAE_PREC_F32.  Synchronises the device (reads one word back) and clears the flag. */
 TAE_API int tae_range_status(tae_handle* h, int32_t* precision, int32_t* overflow);
 
+/* Test hook (no device needed): the host-side fp32 -> fp16 hi/lo split used when packing weights for the fp16-split
+ * kernels: hi = f16(x * scale) (round to nearest even, denormals kept), lo = f16(x * scale - hi).  Writes n values each. */
+TAE_API int tae_debug_split_f16(const float* x, size_t n, float scale, uint16_t* hi, uint16_t* lo);
+
 TAE_API const char* tae_last_error(void);
 TAE_API int tae_abi_version(void);
 

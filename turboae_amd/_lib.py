@@ -49,6 +49,7 @@ SIGNATURES = {
     "tae_generate_inputs": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64, C.c_float, _P]),
     "tae_kernel_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tae_range_status": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "tae_debug_split_f16": (C.c_int, [_P, C.c_size_t, C.c_float, _P, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

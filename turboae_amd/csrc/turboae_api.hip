@@ -1109,6 +1109,16 @@ int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_t* lds_b
     return TAE_OK;
 }
 
+int tae_debug_split_f16(const float* x, size_t n, float scale, uint16_t* hi, uint16_t* lo) {
+    if (!x || !hi || !lo) return fail(TAE_EINVAL, "NULL argument");
+    for (size_t i = 0; i < n; ++i) {
+        const float w = x[i] * scale;
+        hi[i] = f2h(w);
+        lo[i] = f2h(w - h2f(hi[i]));
+    }
+    return TAE_OK;
+}
+
 int tae_range_status(tae_handle* h, int32_t* precision, int32_t* overflow) {
     if (!h) return fail(TAE_EINVAL, "handle is NULL");
     if (precision) *precision = h->prec;
