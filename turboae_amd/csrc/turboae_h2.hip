@@ -105,19 +105,22 @@ struct TileH {
 
 // Padding lanes (positions past the workgroup's blocks) compute on row 2 and store to the write-only dump row, so
 // the epilogue needs no per-tile branches.
+// `gt0` = first position tile of the wave's group (groups are kGroupTiles apart; a wave may walk fewer tiles, PT, when
+// the last ones hold no block at all).
+constexpr int kGroupTiles = 5;
 template <int PT>
-__device__ __forceinline__ void make_tiles_h(TileH<PT>& tc, int* rowtab, int g, int lane, int L, int npos) {
+__device__ __forceinline__ void make_tiles_h(TileH<PT>& tc, int* rowtab, int gt0, int lane, int L, int npos) {
     const int n = lane & 15;
     tc.valid = 0u;
-    tc.m0 = g * PT * 16 + n;
+    tc.m0 = gt0 * 16 + n;
     tc.L = L;
-    tc.rowtab = rowtab + g * PT * 16 + n;
+    tc.rowtab = rowtab + gt0 * 16 + n;
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
         const int m = tc.m0 + 16 * p;
         const bool v = m < npos;
         const int b = (v ? m : 0) / L;
-        if (lane < 16) rowtab[(g * PT + p) * 16 + n] = v ? b * (L + 2) + 2 + (m - b * L) : 2;    // both channel halves write the same values
+        if (lane < 16) rowtab[(gt0 + p) * 16 + n] = v ? b * (L + 2) + 2 + (m - b * L) : 2;    // both channel halves write the same values
         tc.valid |= (v ? 1u : 0u) << p;
     }
     tc.center = tc.valid;
@@ -147,7 +150,7 @@ __device__ __forceinline__ void elu_split4(f32x4 a, float inv_scale, float& vmax
 }
 
 // One SameShapeConv1d stack (cnn_utils.py:36-46) + Linear head; same contract as run_stack in
-// turboae_kernels.hip.  `vmax` collects max |activation| before the fp16-range clamp (overflow report).
+// turboae_kernels.hip, except that `g` is the first position TILE of the wave's group (not the group index).  `vmax` collects max |activation| before the fp16-range clamp (overflow report).
 template <int U, int PT, int C0, int NC, class Epi>
 __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint32_t soff, uint32_t snext, int n_layer, char* smem,
                                             const PanelsH& pn, const XPlane& xin, const TileH<PT>& tc, int g, int lane,
@@ -249,7 +252,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
     if constexpr (C0 != 0) {
 #pragma unroll
         for (int p = 0; p < PT; ++p)
-            *reinterpret_cast<float2*>(HS + ((g * PT + p) * 16 + n) * 8 + 2 * q) = float2{k2[p][0], k2[p][1]};
+            *reinterpret_cast<float2*>(HS + ((g + p) * 16 + n) * 8 + 2 * q) = float2{k2[p][0], k2[p][1]};
     }
     __syncthreads();
     if constexpr (C0 == 0) {
@@ -258,7 +261,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
             float2 other = float2{0.0f, 0.0f};
-            if constexpr (NC < CTT) other = *reinterpret_cast<const float2*>(HS + ((g * PT + p) * 16 + n) * 8 + 2 * q);
+            if constexpr (NC < CTT) other = *reinterpret_cast<const float2*>(HS + ((g + p) * 16 + n) * 8 + 2 * q);
             if (tc.own(p)) {
                 epi(p, 2 * q, (k2[p][0] + other.x) + bq0);
                 epi(p, 2 * q + 1, (k2[p][1] + other.y) + bq1);
@@ -343,12 +346,24 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
     report_range(vmax, P.flags);
     __syncthreads();
 
-    TileH<PT> tc;
-    make_tiles_h<PT>(tc, pn.ROWT, g, lane, L, npos);
-    __syncthreads();
+    // Position tiles that hold no block are not computed: with 3 blocks of 100 the last group walks 4 tiles instead of 5
+    // (-5 % MFMAs; the kernel is power-limited, so fewer MFMAs pay back even off the critical path).
+    const int gt0 = g * kGroupTiles;
+    const int live = __builtin_amdgcn_readfirstlane((npos + 15) / 16 - gt0);
     const bool upper = __builtin_amdgcn_readfirstlane(h) != 0;
-    if (!upper) dec_body_h<U, PT, 0, Split<U>::CTA>(P, smem, pn, tc, g, lane, blk0);
-    else dec_body_h<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, g, lane, blk0);
+    if (PT == kGroupTiles && live == PT - 1) {
+        TileH<PT - 1> tc;
+        make_tiles_h<PT - 1>(tc, pn.ROWT, gt0, lane, L, npos);
+        __syncthreads();
+        if (!upper) dec_body_h<U, PT - 1, 0, Split<U>::CTA>(P, smem, pn, tc, gt0, lane, blk0);
+        else dec_body_h<U, PT - 1, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, gt0, lane, blk0);
+        return;
+    }
+    TileH<PT> tc;
+    make_tiles_h<PT>(tc, pn.ROWT, gt0, lane, L, npos);
+    __syncthreads();
+    if (!upper) dec_body_h<U, PT, 0, Split<U>::CTA>(P, smem, pn, tc, gt0, lane, blk0);
+    else dec_body_h<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, gt0, lane, blk0);
 }
 
 // =============================================================================================
@@ -406,13 +421,23 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
     }
     __syncthreads();
 
-    TileH<PT> tc;
-    make_tiles_h<PT>(tc, pn.ROWT, g, lane, L, npos);
-    __syncthreads();
     double sum = 0.0, sumsq = 0.0;
+    const int gt0 = g * kGroupTiles;
+    const int live = __builtin_amdgcn_readfirstlane((npos + 15) / 16 - gt0);
     const bool upper = __builtin_amdgcn_readfirstlane(h) != 0;
-    if (!upper) enc_body_h<U, PT, 0, Split<U>::CTA>(P, smem, pn, tc, g, lane, blk0, sum, sumsq);
-    else enc_body_h<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, g, lane, blk0, sum, sumsq);
+    if (PT == kGroupTiles && live == PT - 1) {          // see dec_kernel_h
+        TileH<PT - 1> tc;
+        make_tiles_h<PT - 1>(tc, pn.ROWT, gt0, lane, L, npos);
+        __syncthreads();
+        if (!upper) enc_body_h<U, PT - 1, 0, Split<U>::CTA>(P, smem, pn, tc, gt0, lane, blk0, sum, sumsq);
+        else enc_body_h<U, PT - 1, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, gt0, lane, blk0, sum, sumsq);
+    } else {
+        TileH<PT> tc;
+        make_tiles_h<PT>(tc, pn.ROWT, gt0, lane, L, npos);
+        __syncthreads();
+        if (!upper) enc_body_h<U, PT, 0, Split<U>::CTA>(P, smem, pn, tc, gt0, lane, blk0, sum, sumsq);
+        else enc_body_h<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, gt0, lane, blk0, sum, sumsq);
+    }
     block_reduce_stats(smem, tid, sum, sumsq, P.partials);
 }
 
@@ -532,7 +557,7 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
         tc.center = 0u;
         tc.m0 = g * PT * 16 + n;
         tc.L = L;
-        tc.rowtab = pn.ROWT + g * PT * 16 + n;
+        tc.rowtab = pn.ROWT + g * PT * 16 + n;      // (all kGroupTiles = PT tiles are walked here)
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
             const int m = tc.m0 + 16 * p;
@@ -546,8 +571,8 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
     __syncthreads();
     double sum = 0.0, sumsq = 0.0;
     const bool upper = __builtin_amdgcn_readfirstlane(h) != 0;
-    if (!upper) seg_body_h<U, PT, 0, Split<U>::CTA>(P, smem, pn, tc, g, lane, stack, b, tstart, sum, sumsq);
-    else seg_body_h<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, g, lane, stack, b, tstart, sum, sumsq);
+    if (!upper) seg_body_h<U, PT, 0, Split<U>::CTA>(P, smem, pn, tc, g * PT, lane, stack, b, tstart, sum, sumsq);
+    else seg_body_h<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, g * PT, lane, stack, b, tstart, sum, sumsq);
     if (P.mode == 0) block_reduce_stats(smem, tid, sum, sumsq, P.partials);
 }
 
