@@ -417,6 +417,11 @@ __device__ __forceinline__ void load_wh(OpsHA<NC>& o, __amdgpu_buffer_rsrc_t rsr
     for (int i = 0; i < NC; ++i) o.hi[i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (C0 + i) * 2048, soff, 0));
 #pragma unroll
     for (int i = 0; i < NC; ++i) o.lo[i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (C0 + i) * 2048 + 1024, soff, 0));
+    if (TAE_X & 256) {      // timing experiment: ~+25 % weight-load traffic (two extra 1 KB loads per slab, results discarded)
+        const auto d0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + ((C0 + 1) % CTT) * 2048 + 512, soff, 0);
+        const auto d1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + ((C0 + 2) % CTT) * 2048 + 1536, soff, 0);
+        asm volatile("" :: "v"(d0), "v"(d1));
+    }
 }
 
 struct OpsHB {
@@ -432,6 +437,11 @@ __device__ __forceinline__ void load_xh(OpsHB& o, lds_cptr ph, lds_cptr pl) {
     const u32x2v b0 = *reinterpret_cast<lds_u2*>(pl + OFF), b1 = *reinterpret_cast<lds_u2*>(pl + OFF + 8);
     o.hi = __builtin_bit_cast(h8, u32x4w{a0.x, a0.y, a1.x, a1.y});
     o.lo = __builtin_bit_cast(h8, u32x4w{b0.x, b0.y, b1.x, b1.y});
+    if (TAE_X & 512) {      // timing experiment: +100 % LDS operand reads (results discarded)
+        const u32x2v c0 = *reinterpret_cast<lds_u2*>(ph + OFF + 16), c1 = *reinterpret_cast<lds_u2*>(ph + OFF + 24);
+        const u32x2v d0 = *reinterpret_cast<lds_u2*>(pl + OFF + 16), d1 = *reinterpret_cast<lds_u2*>(pl + OFF + 24);
+        asm volatile("" :: "v"(c0), "v"(c1), "v"(d0), "v"(d1));
+    }
 }
 
 template <int NC>
