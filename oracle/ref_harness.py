@@ -41,7 +41,11 @@ def _import_reference():
 def build_reference_model(cfg: dict, batch_size: int, is_parallel: int = 1):
     """Channel_AE(ENC_interCNN, DEC_LargeCNN) built exactly as main.py:109-159 does."""
     _import_reference()
-    argv = ["main.py", "-encoder", "TurboAE_rate3_cnn", "-decoder", cfg.get("decoder", "TurboAE_rate3_cnn"),
+    enc_name = cfg.get("encoder", "TurboAE_rate3_cnn")
+    # get_args.py:10 spells the GRU-encoder choice 'Turboae_rate3_rnn' while main.py:32 tests 'TurboAE_rate3_rnn': pass the
+    # spelling argparse accepts and set the one import_enc understands afterwards
+    argv = ["main.py", "-encoder", "Turboae_rate3_rnn" if enc_name == "TurboAE_rate3_rnn" else enc_name,
+            "-decoder", cfg.get("decoder", "TurboAE_rate3_cnn"),
             "-enc_num_unit", str(cfg["enc_num_unit"]), "-enc_num_layer", str(cfg["enc_num_layer"]),
             "-dec_num_unit", str(cfg["dec_num_unit"]), "-dec_num_layer", str(cfg["dec_num_layer"]),
             "-num_iteration", str(cfg["num_iteration"]), "-num_iter_ft", str(cfg["num_iter_ft"]),
@@ -66,6 +70,7 @@ def build_reference_model(cfg: dict, batch_size: int, is_parallel: int = 1):
         args = get_args()
     finally:
         sys.argv = old
+    args.encoder = enc_name
     from main import import_enc, import_dec
     from channel_ae import Channel_AE
     from numpy import arange
@@ -87,7 +92,7 @@ def load_weights(model, state_dict: Dict[str, np.ndarray], is_parallel: int = 1)
     sd = {}
     for k, v in state_dict.items():
         if is_parallel:
-            k = re.sub(r"^(enc\.enc_cnn_\d|enc\.enc_linear_\d|dec\.dec\d_cnns\.\d+|dec\.dec\d_rnns\.\d+|dec\.dec\d_outputs\.\d+)\.",
+            k = re.sub(r"^(enc\.enc_cnn_\d|enc\.enc_rnn_\d|enc\.enc_linear_\d|dec\.dec\d_cnns\.\d+|dec\.dec\d_rnns\.\d+|dec\.dec\d_outputs\.\d+)\.",
                        r"\1.module.", k)
         sd[k] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
     model.load_state_dict(sd, strict=True)

@@ -128,6 +128,15 @@ def encode_prenorm(u: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor,
     return torch.cat([b1, b2, b3], dim=2)
 
 
+# encoders.py:281-298 (ENC_interRNN.forward): three 2-layer bidirectional GRU(1 -> U) + Linear(2U -> 1) + enc_act; the
+# input is the raw bit tensor (no 2u - 1 here, unlike ENC_interCNN), the third branch sees the interleaved bits.
+def encode_prenorm_rnn(u: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor, hidden: int, enc_act: str = "elu") -> torch.Tensor:
+    def branch(x, i):
+        h = _gru_stack(x, w, f"enc.enc_rnn_{i}", hidden)
+        return _enc_act(F.linear(h, w[f"enc.enc_linear_{i}.weight"], w[f"enc.enc_linear_{i}.bias"]), enc_act)
+    return torch.cat([branch(u, 1), branch(u, 2), branch(interleave(u, p), 3)], dim=2)
+
+
 def encode(u, w, p, enc_num_layer, enc_act="elu", cfg=None, state=None):
     codes, _, _ = power_constraint(encode_prenorm(u, w, p, enc_num_layer, enc_act), cfg, state)
     return codes
@@ -226,7 +235,10 @@ def channel_ae_forward(u: torch.Tensor, fwd_noise: torch.Tensor, w: Dict[str, to
             p = torch.from_numpy(np.asarray(cfg["p_array"], dtype=np.int64))
         else:
             p = torch.from_numpy(rand_interleaver(u.shape[1], cfg.get("interleaver_seed", 0)))
-        x_tx = encode_prenorm(u, w, p, cfg["enc_num_layer"], cfg.get("enc_act", "elu"))
+        if cfg.get("encoder", "TurboAE_rate3_cnn") == "TurboAE_rate3_rnn":
+            x_tx = encode_prenorm_rnn(u, w, p, cfg["enc_num_unit"], cfg.get("enc_act", "elu"))
+        else:
+            x_tx = encode_prenorm(u, w, p, cfg["enc_num_layer"], cfg.get("enc_act", "elu"))
         codes, mean, std = power_constraint(x_tx, cfg, state if state is not None else {})
         received = apply_channel(codes, fwd_noise, cfg, fading)
         if cfg.get("decoder", "TurboAE_rate3_cnn") == "TurboAE_rate3_rnn":

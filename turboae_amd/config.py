@@ -24,6 +24,9 @@ class TurboAEConfig:
     num_iter_ft: int = 5          # get_args.py:84
     extrinsic: int = 1            # get_args.py:83
     enc_act: str = "elu"          # get_args.py:100 ("only elu works")
+    encoder: str = "TurboAE_rate3_cnn"   # main.py:32-36: 'TurboAE_rate3_cnn' (ENC_interCNN) or 'TurboAE_rate3_rnn' (ENC_interRNN,
+                                         # encoders.py:231-298: three 2-layer bidirectional GRU(1 -> U) + Linear(2U -> 1); the
+                                         # reference's own CLI cannot select it - its -encoder choice is spelled 'Turboae_rate3_rnn')
     decoder: str = "TurboAE_rate3_cnn"   # get_args.py:26 / main.py:75-76,87-88: 'TurboAE_rate3_cnn' (DEC_LargeCNN) or
                                          # 'TurboAE_rate3_rnn' (DEC_LargeRNN, 2-layer bidirectional GRU, dec_rnn='gru')
     interleaver_seed: int = 0     # channel_ae.py:33 (RandInterlv(block_len, 0))
@@ -65,6 +68,11 @@ class TurboAEConfig:
             raise ValueError("block_len must be >= 1")
         if self.channel not in ("awgn", "t-dist", "radar", "ge_awgn", "bec", "bsc", "ge", "fading"):
             raise ValueError("channel must be one of awgn, t-dist, radar, ge_awgn, bec, bsc, ge, fading")
+        if self.encoder not in ("TurboAE_rate3_cnn", "TurboAE_rate3_rnn"):
+            raise ValueError("encoder must be 'TurboAE_rate3_cnn' or 'TurboAE_rate3_rnn'")
+        if self.encoder == "TurboAE_rate3_rnn" and (self.enc_num_unit != 100 or self.enc_num_layer != 2 or self.decoder != "TurboAE_rate3_rnn"):
+            raise ValueError("the GRU encoder runs on the GRU decoder's kernels: enc_num_unit = 100, enc_num_layer = 2, decoder = 'TurboAE_rate3_rnn' "
+                             "(with any other decoder the reference switches the decoder to DenseSameShapeConv1d, decoders.py:173-176)")
         if self.decoder not in ("TurboAE_rate3_cnn", "TurboAE_rate3_rnn"):
             raise ValueError("decoder must be 'TurboAE_rate3_cnn' or 'TurboAE_rate3_rnn'")
         if self.decoder == "TurboAE_rate3_rnn" and self.dec_num_unit != 100:
@@ -86,6 +94,8 @@ class TurboAEConfig:
         ke, kd = self.enc_kernel_size, self.dec_kernel_size
         ue, ud, f = self.enc_num_unit, self.dec_num_unit, self.num_iter_ft
         enc = 3 * (1 * ke * ue + (self.enc_num_layer - 1) * ue * ke * ue + ue)
+        if self.encoder == "TurboAE_rate3_rnn":
+            enc = 3 * (2 * (3 * ue * (1 + ue) + 3 * ue * (2 * ue + ue)) + 2 * ue)
         if self.decoder == "TurboAE_rate3_rnn":
             # 2-layer bidirectional GRU(2+F -> ud): per direction 3*ud*(in + ud) MAC per layer (244 200)
             stack = 2 * (3 * ud * ((2 + f) + ud) + 3 * ud * (2 * ud + ud))

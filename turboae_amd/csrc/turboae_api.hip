@@ -238,6 +238,10 @@ struct tae_handle {
     // GRU decoder (dec_type = 1): canonical decoder weights uploaded as they are + per-chunk workspace
     float* d_wrnn = nullptr;
     char* d_wrnn_h = nullptr;   // f16x2 packing of the same (prec == 1)
+    float* d_wernn = nullptr;   // GRU encoder (enc_type = 1): the three ENC_interRNN stacks, packed like the decoder's
+    char* d_wernn_h = nullptr;
+    double* d_rnn_partials = nullptr;   // GRU encoder: per (chunk, stack, head workgroup) partial sums
+    int32_t rnn_partial_slots = 0;
     int32_t rnn_chunk = 0;   // blocks per internal chunk (bounds the workspace)
     float* d_gxa = nullptr;  // (chunk, L, 8) natural-order panel
     float* d_gxb = nullptr;  // (chunk, L, 8) interleaved-order panel
@@ -263,15 +267,18 @@ int check_cfg(const tae_config* c) {
     if (c->dec_type != 0 && c->dec_type != 1) return fail(TAE_EINVAL, "dec_type must be 0 (cnn) or 1 (rnn/gru)");
     if (c->precision != TAE_PREC_AUTO && c->precision != TAE_PREC_F32) return fail(TAE_EINVAL, "precision must be TAE_PREC_AUTO (0) or TAE_PREC_F32 (1)");
     if (c->dec_type == 1 && c->dec_num_unit != 100) return fail(TAE_EINVAL, "the GRU decoder kernels are instantiated for dec_num_unit = 100");
+    if (c->enc_type != 0 && c->enc_type != 1) return fail(TAE_EINVAL, "enc_type must be 0 (cnn) or 1 (rnn/gru)");
+    if (c->enc_type == 1 && (c->dec_type != 1 || c->enc_num_unit != 100 || c->enc_num_layer != 2))
+        return fail(TAE_EINVAL, "the GRU encoder needs the GRU decoder (dec_type = 1), enc_num_unit = 100 and enc_num_layer = 2");
     return TAE_OK;
 }
 
 // canonical GRU stack: per layer l and direction d: weight_ih (3H,cin) weight_hh (3H,H) bias_ih (3H) bias_hh (3H);
 // then Linear (nout,2H), bias (nout)   (turboae_amd/weights.py canonical_entries)
-size_t rnn_stack_floats(size_t H, size_t F, size_t nout) {
+size_t rnn_stack_floats(size_t H, size_t cin0, size_t nout) {
     size_t n = 0;
     for (int l = 0; l < 2; ++l) {
-        const size_t cin = l == 0 ? 2 + F : 2 * H;
+        const size_t cin = l == 0 ? cin0 : 2 * H;
         n += 2 * (3 * H * cin + 3 * H * H + 3 * H + 3 * H);
     }
     return n + nout * 2 * H + nout;
@@ -358,10 +365,10 @@ void pack_gru_pbias(const float* bih, const float* bhh, float* dst) {
 size_t rnn_packed_stack_floats(size_t nout) { return 2 * kGL0Dir + kGProjF + kGPB + 2 * kGL1Dir + (nout * 2 * kGH + nout + 3) / 4 * 4; }
 
 // canonical GRU decoder -> per stack: L0 {dir: REC | XF | BIAS0} | L1 {PROJ (2 dirs) | PBIAS (2 dirs) | dir: REC | BIAS1} | Linear w | b
-void repack_rnn(const float* src, float* dst, size_t H, size_t F, int n_iter) {
-    for (int s = 0; s < 2 * n_iter; ++s) {
-        const size_t nout = (s == 2 * n_iter - 1) ? 1 : F;
-        const size_t cin0 = 2 + F, cin1 = 2 * H;
+void repack_rnn(const float* src, float* dst, size_t H, size_t cin0, const std::vector<size_t>& nouts) {
+    for (size_t s = 0; s < nouts.size(); ++s) {
+        const size_t nout = nouts[s];
+        const size_t cin1 = 2 * H;
         const size_t per0 = 3 * H * cin0 + 3 * H * H + 6 * H, per1 = 3 * H * cin1 + 3 * H * H + 6 * H;
         for (int d = 0; d < 2; ++d) {
             const float* p = src + d * per0;           // weight_ih | weight_hh | bias_ih | bias_hh
@@ -388,11 +395,16 @@ void repack_rnn(const float* src, float* dst, size_t H, size_t F, int n_iter) {
     }
 }
 
-size_t rnn_packed_floats(size_t H, size_t F, int n_iter) {
-    (void)H;
+size_t rnn_packed_floats(const std::vector<size_t>& nouts) {
     size_t n = 0;
-    for (int s = 0; s < 2 * n_iter; ++s) n += rnn_packed_stack_floats((s == 2 * n_iter - 1) ? 1 : F);
+    for (size_t nout : nouts) n += rnn_packed_stack_floats(nout);
     return n;
+}
+// Linear output widths of the GRU stacks: decoder = F for every half-iteration except the last (1); encoder = 1, 1, 1
+std::vector<size_t> dec_rnn_nouts(size_t F, int n_iter) {
+    std::vector<size_t> v((size_t)2 * n_iter, F);
+    v.back() = 1;
+    return v;
 }
 
 // ---- GRU decoder, f16x2 representation (turboae_gru_h2.hip) -----------------------------------------------
@@ -474,18 +486,18 @@ void pack_gru_proj_h(const float* Wih, float scale, char* dst) {
 }
 
 size_t rnn_h_stack_bytes(size_t nout) { return 2 * kGHRec0B + kGHProjB + 2 * kGHRec1B + ((nout * 2 * kGH + nout) * 4 + 15) / 16 * 16; }
-size_t rnn_h_packed_bytes(size_t F, int n_iter) {
+size_t rnn_h_packed_bytes(const std::vector<size_t>& nouts) {
     size_t n = 0;
-    for (int s = 0; s < 2 * n_iter; ++s) n += rnn_h_stack_bytes((s == 2 * n_iter - 1) ? 1 : F);
+    for (size_t nout : nouts) n += rnn_h_stack_bytes(nout);
     return n;
 }
 
 // canonical GRU decoder -> per stack: L0 {dir: REC | NI | BIAS0 * 2^S | 2^-S} | L1 {PROJ (2 dirs) | PBIAS * 2^Sp | 2^-Sp | dir: REC | BN1 * 2^S | 2^-S} | Linear
-void repack_rnn_h(const float* src, char* dst, size_t F, int n_iter) {
+void repack_rnn_h(const float* src, char* dst, size_t cin0, const std::vector<size_t>& nouts) {
     const size_t H = kGH;
-    for (int s = 0; s < 2 * n_iter; ++s) {
-        const size_t nout = (s == 2 * n_iter - 1) ? 1 : F;
-        const size_t cin0 = 2 + F, cin1 = 2 * H;
+    for (size_t s = 0; s < nouts.size(); ++s) {
+        const size_t nout = nouts[s];
+        const size_t cin1 = 2 * H;
         const size_t per0 = 3 * H * cin0 + 3 * H * H + 6 * H, per1 = 3 * H * cin1 + 3 * H * H + 6 * H;
         for (int d = 0; d < 2; ++d) {
             const float* p = src + d * per0;           // weight_ih | weight_hh | bias_ih | bias_hh
@@ -534,6 +546,7 @@ size_t num_weights(const tae_config* c) {
     const size_t U = c->enc_num_unit, F = c->num_iter_ft;
     size_t n = 0;
     for (int s = 0; s < 3; ++s) {
+        if (c->enc_type == 1) { n += rnn_stack_floats(U, 1, 1); continue; }
         for (int l = 0; l < c->enc_num_layer; ++l) n += U * (l == 0 ? 1 : U) * 5 + U;
         n += U + 1;
     }
@@ -541,7 +554,7 @@ size_t num_weights(const tae_config* c) {
         for (int half = 0; half < 2; ++half) {
             const size_t nout = (half == 1 && it == c->num_iteration - 1) ? 1 : F;
             if (c->dec_type == 1) {
-                n += rnn_stack_floats(U, F, nout);
+                n += rnn_stack_floats(U, 2 + F, nout);
             } else {
                 for (int l = 0; l < c->dec_num_layer; ++l) n += U * (l == 0 ? 2 + F : U) * 5 + U;
                 n += nout * U + nout;
@@ -681,7 +694,10 @@ int run_decoder_long(tae_handle* h, const float* rx, float* xdec, int32_t B, hip
     return TAE_OK;
 }
 
+int run_encoder_rnn(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st);
+
 int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st) {
+    if (h->cfg.enc_type == 1) return run_encoder_rnn(h, u, xtx, stats, B, st);
     if (h->nb < 1) return run_encoder_long(h, u, xtx, stats, B, st);
     tae::FusedParams P = base_params(h, B);
     P.wpack = h->d_wenc;
@@ -702,6 +718,61 @@ int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_
     } else
     TAE_HIP(tae::launch_fused(h->U, false, P, grid, st));
     TAE_HIP(tae::launch_reduce_partials(h->d_partials, grid, (double)B * h->cfg.block_len * 3.0, stats, st));
+    return TAE_OK;
+}
+
+// ENC_interRNN.forward before power_constraint (encoders.py:281-296): three GRU stacks on the decoder's kernels
+// (rec layer 0 -> projection -> rec layer 1 -> head in encoder mode), per internal chunk; every head workgroup leaves a
+// partial (sum, sumsq) that reduce_partials adds in fixed order.
+int run_encoder_rnn(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st) {
+    const int L = h->cfg.block_len, H = 100;
+    int slot = 0;
+    for (int32_t c0 = 0; c0 < B; c0 += h->rnn_chunk) {
+        const int32_t Bc = (B - c0 < h->rnn_chunk) ? B - c0 : h->rnn_chunk;
+        const size_t np = (size_t)Bc * L, npg = (size_t)((Bc + 15) / 16) * 16 * L;
+        const float* w = h->d_wernn;
+        const char* wb = h->d_wernn_h;
+        for (int s = 0; s < 3; ++s) {
+            TAE_HIP(tae::launch_gru_prep_enc(u + (size_t)c0 * L, h->d_perm, h->d_gxa, Bc, L, s == 2 ? 1 : 0, st));
+            tae::GruRecParams R0, R1;
+            tae::GruProjParams PP;
+            tae::GruHeadParams HP;
+            memset(&R0, 0, sizeof(R0)); memset(&R1, 0, sizeof(R1)); memset(&HP, 0, sizeof(HP));
+            R0.x = h->d_gxa; R0.B = Bc; R0.L = L; R0.y = h->d_gy0;
+            R1.gi = h->d_ggi; R1.B = Bc; R1.L = L; R1.y = h->d_gy1;
+            PP.yin = h->d_gy0; PP.gi = h->d_ggi; PP.B = Bc; PP.L = L;
+            const float* wl;
+            if (h->prec == 1) {
+                R0.w = reinterpret_cast<const float*>(wb); R0.w_dir_stride = (uint32_t)kGHRec0B;
+                const char* w1 = wb + 2 * kGHRec0B;
+                PP.w = reinterpret_cast<const float*>(w1); PP.npos = npg;
+                R1.w = reinterpret_cast<const float*>(w1 + kGHProjB); R1.w_dir_stride = (uint32_t)kGHRec1B;
+                wl = reinterpret_cast<const float*>(w1 + kGHProjB + 2 * kGHRec1B);
+                TAE_HIP(tae::launch_gru_rec_h(true, R0, st));
+                TAE_HIP(tae::launch_gru_proj_h(PP, st));
+                TAE_HIP(tae::launch_gru_rec_h(false, R1, st));
+                wb += rnn_h_stack_bytes(1);
+            } else {
+                R0.w = w; R0.w_dir_stride = (uint32_t)kGL0Dir;
+                const float* w1 = w + 2 * kGL0Dir;
+                PP.w = w1; PP.npos = np;
+                R1.w = w1 + kGProjF + kGPB; R1.w_dir_stride = (uint32_t)kGL1Dir;
+                wl = w1 + kGProjF + kGPB + 2 * kGL1Dir;
+                TAE_HIP(tae::launch_gru_rec(true, R0, st));
+                TAE_HIP(tae::launch_gru_proj(PP, st));
+                TAE_HIP(tae::launch_gru_rec(false, R1, st));
+                w += rnn_packed_stack_floats(1);
+            }
+            HP.y = h->d_gy1; HP.w = wl; HP.b = wl + 2 * H; HP.npos = h->prec == 1 ? npg : np; HP.L = L; HP.F = 1; HP.nout = 1;
+            HP.grouped = h->prec == 1 ? 1 : 0; HP.B = Bc;
+            HP.enc_stack = s; HP.act = h->cfg.enc_act; HP.xtx = xtx + (size_t)c0 * L * 3;
+            HP.partials = h->d_rnn_partials + (size_t)slot * 2;
+            TAE_HIP(tae::launch_gru_head(HP, st));
+            slot += tae::gru_head_grid(HP.npos);
+        }
+    }
+    if (slot > h->rnn_partial_slots) return fail(TAE_ESTATE, "internal: GRU-encoder partial-sum slots exceeded");
+    TAE_HIP(tae::launch_reduce_partials(h->d_rnn_partials, slot, (double)B * L * 3.0, stats, st));
     return TAE_OK;
 }
 
@@ -739,7 +810,7 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
                 HP.xnext = odd ? h->d_gxa : h->d_gxb; HP.xdec = xdec + (size_t)c0 * L;
                 HP.ptab = odd ? h->d_perm : h->d_inv;
                 HP.npos = npg; HP.L = L; HP.F = F; HP.nout = nout; HP.extrinsic = h->cfg.extrinsic; HP.last = last ? 1 : 0;
-                HP.grouped = 1; HP.B = Bc;
+                HP.grouped = 1; HP.B = Bc; HP.enc_stack = -1;
                 TAE_HIP(tae::launch_gru_head(HP, st));
                 wb += rnn_h_stack_bytes((size_t)nout);
             }
@@ -769,6 +840,7 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
             HP.xnext = odd ? h->d_gxa : h->d_gxb; HP.xdec = xdec + (size_t)c0 * L;
             HP.ptab = odd ? h->d_perm : h->d_inv;     // dec1 -> interleave (row inv[t]); dec2 -> deinterleave (row p[i])
             HP.npos = np; HP.L = L; HP.F = F; HP.nout = nout; HP.extrinsic = h->cfg.extrinsic; HP.last = last ? 1 : 0;
+            HP.enc_stack = -1;
             TAE_HIP(tae::launch_gru_head(HP, st));
             w += rnn_packed_stack_floats((size_t)nout);
         }
@@ -855,7 +927,8 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     h->enc_bytes = (uint32_t)(penc.size() * sizeof(float));
     h->dec_bytes = (uint32_t)(pdec.size() * sizeof(float));
     const float* src = weights;
-    for (int s = 0; s < 3; ++s) src += pack_stack(src, lo, cfg->enc_num_layer, 1, 1, penc.data() + (size_t)s * h->enc_stride);
+    if (cfg->enc_type == 1) src += 3 * rnn_stack_floats(100, 1, 1);       // ENC_interRNN: packed with the GRU kernels' layouts below
+    else for (int s = 0; s < 3; ++s) src += pack_stack(src, lo, cfg->enc_num_layer, 1, 1, penc.data() + (size_t)s * h->enc_stride);
     const float* dec_src = src;
     if (cfg->dec_type == 1) {
         src = weights + n_weights;          // canonical GRU weights are uploaded unchanged below
@@ -894,7 +967,8 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         penc_h.assign((size_t)3 * h->enc_stride_h, 0);
         h->enc_bytes_h = (uint32_t)penc_h.size();
         const float* s2 = weights;
-        for (int s = 0; s < 3; ++s) s2 += pack_stack_h(s2, lh, cfg->enc_num_layer, 1, 1, penc_h.data() + (size_t)s * h->enc_stride_h);
+        if (cfg->enc_type == 0)
+            for (int s = 0; s < 3; ++s) s2 += pack_stack_h(s2, lh, cfg->enc_num_layer, 1, 1, penc_h.data() + (size_t)s * h->enc_stride_h);
         if (cfg->dec_type == 0) {
             pdec_h.assign((size_t)2 * cfg->num_iteration * h->dec_stride_h, 0);
             h->dec_bytes_h = (uint32_t)pdec_h.size();
@@ -933,15 +1007,29 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     if (cfg->dec_type == 1) {
         const size_t nrnn = (size_t)(weights + n_weights - dec_src);
         (void)nrnn;
-        std::vector<float> prnn(rnn_packed_floats(100, (size_t)F, cfg->num_iteration), 0.0f);
-        repack_rnn(dec_src, prnn.data(), 100, (size_t)F, cfg->num_iteration);
+        const std::vector<size_t> nouts = dec_rnn_nouts((size_t)F, cfg->num_iteration);
+        std::vector<float> prnn(rnn_packed_floats(nouts), 0.0f);
+        repack_rnn(dec_src, prnn.data(), 100, 2 + (size_t)F, nouts);
         TAE_HIP_H(hipMalloc(&h->d_wrnn, prnn.size() * sizeof(float)));
         TAE_HIP_H(hipMemcpy(h->d_wrnn, prnn.data(), prnn.size() * sizeof(float), hipMemcpyHostToDevice));
         if (h->prec == 1) {
-            std::vector<char> prnn_h(rnn_h_packed_bytes((size_t)F, cfg->num_iteration), 0);
-            repack_rnn_h(dec_src, prnn_h.data(), (size_t)F, cfg->num_iteration);
+            std::vector<char> prnn_h(rnn_h_packed_bytes(nouts), 0);
+            repack_rnn_h(dec_src, prnn_h.data(), 2 + (size_t)F, nouts);
             TAE_HIP_H(hipMalloc(&h->d_wrnn_h, prnn_h.size()));
             TAE_HIP_H(hipMemcpy(h->d_wrnn_h, prnn_h.data(), prnn_h.size(), hipMemcpyHostToDevice));
+        }
+        if (cfg->enc_type == 1) {
+            const std::vector<size_t> en(3, 1);
+            std::vector<float> pe(rnn_packed_floats(en), 0.0f);
+            repack_rnn(weights, pe.data(), 100, 1, en);
+            TAE_HIP_H(hipMalloc(&h->d_wernn, pe.size() * sizeof(float)));
+            TAE_HIP_H(hipMemcpy(h->d_wernn, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+            if (h->prec == 1) {
+                std::vector<char> peh(rnn_h_packed_bytes(en), 0);
+                repack_rnn_h(weights, peh.data(), 1, en);
+                TAE_HIP_H(hipMalloc(&h->d_wernn_h, peh.size()));
+                TAE_HIP_H(hipMemcpy(h->d_wernn_h, peh.data(), peh.size(), hipMemcpyHostToDevice));
+            }
         }
     }
     TAE_HIP_H(hipMemcpy(h->d_perm, ident.data(), L * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -961,6 +1049,7 @@ int tae_destroy(tae_handle* h) {
     (void)hipFree(h->d_wrnn); (void)hipFree(h->d_gxa); (void)hipFree(h->d_gxb); (void)hipFree(h->d_gy0); (void)hipFree(h->d_gy1);
     (void)hipFree(h->d_ggi);
     (void)hipFree(h->d_wenc_h); (void)hipFree(h->d_wdec_h); (void)hipFree(h->d_flags); (void)hipFree(h->d_wrnn_h);
+    (void)hipFree(h->d_wernn); (void)hipFree(h->d_wernn_h); (void)hipFree(h->d_rnn_partials);
     delete h;
     return TAE_OK;
 }
@@ -1000,6 +1089,13 @@ int tae_reserve(tae_handle* h, int32_t max_batch) {
         TAE_HIP(hipMemset(h->d_gy0, 0, np * 200 * sizeof(float)));
         TAE_HIP(hipMemset(h->d_gy1, 0, np * 200 * sizeof(float)));
         TAE_HIP(hipMemset(h->d_ggi, 0, np * 608 * sizeof(float)));
+        if (h->cfg.enc_type == 1) {
+            (void)hipFree(h->d_rnn_partials);
+            h->d_rnn_partials = nullptr;
+            const int nchunk = (max_batch + h->rnn_chunk - 1) / h->rnn_chunk;
+            h->rnn_partial_slots = nchunk * 3 * tae::gru_head_grid(np);
+            TAE_HIP(hipMalloc(&h->d_rnn_partials, (size_t)h->rnn_partial_slots * 2 * sizeof(double)));
+        }
     }
     h->cap = max_batch;
     return TAE_OK;

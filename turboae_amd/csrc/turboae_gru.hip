@@ -50,6 +50,19 @@ __global__ void gru_prep_kernel(const float* __restrict__ rx, const int32_t* __r
     }
 }
 
+// ENC_interRNN input panel (encoders.py:283-292): column 0 = the bit (raw 0/1 - no 2u - 1 in this encoder), the third
+// branch sees the interleaved bits; columns 1..7 zero
+__global__ void gru_prep_enc_kernel(const float* __restrict__ u, const int32_t* __restrict__ perm, float* __restrict__ X, int B, int L, int interleaved) {
+    const size_t n = (size_t)B * L;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / L;
+        const int t = (int)(i - b * L);
+        const float v = u[b * L + (interleaved ? perm[t] : t)];
+        reinterpret_cast<f32x4*>(X + i * kXWg)[0] = f32x4{v, 0.f, 0.f, 0.f};
+        reinterpret_cast<f32x4*>(X + i * kXWg)[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // ---- recurrent kernel -------------------------------------------------------------------------------
 // Gate rows of one direction are arranged in kRT = 19 MFMA row tiles: tile 3*ut + g (ut < 6, g = r, z, n)
 // holds gate g of units 16*ut .. 16*ut + 15, and the remainder tile 18 holds, in row 4*qq + i, gate i of
@@ -306,6 +319,7 @@ __global__ __launch_bounds__(64 * kHeadWaves) void gru_head_kernel(GruHeadParams
 #pragma unroll
     for (int i = 0; i < 4; ++i) bias[i] = (4 * kq + i) < P.nout ? P.b[4 * kq + i] : 0.0f;
     const size_t ntile = (P.npos + 15) / 16;
+    double esum = 0.0, esq = 0.0;
     for (size_t tile = (size_t)blockIdx.x * kHeadWaves + (threadIdx.x >> 6); tile < ntile; tile += (size_t)gridDim.x * kHeadWaves) {
         const size_t posy = tile * 16 + n;      // row of Y1
         const size_t pc = posy < P.npos ? posy : P.npos - 1;
@@ -322,21 +336,30 @@ __global__ __launch_bounds__(64 * kHeadWaves) void gru_head_kernel(GruHeadParams
         acc[0] = mfma16x16x4(a[48], vl.x, acc[0]);
         acc[1] = mfma16x16x4(a[49], vl.y, acc[1]);
         const f32x4 o = (acc[0] + acc[1]) + (acc[2] + acc[3]);       // rows 4*kq + i = outputs f of position n
-        if (posy >= P.npos || kq >= 2) continue;
-        size_t b;
-        int t;
+        bool live = posy < P.npos && kq < 2;
+        size_t b = 0;
+        int t = 0;
         if (P.grouped) {            // f16x2 path: pos' = ((b / 16) * L + t) * 16 + b % 16
             const size_t row = posy >> 4;
             const size_t grp = row / P.L;
             t = (int)(row - grp * P.L);
             b = grp * 16 + (posy & 15);
-            if (b >= (size_t)P.B) continue;
+            live = live && b < (size_t)P.B;
         } else {
             b = posy / P.L;
             t = (int)(posy - b * P.L);
         }
+        if (!live) continue;
         const size_t pos = b * P.L + t;      // (block, t) order of the X panels
-        if (!P.last) {
+        if (P.enc_stack >= 0) {
+            if (kq == 0) {               // ENC_interRNN: x = enc_act(Linear(2H -> 1)) (encoders.py:284,287,292)
+                float v = o[0];
+                if (P.act == 0) v = v > 0.0f ? v : expm1f(v);
+                P.xtx[pos * 3 + P.enc_stack] = v;
+                esum += (double)v;
+                esq += (double)v * (double)v;
+            }
+        } else if (!P.last) {
             const float* xc = P.xcur + pos * kXWg + 2;
             float* xn = P.xnext + (b * P.L + P.ptab[t]) * kXWg + 2;
 #pragma unroll
@@ -347,6 +370,19 @@ __global__ __launch_bounds__(64 * kHeadWaves) void gru_head_kernel(GruHeadParams
         } else if (kq == 0) {
             P.xdec[b * P.L + P.ptab[t]] = sigmoidf_(o[0]);      // sigmoid(deinterleave(x_plr)), decoders.py:145-147
         }
+    }
+    if (P.enc_stack >= 0) {
+        // per-workgroup partial sums for power_constraint (encoders.py:107-108), fixed-order tree
+        __shared__ double red[2 * 64 * kHeadWaves];
+        const int tid = threadIdx.x;
+        red[tid] = esum;
+        red[64 * kHeadWaves + tid] = esq;
+        __syncthreads();
+        for (int off = 32 * kHeadWaves; off > 0; off >>= 1) {
+            if (tid < off) { red[tid] += red[tid + off]; red[64 * kHeadWaves + tid] += red[64 * kHeadWaves + tid + off]; }
+            __syncthreads();
+        }
+        if (tid == 0) { P.partials[2 * blockIdx.x] = red[0]; P.partials[2 * blockIdx.x + 1] = red[64 * kHeadWaves]; }
     }
 }
 
@@ -382,10 +418,20 @@ hipError_t launch_gru_proj(const GruProjParams& P, hipStream_t st) {
     return hipGetLastError();
 }
 
+int gru_head_grid(size_t npos) {
+    const size_t ntile = (npos + 15) / 16;
+    return (int)std::min<size_t>((ntile + kHeadWaves - 1) / kHeadWaves, 256 * 8);
+}
+
 hipError_t launch_gru_head(const GruHeadParams& P, hipStream_t st) {
-    const size_t ntile = (P.npos + 15) / 16;
-    const unsigned grid = (unsigned)std::min<size_t>((ntile + kHeadWaves - 1) / kHeadWaves, 256 * 8);
-    hipLaunchKernelGGL(gru_head_kernel, dim3(grid), dim3(64 * kHeadWaves), 0, st, P);
+    hipLaunchKernelGGL(gru_head_kernel, dim3(gru_head_grid(P.npos)), dim3(64 * kHeadWaves), 0, st, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_gru_prep_enc(const float* u, const int32_t* perm, float* X, int B, int L, int interleaved, hipStream_t st) {
+    const size_t n = (size_t)B * L;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(gru_prep_enc_kernel, dim3(grid), dim3(256), 0, st, u, perm, X, B, L, interleaved);
     return hipGetLastError();
 }
 

@@ -77,7 +77,13 @@ struct GruHeadParams {
     size_t npos;
     int32_t L, F, nout, extrinsic, last;
     int32_t grouped, B;   // grouped = 1: rows of y are in block-group-major order (f16x2 GRU path), B = blocks
+    // encoder mode (ENC_interRNN, enc_stack >= 0): output = enc_act(Linear) -> xtx[(b, t), enc_stack], per-workgroup (sum, sumsq)
+    int32_t enc_stack, act;
+    float* xtx;           // (B, L, 3)
+    double* partials;     // [gridDim.x][2]
 };
+hipError_t launch_gru_prep_enc(const float* u, const int32_t* perm, float* X, int B, int L, int interleaved, hipStream_t st);
+int gru_head_grid(size_t npos);
 hipError_t launch_gru_prep(const float* rx, const int32_t* perm, float* XA, float* XB, int B, int L, hipStream_t st);
 hipError_t launch_gru_rec(bool layer0, const GruRecParams& P, hipStream_t st);
 hipError_t launch_gru_proj(const GruProjParams& P, hipStream_t st);

@@ -27,6 +27,18 @@ def canonical_entries(cfg: TurboAEConfig) -> List[Tuple[str, Tuple[int, ...]]]:
     ue, ud, f = cfg.enc_num_unit, cfg.dec_num_unit, cfg.num_iter_ft
     ke, kd = cfg.enc_kernel_size, cfg.dec_kernel_size
     for s in (1, 2, 3):
+        if cfg.encoder == "TurboAE_rate3_rnn":
+            # ENC_interRNN: torch.nn.GRU(1, ue, num_layers, bidirectional=True) + Linear(2 ue, 1) (encoders.py:251-268)
+            for l in range(cfg.enc_num_layer):
+                cin = 1 if l == 0 else 2 * ue
+                for sfx in ("", "_reverse"):
+                    out.append((f"enc.enc_rnn_{s}.weight_ih_l{l}{sfx}", (3 * ue, cin)))
+                    out.append((f"enc.enc_rnn_{s}.weight_hh_l{l}{sfx}", (3 * ue, ue)))
+                    out.append((f"enc.enc_rnn_{s}.bias_ih_l{l}{sfx}", (3 * ue,)))
+                    out.append((f"enc.enc_rnn_{s}.bias_hh_l{l}{sfx}", (3 * ue,)))
+            out.append((f"enc.enc_linear_{s}.weight", (1, 2 * ue)))
+            out.append((f"enc.enc_linear_{s}.bias", (1,)))
+            continue
         for l in range(cfg.enc_num_layer):
             cin = cfg.code_rate_k if l == 0 else ue
             out.append((f"enc.enc_cnn_{s}.cnns.{l}.weight", (ue, cin, ke)))
@@ -74,7 +86,7 @@ def add_module(state_dict: Dict[str, object]) -> Dict[str, object]:
     """Inverse of :func:`strip_module`: keys as the reference produces with ``-is_parallel 1``."""
     out = {}
     for k, v in state_dict.items():
-        k2 = re.sub(r"^(enc\.enc_cnn_\d|enc\.enc_linear_\d|dec\.dec\d_cnns\.\d+|dec\.dec\d_rnns\.\d+|dec\.dec\d_outputs\.\d+)\.",
+        k2 = re.sub(r"^(enc\.enc_cnn_\d|enc\.enc_rnn_\d|enc\.enc_linear_\d|dec\.dec\d_cnns\.\d+|dec\.dec\d_rnns\.\d+|dec\.dec\d_outputs\.\d+)\.",
                     r"\1.module.", k)
         out[k2] = v
     return out
