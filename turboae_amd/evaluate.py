@@ -53,11 +53,11 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
     dev = model.this_device
     ber_res, bler_res, bit_res, blk_res = [], [], [], []
     for si, snr in enumerate(snrs):
-        test_ber, test_bler = 0.0, 0.0
-        tot = torch.zeros(2, dtype=torch.int64, device=dev)
+        # per-batch (bit errors, block errors) stay on the device; one host read per SNR point
+        per_batch = torch.zeros((max(num_test_batch, 1), 2), dtype=torch.int64, device=dev)
         for batch_idx in range(num_test_batch):
             first = (si * num_test_batch + batch_idx) * batch_size + lo       # global block index of this shard
-            counts = torch.zeros(2, dtype=torch.int64, device=dev)
+            counts = per_batch[batch_idx]
             fading = None
             if nloc > 0:
                 u, noise = model.generate_inputs(nloc, snr, seed=seed, first_block=first)
@@ -77,13 +77,16 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
                 _, rx = model.normalize(x_tx, stats, noise, want_codes=False, fading=fading)
                 x_dec = model.dec(rx)
                 model.count_errors(x_dec, u, counts)
-            all_reduce_sum_(counts)
-            c = counts.cpu().tolist()
+        all_reduce_sum_(per_batch)
+        pb = per_batch.cpu().tolist()
+        # BER / BLER = mean over batches of the per-batch rates (trainer.py:176-177,215-216), accumulated in the same order
+        test_ber, test_bler = 0.0, 0.0
+        for c in pb[:num_test_batch]:
             test_ber += c[0] / float(batch_size * L)                           # errors_ber, utils.py:6-18
             test_bler += c[1] / float(batch_size)                              # errors_bler, utils.py:49-66
-            tot += counts
         test_ber /= num_test_batch
         test_bler /= num_test_batch
+        tot = per_batch.sum(dim=0)
         say("Test SNR", snr, "with ber ", float(test_ber), "with bler", float(test_bler))
         ber_res.append(float(test_ber))
         bler_res.append(float(test_bler))
