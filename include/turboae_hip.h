@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAE_ABI_VERSION 5
+#define TAE_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define TAE_API __attribute__((visibility("default")))
@@ -64,6 +64,9 @@ typedef struct tae_config {
                                  1 = TurboAE_rate3_rnn (DEC_LargeRNN with dec_rnn=gru, decoders.py:16; needs dec_num_unit=100)  main.py:75-88 */
     int32_t enc_type;         /* -encoder: 0 = TurboAE_rate3_cnn (ENC_interCNN, encoders.py:304), 1 = TurboAE_rate3_rnn (ENC_interRNN with
                                  enc_rnn=gru, encoders.py:231-298; needs dec_type = 1, enc_num_unit = 100, enc_num_layer = 2)  main.py:32-36 */
+    int32_t dense;            /* 1: -encoder TurboAE_rate3_cnn_dense: DenseSameShapeConv1d stacks in encoder AND decoder (cnn_utils.py:49-82; the
+                                 reference keys both on the encoder name, encoders.py:312-330, decoders.py:173-176); needs enc_type =
+                                 dec_type = 0 and precision = TAE_PREC_AUTO */
     int32_t precision;        /* arithmetic of the conv contractions (no reference counterpart; the reference is fp32 on CPU/CUDA):
                                  TAE_PREC_AUTO = 0: fp32 operands carried as two fp16 halves, three v_mfma_f32_16x16x32_f16 products,
                                  fp32 accumulation - fp32-grade results - where the whole-block kernels apply,

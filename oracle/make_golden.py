@@ -45,6 +45,8 @@ CASES = [
     ("fwd_rnn_u100_L40_b3_it2_ft3", dict(decoder="TurboAE_rate3_rnn", block_len=40, num_iteration=2, num_iter_ft=3), 3, 15, 1.0, 1.0),
     # ENC_interRNN (GRU encoder, encoders.py:231-298) in front of the GRU decoder
     ("fwd_encrnn_decrnn_u100_L100_b4", dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", num_iteration=2), 4, 21, 1.0, 2.0),
+    # DenseSameShapeConv1d stacks in encoder and decoder (cnn_utils.py:49-82; -encoder / -decoder TurboAE_rate3_cnn_dense)
+    ("fwd_dense_u100_L100_b3_it2", dict(encoder="TurboAE_rate3_cnn_dense", decoder="TurboAE_rate3_cnn_dense", num_iteration=2), 3, 22, 1.0, 2.0),
     # encoder-output / channel variants on the same kernels; small nets keep them cheap
     ("var_ste2_bsc", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, train_channel_mode="block_norm_ste", channel="bsc"), 5, 16, 1.0, 0.1),
     ("var_ste4_trunc_recq", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, train_channel_mode="block_norm_ste",

@@ -47,7 +47,24 @@ def deinterleave(x: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
 
 # cnn_utils.py:36-46 (SameShapeConv1d.forward; ctor :6-34): x (B,L,C) -> transpose -> for each layer
 # ELU(conv1d(pad=k//2)) -> transpose back.  ELU on every layer, alpha=1.
+DENSE = {"on": False}      # set by channel_ae_forward from cfg["encoder"] (the reference keys encoder AND decoder stacks on it)
+
+
+# cnn_utils.py:49-82 (DenseSameShapeConv1d): layer l convolves cat(inputs, out_0 .. out_{l-1}); the stack returns out_{n-1}
+def dense_same_shape_conv1d(x: torch.Tensor, w: Dict[str, torch.Tensor], prefix: str, num_layer: int) -> torch.Tensor:
+    this_input = x.transpose(1, 2)
+    out = None
+    for l in range(num_layer):
+        if l > 0:
+            this_input = torch.cat([this_input, out], dim=1)
+        wt = w[f"{prefix}.cnns.{l}.weight"]
+        out = F.elu(F.conv1d(this_input, wt, w[f"{prefix}.cnns.{l}.bias"], stride=1, padding=wt.shape[2] // 2))
+    return out.transpose(1, 2)
+
+
 def same_shape_conv1d(x: torch.Tensor, w: Dict[str, torch.Tensor], prefix: str, num_layer: int) -> torch.Tensor:
+    if DENSE["on"]:
+        return dense_same_shape_conv1d(x, w, prefix, num_layer)
     h = x.transpose(1, 2)
     for l in range(num_layer):
         wt = w[f"{prefix}.cnns.{l}.weight"]
@@ -230,6 +247,7 @@ def channel_ae_forward(u: torch.Tensor, fwd_noise: torch.Tensor, w: Dict[str, to
                        fading: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """cfg keys: block_len, enc_num_layer, dec_num_layer, num_iteration, num_iter_ft, extrinsic, enc_act (+ the
     variant flags of power_constraint / apply_channel).  `state` = running norm statistics across calls."""
+    DENSE["on"] = cfg.get("encoder", "TurboAE_rate3_cnn") == "TurboAE_rate3_cnn_dense"     # encoders.py:312-330, decoders.py:173-176
     with torch.no_grad():
         if cfg.get("p_array") is not None:      # enc/dec.set_interleaver(p) (channel_ae.py:35-36)
             p = torch.from_numpy(np.asarray(cfg["p_array"], dtype=np.int64))

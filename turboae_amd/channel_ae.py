@@ -61,7 +61,7 @@ class _Engine:
                            cfg.enc_kernel_size, cfg.dec_num_layer, cfg.dec_num_unit, cfg.dec_kernel_size,
                            cfg.num_iteration, cfg.num_iter_ft, cfg.extrinsic, _ENC_ACT[cfg.enc_act], max_batch,
                            1 if cfg.decoder == "TurboAE_rate3_rnn" else 0, 1 if cfg.encoder == "TurboAE_rate3_rnn" else 0,
-                           1 if cfg.precision == "f32" else 0)
+                           1 if cfg.dense else 0, 1 if cfg.precision == "f32" else 0)
         n = self.lib.tae_num_weights(C.byref(c))
         if n != blob.size:
             raise _lib.TurboAEError(f"weight count mismatch: library wants {n}, blob has {blob.size}")

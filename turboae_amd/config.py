@@ -47,6 +47,12 @@ class TurboAEConfig:
     rec_quantize: bool = False            # get_args.py:205; channel_ae.py:67-69
     rec_quantize_level: int = 2           # get_args.py:207 (the reference also passes it as the clamp limit)
 
+    @property
+    def dense(self) -> bool:
+        """DenseSameShapeConv1d stacks (cnn_utils.py:49-82) in encoder AND decoder: the reference keys both on the encoder
+        name (encoders.py:312-330, decoders.py:173-176)."""
+        return self.encoder == "TurboAE_rate3_cnn_dense"
+
     def validate(self) -> None:
         if self.code_rate_k != 1 or self.code_rate_n != 3:
             raise ValueError("only the rate-1/3 code (code_rate_k=1, code_rate_n=3) is on the hot path")
@@ -68,13 +74,21 @@ class TurboAEConfig:
             raise ValueError("block_len must be >= 1")
         if self.channel not in ("awgn", "t-dist", "radar", "ge_awgn", "bec", "bsc", "ge", "fading"):
             raise ValueError("channel must be one of awgn, t-dist, radar, ge_awgn, bec, bsc, ge, fading")
-        if self.encoder not in ("TurboAE_rate3_cnn", "TurboAE_rate3_rnn"):
-            raise ValueError("encoder must be 'TurboAE_rate3_cnn' or 'TurboAE_rate3_rnn'")
+        if self.encoder not in ("TurboAE_rate3_cnn", "TurboAE_rate3_cnn_dense", "TurboAE_rate3_rnn"):
+            raise ValueError("encoder must be 'TurboAE_rate3_cnn', 'TurboAE_rate3_cnn_dense' or 'TurboAE_rate3_rnn'")
+        if self.dense:
+            if self.decoder not in ("TurboAE_rate3_cnn", "TurboAE_rate3_cnn_dense"):
+                raise ValueError("the dense encoder pairs with the (then also dense) CNN decoder")
+            if self.precision != "auto":
+                raise ValueError("DenseSameShapeConv1d is built on the fp16-split long-block kernels only (precision='auto')")
         if self.encoder == "TurboAE_rate3_rnn" and (self.enc_num_unit != 100 or self.enc_num_layer != 2 or self.decoder != "TurboAE_rate3_rnn"):
             raise ValueError("the GRU encoder runs on the GRU decoder's kernels: enc_num_unit = 100, enc_num_layer = 2, decoder = 'TurboAE_rate3_rnn' "
                              "(with any other decoder the reference switches the decoder to DenseSameShapeConv1d, decoders.py:173-176)")
-        if self.decoder not in ("TurboAE_rate3_cnn", "TurboAE_rate3_rnn"):
-            raise ValueError("decoder must be 'TurboAE_rate3_cnn' or 'TurboAE_rate3_rnn'")
+        if self.decoder not in ("TurboAE_rate3_cnn", "TurboAE_rate3_cnn_dense", "TurboAE_rate3_rnn"):
+            raise ValueError("decoder must be 'TurboAE_rate3_cnn', 'TurboAE_rate3_cnn_dense' or 'TurboAE_rate3_rnn'")
+        if self.decoder == "TurboAE_rate3_cnn_dense" and not self.dense:
+            raise ValueError("the reference builds DenseSameShapeConv1d decoders from the ENCODER name (decoders.py:173-176): "
+                             "use encoder='TurboAE_rate3_cnn_dense'")
         if self.decoder == "TurboAE_rate3_rnn" and self.dec_num_unit != 100:
             raise ValueError("the GRU decoder kernels are instantiated for dec_num_unit = 100")
 
@@ -102,7 +116,11 @@ class TurboAEConfig:
             dec = 2 * self.num_iteration * stack + (2 * self.num_iteration - 1) * 2 * ud * f + 2 * ud
         else:
             stack = (2 + f) * kd * ud + (self.dec_num_layer - 1) * ud * kd * ud
+            if self.dense:      # layer l convolves 2 + F + l * ud input channels (cnn_utils.py:59-62)
+                stack = sum((2 + f + l * ud) * kd * ud for l in range(self.dec_num_layer))
             dec = 2 * self.num_iteration * stack + (2 * self.num_iteration - 1) * ud * f + ud
+        if self.dense:
+            enc = 3 * (sum((1 + l * ue) * ke * ue for l in range(self.enc_num_layer)) + ue)
         return {"enc": enc, "dec": dec, "total": enc + dec}
 
     def flops_per_bit(self) -> int:

@@ -156,6 +156,21 @@ inline float h2f(uint16_t h) {
     return sign ? -v : v;
 }
 
+inline float pow2_scale(float maxabs) {       // power of two that brings maxabs into [2^13, 2^14)
+    if (!(maxabs > 0.0f) || !std::isfinite(maxabs)) return 1.0f;
+    int e = 0;
+    (void)frexpf(maxabs, &e);
+    int S = 14 - e;
+    if (S > 60) S = 60;
+    if (S < -60) S = -60;
+    return ldexpf(1.0f, S);
+}
+inline float max_abs(const float* p, size_t n) {
+    float m = 0.0f;
+    for (size_t i = 0; i < n; ++i) m = fmaxf(m, fabsf(p[i]));
+    return m;
+}
+
 // Conv1d weight (U, cin, 5) -> [slab][channel tile][hi | lo][lane][8 halves]: lane (i = lane & 15, kq = lane >> 4) holds
 // W'[co = 16 ct + i][k = 32 slab + 8 kq + j] * scale, split into hi = f16(w), lo = f16(w - hi)
 void pack_conv_h(const float* W, int U, int cin, int cin_pad, int nslab, int CT, float scale, uint16_t* dst) {
@@ -268,6 +283,9 @@ int check_cfg(const tae_config* c) {
     if (c->precision != TAE_PREC_AUTO && c->precision != TAE_PREC_F32) return fail(TAE_EINVAL, "precision must be TAE_PREC_AUTO (0) or TAE_PREC_F32 (1)");
     if (c->dec_type == 1 && c->dec_num_unit != 100) return fail(TAE_EINVAL, "the GRU decoder kernels are instantiated for dec_num_unit = 100");
     if (c->enc_type != 0 && c->enc_type != 1) return fail(TAE_EINVAL, "enc_type must be 0 (cnn) or 1 (rnn/gru)");
+    if (c->dense != 0 && c->dense != 1) return fail(TAE_EINVAL, "dense must be 0 or 1");
+    if (c->dense && (c->enc_type != 0 || c->dec_type != 0 || c->precision != TAE_PREC_AUTO))
+        return fail(TAE_EINVAL, "DenseSameShapeConv1d stacks need the CNN encoder / decoder and precision = TAE_PREC_AUTO (fp16-split long-block kernels)");
     if (c->enc_type == 1 && (c->dec_type != 1 || c->enc_num_unit != 100 || c->enc_num_layer != 2))
         return fail(TAE_EINVAL, "the GRU encoder needs the GRU decoder (dec_type = 1), enc_num_unit = 100 and enc_num_layer = 2");
     return TAE_OK;
@@ -282,6 +300,62 @@ size_t rnn_stack_floats(size_t H, size_t cin0, size_t nout) {
         n += 2 * (3 * H * cin + 3 * H * H + 3 * H + 3 * H);
     }
     return n + nout * 2 * H + nout;
+}
+
+// ---- DenseSameShapeConv1d (cnn_utils.py:49-82), f16x2 long-block kernels ---------------------------------------
+// Layer l of a dense stack has weight (U, cin0 + l * U, 5).  Its input channels [c_off, c_off + csub) form one part of the
+// contraction (the stack inputs, or the output of one earlier layer); a part is packed exactly like a Conv1d weight.
+void pack_conv_part_h(const float* W, int U, int cin_total, int c_off, int csub, int cin_pad, int nslab, int CT, float scale, uint16_t* dst) {
+    for (int sl = 0; sl < nslab; ++sl)
+        for (int ct = 0; ct < CT; ++ct)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int co = ct * 16 + (lane & 15), k = 32 * sl + 8 * (lane >> 4) + j;
+                    const int tap = k / cin_pad, ci = k % cin_pad;
+                    float w = 0.0f;
+                    if (co < U && tap < 5 && ci < csub) w = W[((size_t)co * cin_total + c_off + ci) * 5 + tap] * scale;
+                    const uint16_t hi = f2h(w), lo = f2h(w - h2f(hi));
+                    const size_t base = ((size_t)(sl * CT + ct) * 2) * 512 + (size_t)lane * 8 + j;
+                    dst[base] = hi;
+                    dst[base + 512] = lo;
+                }
+}
+
+size_t dense_stack_bytes(const LayoutH& lo, int n_layer) {
+    size_t b = 0;
+    for (int l = 0; l < n_layer; ++l) b += (size_t)lo.l0b + (size_t)l * lo.midb + lo.tailb;
+    return b + (size_t)8 * lo.CP * 4 + 32;
+}
+
+// canonical dense stack -> per layer: input-part fragments | l x panel-part fragments | bias * 2^S | 2^-S; then the Linear head
+size_t pack_stack_h_dense(const float* src, const LayoutH& lo, int n_layer, int cin0, int nout, char* dst) {
+    const float* s = src;
+    char* d = dst;
+    for (int l = 0; l < n_layer; ++l) {
+        const int cin = cin0 + l * lo.U;
+        const size_t nw = (size_t)lo.U * cin * 5;
+        const float scale = pow2_scale(max_abs(s, nw)), inv = 1.0f / scale;
+        pack_conv_part_h(s, lo.U, cin, 0, cin0, 8, 2, lo.CT, scale, reinterpret_cast<uint16_t*>(d));
+        d += lo.l0b;
+        for (int k = 0; k < l; ++k) {
+            pack_conv_part_h(s, lo.U, cin, cin0 + k * lo.U, lo.U, lo.U, lo.nsl_mid, lo.CT, scale, reinterpret_cast<uint16_t*>(d));
+            d += lo.midb;
+        }
+        const float* b = s + nw;
+        float* t = reinterpret_cast<float*>(d);
+        for (int c = 0; c < lo.CP; ++c) t[c] = c < lo.U ? b[c] * scale : 0.0f;
+        for (int c = 0; c < 4; ++c) t[lo.CP + c] = inv;
+        d += lo.tailb;
+        s = b + lo.U;
+    }
+    float* t = reinterpret_cast<float*>(d);
+    for (int f = 0; f < 8; ++f)
+        for (int c = 0; c < lo.CP; ++c) t[f * lo.CP + c] = (f < nout && c < lo.U) ? s[(size_t)f * lo.U + c] : 0.0f;
+    t += 8 * lo.CP;
+    s += (size_t)nout * lo.U;
+    for (int f = 0; f < 8; ++f) t[f] = f < nout ? s[f] : 0.0f;
+    s += nout;
+    return (size_t)(s - src);
 }
 
 // ---- GRU decoder packing (kernel-side layout: turboae_gru.hip) ------------------------------------------
@@ -417,21 +491,6 @@ inline void put_split(char* dst, size_t hi_off, size_t lo_off, float w) {
     memcpy(dst + hi_off, &hi, 2);
     memcpy(dst + lo_off, &lo, 2);
 }
-inline float pow2_scale(float maxabs) {       // power of two that brings maxabs into [2^13, 2^14)
-    if (!(maxabs > 0.0f) || !std::isfinite(maxabs)) return 1.0f;
-    int e = 0;
-    (void)frexpf(maxabs, &e);
-    int S = 14 - e;
-    if (S > 60) S = 60;
-    if (S < -60) S = -60;
-    return ldexpf(1.0f, S);
-}
-inline float max_abs(const float* p, size_t n) {
-    float m = 0.0f;
-    for (size_t i = 0; i < n; ++i) m = fmaxf(m, fabsf(p[i]));
-    return m;
-}
-
 // W_hh (3H,H) [+ layer-0 W_ih (3H,cin)] -> per gate tile: 3 slabs x (hi | lo) x [lane][8 halves], then the K = 16 remainder
 // (hi | lo) x [lane][4 halves]: k0 = unit 96 + kq, k1..3 = stack inputs 3kq .. 3kq+2 (layer 0)
 void pack_gru_rec_h(const float* Whh, const float* Wih0, int cin, float scale, char* dst) {
@@ -547,7 +606,7 @@ size_t num_weights(const tae_config* c) {
     size_t n = 0;
     for (int s = 0; s < 3; ++s) {
         if (c->enc_type == 1) { n += rnn_stack_floats(U, 1, 1); continue; }
-        for (int l = 0; l < c->enc_num_layer; ++l) n += U * (l == 0 ? 1 : U) * 5 + U;
+        for (int l = 0; l < c->enc_num_layer; ++l) n += U * (c->dense ? 1 + l * U : (l == 0 ? 1 : U)) * 5 + U;
         n += U + 1;
     }
     for (int it = 0; it < c->num_iteration; ++it)
@@ -556,7 +615,7 @@ size_t num_weights(const tae_config* c) {
             if (c->dec_type == 1) {
                 n += rnn_stack_floats(U, 2 + F, nout);
             } else {
-                for (int l = 0; l < c->dec_num_layer; ++l) n += U * (l == 0 ? 2 + F : U) * 5 + U;
+                for (int l = 0; l < c->dec_num_layer; ++l) n += U * (c->dense ? 2 + F + l * U : (l == 0 ? 2 + F : U)) * 5 + U;
                 n += nout * U + nout;
             }
         }
@@ -573,9 +632,19 @@ int choose_nb(int U, int L, int* lds_out) {
 }
 
 // Segment geometry of the long-block path: T centre positions + 2*H halo positions <= max positions.
-bool choose_seg(int U, int L, int n_layer, int* T, int* nseg, int* lds) {
+bool choose_seg(int U, int L, int n_layer, int* T, int* nseg, int* lds, bool dense = false) {
     const int H = 2 * n_layer;
     int tmax = tae::fused_max_positions() - 2 * H - 3;    // 3 alignment rows: panel origin floored to a multiple of 4
+    if (dense) {
+        // every earlier layer's output stays resident (n_layer - 1 panels): a segment is one position group (5 tiles) at most
+        tmax = 80 - 2 * H - 3;
+        while (tmax >= 8 && tae::seg_lds_bytes_h_dense(U, tmax, n_layer) > 160 * 1024) tmax -= 4;
+        if (tmax < 8) return false;
+        *nseg = (L + tmax - 1) / tmax;
+        *T = (L + *nseg - 1) / *nseg;
+        *lds = tae::seg_lds_bytes_h_dense(U, *T, n_layer);
+        return true;
+    }
     while (tmax >= 16 && tae::seg_lds_bytes(U, tmax, n_layer) > 160 * 1024) tmax -= 16;
     if (tmax < 16) return false;
     const char* cap = getenv("TAE_SEG_T");
@@ -632,6 +701,7 @@ tae::SegParams seg_params(const tae_handle* h, int32_t B) {
     P.extrinsic = h->cfg.extrinsic;
     P.act = h->cfg.enc_act;
     P.super = h->super;
+    P.dense = h->cfg.dense;
     return P;
 }
 
@@ -909,10 +979,11 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     // when whole blocks fit; TAE_SEG_T=<n> caps the centre length of a segment.
     const char* force_seg = getenv("TAE_FORCE_SEGMENTED");
     if (force_seg && force_seg[0] == '1') h->nb = 0;
+    if (cfg->dense) h->nb = 0;            // dense stacks run on the long-block kernels (one stack per launch)
     if (h->nb < 1) {
         h->nb = 0;
-        if (!choose_seg(h->U, cfg->block_len, cfg->enc_num_layer, &h->enc_T, &h->enc_nseg, &h->enc_lds) ||
-            !choose_seg(h->U, cfg->block_len, cfg->dec_num_layer, &h->dec_T, &h->dec_nseg, &h->dec_lds)) {
+        if (!choose_seg(h->U, cfg->block_len, cfg->enc_num_layer, &h->enc_T, &h->enc_nseg, &h->enc_lds, cfg->dense != 0) ||
+            !choose_seg(h->U, cfg->block_len, cfg->dec_num_layer, &h->dec_T, &h->dec_nseg, &h->dec_lds, cfg->dense != 0)) {
             delete h;
             return fail(TAE_EINVAL, "too many conv layers for the segmented long-block kernels (halo exceeds the panel)");
         }
@@ -927,10 +998,11 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     h->enc_bytes = (uint32_t)(penc.size() * sizeof(float));
     h->dec_bytes = (uint32_t)(pdec.size() * sizeof(float));
     const float* src = weights;
-    if (cfg->enc_type == 1) src += 3 * rnn_stack_floats(100, 1, 1);       // ENC_interRNN: packed with the GRU kernels' layouts below
+    if (cfg->dense) src = weights + n_weights;                             // dense stacks: f16x2 packing only (below)
+    else if (cfg->enc_type == 1) src += 3 * rnn_stack_floats(100, 1, 1);   // ENC_interRNN: packed with the GRU kernels' layouts below
     else for (int s = 0; s < 3; ++s) src += pack_stack(src, lo, cfg->enc_num_layer, 1, 1, penc.data() + (size_t)s * h->enc_stride);
     const float* dec_src = src;
-    if (cfg->dec_type == 1) {
+    if (cfg->dec_type == 1 || cfg->dense) {
         src = weights + n_weights;          // canonical GRU weights are uploaded unchanged below
     } else {
         for (int it = 0; it < cfg->num_iteration; ++it)
@@ -959,7 +1031,28 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         h->dec_lds_h = tae::seg_lds_bytes_h(h->U, h->dec_T, cfg->dec_num_layer);
         h2_ok = h->enc_lds_h <= 160 * 1024 && h->dec_lds_h <= 160 * 1024;
     }
-    if (h2_ok) {
+    if (cfg->dense) {
+        if (!want_h2) { delete h; return fail(TAE_EINVAL, "DenseSameShapeConv1d stacks run on the fp16-split kernels only (TAE_PRECISION=f32 given)"); }
+        // the dense geometry of choose_seg already is the f16x2 one
+        h->enc_lds_h = h->enc_lds;
+        h->dec_lds_h = h->dec_lds;
+        h->prec = 1;
+        const LayoutH lh(h->U);
+        h->enc_stride_h = (uint32_t)dense_stack_bytes(lh, cfg->enc_num_layer);
+        h->dec_stride_h = (uint32_t)dense_stack_bytes(lh, cfg->dec_num_layer);
+        penc_h.assign((size_t)3 * h->enc_stride_h, 0);
+        pdec_h.assign((size_t)2 * cfg->num_iteration * h->dec_stride_h, 0);
+        h->enc_bytes_h = (uint32_t)penc_h.size();
+        h->dec_bytes_h = (uint32_t)pdec_h.size();
+        const float* s2 = weights;
+        for (int s = 0; s < 3; ++s) s2 += pack_stack_h_dense(s2, lh, cfg->enc_num_layer, 1, 1, penc_h.data() + (size_t)s * h->enc_stride_h);
+        for (int it = 0; it < cfg->num_iteration; ++it)
+            for (int half = 0; half < 2; ++half) {
+                const int nout = (half == 1 && it == cfg->num_iteration - 1) ? 1 : F;
+                s2 += pack_stack_h_dense(s2, lh, cfg->dec_num_layer, 2 + F, nout, pdec_h.data() + (size_t)(2 * it + half) * h->dec_stride_h);
+            }
+        if ((size_t)(s2 - weights) != n_weights) { delete h; return fail(TAE_EINVAL, "internal: dense weight walk mismatch"); }
+    } else if (h2_ok) {
         h->prec = 1;
         const LayoutH lh(h->U);
         h->enc_stride_h = (uint32_t)lh.stack_bytes(cfg->enc_num_layer);

@@ -54,6 +54,7 @@ struct XPlane {
 
 struct PanelsH {
     int dump;        // write-only row after the slack row (index rows + 1): where padding lanes / padding channels store
+    uint32_t panel_bytes;   // dense stacks: bytes between consecutive layer panels (hi plane | lo plane); AH / AL = panel 0
     char* AH;
     char* AL;
     XPlane XA, XB;
@@ -271,6 +272,142 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
     __syncthreads();
 }
 
+// DenseSameShapeConv1d stack (cnn_utils.py:49-82) + Linear head: layer l convolves cat(inputs, out_0 .. out_{l-1}).  The
+// contraction over that concatenation is the sum of one first-layer-style K loop over the input planes and l
+// mid-layer-style K loops over the panels of the earlier outputs, all into the same accumulators; layer l's ELU output
+// goes to its own panel l (never in place: one barrier per layer).  Packed layer l: input-part fragments (2 slabs) |
+// l x panel-part fragments (NSL_MID slabs each) | bias * 2^S | 2^-S.  `active` = this wave's position group has live
+// tiles (small dense panels fill one group; the others only keep the barriers company).
+template <int U, int PT, int C0, int NC, class Epi>
+__device__ __forceinline__ void run_stack_h_dense(const char* __restrict__ wpack, uint32_t soff, int n_layer, char* smem,
+                                                  const PanelsH& pn, const XPlane& xin, const TileH<PT>& tc, int g, int lane,
+                                                  WeightStreamH<U, C0, NC>& ws, float& vmax, bool active, Epi epi) {
+    using G = GeoH<U>;
+    constexpr int CTT = G::CT;
+    const int q = lane >> 4;
+    const int dump_row = pn.dump;
+    f32x4 acc[PT][NC];
+    uint32_t lo = soff;
+    float inv_scale = 1.0f;
+    for (int l = 0; l < n_layer; ++l) {
+        const uint32_t tail = lo + G::L0B + (uint32_t)l * G::MIDB;
+        if (active) {
+            const float* bias = reinterpret_cast<const float*>(wpack + tail);
+            inv_scale = bias[G::CP];
+            f32x4 b4[NC];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) b4[i] = *reinterpret_cast<const f32x4*>(bias + (C0 + i) * 16 + 4 * q);
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+#pragma unroll
+                for (int i = 0; i < NC; ++i) acc[p][i] = b4[i];
+            uint32_t bh[PT], bl[PT];
+            {   // the stack inputs (2 + F or 1 channels, 8 halves per row)
+                const uint32_t ph = (uint32_t)(xin.h - smem), pl = (uint32_t)(xin.l - smem);
+#pragma unroll
+                for (int p = 0; p < PT; ++p) {
+                    const uint32_t o = (uint32_t)(tc.row(p) - 2) * kXRowB + 16u * q;
+                    bh[p] = ph + o;
+                    bl[p] = pl + o;
+                }
+                ws.prefetch(lo);
+                conv_accumulate_h<CTT, C0, NC, PT, G::NSL_L0>(acc, ws.a, ws.rsrc, ws.voff, lo, smem, bh, bl);
+            }
+            for (int k = 0; k < l; ++k) {          // the outputs of layers 0 .. l-1
+                const uint32_t ph = (uint32_t)(pn.AH - smem) + (uint32_t)k * pn.panel_bytes, pl = ph + (uint32_t)(pn.AL - pn.AH);
+#pragma unroll
+                for (int p = 0; p < PT; ++p) {
+                    const uint32_t o = (uint32_t)(tc.row(p) - 2) * (uint32_t)(U * 2) + 16u * q;
+                    bh[p] = ph + o;
+                    bl[p] = pl + o;
+                }
+                const uint32_t wo = lo + G::L0B + (uint32_t)k * G::MIDB;
+                ws.prefetch(wo);
+                conv_accumulate_h<CTT, C0, NC, PT, G::NSL_MID>(acc, ws.a, ws.rsrc, ws.voff, wo, smem, bh, bl);
+            }
+        }
+        lo = tail + G::TAILB;
+        if (l + 1 < n_layer) {
+            if (active) {
+                char* PH = pn.AH + (size_t)l * pn.panel_bytes;
+                char* PL = PH + (pn.AL - pn.AH);
+#pragma unroll
+                for (int p = 0; p < PT; ++p) {
+                    const int wrow = tc.row(p);
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) {
+                        h4 hi, lw;
+                        elu_split4(acc[p][i], inv_scale, vmax, hi, lw);
+                        const int ch = (C0 + i) * 16 + 4 * q;
+                        const bool inb = (((C0 + i) * 16 + 16 <= U) || (ch < U)) && tc.ok(p);
+                        const int off = inb ? (wrow * U + ch) * 2 : (dump_row * U + 4 * q) * 2;
+                        *reinterpret_cast<h4*>(PH + off) = hi;
+                        *reinterpret_cast<h4*>(PL + off) = lw;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- Linear head (as run_stack_h)
+    const float* wl = reinterpret_cast<const float*>(wpack + lo);
+    float k2[PT][2];
+    if (active) {
+        float part[PT][8];
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int f = 0; f < 8; ++f) part[p][f] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            f32x4 w4[8];
+#pragma unroll
+            for (int f = 0; f < 8; ++f) w4[f] = *reinterpret_cast<const f32x4*>(wl + f * G::CP + (C0 + i) * 16 + 4 * q);
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                f32x4 v = acc[p][i] * inv_scale;
+                v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
+#pragma unroll
+                for (int f = 0; f < 8; ++f) {
+                    float s = part[p][f];
+                    s = fmaf(v.x, w4[f].x, s); s = fmaf(v.y, w4[f].y, s);
+                    s = fmaf(v.z, w4[f].z, s); s = fmaf(v.w, w4[f].w, s);
+                    part[p][f] = s;
+                }
+            }
+        }
+        const bool hi32 = (q & 2) != 0, hi16 = (q & 1) != 0;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) butterfly8(part[p], hi32, hi16, k2[p]);
+    }
+    const int n = lane & 15;
+    float* HS = pn.HS;
+    if constexpr (C0 != 0) {
+        if (active) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+                *reinterpret_cast<float2*>(HS + ((g + p) * 16 + n) * 8 + 2 * q) = float2{k2[p][0], k2[p][1]};
+        }
+    }
+    __syncthreads();
+    if constexpr (C0 == 0) {
+        if (active) {
+            const float* lb = wl + 8 * G::CP;
+            const float bq0 = lb[2 * q], bq1 = lb[2 * q + 1];
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                float2 other = float2{0.0f, 0.0f};
+                if constexpr (NC < CTT) other = *reinterpret_cast<const float2*>(HS + ((g + p) * 16 + n) * 8 + 2 * q);
+                if (tc.own(p)) {
+                    epi(p, 2 * q, (k2[p][0] + other.x) + bq0);
+                    epi(p, 2 * q + 1, (k2[p][1] + other.y) + bq1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ void report_range(float vmax, uint32_t* flags) {
     if (flags != nullptr && !(vmax <= kH2Limit)) atomicOr(flags, 1u);     // also catches NaN
 }
@@ -446,21 +583,25 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
 // Long blocks (block_len > 320): one stack per launch over (block, segment) workgroups with halo recompute -
 // the f16x2 twin of seg_kernel in turboae_kernels.hip (same segment geometry, same exchange buffers; the
 // fp32 extrinsic values are split into halves when they are staged into the X planes).
-template <int U, int PT, int C0, int NC>
+template <int U, int PT, int C0, int NC, bool DENSE>
 __device__ __forceinline__ void seg_body_h(const SegParams& P, char* smem, const PanelsH& pn, const TileH<PT>& tc, int g, int lane,
-                                           int stack, int b, int tstart, double& sum, double& sumsq) {
+                                           int stack, int b, int tstart, bool active, double& sum, double& sumsq) {
     const int L = P.L;
     const char* wpack = reinterpret_cast<const char*>(P.wpack);
     WeightStreamH<U, C0, NC> ws;
     ws.init(wpack, P.wpack_bytes, lane);
     const uint32_t soff = (uint32_t)stack * P.stack_stride;
-    ws.prefetch(soff);
+    if (!DENSE) ws.prefetch(soff);
     const XPlane X = pn.XA;
     float vmax = 0.0f;
+    auto run = [&](auto epi) {
+        if constexpr (DENSE) run_stack_h_dense<U, PT, C0, NC>(wpack, soff, P.n_layer, smem, pn, X, tc, g, lane, ws, vmax, active, epi);
+        else run_stack_h<U, PT, C0, NC>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, vmax, epi);
+    };
     if (P.mode == 0) {
         const bool act_elu = P.act == 0;
         float* xtx = P.out + (size_t)b * L * 3;
-        run_stack_h<U, PT, C0, NC>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, vmax, [&](int p, int f, float v) {
+        run([&](int p, int f, float v) {
             if (f == 0) {
                 if (act_elu) v = elu1(v);
                 xtx[(size_t)(tstart + tc.m0 + 16 * p) * 3 + stack] = v;
@@ -472,7 +613,7 @@ __device__ __forceinline__ void seg_body_h(const SegParams& P, char* smem, const
         const int F = P.F;
         const bool extrinsic = P.extrinsic != 0;
         float* ecur = P.ecur + (size_t)b * L * 8;
-        run_stack_h<U, PT, C0, NC>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, vmax, [&](int p, int f, float v) {
+        run([&](int p, int f, float v) {
             if (f < F) {
                 if (extrinsic) v -= X.read(tc.row(p), 2 + f);
                 vmax = fmaxf(vmax, fabsf(v));
@@ -481,7 +622,7 @@ __device__ __forceinline__ void seg_body_h(const SegParams& P, char* smem, const
         });
     } else {
         float* xdec = P.out + (size_t)b * L;
-        run_stack_h<U, PT, C0, NC>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, vmax, [&](int p, int f, float v) {
+        run([&](int p, int f, float v) {
             if (f == 0) xdec[P.perm[tstart + tc.m0 + 16 * p]] = 1.0f / (1.0f + expf(-v));    // sigmoid(deinterleave), decoders.py:267
         });
     }
@@ -489,13 +630,14 @@ __device__ __forceinline__ void seg_body_h(const SegParams& P, char* smem, const
 }
 
 template <int U>
-__device__ __forceinline__ PanelsH carve_seg_h(char* smem, int rows) {
+__device__ __forceinline__ PanelsH carve_seg_h(char* smem, int rows, int npanel = 1) {
     PanelsH pn;
     pn.dump = rows + 1;
     const size_t ab = (size_t)(rows + 2) * U * 2, xb = (size_t)(rows + 1 + kXSlack) * kXRowB;
     pn.AH = smem;
     pn.AL = pn.AH + ab;
-    pn.XA.h = pn.AL + ab;
+    pn.panel_bytes = (uint32_t)(2 * ab);
+    pn.XA.h = smem + (size_t)npanel * 2 * ab;
     pn.XA.l = pn.XA.h + xb;
     pn.XB = pn.XA;
     pn.PERM = nullptr;
@@ -520,7 +662,7 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
     const int tstart = (s0 - H) - ((s0 - H) & 3);      // same panel origin as the fp32 kernel (floored to a multiple of 4)
     const int NP = s0 + P.T + H - tstart;
     const int rows = P.T + 2 * H + 3 + 4;
-    const PanelsH pn = carve_seg_h<U>(smem, rows);
+    const PanelsH pn = carve_seg_h<U>(smem, rows, P.dense ? (P.n_layer > 1 ? P.n_layer - 1 : 1) : 1);
     const bool odd = (stack & 1) != 0;
 
     zero_lds(smem, P.lds_bytes, tid);
@@ -571,8 +713,14 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
     __syncthreads();
     double sum = 0.0, sumsq = 0.0;
     const bool upper = __builtin_amdgcn_readfirstlane(h) != 0;
-    if (!upper) seg_body_h<U, PT, 0, Split<U>::CTA>(P, smem, pn, tc, g * PT, lane, stack, b, tstart, sum, sumsq);
-    else seg_body_h<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, g * PT, lane, stack, b, tstart, sum, sumsq);
+    if (P.dense) {
+        const bool active = __builtin_amdgcn_readfirstlane((NP + 15) / 16 - g * PT) > 0;      // the group has at least one live tile
+        if (!upper) seg_body_h<U, PT, 0, Split<U>::CTA, true>(P, smem, pn, tc, g * PT, lane, stack, b, tstart, active, sum, sumsq);
+        else seg_body_h<U, PT, Split<U>::CTA, Split<U>::CTB, true>(P, smem, pn, tc, g * PT, lane, stack, b, tstart, active, sum, sumsq);
+    } else {
+        if (!upper) seg_body_h<U, PT, 0, Split<U>::CTA, false>(P, smem, pn, tc, g * PT, lane, stack, b, tstart, true, sum, sumsq);
+        else seg_body_h<U, PT, Split<U>::CTA, Split<U>::CTB, false>(P, smem, pn, tc, g * PT, lane, stack, b, tstart, true, sum, sumsq);
+    }
     if (P.mode == 0) block_reduce_stats(smem, tid, sum, sumsq, P.partials);
 }
 
@@ -621,6 +769,16 @@ hipError_t launch_seg_h(int U, const SegParams& P, int grid, hipStream_t st) {
 int seg_lds_bytes_h(int U, int T, int n_layer) {
     const int rows = T + 4 * n_layer + 3 + 4;
     size_t b = 2 * (size_t)(rows + 2) * U * 2 + 2 * (size_t)(rows + 1 + kXSlack) * kXRowB + (size_t)kHeadSlots * 4;
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)kHeadSlots * 8 * 4;
+    if (b < 2 * kThreads * sizeof(double)) b = 2 * kThreads * sizeof(double);
+    return (int)b;
+}
+
+int seg_lds_bytes_h_dense(int U, int T, int n_layer) {
+    const int rows = T + 4 * n_layer + 3 + 4;
+    const int npanel = n_layer > 1 ? n_layer - 1 : 1;
+    size_t b = (size_t)npanel * 2 * (size_t)(rows + 2) * U * 2 + 2 * (size_t)(rows + 1 + kXSlack) * kXRowB + (size_t)kHeadSlots * 4;
     b = (b + 15) & ~(size_t)15;
     b += (size_t)kHeadSlots * 8 * 4;
     if (b < 2 * kThreads * sizeof(double)) b = 2 * kThreads * sizeof(double);

@@ -48,6 +48,7 @@ struct SegParams {
     int32_t lds_bytes;
     int32_t super;
     uint32_t* flags;        // f16x2 kernels: range flag (stack_stride is in BYTES there)
+    int32_t dense;          // 1: DenseSameShapeConv1d stacks (cnn_utils.py:49-82), f16x2 long-block kernels only
 };
 
 // ---- GRU decoder (turboae_gru.hip)
@@ -98,6 +99,7 @@ hipError_t launch_fused_h(int U, bool decoder, const FusedParams& P, int grid, h
 int fused_lds_bytes_h(int U, int L, int nb);
 hipError_t launch_seg_h(int U, const SegParams& P, int grid, hipStream_t st);
 int seg_lds_bytes_h(int U, int T, int n_layer);
+int seg_lds_bytes_h_dense(int U, int T, int n_layer);
 hipError_t launch_reduce_partials(const double* partials, int n, double count, double* stats, hipStream_t st);
 struct NormOpts {          // device-side view of tae_channel_opts
     int32_t norm_mode; float mean, std;

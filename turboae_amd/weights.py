@@ -41,6 +41,8 @@ def canonical_entries(cfg: TurboAEConfig) -> List[Tuple[str, Tuple[int, ...]]]:
             continue
         for l in range(cfg.enc_num_layer):
             cin = cfg.code_rate_k if l == 0 else ue
+            if cfg.dense:       # DenseSameShapeConv1d: layer l sees the inputs and every earlier layer's output (cnn_utils.py:59-62)
+                cin = cfg.code_rate_k + l * ue
             out.append((f"enc.enc_cnn_{s}.cnns.{l}.weight", (ue, cin, ke)))
             out.append((f"enc.enc_cnn_{s}.cnns.{l}.bias", (ue,)))
         out.append((f"enc.enc_linear_{s}.weight", (1, ue)))
@@ -63,6 +65,8 @@ def canonical_entries(cfg: TurboAEConfig) -> List[Tuple[str, Tuple[int, ...]]]:
             else:
                 for l in range(cfg.dec_num_layer):
                     cin = 2 + f if l == 0 else ud
+                    if cfg.dense:
+                        cin = 2 + f + l * ud
                     out.append((f"dec.dec{half}_cnns.{it}.cnns.{l}.weight", (ud, cin, kd)))
                     out.append((f"dec.dec{half}_cnns.{it}.cnns.{l}.bias", (ud,)))
                 out.append((f"dec.dec{half}_outputs.{it}.weight", (nout, ud)))
