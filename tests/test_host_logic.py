@@ -98,3 +98,27 @@ def test_config_validation():
         TurboAEConfig(enc_num_unit=48, dec_num_unit=48).validate()
     with pytest.raises(ValueError):
         TurboAEConfig(code_rate_n=2).validate()
+
+
+def test_variant_configs_and_param_counts():
+    # GRU decoder: SURVEY.md section 8f-3 measured 2 970 456 parameters for DEC_LargeRNN
+    rnn = TurboAEConfig(decoder="TurboAE_rate3_rnn")
+    assert sum(int(np.prod(s)) for k, s in W.canonical_entries(rnn) if k.startswith("dec.")) == 2970456
+    # GRU encoder needs the GRU decoder; dense stacks need the fp16-split kernels and are keyed on the ENCODER name
+    TurboAEConfig(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn").validate()
+    with pytest.raises(ValueError):
+        TurboAEConfig(encoder="TurboAE_rate3_rnn").validate()
+    dense = TurboAEConfig(encoder="TurboAE_rate3_cnn_dense", decoder="TurboAE_rate3_cnn_dense")
+    dense.validate()
+    assert dense.dense and not TurboAEConfig().dense
+    with pytest.raises(ValueError):
+        TurboAEConfig(encoder="TurboAE_rate3_cnn_dense", precision="f32").validate()
+    with pytest.raises(ValueError):
+        TurboAEConfig(decoder="TurboAE_rate3_cnn_dense").validate()
+    shapes = dict(W.canonical_entries(dense))
+    assert shapes["dec.dec1_cnns.0.cnns.4.weight"] == (100, 7 + 400, 5)        # cnn_utils.py:59-62: in_channels + idx * out_channels
+    assert shapes["enc.enc_cnn_3.cnns.1.weight"] == (100, 1 + 100, 5)
+    assert dense.macs_per_bit()["dec"] > 2 * TurboAEConfig().macs_per_bit()["dec"]
+    with pytest.raises(ValueError):
+        TurboAEConfig(channel="nope").validate()
+    TurboAEConfig(channel="fading").validate()
