@@ -30,8 +30,12 @@ def run_both(cfg, sd, u, noise, dev):
     return xd.cpu().numpy(), codes.cpu().numpy(), xo.numpy(), co.numpy(), taps
 
 
+@pytest.mark.parametrize("fixed_nb", ["1", "0"])
 @pytest.mark.parametrize("B", [1, 2, 3, 7, 16])
-def test_forward_matches_oracle_u100(gpu_device, B):
+def test_forward_matches_oracle_u100(gpu_device, monkeypatch, B, fixed_nb):
+    # TAE_FIXED_NB=1: always the fullest workgroups (3 blocks each); 0: blocks per workgroup picked per call
+    # (small batches: 1 block each)
+    monkeypatch.setenv("TAE_FIXED_NB", fixed_nb)
     cfg = TurboAEConfig()
     sd = W.generate_state_dict(cfg, seed=7, gain=1.0)
     u, noise = make_inputs(B, cfg.block_len)
@@ -44,8 +48,10 @@ def test_forward_matches_oracle_u100(gpu_device, B):
     assert np.all(np.abs(taps["logits"].numpy()[flips]) < 1e-4)
 
 
+@pytest.mark.parametrize("fixed_nb", ["1", "0"])
 @pytest.mark.parametrize("U,L,nl_enc,nl_dec,iters", [(32, 100, 2, 5, 6), (64, 40, 1, 2, 2), (32, 64, 3, 1, 1), (100, 150, 5, 5, 2)])
-def test_forward_matches_oracle_shapes(gpu_device, U, L, nl_enc, nl_dec, iters):
+def test_forward_matches_oracle_shapes(gpu_device, monkeypatch, U, L, nl_enc, nl_dec, iters, fixed_nb):
+    monkeypatch.setenv("TAE_FIXED_NB", fixed_nb)
     cfg = TurboAEConfig(block_len=L, enc_num_unit=U, dec_num_unit=U, enc_num_layer=nl_enc, dec_num_layer=nl_dec,
                         num_iteration=iters)
     sd = W.generate_state_dict(cfg, seed=3, gain=1.0)

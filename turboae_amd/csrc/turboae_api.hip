@@ -226,6 +226,8 @@ struct tae_handle {
     tae_config cfg;
     int device = 0;
     int U = 0, nb = 0, lds_bytes = 0;
+    int ncu = 256;           // compute units of the device (workgroups resident at once: one per CU)
+    bool fixed_nb = false;   // TAE_FIXED_NB=1: always nb blocks per workgroup (testing knob)
     // long-block (segmented) path, used when a whole block does not fit one workgroup (nb == 0)
     int enc_T = 0, enc_nseg = 0, enc_lds = 0, dec_T = 0, dec_nseg = 0, dec_lds = 0;
     uint32_t enc_stride = 0, dec_stride = 0;
@@ -655,6 +657,27 @@ bool choose_seg(int U, int L, int n_layer, int* T, int* nseg, int* lds, bool den
     return true;
 }
 
+// Blocks per workgroup for one call of the whole-block f16x2 kernels.  One workgroup is resident per CU and its time
+// is set by the most loaded of its 4 position groups (group_span in turboae_h2.hip): measured on MI355X, about
+// 0.33 + 0.135 * tiles (ms per decoder workgroup: 2 tiles 0.60, 5 tiles 1.00), i.e. proportional to 5 + 2 * tiles.
+// A large batch wants the fullest workgroups (3 blocks of 100 -> 5 tiles per group); a batch that would leave CUs
+// idle is cheaper spread thinner (500 blocks: 250 workgroups x 4 tiles instead of 167 x 5; <= 256 blocks: one block
+// per workgroup, 2 tiles).  Results do not depend on the choice (blocks never see each other).
+int nb_for_batch(const tae_handle* h, int32_t B) {
+    if (h->fixed_nb || h->prec != 1) return h->nb;
+    const int L = h->cfg.block_len;
+    int best = h->nb;
+    long best_cost = -1;
+    for (int nb = h->nb; nb >= 1; --nb) {              // ties keep the larger nb (fewer passes over the weights)
+        const long grid = ((long)B + nb - 1) / nb;
+        const long rounds = (grid + h->ncu - 1) / h->ncu;
+        const long ntile = ((long)nb * L + 15) / 16;
+        const long cost = rounds * (5 + 2 * ((ntile + 3) / 4));
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nb; }
+    }
+    return best;
+}
+
 int check_batch(tae_handle* h, int32_t B) {
     if (!h) return fail(TAE_EINVAL, "handle is NULL");
     if (B < 1) return fail(TAE_EINVAL, "batch must be >= 1");
@@ -777,12 +800,13 @@ int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_
     P.n_layer = h->cfg.enc_num_layer;
     P.stack_stride = h->enc_stride;
     P.wpack_bytes = h->enc_bytes;
-    const int grid = (B + h->nb - 1) / h->nb;
+    P.nb = nb_for_batch(h, B);
+    const int grid = (B + P.nb - 1) / P.nb;
     if (h->prec == 1) {
         P.wpack = reinterpret_cast<const float*>(h->d_wenc_h);
         P.stack_stride = h->enc_stride_h;
         P.wpack_bytes = h->enc_bytes_h;
-        P.lds_bytes = h->lds_bytes_h;
+        P.lds_bytes = P.nb == h->nb ? h->lds_bytes_h : tae::fused_lds_bytes_h(h->U, h->cfg.block_len, P.nb);
         P.flags = h->d_flags;
         TAE_HIP(tae::launch_fused_h(h->U, false, P, grid, st));
     } else
@@ -928,12 +952,13 @@ int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStrea
     P.n_layer = h->cfg.dec_num_layer;
     P.stack_stride = h->dec_stride;
     P.wpack_bytes = h->dec_bytes;
-    const int grid = (B + h->nb - 1) / h->nb;
+    P.nb = nb_for_batch(h, B);
+    const int grid = (B + P.nb - 1) / P.nb;
     if (h->prec == 1) {
         P.wpack = reinterpret_cast<const float*>(h->d_wdec_h);
         P.stack_stride = h->dec_stride_h;
         P.wpack_bytes = h->dec_bytes_h;
-        P.lds_bytes = h->lds_bytes_h;
+        P.lds_bytes = P.nb == h->nb ? h->lds_bytes_h : tae::fused_lds_bytes_h(h->U, h->cfg.block_len, P.nb);
         P.flags = h->d_flags;
         TAE_HIP(tae::launch_fused_h(h->U, true, P, grid, st));
         return TAE_OK;
@@ -974,6 +999,9 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     h->nopts = default_norm_opts();
     h->U = cfg->enc_num_unit;
     (void)hipGetDevice(&h->device);
+    if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || h->ncu < 1) h->ncu = 256;
+    const char* fixed_nb = getenv("TAE_FIXED_NB");
+    h->fixed_nb = fixed_nb && fixed_nb[0] == '1';
     h->nb = choose_nb(h->U, cfg->block_len, &h->lds_bytes);
     // Testing knobs (documented in DESIGN.md): TAE_FORCE_SEGMENTED=1 selects the long-block path even
     // when whole blocks fit; TAE_SEG_T=<n> caps the centre length of a segment.
@@ -1155,7 +1183,7 @@ int tae_reserve(tae_handle* h, int32_t max_batch) {
     (void)hipFree(h->d_xtx); (void)hipFree(h->d_rx); (void)hipFree(h->d_partials); (void)hipFree(h->d_e0); (void)hipFree(h->d_e1);
     h->d_xtx = h->d_rx = h->d_e0 = h->d_e1 = nullptr; h->d_partials = nullptr; h->cap = 0;
     const size_t n3 = (size_t)max_batch * h->cfg.block_len * 3;
-    const size_t grid = h->nb >= 1 ? ((size_t)max_batch + h->nb - 1) / h->nb : (size_t)3 * max_batch * h->enc_nseg;
+    const size_t grid = h->nb >= 1 ? (size_t)max_batch : (size_t)3 * max_batch * h->enc_nseg;   // workgroups of the encoder at most (nb_for_batch may pick 1 block each)
     if (h->nb < 1) {
         const size_t n8 = (size_t)max_batch * h->cfg.block_len * 8;
         TAE_HIP(hipMalloc(&h->d_e0, n8 * sizeof(float)));

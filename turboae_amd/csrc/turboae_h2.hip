@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include "turboae_internal.hpp"
 #include "turboae_device.hpp"
+#include <type_traits>
 
 namespace tae {
 
@@ -106,9 +107,31 @@ struct TileH {
 
 // Padding lanes (positions past the workgroup's blocks) compute on row 2 and store to the write-only dump row, so
 // the epilogue needs no per-tile branches.
-// `gt0` = first position tile of the wave's group (groups are kGroupTiles apart; a wave may walk fewer tiles, PT, when
-// the last ones hold no block at all).
-constexpr int kGroupTiles = 5;
+// `gt0` = first position tile of the wave's group; a group walks PT <= 5 tiles.
+
+// Even deal of the workgroup's ceil(npos / 16) position tiles over the kGroups position groups (wave-uniform).
+struct GroupSpan { int gt0, live; };
+__device__ __forceinline__ GroupSpan group_span(int npos, int g) {
+    const int ntile = (npos + 15) / 16;
+    const int base = ntile / kGroups, rem = ntile - base * kGroups;
+    GroupSpan s;
+    s.gt0 = __builtin_amdgcn_readfirstlane(g * base + min(g, rem));
+    s.live = __builtin_amdgcn_readfirstlane(base + (g < rem ? 1 : 0));
+    return s;
+}
+
+// Calls f(integral_constant<PT'>) with PT' = clamp(live, 1, PTMAX): one code path per tile count (a group without
+// any tile still walks one all-padding tile: it has to meet the others at the per-layer barriers).
+template <int PTMAX, class F>
+__device__ __forceinline__ void dispatch_tiles(int live, F&& f) {
+    static_assert(PTMAX == 5, "tile-count dispatch is written for 5 tiles per group at most");
+    if (live >= 5) f(std::integral_constant<int, 5>{});
+    else if (live == 4) f(std::integral_constant<int, 4>{});
+    else if (live == 3) f(std::integral_constant<int, 3>{});
+    else if (live == 2) f(std::integral_constant<int, 2>{});
+    else f(std::integral_constant<int, 1>{});
+}
+
 template <int PT>
 __device__ __forceinline__ void make_tiles_h(TileH<PT>& tc, int* rowtab, int gt0, int lane, int L, int npos) {
     const int n = lane & 15;
@@ -483,24 +506,21 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
     report_range(vmax, P.flags);
     __syncthreads();
 
-    // Position tiles that hold no block are not computed: with 3 blocks of 100 the last group walks 4 tiles instead of 5
-    // (-5 % MFMAs; the kernel is power-limited, so fewer MFMAs pay back even off the critical path).
-    const int gt0 = g * kGroupTiles;
-    const int live = __builtin_amdgcn_readfirstlane((npos + 15) / 16 - gt0);
+    // The workgroup's position tiles are dealt out evenly over the 4 position groups and a group walks only its own
+    // tiles (3 blocks of 100 = 19 tiles -> 5, 5, 5, 4; 2 blocks -> 4, 3, 3, 3; 1 block -> 2, 2, 2, 1): tiles that hold no
+    // block are never computed, and a small batch can be spread over more workgroups at a lower cost each (the host
+    // picks blocks per workgroup per call, choose_nb_for_batch in turboae_api.hip).
+    const GroupSpan gs = group_span(npos, g);
     const bool upper = __builtin_amdgcn_readfirstlane(h) != 0;
-    if (PT == kGroupTiles && live == PT - 1) {
-        TileH<PT - 1> tc;
-        make_tiles_h<PT - 1>(tc, pn.ROWT, gt0, lane, L, npos);
+    auto run = [&](auto pt) {
+        constexpr int T = decltype(pt)::value;
+        TileH<T> tc;
+        make_tiles_h<T>(tc, pn.ROWT, gs.gt0, lane, L, npos);
         __syncthreads();
-        if (!upper) dec_body_h<U, PT - 1, 0, Split<U>::CTA>(P, smem, pn, tc, gt0, lane, blk0);
-        else dec_body_h<U, PT - 1, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, gt0, lane, blk0);
-        return;
-    }
-    TileH<PT> tc;
-    make_tiles_h<PT>(tc, pn.ROWT, gt0, lane, L, npos);
-    __syncthreads();
-    if (!upper) dec_body_h<U, PT, 0, Split<U>::CTA>(P, smem, pn, tc, gt0, lane, blk0);
-    else dec_body_h<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, gt0, lane, blk0);
+        if (!upper) dec_body_h<U, T, 0, Split<U>::CTA>(P, smem, pn, tc, gs.gt0, lane, blk0);
+        else dec_body_h<U, T, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, gs.gt0, lane, blk0);
+    };
+    dispatch_tiles<PT>(gs.live, run);
 }
 
 // =============================================================================================
@@ -559,22 +579,17 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
     __syncthreads();
 
     double sum = 0.0, sumsq = 0.0;
-    const int gt0 = g * kGroupTiles;
-    const int live = __builtin_amdgcn_readfirstlane((npos + 15) / 16 - gt0);
+    const GroupSpan gs = group_span(npos, g);          // see dec_kernel_h
     const bool upper = __builtin_amdgcn_readfirstlane(h) != 0;
-    if (PT == kGroupTiles && live == PT - 1) {          // see dec_kernel_h
-        TileH<PT - 1> tc;
-        make_tiles_h<PT - 1>(tc, pn.ROWT, gt0, lane, L, npos);
+    auto run = [&](auto pt) {
+        constexpr int T = decltype(pt)::value;
+        TileH<T> tc;
+        make_tiles_h<T>(tc, pn.ROWT, gs.gt0, lane, L, npos);
         __syncthreads();
-        if (!upper) enc_body_h<U, PT - 1, 0, Split<U>::CTA>(P, smem, pn, tc, gt0, lane, blk0, sum, sumsq);
-        else enc_body_h<U, PT - 1, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, gt0, lane, blk0, sum, sumsq);
-    } else {
-        TileH<PT> tc;
-        make_tiles_h<PT>(tc, pn.ROWT, gt0, lane, L, npos);
-        __syncthreads();
-        if (!upper) enc_body_h<U, PT, 0, Split<U>::CTA>(P, smem, pn, tc, gt0, lane, blk0, sum, sumsq);
-        else enc_body_h<U, PT, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, gt0, lane, blk0, sum, sumsq);
-    }
+        if (!upper) enc_body_h<U, T, 0, Split<U>::CTA>(P, smem, pn, tc, gs.gt0, lane, blk0, sum, sumsq);
+        else enc_body_h<U, T, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, gs.gt0, lane, blk0, sum, sumsq);
+    };
+    dispatch_tiles<PT>(gs.live, run);
     block_reduce_stats(smem, tid, sum, sumsq, P.partials);
 }
 
@@ -699,7 +714,7 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
         tc.center = 0u;
         tc.m0 = g * PT * 16 + n;
         tc.L = L;
-        tc.rowtab = pn.ROWT + g * PT * 16 + n;      // (all kGroupTiles = PT tiles are walked here)
+        tc.rowtab = pn.ROWT + g * PT * 16 + n;      // (a segment's groups always walk all PT tiles)
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
             const int m = tc.m0 + 16 * p;
