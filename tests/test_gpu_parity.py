@@ -343,6 +343,11 @@ def test_eval_sweep_matches_oracle_on_trained_weights(gpu_device, capsys):
         assert abs(res["block_errors"][si] - ble_tot) <= 1
         assert abs(res["ber"][si] - be_tot / (100.0 * L)) <= 1e-4
     assert res["ber"][0] > res["ber"][1] > 0.0          # BER falls with SNR on the trained model
+    # one decoder call per batch instead of one per group of batches: the same numbers
+    one = evaluate.test(model, snr_test_start=0.0, snr_test_end=2.0, snr_points=2, num_block=100, batch_size=50, seed=77,
+                        verbose=False, decode_group=1)
+    assert one["bit_errors"] == res["bit_errors"] and one["block_errors"] == res["block_errors"]
+    assert one["ber"] == res["ber"] and one["bler"] == res["bler"]
     assert abs(res["enc_power"] - 1.0) < 1e-4
 
 

@@ -11,7 +11,12 @@ encoder-power epilogue (trainer.py:238-248) - with three deliberate differences:
     'no pos BER specified.') is not run;
   * with torch.distributed initialised every batch is sharded over the ranks by block; the
     power-constraint statistics and the error counts are all-reduced (turboae_amd/distributed.py), so
-    the numbers equal the single-GPU ones.
+    the numbers equal the single-GPU ones;
+  * the decoder runs once per GROUP of batches (``decode_group``): encoder, power constraint (per-batch
+    statistics, as in the reference) and channel run batch by batch, the received blocks of the group are
+    decoded in one call and the errors are counted per batch again.  The decoder never mixes blocks
+    (tests/test_gpu_parity.py::test_decoder_is_block_independent_and_batch_ragged), so every number is the
+    same as with one decoder call per batch; a batch of 500 alone cannot fill 256 CUs.
 """
 from __future__ import annotations
 
@@ -33,8 +38,10 @@ def snr_sigma2db(sigma: float) -> float:       # utils.py:72-76
 
 
 def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_points: int = 12, num_block: int = 1000,
-         batch_size: int = 100, seed: int = 20190001, verbose: bool = True, enc_power_epilogue: bool = True) -> Dict[str, List[float]]:
-    """model: turboae_amd.Channel_AE_HIP.  Returns {'snrs', 'ber', 'bler', 'bit_errors', 'block_errors', 'enc_power'}."""
+         batch_size: int = 100, seed: int = 20190001, verbose: bool = True, enc_power_epilogue: bool = True,
+         decode_group: Optional[int] = None) -> Dict[str, List[float]]:
+    """model: turboae_amd.Channel_AE_HIP.  Returns {'snrs', 'ber', 'bler', 'bit_errors', 'block_errors', 'enc_power'}.
+    decode_group: batches decoded per decoder call (None: enough for about 24 576 blocks per rank; 1: one call per batch)."""
     import torch.distributed as dist
     rank, world = 0, 1
     if dist.is_available() and dist.is_initialized():
@@ -51,32 +58,40 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
     lo, hi = shard_bounds(batch_size, rank, world)
     nloc = hi - lo
     dev = model.this_device
+    if decode_group is None:
+        decode_group = max(1, -(-24576 // max(nloc, 1)))
+    decode_group = max(1, min(int(decode_group), max(num_test_batch, 1)))
     ber_res, bler_res, bit_res, blk_res = [], [], [], []
     for si, snr in enumerate(snrs):
         # per-batch (bit errors, block errors) stay on the device; one host read per SNR point
         per_batch = torch.zeros((max(num_test_batch, 1), 2), dtype=torch.int64, device=dev)
-        for batch_idx in range(num_test_batch):
-            first = (si * num_test_batch + batch_idx) * batch_size + lo       # global block index of this shard
-            counts = per_batch[batch_idx]
-            fading = None
+        for g0 in range(0, num_test_batch, decode_group):
+            group_u, group_rx = [], []
+            for batch_idx in range(g0, min(g0 + decode_group, num_test_batch)):
+                first = (si * num_test_batch + batch_idx) * batch_size + lo       # global block index of this shard
+                fading = None
+                if nloc > 0:
+                    u, noise = model.generate_inputs(nloc, snr, seed=seed, first_block=first)
+                    if model.cfg.channel != "awgn":
+                        # other channels: generate_noise restated on the device (turboae_amd/channels.py), one generator per
+                        # (seed, global first block of the shard): shards of any world size draw independent streams
+                        gen = torch.Generator(device=dev)
+                        gen.manual_seed((seed * 1000003 + first) & 0x7FFFFFFFFFFFFFFF)
+                        noise = channels.generate_noise((nloc, L, 3), model.cfg, snr, device=dev, generator=gen)
+                        if model.cfg.channel == "fading":
+                            fading = channels.rayleigh_fading((nloc, L, 3), device=dev, generator=gen)
+                    x_tx, stats = model.encode_prenorm(u)
+                else:
+                    stats = torch.zeros(3, dtype=torch.float64, device=dev)
+                all_reduce_sum_(stats)                                            # batch-global mean/std (encoders.py:107-108)
+                if nloc > 0:
+                    _, rx = model.normalize(x_tx, stats, noise, want_codes=False, fading=fading)
+                    group_u.append(u)
+                    group_rx.append(rx)
             if nloc > 0:
-                u, noise = model.generate_inputs(nloc, snr, seed=seed, first_block=first)
-                if model.cfg.channel != "awgn":
-                    # other channels: generate_noise restated on the device (turboae_amd/channels.py), one generator per
-                    # (seed, global first block of the shard): shards of any world size draw independent streams
-                    gen = torch.Generator(device=dev)
-                    gen.manual_seed((seed * 1000003 + first) & 0x7FFFFFFFFFFFFFFF)
-                    noise = channels.generate_noise((nloc, L, 3), model.cfg, snr, device=dev, generator=gen)
-                    if model.cfg.channel == "fading":
-                        fading = channels.rayleigh_fading((nloc, L, 3), device=dev, generator=gen)
-                x_tx, stats = model.encode_prenorm(u)
-            else:
-                stats = torch.zeros(3, dtype=torch.float64, device=dev)
-            all_reduce_sum_(stats)                                            # batch-global mean/std (encoders.py:107-108)
-            if nloc > 0:
-                _, rx = model.normalize(x_tx, stats, noise, want_codes=False, fading=fading)
-                x_dec = model.dec(rx)
-                model.count_errors(x_dec, u, counts)
+                x_dec = model.dec(group_rx[0] if len(group_rx) == 1 else torch.cat(group_rx))
+                for i, u in enumerate(group_u):
+                    model.count_errors(x_dec[i * nloc:(i + 1) * nloc], u, per_batch[g0 + i])
         all_reduce_sum_(per_batch)
         pb = per_batch.cpu().tolist()
         # BER / BLER = mean over batches of the per-batch rates (trainer.py:176-177,215-216), accumulated in the same order
