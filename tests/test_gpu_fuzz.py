@@ -63,3 +63,52 @@ def test_random_shape_matches_oracle_in_both_precisions(gpu_device, monkeypatch,
         assert np.abs(codes - co).max() <= tol_c, (prec, np.abs(codes - co).max())
         assert np.abs(xd - xo).max() <= tol_x, (prec, np.abs(xd - xo).max())
     assert np.abs(out["auto"][0] - out["f32"][0]).max() <= 2e-5
+
+
+def draw_variant_cases(n, seed):
+    """GRU decoder (CNN or GRU encoder) and DenseSameShapeConv1d stacks: fixed widths, random lengths / batches."""
+    rng = np.random.RandomState(seed)
+    cases = []
+    for i in range(n):
+        kind = ["dec_rnn", "enc_rnn", "dense"][i % 3]
+        L = int(rng.choice([1, 2, 5, 15, 16, 17, 33, 64, 100, 127])) if rng.rand() < 0.6 else int(rng.randint(1, 140))
+        B = int(rng.choice([1, 2, 15, 16, 17, 31, 33, int(rng.randint(1, 70))]))
+        c = dict(block_len=L, num_iter_ft=int(rng.randint(1, 7)), num_iteration=int(rng.randint(1, 3)), extrinsic=int(rng.randint(0, 2)),
+                 B=B, wseed=int(rng.randint(1, 1 << 30)), kind=kind)
+        if kind == "dec_rnn":
+            c.update(decoder="TurboAE_rate3_rnn", enc_num_layer=int(rng.randint(1, 4)))
+        elif kind == "enc_rnn":
+            c.update(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn")
+        else:
+            U = int(rng.choice([32, 64]))
+            c.update(encoder="TurboAE_rate3_cnn_dense", decoder="TurboAE_rate3_cnn_dense", enc_num_unit=U, dec_num_unit=U,
+                     enc_num_layer=int(rng.randint(1, 4)), dec_num_layer=int(rng.randint(1, 4)))
+        cases.append(c)
+    return cases
+
+
+VARIANT_CASES = draw_variant_cases(int(os.environ.get("TAE_FUZZ_CASES", "24")), int(os.environ.get("TAE_FUZZ_SEED", "77001")))
+
+
+@pytest.mark.parametrize("case", VARIANT_CASES, ids=lambda c: "{kind}_L{block_len}_B{B}_F{num_iter_ft}_it{num_iteration}".format(**c))
+def test_random_shape_variants_match_oracle(gpu_device, case):
+    from turboae_amd import Channel_AE_HIP
+    case = dict(case)
+    B, wseed, kind = case.pop("B"), case.pop("wseed"), case.pop("kind")
+    cfg = TurboAEConfig(**case)
+    L = cfg.block_len
+    sd = W.generate_state_dict(cfg, seed=wseed, gain=1.0)
+    u = philox.random_bits(wseed, 0, B * L).reshape(B, L, 1)
+    noise = (np.float32(O.snr_db2sigma(1.0)) * philox.random_normal(wseed, 0, B * L * 3)).reshape(B, L, 3).astype(np.float32)
+    ut, nt = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
+    xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict())
+    xo, co = xo.numpy(), co.numpy()
+    for prec in (("auto",) if kind == "dense" else ("auto", "f32")):      # dense stacks exist in f16x2 only
+        model = Channel_AE_HIP(TurboAEConfig(precision=prec, **case), sd, device=gpu_device, max_batch=B)
+        xd, codes = model(ut, nt)
+        model.check_range()
+        xd, codes = xd.cpu().numpy(), codes.cpu().numpy()
+        assert np.isfinite(xd).all() and np.isfinite(codes).all(), prec
+        tol_c, tol_x = (2e-5, 6e-5) if B * L >= 8 else (2e-4, 2e-4)       # GRU recurrences: the golden-vector tests' x_dec tolerance
+        assert np.abs(codes - co).max() <= tol_c, (prec, np.abs(codes - co).max())
+        assert np.abs(xd - xo).max() <= tol_x, (prec, np.abs(xd - xo).max())

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
     for (int s = 0; s < 3; ++s) { bh[s] = h8{0, 0, 0, 0, 0, 0, 0, 0}; bl[s] = bh[s]; }
     h4 rh = {0, 0, 0, 0}, rl = {0, 0, 0, 0};   // remainder slab: k0 = h of unit 96 + q, k1..3 = this lane's share of x_t (layer 0)
 
-    // x_t (layer 0): lane group q carries x[3q .. 3q+2] (q = 2: x[6] only; q = 3: nothing)
+    // x_t (layer 0): lane group q carries x[3q .. 3q+2] (q = 2: x[6], x[7] - the panel is 8 wide; q = 3: nothing)
     auto load_x = [&](int t, f32x4& xa, f32x4& xb) {
         const uint32_t so = (uint32_t)t * kGXW * 4;
         xa = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_in, so, 0));
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
     };
     auto set_x = [&](const f32x4& xa, const f32x4& xb) {
         const float x0 = q == 0 ? xa.x : (q == 1 ? xa.w : (q == 2 ? xb.z : 0.0f));
-        const float x1 = q == 0 ? xa.y : (q == 1 ? xb.x : 0.0f);
+        const float x1 = q == 0 ? xa.y : (q == 1 ? xb.x : (q == 2 ? xb.w : 0.0f));
         const float x2 = q == 0 ? xa.z : (q == 1 ? xb.y : 0.0f);
         const float xs[3] = {x0, x1, x2};
 #pragma unroll
