@@ -70,3 +70,33 @@ def test_product_package_does_not_import_oracle():
                 with open(os.path.join(dirpath, f)) as fh:
                     text = fh.read()
                 assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_header_is_plain_c_and_a_c_host_links(tmp_path):
+    """include/turboae_hip.h must be consumable from C (the boundary other host languages bind): compile it as strict C99,
+    link a C program against the library and call the entry points that need no GPU."""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    _lib.load()
+    libdir = os.path.join(ROOT, "turboae_amd", "lib")
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <string.h>\n#include "turboae_hip.h"\n'
+                   "int main(void) {\n"
+                   "    tae_config c; memset(&c, 0, sizeof c); c.struct_size = (int32_t)sizeof c;\n"
+                   "    c.block_len = 100; c.enc_num_layer = 2; c.enc_num_unit = 100; c.enc_kernel_size = 5; c.dec_num_layer = 5;\n"
+                   "    c.dec_num_unit = 100; c.dec_kernel_size = 5; c.num_iteration = 6; c.num_iter_ft = 5; c.extrinsic = 1; c.max_batch = 1;\n"
+                   '    printf("%d %zu\\n", tae_abi_version(), tae_num_weights(&c));\n'
+                   "    c.enc_num_unit = 48; c.dec_num_unit = 48;\n"
+                   '    { size_t n = tae_num_weights(&c); printf("%zu %s\\n", n, tae_last_error()); }\n'
+                   "    return tae_abi_version() == TAE_ABI_VERSION ? 0 : 1;\n}\n")
+    exe = tmp_path / "abi"
+    subprocess.check_call([cc, "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lturboae_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    first, second = out.stdout.splitlines()
+    assert first.split() == [str(_lib.TAE_ABI_VERSION), str(W.num_params(TurboAEConfig()))]
+    assert second.startswith("0 ") and "channel width" in second

@@ -428,3 +428,32 @@ def test_variable_block_length(gpu_device):
     strict = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4)
     with pytest.raises(ValueError):
         strict(torch.zeros(2, 50, 1, device=gpu_device), torch.zeros(2, 50, 3, device=gpu_device))
+
+
+def test_plain_c_host_reproduces_the_eval_sweep(gpu_device, tmp_path):
+    """examples/c_host/turboae_sweep.c (gcc, no Python / torch in the process) drives the same sweep through the C ABI:
+    identical error counts to evaluate.test for the same Philox seed."""
+    import subprocess
+    from turboae_amd import Channel_AE_HIP, evaluate
+    from turboae_amd.interleaver import rand_interleaver
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "turboae_amd", "lib", "turboae_sweep")
+    assert os.path.exists(exe), "run __graft_entry__.build() first (make -C examples/c_host)"
+    g = np.load(os.path.join(GOLD, "trained_enc2dec5_u100.npz"))
+    cfg = TurboAEConfig(**MANIFEST["trained"]["config"])
+    blob = g["weights_fp16"].astype("<f4")
+    blob.tofile(tmp_path / "w.f32")
+    rand_interleaver(cfg.block_len, cfg.interleaver_seed).astype("<i4").tofile(tmp_path / "perm.i32")
+    out = subprocess.run([exe, str(tmp_path / "w.f32"), str(tmp_path / "perm.i32"), "1000", "250", "3", "0.0", "3.0", "9"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    rows = [l.split() for l in out.stdout.splitlines() if l.startswith("snr ")]
+    assert len(rows) == 3 and "arithmetic f16x2 overflow 0" in out.stdout
+    model = Channel_AE_HIP(cfg, W.unpack_blob(cfg, blob), device=gpu_device, max_batch=250)
+    res = evaluate.test(model, snr_test_start=0.0, snr_test_end=3.0, snr_points=3, num_block=1000, batch_size=250, seed=9,
+                        verbose=False, enc_power_epilogue=False)
+    for si, r in enumerate(rows):
+        assert abs(float(r[1]) - res["snrs"][si]) < 1e-6
+        assert int(r[3]) == res["bit_errors"][si] and int(r[5]) == res["block_errors"][si]
+        assert abs(float(r[7]) - res["ber"][si]) <= 1e-12 and abs(float(r[9]) - res["bler"][si]) <= 1e-12
+    assert res["bit_errors"][0] > res["bit_errors"][2] > 0
