@@ -87,6 +87,7 @@ __device__ __forceinline__ PanelsH carve_h(char* smem, int rows, int L) {
 // B ring leave few registers): everything else is recomputed where it is needed (once per stack).
 template <int PT>
 struct TileH {
+    static constexpr int kTiles = PT;
     const int* rowtab;  // LDS table [PT][16] of this wave's group: panel row of tile p's position n (padding lanes: row 2, real
                         // finite data).  Read on demand (twice per layer) instead of living in - and being spilled from - VGPRs.
     uint32_t valid;     // bit p: in-block position held in this workgroup's panel (its activations are written back)
@@ -707,34 +708,47 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
     }
     report_range(vmax, P.flags);
 
-    TileH<PT> tc;
-    {
+    // tiles of the wave's position group: panel rows [2 + m] of the segment; `center` marks the positions this workgroup owns
+    auto make_tiles = [&](auto& tc, int gt0) {
+        using TC = std::remove_reference_t<decltype(tc)>;
         const int n = lane & 15;
         tc.valid = 0u;
         tc.center = 0u;
-        tc.m0 = g * PT * 16 + n;
+        tc.m0 = gt0 * 16 + n;
         tc.L = L;
-        tc.rowtab = pn.ROWT + g * PT * 16 + n;      // (a segment's groups always walk all PT tiles)
+        tc.rowtab = pn.ROWT + gt0 * 16 + n;
 #pragma unroll
-        for (int p = 0; p < PT; ++p) {
+        for (int p = 0; p < TC::kTiles; ++p) {
             const int m = tc.m0 + 16 * p;
             const int t = tstart + m;
             const bool v = (m < NP) && (t >= 0) && (t < L);
-            if (lane < 16) pn.ROWT[(g * PT + p) * 16 + n] = v ? 2 + m : 2;
+            if (lane < 16) pn.ROWT[(gt0 + p) * 16 + n] = v ? 2 + m : 2;
             tc.valid |= (v ? 1u : 0u) << p;
             tc.center |= ((v && t >= s0 && t < s0 + tlen) ? 1u : 0u) << p;
         }
-    }
-    __syncthreads();
+    };
     double sum = 0.0, sumsq = 0.0;
     const bool upper = __builtin_amdgcn_readfirstlane(h) != 0;
     if (P.dense) {
+        // every earlier layer's output stays resident: a dense segment is one group's PT tiles at most, walked in full
+        TileH<PT> tc;
+        make_tiles(tc, g * PT);
+        __syncthreads();
         const bool active = __builtin_amdgcn_readfirstlane((NP + 15) / 16 - g * PT) > 0;      // the group has at least one live tile
         if (!upper) seg_body_h<U, PT, 0, Split<U>::CTA, true>(P, smem, pn, tc, g * PT, lane, stack, b, tstart, active, sum, sumsq);
         else seg_body_h<U, PT, Split<U>::CTA, Split<U>::CTB, true>(P, smem, pn, tc, g * PT, lane, stack, b, tstart, active, sum, sumsq);
     } else {
-        if (!upper) seg_body_h<U, PT, 0, Split<U>::CTA, false>(P, smem, pn, tc, g * PT, lane, stack, b, tstart, true, sum, sumsq);
-        else seg_body_h<U, PT, Split<U>::CTA, Split<U>::CTB, false>(P, smem, pn, tc, g * PT, lane, stack, b, tstart, true, sum, sumsq);
+        // even deal of the segment's tiles over the position groups (L = 1000: 4 segments of 250 + 2 x 10 halo = 18 tiles -> 5, 5, 4, 4)
+        const GroupSpan gs = group_span(NP, g);
+        auto run = [&](auto pt) {
+            constexpr int T = decltype(pt)::value;
+            TileH<T> tc;
+            make_tiles(tc, gs.gt0);
+            __syncthreads();
+            if (!upper) seg_body_h<U, T, 0, Split<U>::CTA, false>(P, smem, pn, tc, gs.gt0, lane, stack, b, tstart, true, sum, sumsq);
+            else seg_body_h<U, T, Split<U>::CTA, Split<U>::CTB, false>(P, smem, pn, tc, gs.gt0, lane, stack, b, tstart, true, sum, sumsq);
+        };
+        dispatch_tiles<PT>(gs.live, run);
     }
     if (P.mode == 0) block_reduce_stats(smem, tid, sum, sumsq, P.partials);
 }
