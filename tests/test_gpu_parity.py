@@ -348,6 +348,10 @@ def test_eval_sweep_matches_oracle_on_trained_weights(gpu_device, capsys):
                         verbose=False, decode_group=1)
     assert one["bit_errors"] == res["bit_errors"] and one["block_errors"] == res["block_errors"]
     assert one["ber"] == res["ber"] and one["bler"] == res["bler"]
+    # every SNR point captured into one hipGraph: the same numbers again
+    gr = evaluate.test(model, snr_test_start=0.0, snr_test_end=2.0, snr_points=2, num_block=100, batch_size=50, seed=77,
+                       verbose=False, hip_graph=True)
+    assert gr["bit_errors"] == res["bit_errors"] and gr["block_errors"] == res["block_errors"] and gr["ber"] == res["ber"]
     assert abs(res["enc_power"] - 1.0) < 1e-4
 
 
@@ -457,3 +461,36 @@ def test_plain_c_host_reproduces_the_eval_sweep(gpu_device, tmp_path):
         assert int(r[3]) == res["bit_errors"][si] and int(r[5]) == res["block_errors"][si]
         assert abs(float(r[7]) - res["ber"][si]) <= 1e-12 and abs(float(r[9]) - res["bler"][si]) <= 1e-12
     assert res["bit_errors"][0] > res["bit_errors"][2] > 0
+
+
+@pytest.mark.parametrize("decoder", ["TurboAE_rate3_cnn", "TurboAE_rate3_rnn"])
+def test_forward_is_hip_graph_capturable(gpu_device, decoder):
+    """The compute entry points only enqueue work on the caller's stream (no allocation, no synchronisation), so a whole
+    forward - and with it a whole SNR point - can be captured into one hipGraph and replayed on new inputs."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(decoder=decoder, num_iteration=2)
+    sd = W.generate_state_dict(cfg, seed=31, gain=1.0)
+    B = 37
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    u, noise = model.generate_inputs(B, 1.0, seed=5)
+    u2, noise2 = model.generate_inputs(B, 1.0, seed=6)
+    want1 = [t.clone() for t in model(u, noise)]
+    want2 = [t.clone() for t in model(u2, noise2)]
+    su, sn = u.clone(), noise.clone()
+    counts = torch.zeros(2, dtype=torch.int64, device=gpu_device)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        xd, codes = model(su, sn)
+        model.count_errors(xd, su, counts)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(xd, want1[0]) and torch.equal(codes, want1[1])
+    su.copy_(u2)
+    sn.copy_(noise2)
+    counts.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(xd, want2[0]) and torch.equal(codes, want2[1])
+    assert counts.cpu().tolist() == model.count_errors(want2[0], u2).cpu().tolist()
+    model.check_range()

@@ -266,6 +266,11 @@ class Channel_AE_HIP:
     def kernel_info(self):
         return self._eng.kernel_info()
 
+    def reserve(self, max_batch: int) -> None:
+        """Grow the library's workspace to `max_batch` blocks per call now (tae_reserve) instead of on first use - needed
+        before a hipGraph capture, which must not allocate."""
+        self._eng.reserve(max_batch)
+
     def range_status(self):
         return self._eng.range_status()
 

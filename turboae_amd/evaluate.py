@@ -39,9 +39,13 @@ def snr_sigma2db(sigma: float) -> float:       # utils.py:72-76
 
 def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_points: int = 12, num_block: int = 1000,
          batch_size: int = 100, seed: int = 20190001, verbose: bool = True, enc_power_epilogue: bool = True,
-         decode_group: Optional[int] = None) -> Dict[str, List[float]]:
+         decode_group: Optional[int] = None, hip_graph: bool = False) -> Dict[str, List[float]]:
     """model: turboae_amd.Channel_AE_HIP.  Returns {'snrs', 'ber', 'bler', 'bit_errors', 'block_errors', 'enc_power'}.
-    decode_group: batches decoded per decoder call (None: enough for about 24 576 blocks per rank; 1: one call per batch)."""
+    decode_group: batches decoded per decoder call (None: enough for about 24 576 blocks per rank; 1: one call per batch).
+    hip_graph: capture every SNR point (all of its launches, the all-reduces included) into one hipGraph and launch that
+    (AWGN only: the other channels draw their noise from a torch generator).  The sweep is GPU-bound either way; the
+    option exists because the entry points are capturable (no allocation, no synchronisation) and a launch-bound caller
+    (tiny batches) can use it."""
     import torch.distributed as dist
     rank, world = 0, 1
     if dist.is_available() and dist.is_initialized():
@@ -61,10 +65,13 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
     if decode_group is None:
         decode_group = max(1, -(-24576 // max(nloc, 1)))
     decode_group = max(1, min(int(decode_group), max(num_test_batch, 1)))
+    if hip_graph and model.cfg.channel != "awgn":
+        raise ValueError("hip_graph=True needs channel='awgn' (device-side Philox inputs)")
+    if hip_graph and world > 1 and dist.get_backend() != "nccl":
+        raise ValueError("hip_graph=True with torch.distributed needs the nccl (RCCL) backend")
     ber_res, bler_res, bit_res, blk_res = [], [], [], []
-    for si, snr in enumerate(snrs):
-        # per-batch (bit errors, block errors) stay on the device; one host read per SNR point
-        per_batch = torch.zeros((max(num_test_batch, 1), 2), dtype=torch.int64, device=dev)
+
+    def run_point(si, snr, per_batch):
         for g0 in range(0, num_test_batch, decode_group):
             group_u, group_rx = [], []
             for batch_idx in range(g0, min(g0 + decode_group, num_test_batch)):
@@ -93,6 +100,22 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
                 for i, u in enumerate(group_u):
                     model.count_errors(x_dec[i * nloc:(i + 1) * nloc], u, per_batch[g0 + i])
         all_reduce_sum_(per_batch)
+
+    if hip_graph and nloc > 0:
+        model.reserve(decode_group * nloc)           # no workspace growth (an allocation) inside a capture
+    for si, snr in enumerate(snrs):
+        # per-batch (bit errors, block errors) stay on the device; one host read per SNR point
+        per_batch = torch.zeros((max(num_test_batch, 1), 2), dtype=torch.int64, device=dev)
+        if hip_graph:
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                run_point(si, snr, per_batch)
+            graph.replay()
+            torch.cuda.synchronize(dev)
+            del graph
+        else:
+            run_point(si, snr, per_batch)
         pb = per_batch.cpu().tolist()
         # BER / BLER = mean over batches of the per-batch rates (trainer.py:176-177,215-216), accumulated in the same order
         test_ber, test_bler = 0.0, 0.0
