@@ -153,15 +153,34 @@ def test_custom_interleaver(gpu_device):
     sd = W.generate_state_dict(cfg, seed=4, gain=1.0)
     p = np.random.RandomState(123).permutation(cfg.block_len)
     u, noise = make_inputs(4, cfg.block_len, seed=31)
-    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4, is_same_interleaver=0)
+    ut, nt = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
+
+    def check(model, perm):
+        xd, codes = model(ut, nt)
+        ocfg = cfg.to_dict()
+        ocfg["p_array"] = perm
+        xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), ocfg)
+        assert np.abs(codes.cpu().numpy() - co.numpy()).max() <= ATOL_CODES
+        assert np.abs(xd.cpu().numpy() - xo.numpy()).max() <= ATOL_XDEC
+
+    # -is_interleave 0: identity at construction (main.py:129-131); forward leaves a caller-set permutation alone (channel_ae.py:22-23)
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4, is_interleave=0)
+    check(model, np.arange(cfg.block_len))
     model.enc.set_interleaver(p)
     model.dec.set_interleaver(p)
-    xd, codes = model(torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device))
-    ocfg = cfg.to_dict()
-    ocfg["p_array"] = p
-    xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), ocfg)
-    assert np.abs(codes.cpu().numpy() - co.numpy()).max() <= ATOL_CODES
-    assert np.abs(xd.cpu().numpy() - xo.numpy()).max() <= ATOL_XDEC
+    check(model, p)
+    # -is_same_interleaver 0: RandInterlv(block_len, np.random.randint(0, 1000)) per forward (channel_ae.py:25-30)
+    import types
+    rnd = Channel_AE_HIP(types.SimpleNamespace(is_same_interleaver=0, **cfg.to_dict()), sd, device=gpu_device, max_batch=4)
+    for _ in range(2):
+        state = np.random.get_state()
+        seed = int(np.random.randint(0, 1000))
+        np.random.set_state(state)
+        check(rnd, np.random.RandomState(seed).permutation(cfg.block_len))
+    # default: RandInterlv(block_len, 0) on every forward, whatever was set before (channel_ae.py:32-36)
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4)
+    model.enc.set_interleaver(p)
+    check(model, np.random.RandomState(0).permutation(cfg.block_len))
     with pytest.raises(Exception):
         model.enc.set_interleaver(np.zeros(cfg.block_len, dtype=np.int32))     # not a permutation
 

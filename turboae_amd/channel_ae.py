@@ -224,8 +224,19 @@ class Channel_AE_HIP:
     """Drop-in for ``Channel_AE(args, enc, dec)`` on the AWGN / rate-1/3 CNN eval path."""
 
     def __init__(self, args_or_cfg, state_dict: Dict[str, object], device: Optional[torch.device] = None,
-                 max_batch: int = 500, is_same_interleaver: int = 1, is_variable_block_len: Optional[bool] = None):
+                 max_batch: int = 500, is_same_interleaver: Optional[int] = None, is_variable_block_len: Optional[bool] = None,
+                 is_interleave: Optional[int] = None):
         cfg = _as_cfg(args_or_cfg)
+        # -is_interleave / -is_same_interleaver (get_args.py:85,87), taken from a reference-style namespace when not given:
+        #   is_interleave == 0: the identity permutation set at construction (main.py:129-131) and forward leaves whatever
+        #       enc/dec.set_interleaver installed alone (channel_ae.py:22-23);
+        #   is_same_interleaver == 1 (default): RandInterlv(block_len, 0) on every forward (channel_ae.py:32-36);
+        #   is_same_interleaver == 0: a fresh RandInterlv(block_len, np.random.randint(0, 1000)) per forward (:25-30).
+        if is_interleave is None:
+            is_interleave = int(getattr(args_or_cfg, "is_interleave", 1))
+        if is_same_interleaver is None:
+            is_same_interleaver = int(getattr(args_or_cfg, "is_same_interleaver", 1))
+        self.is_interleave = is_interleave
         # --is_variable_block_len (get_args.py:125; encoders.py:353-360, decoders.py:208-215): the fully convolutional
         # model runs on any block length with the seed-0 permutation of that length; one engine per length
         if is_variable_block_len is None:
@@ -240,6 +251,8 @@ class Channel_AE_HIP:
         self.enc = _EncView(self._eng)
         self.dec = _DecView(self._eng)
         self.this_device = self._eng.device
+        if self.is_interleave == 0:
+            self._eng.set_interleaver(np.arange(cfg.block_len))
 
     # -- torch.nn.Module look-alikes used by main.py / trainer.py
     def eval(self):
@@ -307,7 +320,11 @@ class Channel_AE_HIP:
 
     def forward(self, input: torch.Tensor, fwd_noise: torch.Tensor, fading: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         e = self._engine_for(input.shape[1]) if input.dim() == 3 else self._eng
-        if self.is_same_interleaver:   # channel_ae.py:32-36: RandInterlv(block_len, 0) on every call
+        if self.is_interleave == 0:      # channel_ae.py:22-23
+            pass
+        elif self.is_same_interleaver == 0:   # channel_ae.py:25-30 (the global numpy RNG, like the reference)
+            e.set_interleaver(rand_interleaver(e.cfg.block_len, int(np.random.randint(0, 1000))))
+        else:                            # channel_ae.py:32-36: RandInterlv(block_len, 0) on every call
             e.set_interleaver(rand_interleaver(e.cfg.block_len, 0))
         u = e._in(input, 1, "input")
         B = u.shape[0]
