@@ -74,6 +74,7 @@ int main(int argc, char** argv) {
     cfg.extrinsic = 1;
     cfg.max_batch = batch;
     cfg.precision = TAE_PREC_AUTO;
+    cfg.dec_act = TAE_ACT_LINEAR;       /* the reference default (only the GRU decoder reads it) */
 
     const size_t nw = tae_num_weights(&cfg);
     float* w = (float*)malloc(nw * sizeof(float));

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAE_ABI_VERSION 6
+#define TAE_ABI_VERSION 7
 
 #if defined(__GNUC__)
 #define TAE_API __attribute__((visibility("default")))
@@ -58,7 +58,7 @@ typedef struct tae_config {
     int32_t num_iteration;    /* -num_iteration    get_args.py:82  */
     int32_t num_iter_ft;      /* -num_iter_ft      get_args.py:84  */
     int32_t extrinsic;        /* -extrinsic        get_args.py:83  */
-    int32_t enc_act;          /* -enc_act: 0 = elu (default), 1 = linear   get_args.py:100 */
+    int32_t enc_act;          /* -enc_act (get_args.py:100, encoders.py:86-100): TAE_ACT_* below; 0 = elu, the reference default */
     int32_t max_batch;        /* blocks per call the workspace is sized for (grown by tae_reserve) */
     int32_t dec_type;         /* -decoder: 0 = TurboAE_rate3_cnn (DEC_LargeCNN, decoders.py:157),
                                  1 = TurboAE_rate3_rnn (DEC_LargeRNN with dec_rnn=gru, decoders.py:16; needs dec_num_unit=100)  main.py:75-88 */
@@ -71,7 +71,16 @@ typedef struct tae_config {
                                  TAE_PREC_AUTO = 0: fp32 operands carried as two fp16 halves, three v_mfma_f32_16x16x32_f16 products,
                                  fp32 accumulation - fp32-grade results - where the whole-block kernels apply,
                                  TAE_PREC_F32 otherwise; TAE_PREC_F32 = 1: v_mfma_f32_16x16x4_f32 on the fp32 operands everywhere */
+    int32_t dec_act;          /* -dec_act (get_args.py:101, decoders.py:59-73): TAE_ACT_* on the GRU decoder's Linear outputs (DEC_LargeCNN
+                                 has no dec_act; ignored for dec_type = 0).  The reference default is TAE_ACT_LINEAR (= 1, NOT 0) */
 } tae_config;
+
+#define TAE_ACT_ELU 0
+#define TAE_ACT_LINEAR 1
+#define TAE_ACT_TANH 2
+#define TAE_ACT_RELU 3
+#define TAE_ACT_SELU 4
+#define TAE_ACT_SIGMOID 5
 
 #define TAE_PREC_AUTO 0
 #define TAE_PREC_F32 1

@@ -55,6 +55,14 @@ CASES = [
     ("var_nonorm_bec", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, no_code_norm=True, channel="bec"), 5, 18, 1.0, 0.2),
     ("var_precomp_trunc", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, precompute_norm_stats=True,
                                enc_truncate_limit=1.5), 5, 19, 1.0, 2.0),
+    # the other -enc_act / -dec_act choices (encoders.py:86-100, decoders.py:59-73)
+    ("var_encact_tanh", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, enc_act="tanh"), 5, 23, 1.0, 2.0),
+    ("var_encact_selu", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, enc_act="selu"), 5, 24, 1.0, 2.0),
+    ("var_encact_relu", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, enc_act="relu"), 5, 25, 1.0, 2.0),
+    ("var_encact_sigmoid_L1000", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=1, block_len=1000, enc_act="sigmoid"), 2, 26, 1.0, 2.0),
+    ("fwd_rnn_decact_tanh_encact_linear", dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", num_iteration=2, block_len=50,
+                                               enc_act="linear", dec_act="tanh"), 3, 27, 1.0, 2.0),
+    ("fwd_rnn_decact_selu", dict(decoder="TurboAE_rate3_rnn", num_iteration=2, block_len=50, dec_act="selu", enc_act="sigmoid"), 3, 28, 1.0, 2.0),
     # -channel fading: the reference draws fading_h from the torch global stream inside forward (channel_ae.py:51-56);
     # seeded here and reproduced draw for draw, the coefficients travel in the fixture
     ("var_fading", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, channel="fading"), 5, 20, 1.0, 3.0),
@@ -162,7 +170,12 @@ def main():
             manifest = json.load(fh)
         manifest.setdefault("cases", {})
     only_trained = len(sys.argv) > 2 and sys.argv[1] == "--trained"
-    if not only_trained:
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":       # python oracle/make_golden.py --only encact,decact : just the matching cases
+        keys = sys.argv[2].split(",")
+        for case in CASES:
+            if any(k in case[0] for k in keys):
+                run_case(*case, manifest)
+    elif not only_trained:
         manifest["environment"] = {"torch": torch.__version__, "numpy": np.__version__,
                                    "threads": torch.get_num_threads(),
                                    "generated_by": "oracle/make_golden.py against /root/reference"}

@@ -124,12 +124,18 @@ def apply_channel(codes: torch.Tensor, fwd_noise: torch.Tensor, cfg: dict, fadin
 
 
 def _enc_act(x: torch.Tensor, enc_act: str) -> torch.Tensor:
-    # encoders.py:87-100 (only 'elu' and 'linear' are supported by the HIP path)
+    # encoders.py:86-100 / decoders.py:59-73 (enc_act and dec_act share the table)
+    if enc_act == "tanh":
+        return torch.tanh(x)
     if enc_act == "elu":
         return F.elu(x)
-    if enc_act == "linear":
-        return x
-    raise ValueError(enc_act)
+    if enc_act == "relu":
+        return F.relu(x)
+    if enc_act == "selu":
+        return F.selu(x)
+    if enc_act == "sigmoid":
+        return torch.sigmoid(x)
+    return x
 
 
 # encoders.py:351-377 (ENC_interCNN.forward), non-Dense branch.
@@ -213,7 +219,7 @@ def _gru_stack(x: torch.Tensor, w: Dict[str, torch.Tensor], prefix: str, hidden:
 
 
 def decode_rnn(received: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor, hidden: int, num_iteration: int,
-               num_iter_ft: int, extrinsic: int = 1, taps: Optional[dict] = None) -> torch.Tensor:
+               num_iter_ft: int, extrinsic: int = 1, taps: Optional[dict] = None, dec_act: str = "linear") -> torch.Tensor:
     B, L, _ = received.shape
     r_sys = received[:, :, 0:1]
     r_sys_int = interleave(r_sys, p)
@@ -223,12 +229,12 @@ def decode_rnn(received: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tens
     x_plr = None
     for it in range(num_iteration):
         h = _gru_stack(torch.cat([r_sys, r_par1, prior], dim=2), w, f"dec.dec1_rnns.{it}", hidden)
-        x_plr = F.linear(h, w[f"dec.dec1_outputs.{it}.weight"], w[f"dec.dec1_outputs.{it}.bias"])
+        x_plr = _enc_act(F.linear(h, w[f"dec.dec1_outputs.{it}.weight"], w[f"dec.dec1_outputs.{it}.bias"]), dec_act)   # decoders.py:103
         if extrinsic:
             x_plr = x_plr - prior
         x_plr_int = interleave(x_plr, p)
         h = _gru_stack(torch.cat([r_sys_int, r_par2, x_plr_int], dim=2), w, f"dec.dec2_rnns.{it}", hidden)
-        x_plr = F.linear(h, w[f"dec.dec2_outputs.{it}.weight"], w[f"dec.dec2_outputs.{it}.bias"])
+        x_plr = _enc_act(F.linear(h, w[f"dec.dec2_outputs.{it}.weight"], w[f"dec.dec2_outputs.{it}.bias"]), dec_act)   # decoders.py:115,143
         if it < num_iteration - 1:
             if extrinsic:
                 x_plr = x_plr - x_plr_int
@@ -261,7 +267,7 @@ def channel_ae_forward(u: torch.Tensor, fwd_noise: torch.Tensor, w: Dict[str, to
         received = apply_channel(codes, fwd_noise, cfg, fading)
         if cfg.get("decoder", "TurboAE_rate3_cnn") == "TurboAE_rate3_rnn":
             x_dec = decode_rnn(received, w, p, cfg["dec_num_unit"], cfg["num_iteration"], cfg["num_iter_ft"],
-                               cfg.get("extrinsic", 1), taps)
+                               cfg.get("extrinsic", 1), taps, cfg.get("dec_act", "linear"))
         else:
             x_dec = decode(received, w, p, cfg["dec_num_layer"], cfg["num_iteration"], cfg["num_iter_ft"],
                            cfg.get("extrinsic", 1), taps)

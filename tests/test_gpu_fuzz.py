@@ -27,7 +27,7 @@ def draw_cases(n, seed):
         cases.append(dict(block_len=L, enc_num_unit=U, dec_num_unit=U, enc_num_layer=int(rng.randint(1, 6)),
                           dec_num_layer=int(rng.randint(1, 6)), num_iter_ft=int(rng.randint(1, 7)),
                           num_iteration=int(rng.randint(1, 4)), extrinsic=int(rng.randint(0, 2)),
-                          enc_act=str(rng.choice(["elu", "linear"])), B=B, fixed_nb=str(int(rng.randint(0, 2))), wseed=int(rng.randint(1, 1 << 30))))
+                          enc_act=str(rng.choice(["elu", "linear", "elu", "tanh", "relu", "selu", "sigmoid"])), B=B, fixed_nb=str(int(rng.randint(0, 2))), wseed=int(rng.randint(1, 1 << 30))))
     return cases
 
 
@@ -75,10 +75,11 @@ def draw_variant_cases(n, seed):
         B = int(rng.choice([1, 2, 15, 16, 17, 31, 33, int(rng.randint(1, 70))]))
         c = dict(block_len=L, num_iter_ft=int(rng.randint(1, 7)), num_iteration=int(rng.randint(1, 3)), extrinsic=int(rng.randint(0, 2)),
                  B=B, wseed=int(rng.randint(1, 1 << 30)), kind=kind)
+        acts = ["linear", "elu", "tanh", "relu", "selu", "sigmoid"]
         if kind == "dec_rnn":
-            c.update(decoder="TurboAE_rate3_rnn", enc_num_layer=int(rng.randint(1, 4)))
+            c.update(decoder="TurboAE_rate3_rnn", enc_num_layer=int(rng.randint(1, 4)), dec_act=str(rng.choice(acts)))
         elif kind == "enc_rnn":
-            c.update(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn")
+            c.update(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_act=str(rng.choice(acts)), dec_act=str(rng.choice(acts)))
         else:
             U = int(rng.choice([32, 64]))
             c.update(encoder="TurboAE_rate3_cnn_dense", decoder="TurboAE_rate3_cnn_dense", enc_num_unit=U, dec_num_unit=U,
@@ -87,7 +88,7 @@ def draw_variant_cases(n, seed):
     return cases
 
 
-VARIANT_CASES = draw_variant_cases(int(os.environ.get("TAE_FUZZ_CASES", "24")), int(os.environ.get("TAE_FUZZ_SEED", "77001")))
+VARIANT_CASES = draw_variant_cases(int(os.environ.get("TAE_FUZZ_CASES", "15")), int(os.environ.get("TAE_FUZZ_SEED", "77001")))
 
 
 @pytest.mark.parametrize("case", VARIANT_CASES, ids=lambda c: "{kind}_L{block_len}_B{B}_F{num_iter_ft}_it{num_iteration}".format(**c))

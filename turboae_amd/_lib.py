@@ -12,14 +12,14 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TAE_LIB", os.path.join(_HERE, "lib", "libturboae_hip.so"))   # TAE_LIB: kernel-variant experiments
 
-TAE_ABI_VERSION = 6
+TAE_ABI_VERSION = 7
 
 
 class TaeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "struct_size", "block_len", "enc_num_layer", "enc_num_unit", "enc_kernel_size",
         "dec_num_layer", "dec_num_unit", "dec_kernel_size", "num_iteration", "num_iter_ft",
-        "extrinsic", "enc_act", "max_batch", "dec_type", "enc_type", "dense", "precision")]
+        "extrinsic", "enc_act", "max_batch", "dec_type", "enc_type", "dense", "precision", "dec_act")]
 
 
 class TaeChannelOpts(C.Structure):

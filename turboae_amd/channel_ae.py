@@ -26,7 +26,7 @@ from .config import TurboAEConfig
 from .interleaver import rand_interleaver
 from . import weights as W
 
-_ENC_ACT = {"elu": 0, "linear": 1}
+_ACT = {"elu": 0, "linear": 1, "tanh": 2, "relu": 3, "selu": 4, "sigmoid": 5}      # TAE_ACT_* (include/turboae_hip.h)
 
 
 def _as_cfg(args_or_cfg) -> TurboAEConfig:
@@ -59,9 +59,9 @@ class _Engine:
         blob = W.pack_blob(cfg, self._state)
         c = _lib.TaeConfig(C.sizeof(_lib.TaeConfig), cfg.block_len, cfg.enc_num_layer, cfg.enc_num_unit,
                            cfg.enc_kernel_size, cfg.dec_num_layer, cfg.dec_num_unit, cfg.dec_kernel_size,
-                           cfg.num_iteration, cfg.num_iter_ft, cfg.extrinsic, _ENC_ACT[cfg.enc_act], max_batch,
+                           cfg.num_iteration, cfg.num_iter_ft, cfg.extrinsic, _ACT[cfg.enc_act], max_batch,
                            1 if cfg.decoder == "TurboAE_rate3_rnn" else 0, 1 if cfg.encoder == "TurboAE_rate3_rnn" else 0,
-                           1 if cfg.dense else 0, 1 if cfg.precision == "f32" else 0)
+                           1 if cfg.dense else 0, 1 if cfg.precision == "f32" else 0, _ACT[cfg.dec_act])
         n = self.lib.tae_num_weights(C.byref(c))
         if n != blob.size:
             raise _lib.TurboAEError(f"weight count mismatch: library wants {n}, blob has {blob.size}")

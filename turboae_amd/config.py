@@ -23,7 +23,9 @@ class TurboAEConfig:
     num_iteration: int = 6        # get_args.py:82
     num_iter_ft: int = 5          # get_args.py:84
     extrinsic: int = 1            # get_args.py:83
-    enc_act: str = "elu"          # get_args.py:100 ("only elu works")
+    enc_act: str = "elu"          # get_args.py:100 ("only elu works"): tanh / selu / relu / elu / sigmoid / linear (encoders.py:86-100)
+    dec_act: str = "linear"       # get_args.py:101: the same choices on the GRU decoder's Linear outputs (decoders.py:59-73,103-143);
+                                  # DEC_LargeCNN has no dec_act
     encoder: str = "TurboAE_rate3_cnn"   # main.py:32-36: 'TurboAE_rate3_cnn' (ENC_interCNN) or 'TurboAE_rate3_rnn' (ENC_interRNN,
                                          # encoders.py:231-298: three 2-layer bidirectional GRU(1 -> U) + Linear(2U -> 1); the
                                          # reference's own CLI cannot select it - its -encoder choice is spelled 'Turboae_rate3_rnn')
@@ -60,8 +62,9 @@ class TurboAEConfig:
             raise ValueError("HIP path implements kernel_size=5 (the reference default and all BASELINE configs)")
         if self.precision not in ("auto", "f32"):
             raise ValueError("precision must be 'auto' or 'f32'")
-        if self.enc_act not in ("elu", "linear"):
-            raise ValueError("enc_act must be 'elu' (reference default) or 'linear'")
+        acts = ("tanh", "selu", "relu", "elu", "sigmoid", "linear")
+        if self.enc_act not in acts or self.dec_act not in acts:
+            raise ValueError("enc_act / dec_act must be one of tanh, selu, relu, elu, sigmoid, linear (get_args.py:100-101)")
         if self.enc_num_unit != self.dec_num_unit:
             raise ValueError("enc_num_unit must equal dec_num_unit (one channel width per build)")
         if self.enc_num_unit not in (32, 64, 100):

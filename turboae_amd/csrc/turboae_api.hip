@@ -280,7 +280,8 @@ int check_cfg(const tae_config* c) {
     if (c->enc_num_layer < 1 || c->dec_num_layer < 1 || c->num_iteration < 1) return fail(TAE_EINVAL, "layer/iteration counts must be >= 1");
     if (c->num_iter_ft < 1 || c->num_iter_ft > 6) return fail(TAE_EINVAL, "num_iter_ft must be in 1..6");
     if (c->block_len < 1) return fail(TAE_EINVAL, "block_len must be >= 1");
-    if (c->enc_act != 0 && c->enc_act != 1) return fail(TAE_EINVAL, "enc_act must be 0 (elu) or 1 (linear)");
+    if (c->enc_act < 0 || c->enc_act > 5) return fail(TAE_EINVAL, "enc_act must be 0 (elu), 1 (linear), 2 (tanh), 3 (relu), 4 (selu) or 5 (sigmoid)");
+    if (c->dec_act < 0 || c->dec_act > 5) return fail(TAE_EINVAL, "dec_act must be 0 (elu), 1 (linear), 2 (tanh), 3 (relu), 4 (selu) or 5 (sigmoid)");
     if (c->dec_type != 0 && c->dec_type != 1) return fail(TAE_EINVAL, "dec_type must be 0 (cnn) or 1 (rnn/gru)");
     if (c->precision != TAE_PREC_AUTO && c->precision != TAE_PREC_F32) return fail(TAE_EINVAL, "precision must be TAE_PREC_AUTO (0) or TAE_PREC_F32 (1)");
     if (c->dec_type == 1 && c->dec_num_unit != 100) return fail(TAE_EINVAL, "the GRU decoder kernels are instantiated for dec_num_unit = 100");
@@ -904,7 +905,7 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
                 HP.xnext = odd ? h->d_gxa : h->d_gxb; HP.xdec = xdec + (size_t)c0 * L;
                 HP.ptab = odd ? h->d_perm : h->d_inv;
                 HP.npos = npg; HP.L = L; HP.F = F; HP.nout = nout; HP.extrinsic = h->cfg.extrinsic; HP.last = last ? 1 : 0;
-                HP.grouped = 1; HP.B = Bc; HP.enc_stack = -1;
+                HP.grouped = 1; HP.B = Bc; HP.enc_stack = -1; HP.act = h->cfg.dec_act;
                 TAE_HIP(tae::launch_gru_head(HP, st));
                 wb += rnn_h_stack_bytes((size_t)nout);
             }
@@ -934,7 +935,7 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
             HP.xnext = odd ? h->d_gxa : h->d_gxb; HP.xdec = xdec + (size_t)c0 * L;
             HP.ptab = odd ? h->d_perm : h->d_inv;     // dec1 -> interleave (row inv[t]); dec2 -> deinterleave (row p[i])
             HP.npos = np; HP.L = L; HP.F = F; HP.nout = nout; HP.extrinsic = h->cfg.extrinsic; HP.last = last ? 1 : 0;
-            HP.enc_stack = -1;
+            HP.enc_stack = -1; HP.act = h->cfg.dec_act;
             TAE_HIP(tae::launch_gru_head(HP, st));
             w += rnn_packed_stack_floats((size_t)nout);
         }

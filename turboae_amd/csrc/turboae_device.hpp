@@ -27,6 +27,19 @@ __device__ __forceinline__ float elu1(float x) {
     return __builtin_amdgcn_fmed3f(x, e, 0.0f);
 }
 
+// -enc_act / -dec_act (encoders.py:86-100, decoders.py:59-73): 0 elu, 1 linear, 2 tanh, 3 relu, 4 selu, 5 sigmoid.  Applied to a
+// handful of scalars per position (the Linear heads' outputs), so the accurate library functions are used.
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case 0: return elu1(v);
+        case 2: return tanhf(v);
+        case 3: return fmaxf(v, 0.0f);
+        case 4: return 1.0507009873554804934f * (v > 0.0f ? v : 1.6732632423543772848f * expm1f(v));
+        case 5: return 1.0f / (1.0f + expf(-v));
+        default: return v;
+    }
+}
+
 __device__ __forceinline__ f32x4 mfma16x16x4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

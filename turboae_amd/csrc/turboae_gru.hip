@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64 * kHeadWaves) void gru_head_kernel(GruHeadParams
         if (P.enc_stack >= 0) {
             if (kq == 0) {               // ENC_interRNN: x = enc_act(Linear(2H -> 1)) (encoders.py:284,287,292)
                 float v = o[0];
-                if (P.act == 0) v = v > 0.0f ? v : expm1f(v);
+                v = P.act == 0 ? (v > 0.0f ? v : expm1f(v)) : act_apply(v, P.act);
                 P.xtx[pos * 3 + P.enc_stack] = v;
                 esum += (double)v;
                 esq += (double)v * (double)v;
@@ -365,10 +365,10 @@ __global__ __launch_bounds__(64 * kHeadWaves) void gru_head_kernel(GruHeadParams
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int f = 4 * kq + i;
-                if (f < P.F) xn[f] = o[i] - (P.extrinsic ? xc[f] : 0.0f);
+                if (f < P.F) xn[f] = act_apply(o[i], P.act) - (P.extrinsic ? xc[f] : 0.0f);      // dec_act, then extrinsic (decoders.py:103-106)
             }
         } else if (kq == 0) {
-            P.xdec[b * P.L + P.ptab[t]] = sigmoidf_(o[0]);      // sigmoid(deinterleave(x_plr)), decoders.py:145-147
+            P.xdec[b * P.L + P.ptab[t]] = sigmoidf_(act_apply(o[0], P.act));      // sigmoid(deinterleave(dec_act(x_plr))), decoders.py:143-147
         }
     }
     if (P.enc_stack >= 0) {

@@ -531,7 +531,7 @@ __device__ __forceinline__ void enc_body_h(const FusedParams& P, char* smem, con
                                            int blk0, double& sum, double& sumsq) {
     const int L = P.L;
     float* xtx = P.out + (size_t)blk0 * L * 3;
-    const bool act_elu = P.act == 0;
+    const int act = P.act;
     const char* wpack = reinterpret_cast<const char*>(P.wpack);
     WeightStreamH<U, C0, NC> ws;
     ws.init(wpack, P.wpack_bytes, lane);
@@ -543,7 +543,7 @@ __device__ __forceinline__ void enc_body_h(const FusedParams& P, char* smem, con
         run_stack_h<U, PT, C0, NC>(wpack, s * sstride, s < 2 ? (s + 1) * sstride : 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, vmax,
                                    [&](int p, int f, float v) {
             if (f == 0) {
-                if (act_elu) v = elu1(v);                                  // enc_act (encoders.py:364)
+                v = act_apply(v, act);                                     // enc_act (encoders.py:364)
                 xtx[(size_t)(tc.blk(p) * L + tc.t(p)) * 3 + s] = v;        // x_p2 stays in interleaved order (encoders.py:371-373)
                 sum += (double)v;
                 sumsq += (double)v * (double)v;
@@ -615,11 +615,11 @@ __device__ __forceinline__ void seg_body_h(const SegParams& P, char* smem, const
         else run_stack_h<U, PT, C0, NC>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, vmax, epi);
     };
     if (P.mode == 0) {
-        const bool act_elu = P.act == 0;
+        const int act = P.act;
         float* xtx = P.out + (size_t)b * L * 3;
         run([&](int p, int f, float v) {
             if (f == 0) {
-                if (act_elu) v = elu1(v);
+                v = act_apply(v, act);
                 xtx[(size_t)(tstart + tc.m0 + 16 * p) * 3 + stack] = v;
                 sum += (double)v;
                 sumsq += (double)v * (double)v;

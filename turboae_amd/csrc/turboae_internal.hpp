@@ -20,7 +20,7 @@ struct FusedParams {
     int32_t n_iter;         // decoder iterations
     int32_t F;              // num_iter_ft
     int32_t extrinsic;
-    int32_t act;            // encoder output activation: 0 = elu, 1 = linear
+    int32_t act;            // encoder output activation (act_apply codes: 0 elu, 1 linear, 2 tanh, 3 relu, 4 selu, 5 sigmoid)
     uint32_t stack_stride;  // floats between consecutive stacks in wpack
     uint32_t wpack_bytes;   // size of the packed weight buffer (buffer-resource bound)
     int32_t lds_bytes;
@@ -78,7 +78,8 @@ struct GruHeadParams {
     size_t npos;
     int32_t L, F, nout, extrinsic, last;
     int32_t grouped, B;   // grouped = 1: rows of y are in block-group-major order (f16x2 GRU path), B = blocks
-    // encoder mode (ENC_interRNN, enc_stack >= 0): output = enc_act(Linear) -> xtx[(b, t), enc_stack], per-workgroup (sum, sumsq)
+    // encoder mode (ENC_interRNN, enc_stack >= 0): output = enc_act(Linear) -> xtx[(b, t), enc_stack], per-workgroup (sum, sumsq);
+    // `act` = enc_act there, dec_act in decoder mode (act_apply codes)
     int32_t enc_stack, act;
     float* xtx;           // (B, L, 3)
     double* partials;     // [gridDim.x][2]

@@ -338,7 +338,7 @@ __device__ __forceinline__ void enc_body(const FusedParams& P, char* smem, const
                                          const SuperCtx& sc, int g, int lane, int blk0, double& sum, double& sumsq) {
     const int L = P.L;
     float* xtx = P.out + (size_t)blk0 * L * 3;
-    const bool act_elu = P.act == 0;
+    const int act = P.act;
     WeightStream<U, PT, C0, NC> ws;
     ws.init(P.wpack, P.wpack_bytes, lane);
     ws.prefetch(0);
@@ -348,7 +348,7 @@ __device__ __forceinline__ void enc_body(const FusedParams& P, char* smem, const
         run_stack<U, PT, C0, NC, SUPER>(P.wpack, s * sstride, s < 2 ? (s + 1) * sstride : 0xffffffffu, P.n_layer, smem, pn.ACT,
                                         Xin, pn.HS, tc, sc, g, lane, ws, [&](int p, int f, float v) {
             if (f == 0) {
-                if (act_elu) v = elu1(v);                      // enc_act (encoders.py:364)
+                v = act_apply(v, act);                         // enc_act (encoders.py:364)
                 xtx[(size_t)(tc.blk[p] * L + tc.t[p]) * 3 + s] = v;   // x_p2 stays in interleaved order (encoders.py:371-373)
                 sum += (double)v;
                 sumsq += (double)v * (double)v;
@@ -422,11 +422,11 @@ __device__ __forceinline__ void seg_body(const SegParams& P, char* smem, float* 
     const uint32_t soff = (uint32_t)stack * P.stack_stride * 4u;
     ws.prefetch(soff);
     if (P.mode == 0) {
-        const bool act_elu = P.act == 0;
+        const int act = P.act;
         float* xtx = P.out + (size_t)b * L * 3;
         run_stack<U, PT, C0, NC, SUPER>(P.wpack, soff, 0xffffffffu, P.n_layer, smem, ACT, X, HS, tc, sc, g, lane, ws, [&](int p, int f, float v) {
             if (f == 0) {
-                if (act_elu) v = elu1(v);
+                v = act_apply(v, act);
                 xtx[(size_t)tc.t[p] * 3 + stack] = v;
                 sum += (double)v;
                 sumsq += (double)v * (double)v;
