@@ -1,7 +1,10 @@
 /* The reference's eval sweep (trainer.test, trainer.py:135-248) driven from plain C through the C ABI of
  * libturboae_hip.so - no Python, no torch: what a cgo / JNI / FFI binding of another host language would do.
  *
- *   turboae_sweep <weights.f32> <perm.i32> [blocks_per_snr=10000] [batch=500] [snr_points=12] [snr_lo=-1.5] [snr_hi=4.0] [seed=1]
+ *   turboae_sweep <weights.f32> <perm.i32> [blocks_per_snr=10000] [batch=500] [snr_points=12] [snr_lo=-1.5] [snr_hi=4.0] [seed=1] [mode=0]
+ *
+ * mode 0: one tae_eval_snr call per SNR point (the library decodes groups of batches in one launch);
+ * mode 1: the same protocol spelled out call by call (tae_generate_inputs -> tae_forward -> tae_count_errors per batch).
  *
  * <weights.f32>: the canonical flat float32 weight blob of the configuration below (turboae_amd.weights.pack_blob;
  * tae_num_weights(cfg) floats).  <perm.i32>: the interleaver, block_len int32 values - the reference draws it with numpy's
@@ -53,6 +56,7 @@ int main(int argc, char** argv) {
     const double snr_lo = argc > 6 ? atof(argv[6]) : -1.5;
     const double snr_hi = argc > 7 ? atof(argv[7]) : 4.0;
     const uint64_t seed = argc > 8 ? (uint64_t)strtoull(argv[8], NULL, 10) : 1u;
+    const int mode = argc > 9 ? atoi(argv[9]) : 0;
     if (tae_abi_version() != TAE_ABI_VERSION) {
         fprintf(stderr, "header / library ABI mismatch (%d vs %d)\n", TAE_ABI_VERSION, tae_abi_version());
         return 1;
@@ -114,8 +118,12 @@ int main(int argc, char** argv) {
     const double t0 = now_s();
     for (int si = 0; si < snr_points; ++si) {
         const double snr = snr_points > 1 ? snr_lo + (snr_hi - snr_lo) * si / (snr_points - 1) : snr_lo;   /* trainer.py:157-158 */
-        HIP_OK(hipMemsetAsync(counts, 0, (size_t)nbatch * 2 * sizeof(uint64_t), st));
-        for (int bi = 0; bi < nbatch; ++bi) {
+        if (mode == 0) {
+            TAE_CHECK(tae_eval_snr(h, (float)snr, batch, nbatch, (int64_t)si * nbatch * batch, seed, seed, counts, st));
+        } else {
+            HIP_OK(hipMemsetAsync(counts, 0, (size_t)nbatch * 2 * sizeof(uint64_t), st));
+        }
+        for (int bi = 0; mode != 0 && bi < nbatch; ++bi) {
             const int64_t first = ((int64_t)si * nbatch + bi) * batch;      /* global block index: the Philox key */
             TAE_CHECK(tae_generate_inputs(h, u, noise, batch, first, seed, seed, (float)snr, st));
             TAE_CHECK(tae_forward(h, u, noise, x_dec, codes, batch, st));   /* Channel_AE.forward, channel_ae.py:32-78 */

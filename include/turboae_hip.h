@@ -166,6 +166,17 @@ TAE_API int tae_generate_inputs(tae_handle* h, float* u, float* noise, int32_t B
                         uint64_t seed_noise, float snr_db, void* stream);
 
 /* Blocks per workgroup and dynamic LDS bytes of the fused kernels (for DESIGN / bench reporting). */
+/* One SNR point of the reference's eval sweep (trainer.test, trainer.py:160-217; the entry point SURVEY.md section 8b sketches as
+ * tae_eval_snr) entirely on the device: n_batches batches of `batch` blocks.  Batch i (global blocks first_block + i*batch ...) gets
+ * the Philox inputs of tae_generate_inputs, runs encoder -> power constraint with ITS OWN statistics -> additive noise; the
+ * received blocks of a group of batches (about 24 576 blocks) are decoded in one call - the decoder never mixes blocks - and
+ * the errors are counted per batch: counts (device, 2*n_batches uint64, zeroed by the call) = (bit errors, block errors) of
+ * batch i at [2i], [2i+1], so BER = mean_i counts[2i] / (batch * block_len) exactly as trainer.py:176-177,215-216 average it.
+ * Needs an additive channel (tae_channel_opts.channel = 0).  The first call for a geometry grows the workspace (allocates,
+ * synchronises); after that the call only enqueues work on `stream`. */
+TAE_API int tae_eval_snr(tae_handle* h, float snr_db, int32_t batch, int32_t n_batches, int64_t first_block, uint64_t seed_bits,
+                         uint64_t seed_noise, uint64_t* counts, void* stream);
+
 TAE_API int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_t* lds_bytes);
 
 /* Arithmetic actually in use (*precision = 0: fp32 MFMA, 1: fp16-split MFMA) and its sticky range flag:

@@ -467,11 +467,16 @@ def test_plain_c_host_reproduces_the_eval_sweep(gpu_device, tmp_path):
     blob = g["weights_fp16"].astype("<f4")
     blob.tofile(tmp_path / "w.f32")
     rand_interleaver(cfg.block_len, cfg.interleaver_seed).astype("<i4").tofile(tmp_path / "perm.i32")
-    out = subprocess.run([exe, str(tmp_path / "w.f32"), str(tmp_path / "perm.i32"), "1000", "250", "3", "0.0", "3.0", "9"],
-                         capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr
-    rows = [l.split() for l in out.stdout.splitlines() if l.startswith("snr ")]
-    assert len(rows) == 3 and "arithmetic f16x2 overflow 0" in out.stdout
+    runs = []
+    for mode in ("0", "1"):       # one tae_eval_snr call per SNR point / the per-batch call sequence
+        out = subprocess.run([exe, str(tmp_path / "w.f32"), str(tmp_path / "perm.i32"), "1000", "250", "3", "0.0", "3.0", "9", mode],
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert "arithmetic f16x2 overflow 0" in out.stdout
+        runs.append([l.split() for l in out.stdout.splitlines() if l.startswith("snr ")])
+    assert runs[0] == runs[1]
+    rows = runs[0]
+    assert len(rows) == 3
     model = Channel_AE_HIP(cfg, W.unpack_blob(cfg, blob), device=gpu_device, max_batch=250)
     res = evaluate.test(model, snr_test_start=0.0, snr_test_end=3.0, snr_points=3, num_block=1000, batch_size=250, seed=9,
                         verbose=False, enc_power_epilogue=False)
@@ -480,6 +485,10 @@ def test_plain_c_host_reproduces_the_eval_sweep(gpu_device, tmp_path):
         assert int(r[3]) == res["bit_errors"][si] and int(r[5]) == res["block_errors"][si]
         assert abs(float(r[7]) - res["ber"][si]) <= 1e-12 and abs(float(r[9]) - res["bler"][si]) <= 1e-12
     assert res["bit_errors"][0] > res["bit_errors"][2] > 0
+    # the same SNR points through Channel_AE_HIP.eval_snr (tae_eval_snr from Python)
+    for si in range(3):
+        c = model.eval_snr(res["snrs"][si], 250, 4, seed=9, first_block=si * 1000).sum(dim=0).cpu().tolist()
+        assert c == [res["bit_errors"][si], res["block_errors"][si]]
 
 
 @pytest.mark.parametrize("decoder", ["TurboAE_rate3_cnn", "TurboAE_rate3_rnn"])

@@ -47,6 +47,7 @@ SIGNATURES = {
     "tae_decode": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
     "tae_count_errors": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
     "tae_generate_inputs": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64, C.c_float, _P]),
+    "tae_eval_snr": (C.c_int, [_P, C.c_float, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64, _P, _P]),
     "tae_kernel_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tae_range_status": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tae_debug_split_f16": (C.c_int, [_P, C.c_size_t, C.c_float, _P, _P]),

@@ -383,6 +383,19 @@ class Channel_AE_HIP:
             _lib.check(e.lib.tae_count_errors(e.h, _ptr(xd), _ptr(uu), xd.shape[0], _ptr(counts), _stream()))
         return counts
 
+    def eval_snr(self, snr_db: float, batch: int, n_batches: int, seed: int, first_block: int = 0,
+                 seed_noise: Optional[int] = None) -> torch.Tensor:
+        """One SNR point of trainer.test on the device (tae_eval_snr): int64 (n_batches, 2) tensor of per-batch
+        (bit errors, block errors) for the Philox inputs of generate_inputs(batch, snr_db, seed, first_block + i * batch)."""
+        e = self._eng
+        counts = torch.empty((n_batches, 2), dtype=torch.int64, device=e.device)
+        sn = seed if seed_noise is None else seed_noise
+        with torch.cuda.device(e.device):
+            _lib.check(e.lib.tae_eval_snr(e.h, float(snr_db), int(batch), int(n_batches), int(first_block), int(seed), int(sn),
+                                          _ptr(counts), _stream()))
+        e.cap = max(e.cap, min(n_batches, -(-24576 // batch)) * batch)      # the library grew its workspace to one decode group
+        return counts
+
     def generate_inputs(self, B: int, snr_db: float, seed: int, first_block: int = 0,
                         seed_noise: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """Device-side test inputs (replaces trainer.py:167-169), Philox streams of turboae_amd/philox.py."""

@@ -257,6 +257,12 @@ struct tae_handle {
     char* d_wrnn_h = nullptr;   // f16x2 packing of the same (prec == 1)
     float* d_wernn = nullptr;   // GRU encoder (enc_type = 1): the three ENC_interRNN stacks, packed like the decoder's
     char* d_wernn_h = nullptr;
+    // tae_eval_snr workspace (grown on demand)
+    float* d_eval_u = nullptr;       // bits of one decode group (kept for the error count)
+    float* d_eval_noise = nullptr;   // noise of one batch
+    float* d_eval_xdec = nullptr;    // decisions of one decode group
+    int64_t eval_group_blocks = 0;
+    int32_t eval_batch = 0;
     double* d_rnn_partials = nullptr;   // GRU encoder: per (chunk, stack, head workgroup) partial sums
     int32_t rnn_partial_slots = 0;
     int32_t rnn_chunk = 0;   // blocks per internal chunk (bounds the workspace)
@@ -1172,6 +1178,7 @@ int tae_destroy(tae_handle* h) {
     (void)hipFree(h->d_ggi);
     (void)hipFree(h->d_wenc_h); (void)hipFree(h->d_wdec_h); (void)hipFree(h->d_flags); (void)hipFree(h->d_wrnn_h);
     (void)hipFree(h->d_wernn); (void)hipFree(h->d_wernn_h); (void)hipFree(h->d_rnn_partials);
+    (void)hipFree(h->d_eval_u); (void)hipFree(h->d_eval_noise); (void)hipFree(h->d_eval_xdec);
     delete h;
     return TAE_OK;
 }
@@ -1300,6 +1307,53 @@ int tae_forward(tae_handle* h, const float* u, const float* noise, float* x_dec,
     rc = tae_normalize(h, h->d_xtx, h->d_stats, noise, codes, h->d_rx, B, stream);
     if (rc != TAE_OK) return rc;
     return run_decoder(h, h->d_rx, x_dec, B, st);
+}
+
+// One SNR point of trainer.test (trainer.py:160-217) on the device: per batch generate inputs -> encoder -> power constraint with
+// that batch's statistics -> AWGN; the received blocks of a group of batches are decoded in one call (the decoder never mixes
+// blocks) and the errors are counted per batch.
+int tae_eval_snr(tae_handle* h, float snr_db, int32_t batch, int32_t n_batches, int64_t first_block, uint64_t seed_bits,
+                 uint64_t seed_noise, uint64_t* counts, void* stream) {
+    if (!h || !counts) return fail(TAE_EINVAL, "NULL argument");
+    if (batch < 1 || n_batches < 1 || first_block < 0) return fail(TAE_EINVAL, "bad batch geometry");
+    if (h->nopts.channel != 0) return fail(TAE_EINVAL, "tae_eval_snr generates AWGN inputs: the configured channel must be additive (channel = 0)");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t L = h->cfg.block_len;
+    int64_t group = (24576 + batch - 1) / batch;           // batches per decoder call: about 24 576 blocks
+    if (group > n_batches) group = n_batches;
+    if (group * batch > h->cap || group * batch > h->eval_group_blocks || batch > h->eval_batch) {
+        // workspace growth: synchronises and allocates (first call for a geometry only - afterwards the call only enqueues work)
+        int rc = tae_reserve(h, (int32_t)(group * batch));
+        if (rc != TAE_OK) return rc;
+        TAE_HIP(hipDeviceSynchronize());
+        (void)hipFree(h->d_eval_u); (void)hipFree(h->d_eval_noise); (void)hipFree(h->d_eval_xdec);
+        h->d_eval_u = h->d_eval_noise = h->d_eval_xdec = nullptr;
+        h->eval_group_blocks = 0; h->eval_batch = 0;
+        TAE_HIP(hipMalloc(&h->d_eval_u, (size_t)group * batch * L * sizeof(float)));
+        TAE_HIP(hipMalloc(&h->d_eval_xdec, (size_t)group * batch * L * sizeof(float)));
+        TAE_HIP(hipMalloc(&h->d_eval_noise, (size_t)batch * L * 3 * sizeof(float)));
+        h->eval_group_blocks = group * batch;
+        h->eval_batch = batch;
+    }
+    TAE_HIP(hipMemsetAsync(counts, 0, (size_t)n_batches * 2 * sizeof(uint64_t), st));
+    for (int64_t g0 = 0; g0 < n_batches; g0 += group) {
+        const int64_t ng = g0 + group <= n_batches ? group : n_batches - g0;
+        for (int64_t i = 0; i < ng; ++i) {
+            float* u = h->d_eval_u + (size_t)i * batch * L;
+            int rc = tae_generate_inputs(h, u, h->d_eval_noise, batch, first_block + (g0 + i) * batch, seed_bits, seed_noise, snr_db, stream);
+            if (rc != TAE_OK) return rc;
+            rc = run_encoder(h, u, h->d_xtx, h->d_stats, batch, st);
+            if (rc != TAE_OK) return rc;
+            rc = tae_normalize(h, h->d_xtx, h->d_stats, h->d_eval_noise, nullptr, h->d_rx + (size_t)i * batch * L * 3, batch, stream);
+            if (rc != TAE_OK) return rc;
+        }
+        int rc = run_decoder(h, h->d_rx, h->d_eval_xdec, (int32_t)(ng * batch), st);
+        if (rc != TAE_OK) return rc;
+        for (int64_t i = 0; i < ng; ++i)
+            TAE_HIP(tae::launch_count_errors(h->d_eval_xdec + (size_t)i * batch * L, h->d_eval_u + (size_t)i * batch * L, batch, (int)L,
+                                             (unsigned long long*)(counts + 2 * (g0 + i)), st));
+    }
+    return TAE_OK;
 }
 
 int tae_count_errors(tae_handle* h, const float* x_dec, const float* u, int32_t B, uint64_t* counts2, void* stream) {
