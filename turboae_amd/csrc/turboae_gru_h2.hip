@@ -35,7 +35,6 @@ constexpr int kRecFragB = 19 * kRecTileB;                   // 136 192
 constexpr int kNiFragB = 6 * 1024;                          // layer 0: n-gate input tiles (K = 16, hi | lo)
 constexpr int kRec0B = kRecFragB + kNiFragB + 25 * 64 + 16; // + accumulator-init rows + 2^-S
 constexpr int kRec1B = kRecFragB + 7 * 64 + 16;             // + b_hn rows + 2^-S
-constexpr int kGiRowF = 2 * 19 * 16;
 
 __device__ __forceinline__ f32x4 mfma16x16x16h(h4 a, h4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
