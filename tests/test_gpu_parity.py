@@ -522,3 +522,54 @@ def test_forward_is_hip_graph_capturable(gpu_device, decoder):
     assert torch.equal(xd, want2[0]) and torch.equal(codes, want2[1])
     assert counts.cpu().tolist() == model.count_errors(want2[0], u2).cpu().tolist()
     model.check_range()
+
+
+def test_eval_sweep_with_precomputed_norm_stats(gpu_device):
+    """--precompute_norm_stats through evaluate.test: the encoder-only pre-pass of trainer.py:145-153 fills the running
+    mean / std, every later batch keeps averaging (encoders.py:110-114); the oracle replays the same call sequence."""
+    from turboae_amd import Channel_AE_HIP, evaluate
+    cfg = TurboAEConfig(enc_num_unit=32, dec_num_unit=32, num_iteration=2, precompute_norm_stats=True)
+    sd = W.generate_state_dict(cfg, seed=41, gain=1.0)
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=50)
+    res = evaluate.test(model, snr_test_start=0.0, snr_test_end=2.0, snr_points=2, num_block=100, batch_size=50, seed=5,
+                        verbose=False, enc_power_epilogue=False)
+    L, w, state, ocfg = cfg.block_len, O.to_torch(sd), {}, cfg.to_dict()
+    p = torch.from_numpy(O.rand_interleaver(L, 0))
+    for idx in range(2):                                                   # the pre-pass: blocks past the sweep's and the epilogue's
+        first = ((2 + 1) * 2 + idx) * 50
+        u = torch.from_numpy(philox.random_bits(5, first * L, 50 * L).reshape(50, L, 1))
+        O.encode(u, w, p, cfg.enc_num_layer, cfg.enc_act, ocfg, state)
+    assert state["num_test_block"] == 2.0
+    for si, snr in enumerate(res["snrs"]):
+        be_tot = 0
+        for b in range(2):
+            first = (si * 2 + b) * 50
+            u = torch.from_numpy(philox.random_bits(5, first * L, 50 * L).reshape(50, L, 1))
+            noise = torch.from_numpy((np.float32(O.snr_db2sigma(snr)) * philox.random_normal(5, first * L * 3, 50 * L * 3)).reshape(50, L, 3))
+            x, _ = O.channel_ae_forward(u, noise, w, ocfg, None, state)
+            be_tot += O.error_counts(u, x)[0]
+        assert abs(res["bit_errors"][si] - be_tot) <= 2, (si, res["bit_errors"][si], be_tot)
+    assert abs(model._eng.mean_scalar - float(state["mean_scalar"])) <= 1e-6 and abs(model._eng.std_scalar - float(state["std_scalar"])) <= 1e-6
+
+
+def test_eval_sweep_positional_outputs(gpu_device):
+    """--print_pos_ber / --print_pos_power of trainer.test (trainer.py:179-193): per-position error rate and code power."""
+    from turboae_amd import Channel_AE_HIP, evaluate
+    g = np.load(os.path.join(GOLD, "trained_enc2dec5_u100.npz"))
+    cfg = TurboAEConfig(**MANIFEST["trained"]["config"])
+    model = Channel_AE_HIP(cfg, W.unpack_blob(cfg, g["weights_fp16"].astype(np.float32)), device=gpu_device, max_batch=100)
+    kw = dict(snr_test_start=0.0, snr_test_end=0.0, snr_points=1, num_block=300, batch_size=100, seed=8, verbose=False, enc_power_epilogue=False)
+    res = evaluate.test(model, print_pos_ber=True, print_pos_power=True, **kw)
+    L = cfg.block_len
+    pos_ber, pos_pow = np.array(res["pos_ber"][0]), np.array(res["pos_power"][0])
+    assert pos_ber.shape == (L,) and pos_pow.shape == (L,)
+    assert abs(pos_ber.mean() - res["ber"][0]) <= 1e-12                    # the positional rates average to the BER
+    assert abs(pos_pow.mean() - 1.0) <= 0.02                               # power-normalised codes: unit mean power (N-1 in the std)
+    # the same three batches by hand (errors_ber_pos / code_power, utils.py:31-48)
+    want_ber, want_pow = np.zeros(L), np.zeros(L)
+    for b in range(3):
+        u, noise = model.generate_inputs(100, 0.0, seed=8, first_block=b * 100)
+        xd, codes = model(u, noise)
+        want_ber += ((xd > 0.5) != (u > 0.5)).double().mean(dim=0).squeeze(1).cpu().numpy() / 3
+        want_pow += (codes.double() ** 2).mean(dim=2).mean(dim=0).cpu().numpy() / 3
+    assert np.abs(pos_ber - want_ber).max() <= 1e-12 and np.abs(pos_pow - want_pow).max() <= 1e-9

@@ -383,6 +383,13 @@ class Channel_AE_HIP:
             _lib.check(e.lib.tae_count_errors(e.h, _ptr(xd), _ptr(uu), xd.shape[0], _ptr(counts), _stream()))
         return counts
 
+    def update_precomp(self, stats: torch.Tensor) -> None:
+        """--precompute_norm_stats: fold one call's (all-reduced) statistics into the running mean / std that normalize()
+        then uses (ENCBase.power_constraint, encoders.py:110-114).  model(...) and model.enc(...) do this themselves; callers of
+        the split form encode_prenorm -> normalize do it in between.  Reads the statistics back (synchronises)."""
+        if self._eng.cfg.precompute_norm_stats and not self._eng.cfg.no_code_norm:
+            self._eng.update_precomp(stats)
+
     def eval_snr(self, snr_db: float, batch: int, n_batches: int, seed: int, first_block: int = 0,
                  seed_noise: Optional[int] = None) -> torch.Tensor:
         """One SNR point of trainer.test on the device (tae_eval_snr): int64 (n_batches, 2) tensor of per-batch

@@ -4,7 +4,8 @@ Same protocol - ``snr_points`` SNRs from ``snr_test_start`` to ``snr_test_end`` 
 ``num_block / batch_size`` batches per SNR (trainer.py:165), BER = mean over batches of the per-batch
 bit error rate, BLER likewise (trainer.py:176-177,215-216), the same printed lines
 (``Test SNR <snr> with ber <x> with bler <y>``, trainer.py:217; final lists :230-235) and the
-encoder-power epilogue (trainer.py:238-248) - with three deliberate differences:
+encoder-power epilogue (trainer.py:238-248), the ``--precompute_norm_stats`` pre-pass (trainer.py:145-153) and the
+``--print_pos_ber`` / ``--print_pos_power`` outputs (trainer.py:179-193) - with these deliberate differences:
   * inputs come from the counter-based Philox streams on the device instead of the unseeded host
     RNG (trainer.py:167-169), keyed by (seed, snr index, global block index);
   * the accidental extra forward per SNR point (trainer.py:194-213, dies with NameError and prints
@@ -39,7 +40,8 @@ def snr_sigma2db(sigma: float) -> float:       # utils.py:72-76
 
 def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_points: int = 12, num_block: int = 1000,
          batch_size: int = 100, seed: int = 20190001, verbose: bool = True, enc_power_epilogue: bool = True,
-         decode_group: Optional[int] = None, hip_graph: bool = False) -> Dict[str, List[float]]:
+         decode_group: Optional[int] = None, hip_graph: bool = False, test_ratio: int = 1,
+         print_pos_ber: bool = False, print_pos_power: bool = False) -> Dict[str, List[float]]:
     """model: turboae_amd.Channel_AE_HIP.  Returns {'snrs', 'ber', 'bler', 'bit_errors', 'block_errors', 'enc_power'}.
     decode_group: batches decoded per decoder call (None: enough for about 24 576 blocks per rank; 1: one call per batch).
     hip_graph: capture every SNR point (all of its launches, the all-reduces included) into one hipGraph and launch that
@@ -67,9 +69,30 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
     decode_group = max(1, min(int(decode_group), max(num_test_batch, 1)))
     if hip_graph and model.cfg.channel != "awgn":
         raise ValueError("hip_graph=True needs channel='awgn' (device-side Philox inputs)")
+    precomp = bool(model.cfg.precompute_norm_stats) and not model.cfg.no_code_norm
+    if hip_graph and precomp:
+        raise ValueError("hip_graph=True cannot be combined with precompute_norm_stats (the running statistics live on the host)")
+    if precomp:
+        # trainer.py:145-153: the encoder alone over int(num_block / batch_size * test_ratio) batches fills the running mean / std
+        # (ENCBase.power_constraint, encoders.py:110-114); they keep averaging over every later call, as in the reference
+        for idx in range(int(num_block / batch_size * test_ratio)):
+            first = ((snr_points + 1) * num_test_batch + idx) * batch_size + lo
+            stats = torch.zeros(3, dtype=torch.float64, device=dev)
+            if nloc > 0:
+                u, _ = model.generate_inputs(nloc, 0.0, seed=seed, first_block=first)
+                _, stats = model.encode_prenorm(u)
+            all_reduce_sum_(stats)
+            model.update_precomp(stats)
+        say("Pre-computed norm statistics mean ", model._eng.mean_scalar, "std ", model._eng.std_scalar)
     if hip_graph and world > 1 and dist.get_backend() != "nccl":
         raise ValueError("hip_graph=True with torch.distributed needs the nccl (RCCL) backend")
     ber_res, bler_res, bit_res, blk_res = [], [], [], []
+    pos_ber_res, pos_power_res = [], []
+    # --print_pos_ber / --print_pos_power (trainer.py:179-193): per-position error rate (errors_ber_pos, utils.py:31-40) and
+    # per-position code power (code_power, utils.py:42-48), both averaged over the batches of the SNR point
+    want_pos = print_pos_ber or print_pos_power
+    pos_err = torch.zeros(L, dtype=torch.float64, device=dev)
+    pos_pow = torch.zeros(L, dtype=torch.float64, device=dev)
 
     def run_point(si, snr, per_batch):
         for g0 in range(0, num_test_batch, decode_group):
@@ -91,21 +114,32 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
                 else:
                     stats = torch.zeros(3, dtype=torch.float64, device=dev)
                 all_reduce_sum_(stats)                                            # batch-global mean/std (encoders.py:107-108)
+                if precomp:
+                    model.update_precomp(stats)                                   # running averages (encoders.py:110-114)
                 if nloc > 0:
-                    _, rx = model.normalize(x_tx, stats, noise, want_codes=False, fading=fading)
+                    codes, rx = model.normalize(x_tx, stats, noise, want_codes=print_pos_power, fading=fading)
+                    if print_pos_power:
+                        pos_pow.add_((codes.double() ** 2).sum(dim=2).sum(dim=0) / 3.0)
                     group_u.append(u)
                     group_rx.append(rx)
             if nloc > 0:
                 x_dec = model.dec(group_rx[0] if len(group_rx) == 1 else torch.cat(group_rx))
                 for i, u in enumerate(group_u):
                     model.count_errors(x_dec[i * nloc:(i + 1) * nloc], u, per_batch[g0 + i])
+                    if print_pos_ber:      # torch.round is half-to-even: round(y) != round(x) <=> (y > 0.5) != (x > 0.5)
+                        pos_err.add_(((x_dec[i * nloc:(i + 1) * nloc] > 0.5) != (u > 0.5)).sum(dim=0).squeeze(1).double())
         all_reduce_sum_(per_batch)
+        if want_pos:
+            all_reduce_sum_(pos_err)
+            all_reduce_sum_(pos_pow)
 
     if hip_graph and nloc > 0:
         model.reserve(decode_group * nloc)           # no workspace growth (an allocation) inside a capture
     for si, snr in enumerate(snrs):
         # per-batch (bit errors, block errors) stay on the device; one host read per SNR point
         per_batch = torch.zeros((max(num_test_batch, 1), 2), dtype=torch.int64, device=dev)
+        pos_err.zero_()
+        pos_pow.zero_()
         if hip_graph:
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
@@ -125,6 +159,14 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
         test_ber /= num_test_batch
         test_bler /= num_test_batch
         tot = per_batch.sum(dim=0)
+        if print_pos_power:
+            pos_power_res.append((pos_pow / float(batch_size * num_test_batch)).cpu().tolist())
+            say("code power", pos_power_res[-1])
+        if print_pos_ber:
+            res_pos = pos_err / float(batch_size * num_test_batch)
+            pos_ber_res.append(res_pos.cpu().tolist())
+            say("positional ber", pos_ber_res[-1])
+            say("positional argmax", torch.argsort(res_pos, descending=True, stable=True).cpu().tolist())
         say("Test SNR", snr, "with ber ", float(test_ber), "with bler", float(test_bler))
         ber_res.append(float(test_ber))
         bler_res.append(float(test_bler))
@@ -136,6 +178,10 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
     say("BER", ber_res)
     say("BLER", bler_res)
     out = {"snrs": snrs, "ber": ber_res, "bler": bler_res, "bit_errors": bit_res, "block_errors": blk_res}
+    if print_pos_ber:
+        out["pos_ber"] = pos_ber_res
+    if print_pos_power:
+        out["pos_power"] = pos_power_res
     if enc_power_epilogue:
         # trainer.py:238-248: mean over batches of std(model.enc(X)); 1.0 for the power-normalised encoder
         enc_power = 0.0
@@ -146,6 +192,8 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
                 u, _ = model.generate_inputs(nloc, 0.0, seed=seed, first_block=first)
                 x_tx, stats = model.encode_prenorm(u)
             all_reduce_sum_(stats)
+            if precomp:
+                model.update_precomp(stats)
             loc = torch.zeros(3, dtype=torch.float64, device=dev)
             if nloc > 0:
                 codes, _ = model.normalize(x_tx, stats)
