@@ -8,8 +8,8 @@ encoder-power epilogue (trainer.py:238-248), the ``--precompute_norm_stats`` pre
 ``--print_pos_ber`` / ``--print_pos_power`` outputs (trainer.py:179-193) - with these deliberate differences:
   * inputs come from the counter-based Philox streams on the device instead of the unseeded host
     RNG (trainer.py:167-169), keyed by (seed, snr index, global block index);
-  * the accidental extra forward per SNR point (trainer.py:194-213, dies with NameError and prints
-    'no pos BER specified.') is not run;
+  * the second, "punctured" pass per SNR point (trainer.py:194-213) runs only with ``print_pos_ber`` - without it the
+    reference's own pass dies with a NameError on the first batch and prints 'no pos BER specified.';
   * with torch.distributed initialised every batch is sharded over the ranks by block; the
     power-constraint statistics and the error counts are all-reduced (turboae_amd/distributed.py), so
     the numbers equal the single-GPU ones;
@@ -41,7 +41,7 @@ def snr_sigma2db(sigma: float) -> float:       # utils.py:72-76
 def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_points: int = 12, num_block: int = 1000,
          batch_size: int = 100, seed: int = 20190001, verbose: bool = True, enc_power_epilogue: bool = True,
          decode_group: Optional[int] = None, hip_graph: bool = False, test_ratio: int = 1,
-         print_pos_ber: bool = False, print_pos_power: bool = False) -> Dict[str, List[float]]:
+         print_pos_ber: bool = False, print_pos_power: bool = False, num_ber_puncture: int = 5) -> Dict[str, List[float]]:
     """model: turboae_amd.Channel_AE_HIP.  Returns {'snrs', 'ber', 'bler', 'bit_errors', 'block_errors', 'enc_power'}.
     decode_group: batches decoded per decoder call (None: enough for about 24 576 blocks per rank; 1: one call per batch).
     hip_graph: capture every SNR point (all of its launches, the all-reduces included) into one hipGraph and launch that
@@ -87,12 +87,53 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
     if hip_graph and world > 1 and dist.get_backend() != "nccl":
         raise ValueError("hip_graph=True with torch.distributed needs the nccl (RCCL) backend")
     ber_res, bler_res, bit_res, blk_res = [], [], [], []
-    pos_ber_res, pos_power_res = [], []
+    pos_ber_res, pos_power_res, ber_punc_res, bler_punc_res = [], [], [], []
     # --print_pos_ber / --print_pos_power (trainer.py:179-193): per-position error rate (errors_ber_pos, utils.py:31-40) and
     # per-position code power (code_power, utils.py:42-48), both averaged over the batches of the SNR point
     want_pos = print_pos_ber or print_pos_power
     pos_err = torch.zeros(L, dtype=torch.float64, device=dev)
     pos_pow = torch.zeros(L, dtype=torch.float64, device=dev)
+
+    def make_batch(first, snr):
+        """(u, noise, fading) of this rank's shard of the batch whose first global block is `first`."""
+        u, noise = model.generate_inputs(nloc, snr, seed=seed, first_block=first)
+        fading = None
+        if model.cfg.channel != "awgn":
+            # other channels: generate_noise restated on the device (turboae_amd/channels.py), one generator per
+            # (seed, global first block of the shard): shards of any world size draw independent streams
+            gen = torch.Generator(device=dev)
+            gen.manual_seed((seed * 1000003 + first) & 0x7FFFFFFFFFFFFFFF)
+            noise = channels.generate_noise((nloc, L, 3), model.cfg, snr, device=dev, generator=gen)
+            if model.cfg.channel == "fading":
+                fading = channels.rayleigh_fading((nloc, L, 3), device=dev, generator=gen)
+        return u, noise, fading
+
+    def punctured_point(si, snr, positions):
+        """The second pass of trainer.py:194-213 (it only runs when --print_pos_ber defined the position ranking): fresh batches,
+        errors at the `positions` with the worst positional BER are not counted (errors_ber / errors_bler with positions,
+        utils.py:6-18,49-66 - the BER still divides by the full block length)."""
+        keep = torch.ones(L, dtype=torch.bool, device=dev)
+        keep[torch.as_tensor(positions, dtype=torch.long, device=dev)] = False
+        acc = torch.zeros((max(num_test_batch, 1), 2), dtype=torch.int64, device=dev)
+        for batch_idx in range(num_test_batch):
+            first = ((snr_points + 2 + si) * num_test_batch + batch_idx) * batch_size + lo
+            stats = torch.zeros(3, dtype=torch.float64, device=dev)
+            if nloc > 0:
+                u, noise, fading = make_batch(first, snr)
+                x_tx, stats = model.encode_prenorm(u)
+            all_reduce_sum_(stats)
+            if precomp:
+                model.update_precomp(stats)
+            if nloc > 0:
+                _, rx = model.normalize(x_tx, stats, noise, want_codes=False, fading=fading)
+                err = ((model.dec(rx) > 0.5) != (u > 0.5)).squeeze(2) & keep
+                acc[batch_idx, 0] = err.sum()
+                acc[batch_idx, 1] = err.any(dim=1).sum()
+        all_reduce_sum_(acc)
+        pb = acc.cpu().tolist()
+        ber = sum(c[0] / float(batch_size * L) for c in pb[:num_test_batch]) / num_test_batch
+        bler = sum(c[1] / float(batch_size) for c in pb[:num_test_batch]) / num_test_batch
+        return ber, bler
 
     def run_point(si, snr, per_batch):
         for g0 in range(0, num_test_batch, decode_group):
@@ -101,15 +142,7 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
                 first = (si * num_test_batch + batch_idx) * batch_size + lo       # global block index of this shard
                 fading = None
                 if nloc > 0:
-                    u, noise = model.generate_inputs(nloc, snr, seed=seed, first_block=first)
-                    if model.cfg.channel != "awgn":
-                        # other channels: generate_noise restated on the device (turboae_amd/channels.py), one generator per
-                        # (seed, global first block of the shard): shards of any world size draw independent streams
-                        gen = torch.Generator(device=dev)
-                        gen.manual_seed((seed * 1000003 + first) & 0x7FFFFFFFFFFFFFFF)
-                        noise = channels.generate_noise((nloc, L, 3), model.cfg, snr, device=dev, generator=gen)
-                        if model.cfg.channel == "fading":
-                            fading = channels.rayleigh_fading((nloc, L, 3), device=dev, generator=gen)
+                    u, noise, fading = make_batch(first, snr)
                     x_tx, stats = model.encode_prenorm(u)
                 else:
                     stats = torch.zeros(3, dtype=torch.float64, device=dev)
@@ -166,8 +199,16 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
             res_pos = pos_err / float(batch_size * num_test_batch)
             pos_ber_res.append(res_pos.cpu().tolist())
             say("positional ber", pos_ber_res[-1])
-            say("positional argmax", torch.argsort(res_pos, descending=True, stable=True).cpu().tolist())
+            res_pos_arg = torch.argsort(res_pos, descending=True, stable=True).cpu().tolist()
+            say("positional argmax", res_pos_arg)
         say("Test SNR", snr, "with ber ", float(test_ber), "with bler", float(test_bler))
+        if print_pos_ber:
+            ber_p, bler_p = punctured_point(si, snr, res_pos_arg[:num_ber_puncture])
+            say("Punctured Test SNR", snr, "with ber ", float(ber_p), "with bler", float(bler_p))
+            ber_punc_res.append(float(ber_p))
+            bler_punc_res.append(float(bler_p))
+        else:
+            say("No puncturation is there.")
         ber_res.append(float(test_ber))
         bler_res.append(float(test_bler))
         t = tot.cpu().tolist()
@@ -178,8 +219,12 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
     say("BER", ber_res)
     say("BLER", bler_res)
     out = {"snrs": snrs, "ber": ber_res, "bler": bler_res, "bit_errors": bit_res, "block_errors": blk_res}
+    say("final results on punctured SNRs ", snrs)
+    say("BER", ber_punc_res)
+    say("BLER", bler_punc_res)
     if print_pos_ber:
         out["pos_ber"] = pos_ber_res
+        out["ber_punc"], out["bler_punc"] = ber_punc_res, bler_punc_res
     if print_pos_power:
         out["pos_power"] = pos_power_res
     if enc_power_epilogue:
