@@ -254,3 +254,20 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
         out["enc_power"] = enc_power
         out["adjusted_snrs"] = adj
     return out
+
+
+def test_from_args(model, args, **overrides) -> Dict[str, List[float]]:
+    """`test(model, args)` of the reference (trainer.py:135) with the sweep read from a reference-style namespace:
+    snr_test_start / snr_test_end / snr_points / num_block / batch_size / test_ratio / print_pos_ber / print_pos_power /
+    num_ber_puncture (get_args.py:103-120,212-215); keyword overrides win (seed, decode_group, hip_graph, verbose ...)."""
+    kw = dict(snr_test_start=getattr(args, "snr_test_start", -1.5), snr_test_end=getattr(args, "snr_test_end", 4.0),
+              snr_points=getattr(args, "snr_points", 12), num_block=getattr(args, "num_block", 1000),
+              batch_size=getattr(args, "batch_size", 100), test_ratio=getattr(args, "test_ratio", 1),
+              print_pos_ber=bool(getattr(args, "print_pos_ber", False)), print_pos_power=bool(getattr(args, "print_pos_power", False)),
+              num_ber_puncture=getattr(args, "num_ber_puncture", 5))
+    kw.update(overrides)
+    return test(model, **kw)
+
+
+test.__test__ = False            # not pytest tests (the names follow the reference)
+test_from_args.__test__ = False
