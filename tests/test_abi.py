@@ -33,7 +33,8 @@ def test_library_exports_every_declared_symbol():
 def test_num_weights_matches_python_side():
     lib = _lib.load()
     for over in (dict(), dict(enc_num_layer=5), dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, num_iter_ft=3),
-                 dict(decoder="TurboAE_rate3_rnn"), dict(decoder="TurboAE_rate3_rnn", num_iteration=2, num_iter_ft=3)):
+                 dict(decoder="TurboAE_rate3_rnn"), dict(decoder="TurboAE_rate3_rnn", num_iteration=2, num_iter_ft=3),
+                 dict(enc_num_unit=64, dec_num_unit=32), dict(enc_num_unit=32, decoder="TurboAE_rate3_rnn")):
         cfg = TurboAEConfig(**over)
         c = _lib.TaeConfig(C.sizeof(_lib.TaeConfig), cfg.block_len, cfg.enc_num_layer, cfg.enc_num_unit, 5,
                            cfg.dec_num_layer, cfg.dec_num_unit, 5, cfg.num_iteration, cfg.num_iter_ft, 1, 0, 1,

@@ -21,10 +21,11 @@ def draw_cases(n, seed):
     cases = []
     for i in range(n):
         U = int(rng.choice([32, 64, 100], p=[0.25, 0.25, 0.5]))
+        Ud = U if rng.rand() < 0.5 else int(rng.choice([32, 64, 100]))        # encoder and decoder widths are independent
         L = int(rng.choice(EDGE_LENS)) if rng.rand() < 0.6 else int(rng.randint(1, 420))
         nb_guess = max(1, 320 // L)
         B = int(rng.choice([1, 2, nb_guess, nb_guess + 1, 2 * nb_guess + 1, int(rng.randint(1, 48))]))
-        cases.append(dict(block_len=L, enc_num_unit=U, dec_num_unit=U, enc_num_layer=int(rng.randint(1, 6)),
+        cases.append(dict(block_len=L, enc_num_unit=U, dec_num_unit=Ud, enc_num_layer=int(rng.randint(1, 6)),
                           dec_num_layer=int(rng.randint(1, 6)), num_iter_ft=int(rng.randint(1, 7)),
                           num_iteration=int(rng.randint(1, 4)), extrinsic=int(rng.randint(0, 2)),
                           enc_act=str(rng.choice(["elu", "linear", "elu", "tanh", "relu", "selu", "sigmoid"])), B=B, fixed_nb=str(int(rng.randint(0, 2))), wseed=int(rng.randint(1, 1 << 30))))
@@ -35,7 +36,7 @@ def draw_cases(n, seed):
 CASES = draw_cases(int(os.environ.get("TAE_FUZZ_CASES", "48")), int(os.environ.get("TAE_FUZZ_SEED", "20240607")))
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "U{enc_num_unit}_L{block_len}_B{B}_e{enc_num_layer}d{dec_num_layer}_F{num_iter_ft}_it{num_iteration}_nb{fixed_nb}".format(**c))
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "U{enc_num_unit}x{dec_num_unit}_L{block_len}_B{B}_e{enc_num_layer}d{dec_num_layer}_F{num_iter_ft}_it{num_iteration}_nb{fixed_nb}".format(**c))
 def test_random_shape_matches_oracle_in_both_precisions(gpu_device, monkeypatch, case):
     from turboae_amd import Channel_AE_HIP
     case = dict(case)
@@ -77,12 +78,13 @@ def draw_variant_cases(n, seed):
                  B=B, wseed=int(rng.randint(1, 1 << 30)), kind=kind)
         acts = ["linear", "elu", "tanh", "relu", "selu", "sigmoid"]
         if kind == "dec_rnn":
-            c.update(decoder="TurboAE_rate3_rnn", enc_num_layer=int(rng.randint(1, 4)), dec_act=str(rng.choice(acts)))
+            c.update(decoder="TurboAE_rate3_rnn", enc_num_layer=int(rng.randint(1, 4)), dec_act=str(rng.choice(acts)),
+                     enc_num_unit=int(rng.choice([32, 64, 100])))
         elif kind == "enc_rnn":
             c.update(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_act=str(rng.choice(acts)), dec_act=str(rng.choice(acts)))
         else:
             U = int(rng.choice([32, 64]))
-            c.update(encoder="TurboAE_rate3_cnn_dense", decoder="TurboAE_rate3_cnn_dense", enc_num_unit=U, dec_num_unit=U,
+            c.update(encoder="TurboAE_rate3_cnn_dense", decoder="TurboAE_rate3_cnn_dense", enc_num_unit=U, dec_num_unit=int(rng.choice([32, 64])),
                      enc_num_layer=int(rng.randint(1, 4)), dec_num_layer=int(rng.randint(1, 4)))
         cases.append(c)
     return cases

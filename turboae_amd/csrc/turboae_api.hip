@@ -225,17 +225,19 @@ size_t pack_stack_h(const float* src, const LayoutH& lo, int n_layer, int cin0, 
 struct tae_handle {
     tae_config cfg;
     int device = 0;
-    int U = 0, nb = 0, lds_bytes = 0;
+    // per side (encoder / decoder): channel width, blocks per workgroup of the whole-block kernels (0: long-block path), LDS bytes
+    int U = 0, nb = 0, lds_bytes = 0;            // encoder
+    int Ud = 0, nbd = 0, lds_bytes_d = 0;        // decoder
     int ncu = 256;           // compute units of the device (workgroups resident at once: one per CU)
     bool fixed_nb = false;   // TAE_FIXED_NB=1: always nb blocks per workgroup (testing knob)
     // long-block (segmented) path, used when a whole block does not fit one workgroup (nb == 0)
     int enc_T = 0, enc_nseg = 0, enc_lds = 0, dec_T = 0, dec_nseg = 0, dec_lds = 0;
     uint32_t enc_stride = 0, dec_stride = 0;
     uint32_t enc_bytes = 0, dec_bytes = 0;
-    int super = 0;           // remainder channels via super-tiles (U % 16 == 4 and block_len % 4 == 0)
+    int super = 0, super_d = 0;   // remainder channels via super-tiles (U % 16 == 4 and block_len % 4 == 0), encoder / decoder
     // f16x2 representation of the whole-block kernels (prec == 1); the fp32 packs above stay resident for the long-block path
     int prec = 0;            // 0: v_mfma_f32_16x16x4_f32 on fp32 operands; 1: 3 x v_mfma_f32_16x16x32_f16 on hi/lo halves
-    int lds_bytes_h = 0, enc_lds_h = 0, dec_lds_h = 0;
+    int lds_bytes_h = 0, lds_bytes_hd = 0, enc_lds_h = 0, dec_lds_h = 0;
     uint32_t enc_stride_h = 0, dec_stride_h = 0, enc_bytes_h = 0, dec_bytes_h = 0;
     char* d_wenc_h = nullptr;
     char* d_wdec_h = nullptr;
@@ -280,9 +282,9 @@ int check_cfg(const tae_config* c) {
     if (!c) return fail(TAE_EINVAL, "config is NULL");
     if (c->struct_size != (int32_t)sizeof(tae_config)) return fail(TAE_EINVAL, "tae_config.struct_size mismatch (ABI)");
     if (c->enc_kernel_size != 5 || c->dec_kernel_size != 5) return fail(TAE_EINVAL, "only kernel_size 5 is supported");
-    if (c->enc_num_unit != c->dec_num_unit) return fail(TAE_EINVAL, "enc_num_unit must equal dec_num_unit");
-    if (c->enc_num_unit != 100 && c->enc_num_unit != 64 && c->enc_num_unit != 32)
-        return fail(TAE_EINVAL, "channel width must be 32, 64 or 100");
+    if ((c->enc_num_unit != 100 && c->enc_num_unit != 64 && c->enc_num_unit != 32) ||
+        (c->dec_num_unit != 100 && c->dec_num_unit != 64 && c->dec_num_unit != 32))
+        return fail(TAE_EINVAL, "channel width (enc_num_unit, dec_num_unit) must be 32, 64 or 100");
     if (c->enc_num_layer < 1 || c->dec_num_layer < 1 || c->num_iteration < 1) return fail(TAE_EINVAL, "layer/iteration counts must be >= 1");
     if (c->num_iter_ft < 1 || c->num_iter_ft > 6) return fail(TAE_EINVAL, "num_iter_ft must be in 1..6");
     if (c->block_len < 1) return fail(TAE_EINVAL, "block_len must be >= 1");
@@ -611,13 +613,15 @@ void repack_rnn_h(const float* src, char* dst, size_t cin0, const std::vector<si
 }
 
 size_t num_weights(const tae_config* c) {
-    const size_t U = c->enc_num_unit, F = c->num_iter_ft;
+    size_t U = c->enc_num_unit;
+    const size_t F = c->num_iter_ft;
     size_t n = 0;
     for (int s = 0; s < 3; ++s) {
         if (c->enc_type == 1) { n += rnn_stack_floats(U, 1, 1); continue; }
         for (int l = 0; l < c->enc_num_layer; ++l) n += U * (c->dense ? 1 + l * U : (l == 0 ? 1 : U)) * 5 + U;
         n += U + 1;
     }
+    U = c->dec_num_unit;
     for (int it = 0; it < c->num_iteration; ++it)
         for (int half = 0; half < 2; ++half) {
             const size_t nout = (half == 1 && it == c->num_iteration - 1) ? 1 : F;
@@ -670,12 +674,12 @@ bool choose_seg(int U, int L, int n_layer, int* T, int* nseg, int* lds, bool den
 // A large batch wants the fullest workgroups (3 blocks of 100 -> 5 tiles per group); a batch that would leave CUs
 // idle is cheaper spread thinner (500 blocks: 250 workgroups x 4 tiles instead of 167 x 5; <= 256 blocks: one block
 // per workgroup, 2 tiles).  Results do not depend on the choice (blocks never see each other).
-int nb_for_batch(const tae_handle* h, int32_t B) {
-    if (h->fixed_nb || h->prec != 1) return h->nb;
+int nb_for_batch(const tae_handle* h, int32_t B, int nb_max) {
+    if (h->fixed_nb || h->prec != 1) return nb_max;
     const int L = h->cfg.block_len;
-    int best = h->nb;
+    int best = nb_max;
     long best_cost = -1;
-    for (int nb = h->nb; nb >= 1; --nb) {              // ties keep the larger nb (fewer passes over the weights)
+    for (int nb = nb_max; nb >= 1; --nb) {              // ties keep the larger nb (fewer passes over the weights)
         const long grid = ((long)B + nb - 1) / nb;
         const long rounds = (grid + h->ncu - 1) / h->ncu;
         const long ntile = ((long)nb * L + 15) / 16;
@@ -703,24 +707,24 @@ tae::NormOpts default_norm_opts() {
     return o;
 }
 
-tae::FusedParams base_params(const tae_handle* h, int32_t B) {
+tae::FusedParams base_params(const tae_handle* h, int32_t B, bool decoder) {
     tae::FusedParams P;
     memset(&P, 0, sizeof(P));
     P.perm = h->d_perm;
     P.inv = h->d_inv;
     P.B = B;
     P.L = h->cfg.block_len;
-    P.nb = h->nb;
+    P.nb = decoder ? h->nbd : h->nb;
     P.n_iter = h->cfg.num_iteration;
     P.F = h->cfg.num_iter_ft;
     P.extrinsic = h->cfg.extrinsic;
     P.act = h->cfg.enc_act;
-    P.lds_bytes = h->lds_bytes;
-    P.super = h->super;
+    P.lds_bytes = decoder ? h->lds_bytes_d : h->lds_bytes;
+    P.super = decoder ? h->super_d : h->super;
     return P;
 }
 
-tae::SegParams seg_params(const tae_handle* h, int32_t B) {
+tae::SegParams seg_params(const tae_handle* h, int32_t B, bool decoder) {
     tae::SegParams P;
     memset(&P, 0, sizeof(P));
     P.perm = h->d_perm;
@@ -730,13 +734,13 @@ tae::SegParams seg_params(const tae_handle* h, int32_t B) {
     P.F = h->cfg.num_iter_ft;
     P.extrinsic = h->cfg.extrinsic;
     P.act = h->cfg.enc_act;
-    P.super = h->super;
+    P.super = decoder ? h->super_d : h->super;
     P.dense = h->cfg.dense;
     return P;
 }
 
 int run_encoder_long(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st) {
-    tae::SegParams P = seg_params(h, B);
+    tae::SegParams P = seg_params(h, B, false);
     P.wpack = h->d_wenc;
     P.in = u;
     P.out = xtx;
@@ -763,7 +767,7 @@ int run_encoder_long(tae_handle* h, const float* u, float* xtx, double* stats, i
 }
 
 int run_decoder_long(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st) {
-    tae::SegParams P = seg_params(h, B);
+    tae::SegParams P = seg_params(h, B, true);
     P.wpack = h->d_wdec;
     P.in = rx;
     P.out = xdec;
@@ -788,8 +792,8 @@ int run_decoder_long(tae_handle* h, const float* rx, float* xdec, int32_t B, hip
         P.last = (s == n_stack - 1);
         P.eprev = (s & 1) ? h->d_e0 : h->d_e1;
         P.ecur = (s & 1) ? h->d_e1 : h->d_e0;
-        if (h->prec == 1) TAE_HIP(tae::launch_seg_h(h->U, P, grid, st));
-        else TAE_HIP(tae::launch_seg(h->U, P, grid, st));
+        if (h->prec == 1) TAE_HIP(tae::launch_seg_h(h->Ud, P, grid, st));
+        else TAE_HIP(tae::launch_seg(h->Ud, P, grid, st));
     }
     return TAE_OK;
 }
@@ -799,7 +803,7 @@ int run_encoder_rnn(tae_handle* h, const float* u, float* xtx, double* stats, in
 int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st) {
     if (h->cfg.enc_type == 1) return run_encoder_rnn(h, u, xtx, stats, B, st);
     if (h->nb < 1) return run_encoder_long(h, u, xtx, stats, B, st);
-    tae::FusedParams P = base_params(h, B);
+    tae::FusedParams P = base_params(h, B, false);
     P.wpack = h->d_wenc;
     P.in = u;
     P.out = xtx;
@@ -807,7 +811,7 @@ int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_
     P.n_layer = h->cfg.enc_num_layer;
     P.stack_stride = h->enc_stride;
     P.wpack_bytes = h->enc_bytes;
-    P.nb = nb_for_batch(h, B);
+    P.nb = nb_for_batch(h, B, h->nb);
     const int grid = (B + P.nb - 1) / P.nb;
     if (h->prec == 1) {
         P.wpack = reinterpret_cast<const float*>(h->d_wenc_h);
@@ -951,26 +955,26 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
 
 int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st) {
     if (h->cfg.dec_type == 1) return run_decoder_rnn(h, rx, xdec, B, st);
-    if (h->nb < 1) return run_decoder_long(h, rx, xdec, B, st);
-    tae::FusedParams P = base_params(h, B);
+    if (h->nbd < 1) return run_decoder_long(h, rx, xdec, B, st);
+    tae::FusedParams P = base_params(h, B, true);
     P.wpack = h->d_wdec;
     P.in = rx;
     P.out = xdec;
     P.n_layer = h->cfg.dec_num_layer;
     P.stack_stride = h->dec_stride;
     P.wpack_bytes = h->dec_bytes;
-    P.nb = nb_for_batch(h, B);
+    P.nb = nb_for_batch(h, B, h->nbd);
     const int grid = (B + P.nb - 1) / P.nb;
     if (h->prec == 1) {
         P.wpack = reinterpret_cast<const float*>(h->d_wdec_h);
         P.stack_stride = h->dec_stride_h;
         P.wpack_bytes = h->dec_bytes_h;
-        P.lds_bytes = P.nb == h->nb ? h->lds_bytes_h : tae::fused_lds_bytes_h(h->U, h->cfg.block_len, P.nb);
+        P.lds_bytes = P.nb == h->nbd ? h->lds_bytes_hd : tae::fused_lds_bytes_h(h->Ud, h->cfg.block_len, P.nb);
         P.flags = h->d_flags;
-        TAE_HIP(tae::launch_fused_h(h->U, true, P, grid, st));
+        TAE_HIP(tae::launch_fused_h(h->Ud, true, P, grid, st));
         return TAE_OK;
     }
-    TAE_HIP(tae::launch_fused(h->U, true, P, grid, st));
+    TAE_HIP(tae::launch_fused(h->Ud, true, P, grid, st));
     return TAE_OK;
 }
 
@@ -1005,30 +1009,33 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     h->cfg = *cfg;
     h->nopts = default_norm_opts();
     h->U = cfg->enc_num_unit;
+    h->Ud = cfg->dec_num_unit;
     (void)hipGetDevice(&h->device);
     if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || h->ncu < 1) h->ncu = 256;
     const char* fixed_nb = getenv("TAE_FIXED_NB");
     h->fixed_nb = fixed_nb && fixed_nb[0] == '1';
     h->nb = choose_nb(h->U, cfg->block_len, &h->lds_bytes);
+    h->nbd = choose_nb(h->Ud, cfg->block_len, &h->lds_bytes_d);
     // Testing knobs (documented in DESIGN.md): TAE_FORCE_SEGMENTED=1 selects the long-block path even
     // when whole blocks fit; TAE_SEG_T=<n> caps the centre length of a segment.
     const char* force_seg = getenv("TAE_FORCE_SEGMENTED");
-    if (force_seg && force_seg[0] == '1') h->nb = 0;
-    if (cfg->dense) h->nb = 0;            // dense stacks run on the long-block kernels (one stack per launch)
-    if (h->nb < 1) {
-        h->nb = 0;
+    if (force_seg && force_seg[0] == '1') h->nb = h->nbd = 0;
+    if (cfg->dense) h->nb = h->nbd = 0;   // dense stacks run on the long-block kernels (one stack per launch)
+    if (h->nb < 1 || h->nbd < 1) {
+        h->nb = h->nbd = 0;               // one path for both sides (the exchange buffers and the workspace follow it)
         if (!choose_seg(h->U, cfg->block_len, cfg->enc_num_layer, &h->enc_T, &h->enc_nseg, &h->enc_lds, cfg->dense != 0) ||
-            !choose_seg(h->U, cfg->block_len, cfg->dec_num_layer, &h->dec_T, &h->dec_nseg, &h->dec_lds, cfg->dense != 0)) {
+            !choose_seg(h->Ud, cfg->block_len, cfg->dec_num_layer, &h->dec_T, &h->dec_nseg, &h->dec_lds, cfg->dense != 0)) {
             delete h;
             return fail(TAE_EINVAL, "too many conv layers for the segmented long-block kernels (halo exceeds the panel)");
         }
     }
-    const Layout lo(h->U);
+    const Layout lo(h->U), lod(h->Ud);
     const int F = cfg->num_iter_ft;
     const char* nosup = getenv("TAE_NO_SUPER");     // testing knob: force the padded-tile path
     h->super = (lo.sup && cfg->block_len % 4 == 0 && !(nosup && nosup[0] == '1')) ? 1 : 0;
+    h->super_d = (lod.sup && cfg->block_len % 4 == 0 && !(nosup && nosup[0] == '1')) ? 1 : 0;
     h->enc_stride = (uint32_t)lo.stack_stride(cfg->enc_num_layer);
-    h->dec_stride = (uint32_t)lo.stack_stride(cfg->dec_num_layer);
+    h->dec_stride = (uint32_t)lod.stack_stride(cfg->dec_num_layer);
     std::vector<float> penc((size_t)3 * h->enc_stride, 0.0f), pdec((size_t)2 * cfg->num_iteration * h->dec_stride, 0.0f);
     h->enc_bytes = (uint32_t)(penc.size() * sizeof(float));
     h->dec_bytes = (uint32_t)(pdec.size() * sizeof(float));
@@ -1043,7 +1050,7 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         for (int it = 0; it < cfg->num_iteration; ++it)
             for (int half = 0; half < 2; ++half) {
                 const int nout = (half == 1 && it == cfg->num_iteration - 1) ? 1 : F;
-                src += pack_stack(src, lo, cfg->dec_num_layer, 2 + F, nout, pdec.data() + (size_t)(2 * it + half) * h->dec_stride);
+                src += pack_stack(src, lod, cfg->dec_num_layer, 2 + F, nout, pdec.data() + (size_t)(2 * it + half) * h->dec_stride);
             }
     }
     if ((size_t)(src - weights) != n_weights) {
@@ -1060,10 +1067,11 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     bool h2_ok = false;
     if (want_h2 && h->nb >= 1) {
         h->lds_bytes_h = tae::fused_lds_bytes_h(h->U, cfg->block_len, h->nb);
-        h2_ok = h->lds_bytes_h <= 160 * 1024;
+        h->lds_bytes_hd = tae::fused_lds_bytes_h(h->Ud, cfg->block_len, h->nbd);
+        h2_ok = h->lds_bytes_h <= 160 * 1024 && h->lds_bytes_hd <= 160 * 1024;
     } else if (want_h2) {               // long-block path: same segment geometry, f16x2 panels
         h->enc_lds_h = tae::seg_lds_bytes_h(h->U, h->enc_T, cfg->enc_num_layer);
-        h->dec_lds_h = tae::seg_lds_bytes_h(h->U, h->dec_T, cfg->dec_num_layer);
+        h->dec_lds_h = tae::seg_lds_bytes_h(h->Ud, h->dec_T, cfg->dec_num_layer);
         h2_ok = h->enc_lds_h <= 160 * 1024 && h->dec_lds_h <= 160 * 1024;
     }
     if (cfg->dense) {
@@ -1072,9 +1080,9 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         h->enc_lds_h = h->enc_lds;
         h->dec_lds_h = h->dec_lds;
         h->prec = 1;
-        const LayoutH lh(h->U);
+        const LayoutH lh(h->U), lhd(h->Ud);
         h->enc_stride_h = (uint32_t)dense_stack_bytes(lh, cfg->enc_num_layer);
-        h->dec_stride_h = (uint32_t)dense_stack_bytes(lh, cfg->dec_num_layer);
+        h->dec_stride_h = (uint32_t)dense_stack_bytes(lhd, cfg->dec_num_layer);
         penc_h.assign((size_t)3 * h->enc_stride_h, 0);
         pdec_h.assign((size_t)2 * cfg->num_iteration * h->dec_stride_h, 0);
         h->enc_bytes_h = (uint32_t)penc_h.size();
@@ -1084,14 +1092,14 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         for (int it = 0; it < cfg->num_iteration; ++it)
             for (int half = 0; half < 2; ++half) {
                 const int nout = (half == 1 && it == cfg->num_iteration - 1) ? 1 : F;
-                s2 += pack_stack_h_dense(s2, lh, cfg->dec_num_layer, 2 + F, nout, pdec_h.data() + (size_t)(2 * it + half) * h->dec_stride_h);
+                s2 += pack_stack_h_dense(s2, lhd, cfg->dec_num_layer, 2 + F, nout, pdec_h.data() + (size_t)(2 * it + half) * h->dec_stride_h);
             }
         if ((size_t)(s2 - weights) != n_weights) { delete h; return fail(TAE_EINVAL, "internal: dense weight walk mismatch"); }
     } else if (h2_ok) {
         h->prec = 1;
-        const LayoutH lh(h->U);
+        const LayoutH lh(h->U), lhd(h->Ud);
         h->enc_stride_h = (uint32_t)lh.stack_bytes(cfg->enc_num_layer);
-        h->dec_stride_h = (uint32_t)lh.stack_bytes(cfg->dec_num_layer);
+        h->dec_stride_h = (uint32_t)lhd.stack_bytes(cfg->dec_num_layer);
         penc_h.assign((size_t)3 * h->enc_stride_h, 0);
         h->enc_bytes_h = (uint32_t)penc_h.size();
         const float* s2 = weights;
@@ -1103,7 +1111,7 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
             for (int it = 0; it < cfg->num_iteration; ++it)
                 for (int half = 0; half < 2; ++half) {
                     const int nout = (half == 1 && it == cfg->num_iteration - 1) ? 1 : F;
-                    s2 += pack_stack_h(s2, lh, cfg->dec_num_layer, 2 + F, nout, pdec_h.data() + (size_t)(2 * it + half) * h->dec_stride_h);
+                    s2 += pack_stack_h(s2, lhd, cfg->dec_num_layer, 2 + F, nout, pdec_h.data() + (size_t)(2 * it + half) * h->dec_stride_h);
                 }
         }
     }
@@ -1192,7 +1200,7 @@ int tae_reserve(tae_handle* h, int32_t max_batch) {
     h->d_xtx = h->d_rx = h->d_e0 = h->d_e1 = nullptr; h->d_partials = nullptr; h->cap = 0;
     const size_t n3 = (size_t)max_batch * h->cfg.block_len * 3;
     const size_t grid = h->nb >= 1 ? (size_t)max_batch : (size_t)3 * max_batch * h->enc_nseg;   // workgroups of the encoder at most (nb_for_batch may pick 1 block each)
-    if (h->nb < 1) {
+    if (h->nbd < 1) {
         const size_t n8 = (size_t)max_batch * h->cfg.block_len * 8;
         TAE_HIP(hipMalloc(&h->d_e0, n8 * sizeof(float)));
         TAE_HIP(hipMalloc(&h->d_e1, n8 * sizeof(float)));
@@ -1376,8 +1384,8 @@ int tae_generate_inputs(tae_handle* h, float* u, float* noise, int32_t B, int64_
 
 int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_t* lds_bytes) {
     if (!h) return fail(TAE_EINVAL, "handle is NULL");
-    if (blocks_per_workgroup) *blocks_per_workgroup = h->nb;
-    if (lds_bytes) *lds_bytes = h->nb >= 1 ? (h->prec == 1 ? h->lds_bytes_h : h->lds_bytes) : (h->prec == 1 ? h->dec_lds_h : h->dec_lds);
+    if (blocks_per_workgroup) *blocks_per_workgroup = h->nbd;        // the decoder's (the dominant kernel)
+    if (lds_bytes) *lds_bytes = h->nbd >= 1 ? (h->prec == 1 ? h->lds_bytes_hd : h->lds_bytes_d) : (h->prec == 1 ? h->dec_lds_h : h->dec_lds);
     return TAE_OK;
 }
 
