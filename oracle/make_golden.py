@@ -63,6 +63,9 @@ CASES = [
     ("fwd_rnn_decact_tanh_encact_linear", dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", num_iteration=2, block_len=50,
                                                enc_act="linear", dec_act="tanh"), 3, 27, 1.0, 2.0),
     ("fwd_rnn_decact_selu", dict(decoder="TurboAE_rate3_rnn", num_iteration=2, block_len=50, dec_act="selu", enc_act="sigmoid"), 3, 28, 1.0, 2.0),
+    # kernel sizes below the default 5 (-enc_kernel_size / -dec_kernel_size)
+    ("var_kernel_e3_d1", dict(enc_num_unit=32, dec_num_unit=64, num_iteration=2, enc_kernel_size=3, dec_kernel_size=1), 5, 29, 1.0, 2.0),
+    ("var_kernel_e1_d3_L400", dict(enc_num_unit=64, dec_num_unit=32, num_iteration=1, block_len=400, enc_kernel_size=1, dec_kernel_size=3), 2, 30, 1.0, 2.0),
     # -channel fading: the reference draws fading_h from the torch global stream inside forward (channel_ae.py:51-56);
     # seeded here and reproduced draw for draw, the coefficients travel in the fixture
     ("var_fading", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, channel="fading"), 5, 20, 1.0, 3.0),

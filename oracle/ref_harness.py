@@ -50,6 +50,7 @@ def build_reference_model(cfg: dict, batch_size: int, is_parallel: int = 1):
             "-dec_num_unit", str(cfg["dec_num_unit"]), "-dec_num_layer", str(cfg["dec_num_layer"]),
             "-num_iteration", str(cfg["num_iteration"]), "-num_iter_ft", str(cfg["num_iter_ft"]),
             "-extrinsic", str(cfg.get("extrinsic", 1)), "-enc_act", cfg.get("enc_act", "elu"), "-dec_act", cfg.get("dec_act", "linear"),
+            "-enc_kernel_size", str(cfg.get("enc_kernel_size", 5)), "-dec_kernel_size", str(cfg.get("dec_kernel_size", 5)),
             "-is_parallel", str(is_parallel), "-batch_size", str(batch_size),
             "-block_len", str(cfg["block_len"]), "--no-cuda",
             "-channel", cfg.get("channel", "awgn"), "-train_channel_mode", cfg.get("train_channel_mode", "block_norm"),

@@ -34,10 +34,11 @@ def test_num_weights_matches_python_side():
     lib = _lib.load()
     for over in (dict(), dict(enc_num_layer=5), dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, num_iter_ft=3),
                  dict(decoder="TurboAE_rate3_rnn"), dict(decoder="TurboAE_rate3_rnn", num_iteration=2, num_iter_ft=3),
-                 dict(enc_num_unit=64, dec_num_unit=32), dict(enc_num_unit=32, decoder="TurboAE_rate3_rnn")):
+                 dict(enc_num_unit=64, dec_num_unit=32), dict(enc_num_unit=32, decoder="TurboAE_rate3_rnn"),
+                 dict(enc_kernel_size=3, dec_kernel_size=1)):
         cfg = TurboAEConfig(**over)
-        c = _lib.TaeConfig(C.sizeof(_lib.TaeConfig), cfg.block_len, cfg.enc_num_layer, cfg.enc_num_unit, 5,
-                           cfg.dec_num_layer, cfg.dec_num_unit, 5, cfg.num_iteration, cfg.num_iter_ft, 1, 0, 1,
+        c = _lib.TaeConfig(C.sizeof(_lib.TaeConfig), cfg.block_len, cfg.enc_num_layer, cfg.enc_num_unit, cfg.enc_kernel_size,
+                           cfg.dec_num_layer, cfg.dec_num_unit, cfg.dec_kernel_size, cfg.num_iteration, cfg.num_iter_ft, 1, 0, 1,
                            1 if cfg.decoder == "TurboAE_rate3_rnn" else 0)
         assert lib.tae_num_weights(C.byref(c)) == W.num_params(cfg)
 

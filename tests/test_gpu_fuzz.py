@@ -28,6 +28,7 @@ def draw_cases(n, seed):
         cases.append(dict(block_len=L, enc_num_unit=U, dec_num_unit=Ud, enc_num_layer=int(rng.randint(1, 6)),
                           dec_num_layer=int(rng.randint(1, 6)), num_iter_ft=int(rng.randint(1, 7)),
                           num_iteration=int(rng.randint(1, 4)), extrinsic=int(rng.randint(0, 2)),
+                          enc_kernel_size=int(rng.choice([5, 5, 3, 1])), dec_kernel_size=int(rng.choice([5, 5, 3, 1])),
                           enc_act=str(rng.choice(["elu", "linear", "elu", "tanh", "relu", "selu", "sigmoid"])), B=B, fixed_nb=str(int(rng.randint(0, 2))), wseed=int(rng.randint(1, 1 << 30))))
     return cases
 
@@ -48,14 +49,16 @@ def test_random_shape_matches_oracle_in_both_precisions(gpu_device, monkeypatch,
     u = philox.random_bits(wseed, 0, B * L).reshape(B, L, 1)
     noise = (np.float32(O.snr_db2sigma(1.0)) * philox.random_normal(wseed, 0, B * L * 3)).reshape(B, L, 3).astype(np.float32)
     ut, nt = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
+    xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict())
+    xo, co = xo.numpy(), co.numpy()
+    if not (np.isfinite(xo).all() and np.isfinite(co).all()):
+        pytest.skip("degenerate draw: the encoder output is constant (e.g. relu of all-negative values), the power constraint divides by 0")
     out = {}
     for prec in ("auto", "f32"):
         model = Channel_AE_HIP(TurboAEConfig(precision=prec, **case), sd, device=gpu_device, max_batch=B)
         xd, codes = model(ut, nt)
         model.check_range()
         out[prec] = (xd.cpu().numpy(), codes.cpu().numpy())
-    xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict())
-    xo, co = xo.numpy(), co.numpy()
     for prec, (xd, codes) in out.items():
         assert np.isfinite(xd).all() and np.isfinite(codes).all(), prec
         assert xd.shape == (B, L, 1) and codes.shape == (B, L, 3)
@@ -106,6 +109,8 @@ def test_random_shape_variants_match_oracle(gpu_device, case):
     ut, nt = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
     xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict())
     xo, co = xo.numpy(), co.numpy()
+    if not (np.isfinite(xo).all() and np.isfinite(co).all()):
+        pytest.skip("degenerate draw: constant encoder output, the power constraint divides by 0")
     for prec in (("auto",) if kind == "dense" else ("auto", "f32")):      # dense stacks exist in f16x2 only
         model = Channel_AE_HIP(TurboAEConfig(precision=prec, **case), sd, device=gpu_device, max_batch=B)
         xd, codes = model(ut, nt)

@@ -92,8 +92,9 @@ def test_generated_weights_are_reproducible():
 
 def test_config_validation():
     TurboAEConfig().validate()
+    TurboAEConfig(enc_kernel_size=3, dec_kernel_size=1, enc_num_unit=32, dec_num_unit=64).validate()
     with pytest.raises(ValueError):
-        TurboAEConfig(enc_kernel_size=3).validate()
+        TurboAEConfig(enc_kernel_size=7).validate()
     with pytest.raises(ValueError):
         TurboAEConfig(enc_num_unit=48, dec_num_unit=48).validate()
     with pytest.raises(ValueError):

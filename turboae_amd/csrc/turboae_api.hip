@@ -281,7 +281,8 @@ namespace {
 int check_cfg(const tae_config* c) {
     if (!c) return fail(TAE_EINVAL, "config is NULL");
     if (c->struct_size != (int32_t)sizeof(tae_config)) return fail(TAE_EINVAL, "tae_config.struct_size mismatch (ABI)");
-    if (c->enc_kernel_size != 5 || c->dec_kernel_size != 5) return fail(TAE_EINVAL, "only kernel_size 5 is supported");
+    for (int ks : {c->enc_kernel_size, c->dec_kernel_size})
+        if (ks != 1 && ks != 3 && ks != 5) return fail(TAE_EINVAL, "kernel_size must be 1, 3 or 5 (the kernels contract 5 taps; smaller odd kernels are embedded)");
     if ((c->enc_num_unit != 100 && c->enc_num_unit != 64 && c->enc_num_unit != 32) ||
         (c->dec_num_unit != 100 && c->dec_num_unit != 64 && c->dec_num_unit != 32))
         return fail(TAE_EINVAL, "channel width (enc_num_unit, dec_num_unit) must be 32, 64 or 100");
@@ -612,27 +613,51 @@ void repack_rnn_h(const float* src, char* dst, size_t cin0, const std::vector<si
     }
 }
 
-size_t num_weights(const tae_config* c) {
+// Canonical weight order (turboae_amd/weights.py::canonical_entries): f(true, co, cin, ks) for a Conv1d weight (co, cin, ks),
+// f(false, n, 0, 0) for a plain run of n floats (biases, Linear layers, whole GRU stacks).
+template <class Fn>
+void walk_weights(const tae_config* c, Fn&& f) {
     size_t U = c->enc_num_unit;
     const size_t F = c->num_iter_ft;
-    size_t n = 0;
     for (int s = 0; s < 3; ++s) {
-        if (c->enc_type == 1) { n += rnn_stack_floats(U, 1, 1); continue; }
-        for (int l = 0; l < c->enc_num_layer; ++l) n += U * (c->dense ? 1 + l * U : (l == 0 ? 1 : U)) * 5 + U;
-        n += U + 1;
+        if (c->enc_type == 1) { f(false, rnn_stack_floats(U, 1, 1), 0, 0); continue; }
+        for (int l = 0; l < c->enc_num_layer; ++l) {
+            f(true, U, c->dense ? 1 + l * U : (l == 0 ? 1 : U), (size_t)c->enc_kernel_size);
+            f(false, U, 0, 0);
+        }
+        f(false, U + 1, 0, 0);
     }
     U = c->dec_num_unit;
     for (int it = 0; it < c->num_iteration; ++it)
         for (int half = 0; half < 2; ++half) {
             const size_t nout = (half == 1 && it == c->num_iteration - 1) ? 1 : F;
-            if (c->dec_type == 1) {
-                n += rnn_stack_floats(U, 2 + F, nout);
-            } else {
-                for (int l = 0; l < c->dec_num_layer; ++l) n += U * (c->dense ? 2 + F + l * U : (l == 0 ? 2 + F : U)) * 5 + U;
-                n += nout * U + nout;
+            if (c->dec_type == 1) { f(false, rnn_stack_floats(U, 2 + F, nout), 0, 0); continue; }
+            for (int l = 0; l < c->dec_num_layer; ++l) {
+                f(true, U, c->dense ? 2 + F + l * U : (l == 0 ? 2 + F : U), (size_t)c->dec_kernel_size);
+                f(false, U, 0, 0);
             }
+            f(false, nout * U + nout, 0, 0);
         }
+}
+
+size_t num_weights(const tae_config* c) {
+    size_t n = 0;
+    walk_weights(c, [&](bool conv, size_t a, size_t b, size_t ks) { n += conv ? a * b * ks : a; });
     return n;
+}
+
+// The kernels contract 5 taps.  A SameShapeConv1d of kernel size 1 or 3 (padding ks / 2) is the 5-tap convolution whose
+// outer taps are zero, so smaller kernels are embedded - exactly - into the 5-tap layout before packing.
+std::vector<float> embed_in_5_taps(const tae_config* c, const float* w) {
+    std::vector<float> out;
+    walk_weights(c, [&](bool conv, size_t a, size_t b, size_t ks) {
+        if (!conv) { out.insert(out.end(), w, w + a); w += a; return; }
+        const size_t off = (5 - ks) / 2;
+        for (size_t i = 0; i < a * b; ++i)
+            for (size_t j = 0; j < 5; ++j) out.push_back(j >= off && j < off + ks ? w[i * ks + (j - off)] : 0.0f);
+        w += a * b * ks;
+    });
+    return out;
 }
 
 int choose_nb(int U, int L, int* lds_out) {
@@ -1005,6 +1030,15 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(TAE_EHIP, "no HIP device available: libturboae_hip needs an AMD GPU (no CPU fallback)");
+    std::vector<float> w5;
+    tae_config cfg5 = *cfg;
+    if (cfg->enc_kernel_size != 5 || cfg->dec_kernel_size != 5) {
+        w5 = embed_in_5_taps(cfg, weights);
+        cfg5.enc_kernel_size = cfg5.dec_kernel_size = 5;
+        cfg = &cfg5;
+        weights = w5.data();
+        n_weights = w5.size();
+    }
     tae_handle* h = new tae_handle();
     h->cfg = *cfg;
     h->nopts = default_norm_opts();
