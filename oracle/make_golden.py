@@ -66,6 +66,8 @@ CASES = [
     # kernel sizes below the default 5 (-enc_kernel_size / -dec_kernel_size)
     ("var_kernel_e3_d1", dict(enc_num_unit=32, dec_num_unit=64, num_iteration=2, enc_kernel_size=3, dec_kernel_size=1), 5, 29, 1.0, 2.0),
     ("var_kernel_e1_d3_L400", dict(enc_num_unit=64, dec_num_unit=32, num_iteration=1, block_len=400, enc_kernel_size=1, dec_kernel_size=3), 2, 30, 1.0, 2.0),
+    ("var_kernel_e7_d9", dict(enc_num_unit=64, dec_num_unit=100, num_iteration=2, enc_kernel_size=7, dec_kernel_size=9), 4, 31, 1.0, 2.0),
+    ("var_kernel_e9_d7_L500", dict(enc_num_unit=32, dec_num_unit=64, num_iteration=1, block_len=500, enc_kernel_size=9, dec_kernel_size=7), 2, 32, 1.0, 2.0),
     # -channel fading: the reference draws fading_h from the torch global stream inside forward (channel_ae.py:51-56);
     # seeded here and reproduced draw for draw, the coefficients travel in the fixture
     ("var_fading", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, channel="fading"), 5, 20, 1.0, 3.0),

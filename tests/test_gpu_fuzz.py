@@ -28,7 +28,7 @@ def draw_cases(n, seed):
         cases.append(dict(block_len=L, enc_num_unit=U, dec_num_unit=Ud, enc_num_layer=int(rng.randint(1, 6)),
                           dec_num_layer=int(rng.randint(1, 6)), num_iter_ft=int(rng.randint(1, 7)),
                           num_iteration=int(rng.randint(1, 4)), extrinsic=int(rng.randint(0, 2)),
-                          enc_kernel_size=int(rng.choice([5, 5, 3, 1])), dec_kernel_size=int(rng.choice([5, 5, 3, 1])),
+                          enc_kernel_size=int(rng.choice([5, 5, 3, 1, 7, 9])), dec_kernel_size=int(rng.choice([5, 5, 3, 1, 7, 9])),
                           enc_act=str(rng.choice(["elu", "linear", "elu", "tanh", "relu", "selu", "sigmoid"])), B=B, fixed_nb=str(int(rng.randint(0, 2))), wseed=int(rng.randint(1, 1 << 30))))
     return cases
 
@@ -37,7 +37,7 @@ def draw_cases(n, seed):
 CASES = draw_cases(int(os.environ.get("TAE_FUZZ_CASES", "48")), int(os.environ.get("TAE_FUZZ_SEED", "20240607")))
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "U{enc_num_unit}x{dec_num_unit}_L{block_len}_B{B}_e{enc_num_layer}d{dec_num_layer}_F{num_iter_ft}_it{num_iteration}_nb{fixed_nb}".format(**c))
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "U{enc_num_unit}x{dec_num_unit}_k{enc_kernel_size}{dec_kernel_size}_L{block_len}_B{B}_e{enc_num_layer}d{dec_num_layer}_F{num_iter_ft}_it{num_iteration}_nb{fixed_nb}".format(**c))
 def test_random_shape_matches_oracle_in_both_precisions(gpu_device, monkeypatch, case):
     from turboae_amd import Channel_AE_HIP
     case = dict(case)
@@ -49,12 +49,16 @@ def test_random_shape_matches_oracle_in_both_precisions(gpu_device, monkeypatch,
     u = philox.random_bits(wseed, 0, B * L).reshape(B, L, 1)
     noise = (np.float32(O.snr_db2sigma(1.0)) * philox.random_normal(wseed, 0, B * L * 3)).reshape(B, L, 3).astype(np.float32)
     ut, nt = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
-    xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict())
+    taps = {}
+    xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict(), taps)
     xo, co = xo.numpy(), co.numpy()
     if not (np.isfinite(xo).all() and np.isfinite(co).all()):
         pytest.skip("degenerate draw: the encoder output is constant (e.g. relu of all-negative values), the power constraint divides by 0")
+    # the power constraint divides by std(x_tx): a draw whose encoder output barely varies amplifies fp32 noise by 1 / std
+    amplify = max(1.0, 0.25 / float(taps["std"]))
     out = {}
-    for prec in ("auto", "f32"):
+    precs = ("auto", "f32") if max(cfg.enc_kernel_size, cfg.dec_kernel_size) <= 5 else ("auto",)     # kernel sizes 7, 9: f16x2 only
+    for prec in precs:
         model = Channel_AE_HIP(TurboAEConfig(precision=prec, **case), sd, device=gpu_device, max_batch=B)
         xd, codes = model(ut, nt)
         model.check_range()
@@ -63,10 +67,11 @@ def test_random_shape_matches_oracle_in_both_precisions(gpu_device, monkeypatch,
         assert np.isfinite(xd).all() and np.isfinite(codes).all(), prec
         assert xd.shape == (B, L, 1) and codes.shape == (B, L, 3)
         # a one-position block normalises a constant per stream: the statistics, not the kernels, decide; keep it loose there
-        tol_c, tol_x = (1e-5, 2e-5) if B * L >= 8 else (1e-4, 1e-4)
+        tol_c, tol_x = (1e-5 * amplify, 2e-5 * amplify) if B * L >= 8 else (1e-4 * amplify, 1e-4 * amplify)
         assert np.abs(codes - co).max() <= tol_c, (prec, np.abs(codes - co).max())
         assert np.abs(xd - xo).max() <= tol_x, (prec, np.abs(xd - xo).max())
-    assert np.abs(out["auto"][0] - out["f32"][0]).max() <= 2e-5
+    if "f32" in out:
+        assert np.abs(out["auto"][0] - out["f32"][0]).max() <= 2e-5 * amplify
 
 
 def draw_variant_cases(n, seed):

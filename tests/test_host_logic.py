@@ -93,8 +93,11 @@ def test_generated_weights_are_reproducible():
 def test_config_validation():
     TurboAEConfig().validate()
     TurboAEConfig(enc_kernel_size=3, dec_kernel_size=1, enc_num_unit=32, dec_num_unit=64).validate()
+    TurboAEConfig(enc_kernel_size=7, dec_kernel_size=9).validate()
     with pytest.raises(ValueError):
-        TurboAEConfig(enc_kernel_size=7).validate()
+        TurboAEConfig(enc_kernel_size=7, precision="f32").validate()
+    with pytest.raises(ValueError):
+        TurboAEConfig(enc_kernel_size=4).validate()
     with pytest.raises(ValueError):
         TurboAEConfig(enc_num_unit=48, dec_num_unit=48).validate()
     with pytest.raises(ValueError):

@@ -58,9 +58,11 @@ class TurboAEConfig:
     def validate(self) -> None:
         if self.code_rate_k != 1 or self.code_rate_n != 3:
             raise ValueError("only the rate-1/3 code (code_rate_k=1, code_rate_n=3) is on the hot path")
-        if self.enc_kernel_size not in (1, 3, 5) or self.dec_kernel_size not in (1, 3, 5):
-            raise ValueError("kernel sizes must be 1, 3 or 5 (the kernels contract 5 taps - the reference default and every BASELINE "
-                             "config; smaller odd kernels are embedded exactly, larger ones are not built)")
+        ks = (self.enc_kernel_size, self.dec_kernel_size)
+        if any(k not in (1, 3, 5, 7, 9) for k in ks):
+            raise ValueError("kernel sizes must be 1, 3, 5, 7 or 9 (odd: SameShapeConv1d pads with kernel_size // 2)")
+        if max(ks) > 5 and (self.precision != "auto" or self.dense):
+            raise ValueError("kernel sizes 7 and 9 are built in the fp16-split kernels only (precision='auto', no dense stacks)")
         if self.precision not in ("auto", "f32"):
             raise ValueError("precision must be 'auto' or 'f32'")
         acts = ("tanh", "selu", "relu", "elu", "sigmoid", "linear")

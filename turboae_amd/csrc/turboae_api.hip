@@ -46,9 +46,9 @@ struct Layout {   // must mirror tae::Geo<U> in turboae_kernels.hip
 };
 
 // im2col-flattened weight W'[co][k], k = tap * cin_pad + ci (tap-major), zero outside the real tensor.
-inline float wflat(const float* W, int U, int cin, int cin_pad, int co, int k) {
+inline float wflat(const float* W, int U, int cin, int cin_pad, int co, int k, int taps = 5) {
     const int j = k / cin_pad, ci = k % cin_pad;
-    return (co < U && j < 5 && ci < cin) ? W[((size_t)co * cin + ci) * 5 + j] : 0.0f;
+    return (co < U && j < taps && ci < cin) ? W[((size_t)co * cin + ci) * taps + j] : 0.0f;
 }
 
 // Tile one Conv1d weight (U, cin, 5) into MFMA A-fragment order.  Lane (i = lane & 15, kq = lane >> 4)
@@ -110,16 +110,17 @@ size_t pack_stack(const float* src, const Layout& lo, int n_layer, int cin0, int
 }
 
 // ---- f16x2 representation (turboae_h2.hip) -----------------------------------------------------------------
-struct LayoutH {   // must mirror tae::GeoH<U>
-    int U, CT, CP, nsl_mid;
+struct LayoutH {   // must mirror tae::GeoH<U> / tae::tap_geo<U>(taps)
+    int U, CT, CP, nsl_mid, nsl_l0, taps;
     uint32_t slb, midb, l0b, tailb;
-    explicit LayoutH(int u) : U(u) {
+    explicit LayoutH(int u, int taps_ = 5) : U(u), taps(taps_) {
         CT = (U + 15) / 16;
         CP = CT * 16;
-        nsl_mid = (5 * U + 31) / 32;
+        nsl_mid = (taps * U + 31) / 32;
+        nsl_l0 = (taps * 8 + 31) / 32;
         slb = (uint32_t)CT * 2048u;
         midb = (uint32_t)nsl_mid * slb;
-        l0b = 2u * slb;
+        l0b = (uint32_t)nsl_l0 * slb;
         tailb = (uint32_t)CP * 4u + 16u;
     }
     size_t stack_bytes(int n_layer) const {
@@ -173,12 +174,12 @@ inline float max_abs(const float* p, size_t n) {
 
 // Conv1d weight (U, cin, 5) -> [slab][channel tile][hi | lo][lane][8 halves]: lane (i = lane & 15, kq = lane >> 4) holds
 // W'[co = 16 ct + i][k = 32 slab + 8 kq + j] * scale, split into hi = f16(w), lo = f16(w - hi)
-void pack_conv_h(const float* W, int U, int cin, int cin_pad, int nslab, int CT, float scale, uint16_t* dst) {
+void pack_conv_h(const float* W, int U, int cin, int cin_pad, int nslab, int CT, float scale, uint16_t* dst, int taps = 5) {
     for (int sl = 0; sl < nslab; ++sl)
         for (int ct = 0; ct < CT; ++ct)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
-                    const float w = wflat(W, U, cin, cin_pad, ct * 16 + (lane & 15), 32 * sl + 8 * (lane >> 4) + j) * scale;
+                    const float w = wflat(W, U, cin, cin_pad, ct * 16 + (lane & 15), 32 * sl + 8 * (lane >> 4) + j, taps) * scale;
                     const uint16_t hi = f2h(w), lo = f2h(w - h2f(hi));
                     const size_t base = ((size_t)(sl * CT + ct) * 2) * 512 + (size_t)lane * 8 + j;
                     dst[base] = hi;
@@ -192,7 +193,7 @@ size_t pack_stack_h(const float* src, const LayoutH& lo, int n_layer, int cin0, 
     char* d = dst;
     for (int l = 0; l < n_layer; ++l) {
         const int cin = l == 0 ? cin0 : lo.U;
-        const size_t nw = (size_t)lo.U * cin * 5;
+        const size_t nw = (size_t)lo.U * cin * lo.taps;
         float maxabs = 0.0f;
         for (size_t i = 0; i < nw; ++i) maxabs = fmaxf(maxabs, fabsf(s[i]));
         int e = 0;
@@ -201,7 +202,7 @@ size_t pack_stack_h(const float* src, const LayoutH& lo, int n_layer, int cin0, 
         if (S > 60) S = 60;
         if (S < -60) S = -60;
         const float scale = ldexpf(1.0f, S), inv = ldexpf(1.0f, -S);
-        pack_conv_h(s, lo.U, cin, l == 0 ? 8 : lo.U, l == 0 ? 2 : lo.nsl_mid, lo.CT, scale, reinterpret_cast<uint16_t*>(d));
+        pack_conv_h(s, lo.U, cin, l == 0 ? 8 : lo.U, l == 0 ? lo.nsl_l0 : lo.nsl_mid, lo.CT, scale, reinterpret_cast<uint16_t*>(d), lo.taps);
         d += l == 0 ? lo.l0b : lo.midb;
         const float* b = s + nw;
         float* t = reinterpret_cast<float*>(d);
@@ -281,8 +282,11 @@ namespace {
 int check_cfg(const tae_config* c) {
     if (!c) return fail(TAE_EINVAL, "config is NULL");
     if (c->struct_size != (int32_t)sizeof(tae_config)) return fail(TAE_EINVAL, "tae_config.struct_size mismatch (ABI)");
-    for (int ks : {c->enc_kernel_size, c->dec_kernel_size})
-        if (ks != 1 && ks != 3 && ks != 5) return fail(TAE_EINVAL, "kernel_size must be 1, 3 or 5 (the kernels contract 5 taps; smaller odd kernels are embedded)");
+    for (int ks : {c->enc_kernel_size, c->dec_kernel_size}) {
+        if (ks != 1 && ks != 3 && ks != 5 && ks != 7 && ks != 9) return fail(TAE_EINVAL, "kernel_size must be 1, 3, 5, 7 or 9");
+        if (ks > 5 && (c->precision != TAE_PREC_AUTO || c->dense))
+            return fail(TAE_EINVAL, "kernel sizes 7 and 9 are built in the fp16-split kernels only (precision = TAE_PREC_AUTO, no dense stacks)");
+    }
     if ((c->enc_num_unit != 100 && c->enc_num_unit != 64 && c->enc_num_unit != 32) ||
         (c->dec_num_unit != 100 && c->dec_num_unit != 64 && c->dec_num_unit != 32))
         return fail(TAE_EINVAL, "channel width (enc_num_unit, dec_num_unit) must be 32, 64 or 100");
@@ -651,7 +655,7 @@ size_t num_weights(const tae_config* c) {
 std::vector<float> embed_in_5_taps(const tae_config* c, const float* w) {
     std::vector<float> out;
     walk_weights(c, [&](bool conv, size_t a, size_t b, size_t ks) {
-        if (!conv) { out.insert(out.end(), w, w + a); w += a; return; }
+        if (!conv || ks >= 5) { const size_t n = conv ? a * b * ks : a; out.insert(out.end(), w, w + n); w += n; return; }
         const size_t off = (5 - ks) / 2;
         for (size_t i = 0; i < a * b; ++i)
             for (size_t j = 0; j < 5; ++j) out.push_back(j >= off && j < off + ks ? w[i * ks + (j - off)] : 0.0f);
@@ -660,18 +664,21 @@ std::vector<float> embed_in_5_taps(const tae_config* c, const float* w) {
     return out;
 }
 
-int choose_nb(int U, int L, int* lds_out) {
+// `h2`: size for the f16x2 kernels' panels (the arithmetic that will run); `taps` > 5 exists there only
+int choose_nb(int U, int L, int* lds_out, bool h2 = false, int taps = 5) {
     const int max_pos = tae::fused_max_positions();
     int nb = max_pos / L;
-    while (nb >= 1 && tae::fused_lds_bytes(U, L, nb) > 160 * 1024) --nb;
+    auto bytes = [&](int n) { return h2 ? tae::fused_lds_bytes_h(U, L, n, taps) : tae::fused_lds_bytes(U, L, n); };
+    while (nb >= 1 && bytes(nb) > 160 * 1024) --nb;
     if (nb < 1) return 0;
-    *lds_out = tae::fused_lds_bytes(U, L, nb);
+    *lds_out = bytes(nb);
     return nb;
 }
 
 // Segment geometry of the long-block path: T centre positions + 2*H halo positions <= max positions.
-bool choose_seg(int U, int L, int n_layer, int* T, int* nseg, int* lds, bool dense = false) {
-    const int H = 2 * n_layer;
+bool choose_seg(int U, int L, int n_layer, int* T, int* nseg, int* lds, bool dense = false, bool h2 = false, int taps = 5) {
+    const int H = (taps / 2) * n_layer;
+    auto seg_bytes = [&](int t) { return h2 ? tae::seg_lds_bytes_h(U, t, n_layer, taps) : tae::seg_lds_bytes(U, t, n_layer); };
     int tmax = tae::fused_max_positions() - 2 * H - 3;    // 3 alignment rows: panel origin floored to a multiple of 4
     if (dense) {
         // every earlier layer's output stays resident (n_layer - 1 panels): a segment is one position group (5 tiles) at most
@@ -683,13 +690,13 @@ bool choose_seg(int U, int L, int n_layer, int* T, int* nseg, int* lds, bool den
         *lds = tae::seg_lds_bytes_h_dense(U, *T, n_layer);
         return true;
     }
-    while (tmax >= 16 && tae::seg_lds_bytes(U, tmax, n_layer) > 160 * 1024) tmax -= 16;
+    while (tmax >= 16 && seg_bytes(tmax) > 160 * 1024) tmax -= 16;
     if (tmax < 16) return false;
     const char* cap = getenv("TAE_SEG_T");
     if (cap && atoi(cap) >= 1 && atoi(cap) < tmax) tmax = atoi(cap);
     *nseg = (L + tmax - 1) / tmax;
     *T = (L + *nseg - 1) / *nseg;      // balanced segments
-    *lds = tae::seg_lds_bytes(U, *T, n_layer);
+    *lds = seg_bytes(*T);
     return true;
 }
 
@@ -740,6 +747,7 @@ tae::FusedParams base_params(const tae_handle* h, int32_t B, bool decoder) {
     P.B = B;
     P.L = h->cfg.block_len;
     P.nb = decoder ? h->nbd : h->nb;
+    P.taps = decoder ? h->cfg.dec_kernel_size : h->cfg.enc_kernel_size;
     P.n_iter = h->cfg.num_iteration;
     P.F = h->cfg.num_iter_ft;
     P.extrinsic = h->cfg.extrinsic;
@@ -760,6 +768,7 @@ tae::SegParams seg_params(const tae_handle* h, int32_t B, bool decoder) {
     P.extrinsic = h->cfg.extrinsic;
     P.act = h->cfg.enc_act;
     P.super = decoder ? h->super_d : h->super;
+    P.taps = decoder ? h->cfg.dec_kernel_size : h->cfg.enc_kernel_size;
     P.dense = h->cfg.dense;
     return P;
 }
@@ -842,7 +851,7 @@ int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_
         P.wpack = reinterpret_cast<const float*>(h->d_wenc_h);
         P.stack_stride = h->enc_stride_h;
         P.wpack_bytes = h->enc_bytes_h;
-        P.lds_bytes = P.nb == h->nb ? h->lds_bytes_h : tae::fused_lds_bytes_h(h->U, h->cfg.block_len, P.nb);
+        P.lds_bytes = P.nb == h->nb ? h->lds_bytes_h : tae::fused_lds_bytes_h(h->U, h->cfg.block_len, P.nb, P.taps);
         P.flags = h->d_flags;
         TAE_HIP(tae::launch_fused_h(h->U, false, P, grid, st));
     } else
@@ -994,7 +1003,7 @@ int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStrea
         P.wpack = reinterpret_cast<const float*>(h->d_wdec_h);
         P.stack_stride = h->dec_stride_h;
         P.wpack_bytes = h->dec_bytes_h;
-        P.lds_bytes = P.nb == h->nbd ? h->lds_bytes_hd : tae::fused_lds_bytes_h(h->Ud, h->cfg.block_len, P.nb);
+        P.lds_bytes = P.nb == h->nbd ? h->lds_bytes_hd : tae::fused_lds_bytes_h(h->Ud, h->cfg.block_len, P.nb, P.taps);
         P.flags = h->d_flags;
         TAE_HIP(tae::launch_fused_h(h->Ud, true, P, grid, st));
         return TAE_OK;
@@ -1032,9 +1041,10 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         return fail(TAE_EHIP, "no HIP device available: libturboae_hip needs an AMD GPU (no CPU fallback)");
     std::vector<float> w5;
     tae_config cfg5 = *cfg;
-    if (cfg->enc_kernel_size != 5 || cfg->dec_kernel_size != 5) {
+    if (cfg->enc_kernel_size < 5 || cfg->dec_kernel_size < 5) {
         w5 = embed_in_5_taps(cfg, weights);
-        cfg5.enc_kernel_size = cfg5.dec_kernel_size = 5;
+        if (cfg5.enc_kernel_size < 5) cfg5.enc_kernel_size = 5;
+        if (cfg5.dec_kernel_size < 5) cfg5.dec_kernel_size = 5;
         cfg = &cfg5;
         weights = w5.data();
         n_weights = w5.size();
@@ -1048,8 +1058,16 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || h->ncu < 1) h->ncu = 256;
     const char* fixed_nb = getenv("TAE_FIXED_NB");
     h->fixed_nb = fixed_nb && fixed_nb[0] == '1';
-    h->nb = choose_nb(h->U, cfg->block_len, &h->lds_bytes);
-    h->nbd = choose_nb(h->Ud, cfg->block_len, &h->lds_bytes_d);
+    const int taps_e = cfg->enc_kernel_size, taps_d = cfg->dec_kernel_size;      // 5, 7 or 9 here (1 and 3 were embedded)
+    const bool big_taps = taps_e > 5 || taps_d > 5;                               // f16x2 kernels only: no fp32 packing
+    // precision of the conv kernels: config field, overridden by env TAE_PRECISION=f32|f16x2 (testing knob)
+    int want_h2 = cfg->precision == TAE_PREC_F32 ? 0 : 1;
+    if (const char* pe = getenv("TAE_PRECISION")) {
+        if (!strcmp(pe, "f32")) want_h2 = 0;
+        else if (!strcmp(pe, "f16x2")) want_h2 = 1;
+    }
+    h->nb = choose_nb(h->U, cfg->block_len, &h->lds_bytes, want_h2 != 0, taps_e);
+    h->nbd = choose_nb(h->Ud, cfg->block_len, &h->lds_bytes_d, want_h2 != 0, taps_d);
     // Testing knobs (documented in DESIGN.md): TAE_FORCE_SEGMENTED=1 selects the long-block path even
     // when whole blocks fit; TAE_SEG_T=<n> caps the centre length of a segment.
     const char* force_seg = getenv("TAE_FORCE_SEGMENTED");
@@ -1057,8 +1075,8 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     if (cfg->dense) h->nb = h->nbd = 0;   // dense stacks run on the long-block kernels (one stack per launch)
     if (h->nb < 1 || h->nbd < 1) {
         h->nb = h->nbd = 0;               // one path for both sides (the exchange buffers and the workspace follow it)
-        if (!choose_seg(h->U, cfg->block_len, cfg->enc_num_layer, &h->enc_T, &h->enc_nseg, &h->enc_lds, cfg->dense != 0) ||
-            !choose_seg(h->Ud, cfg->block_len, cfg->dec_num_layer, &h->dec_T, &h->dec_nseg, &h->dec_lds, cfg->dense != 0)) {
+        if (!choose_seg(h->U, cfg->block_len, cfg->enc_num_layer, &h->enc_T, &h->enc_nseg, &h->enc_lds, cfg->dense != 0, want_h2 != 0, taps_e) ||
+            !choose_seg(h->Ud, cfg->block_len, cfg->dec_num_layer, &h->dec_T, &h->dec_nseg, &h->dec_lds, cfg->dense != 0, want_h2 != 0, taps_d)) {
             delete h;
             return fail(TAE_EINVAL, "too many conv layers for the segmented long-block kernels (halo exceeds the panel)");
         }
@@ -1074,11 +1092,16 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     h->enc_bytes = (uint32_t)(penc.size() * sizeof(float));
     h->dec_bytes = (uint32_t)(pdec.size() * sizeof(float));
     const float* src = weights;
-    if (cfg->dense) src = weights + n_weights;                             // dense stacks: f16x2 packing only (below)
+    if (cfg->dense || big_taps) src = weights + n_weights;                 // dense stacks / kernel sizes 7, 9: f16x2 packing only (below)
     else if (cfg->enc_type == 1) src += 3 * rnn_stack_floats(100, 1, 1);   // ENC_interRNN: packed with the GRU kernels' layouts below
     else for (int s = 0; s < 3; ++s) src += pack_stack(src, lo, cfg->enc_num_layer, 1, 1, penc.data() + (size_t)s * h->enc_stride);
-    const float* dec_src = src;
-    if (cfg->dec_type == 1 || cfg->dense) {
+    const float* dec_src;                   // first decoder weight in the canonical blob
+    {
+        tae_config enc_only = *cfg;
+        enc_only.num_iteration = 0;
+        dec_src = weights + num_weights(&enc_only);
+    }
+    if (cfg->dec_type == 1 || cfg->dense || big_taps) {
         src = weights + n_weights;          // canonical GRU weights are uploaded unchanged below
     } else {
         for (int it = 0; it < cfg->num_iteration; ++it)
@@ -1091,21 +1114,15 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         delete h;
         return fail(TAE_EINVAL, "internal: weight walk mismatch");
     }
-    // precision of the whole-block kernels: config field, overridden by env TAE_PRECISION=f32|f16x2 (testing knob)
-    int want_h2 = cfg->precision == TAE_PREC_F32 ? 0 : 1;
-    if (const char* pe = getenv("TAE_PRECISION")) {
-        if (!strcmp(pe, "f32")) want_h2 = 0;
-        else if (!strcmp(pe, "f16x2")) want_h2 = 1;
-    }
     std::vector<char> penc_h, pdec_h;
     bool h2_ok = false;
     if (want_h2 && h->nb >= 1) {
-        h->lds_bytes_h = tae::fused_lds_bytes_h(h->U, cfg->block_len, h->nb);
-        h->lds_bytes_hd = tae::fused_lds_bytes_h(h->Ud, cfg->block_len, h->nbd);
+        h->lds_bytes_h = tae::fused_lds_bytes_h(h->U, cfg->block_len, h->nb, taps_e);
+        h->lds_bytes_hd = tae::fused_lds_bytes_h(h->Ud, cfg->block_len, h->nbd, taps_d);
         h2_ok = h->lds_bytes_h <= 160 * 1024 && h->lds_bytes_hd <= 160 * 1024;
     } else if (want_h2) {               // long-block path: same segment geometry, f16x2 panels
-        h->enc_lds_h = tae::seg_lds_bytes_h(h->U, h->enc_T, cfg->enc_num_layer);
-        h->dec_lds_h = tae::seg_lds_bytes_h(h->Ud, h->dec_T, cfg->dec_num_layer);
+        h->enc_lds_h = tae::seg_lds_bytes_h(h->U, h->enc_T, cfg->enc_num_layer, taps_e);
+        h->dec_lds_h = tae::seg_lds_bytes_h(h->Ud, h->dec_T, cfg->dec_num_layer, taps_d);
         h2_ok = h->enc_lds_h <= 160 * 1024 && h->dec_lds_h <= 160 * 1024;
     }
     if (cfg->dense) {
@@ -1129,9 +1146,12 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
                 s2 += pack_stack_h_dense(s2, lhd, cfg->dec_num_layer, 2 + F, nout, pdec_h.data() + (size_t)(2 * it + half) * h->dec_stride_h);
             }
         if ((size_t)(s2 - weights) != n_weights) { delete h; return fail(TAE_EINVAL, "internal: dense weight walk mismatch"); }
+    } else if (big_taps && !h2_ok) {
+        delete h;
+        return fail(TAE_EINVAL, "kernel sizes 7 and 9 need the fp16-split kernels (precision auto; TAE_PRECISION=f32 given, or the panels do not fit the LDS)");
     } else if (h2_ok) {
         h->prec = 1;
-        const LayoutH lh(h->U), lhd(h->Ud);
+        const LayoutH lh(h->U, taps_e), lhd(h->Ud, taps_d);
         h->enc_stride_h = (uint32_t)lh.stack_bytes(cfg->enc_num_layer);
         h->dec_stride_h = (uint32_t)lhd.stack_bytes(cfg->dec_num_layer);
         penc_h.assign((size_t)3 * h->enc_stride_h, 0);

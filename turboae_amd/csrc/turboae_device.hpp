@@ -473,10 +473,13 @@ __device__ __forceinline__ void mma_tile_h(f32x4 (&acc)[NC], const OpsHA<NC>& a,
 // walked one at a time, their B fragments fetched two tiles ahead from LDS.
 // soff  : wave-uniform byte offset of this layer's A fragments
 // bh/bl : per position tile, LDS byte address of (row-2)*stride + 16*kq in the hi / lo plane
+// NSLAB = 0: the slab count is the (wave-uniform) run-time argument `nslab_rt` (conv stacks: it follows the kernel size).
 template <int CTT, int C0, int NC, int PT, int NSLAB>
 __device__ __forceinline__ void conv_accumulate_h(f32x4 (&acc)[PT][NC], OpsHA<NC>& a0, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff,
-                                                  uint32_t soff, const char* lds, const uint32_t (&bh)[PT], const uint32_t (&bl)[PT]) {
+                                                  uint32_t soff, const char* lds, const uint32_t (&bh)[PT], const uint32_t (&bl)[PT],
+                                                  int nslab_rt = 0) {
     constexpr uint32_t SB = CTT * 2048;       // bytes of A fragments per slab
+    const int nslab = NSLAB > 0 ? NSLAB : nslab_rt;
     const lds_cptr lds3 = (lds_cptr)lds;
     lds_cptr ch[PT], cl[PT];
 #pragma unroll
@@ -510,16 +513,16 @@ __device__ __forceinline__ void conv_accumulate_h(f32x4 (&acc)[PT][NC], OpsHA<NC
     }
     int s = 0;
 #pragma unroll 1
-    for (; s + 1 < NSLAB; s += 2) {
+    for (; s + 1 < nslab; s += 2) {
         load_wh<CTT, C0, NC>(a1, rsrc, voff, soff + SB);
         TAE_H_SLAB(a0, 0, 0)
-        if (s + 2 < NSLAB) load_wh<CTT, C0, NC>(a0, rsrc, voff, soff + 2 * SB);   // no fetch past the layer: the caller refills a0
+        if (s + 2 < nslab) load_wh<CTT, C0, NC>(a0, rsrc, voff, soff + 2 * SB);   // no fetch past the layer: the caller refills a0
         TAE_H_SLAB(a1, 64, PT % 2)
         soff += 2 * SB;
 #pragma unroll
         for (int p = 0; p < PT; ++p) { ch[p] += 128; cl[p] += 128; }
     }
-    if constexpr (NSLAB % 2 == 1) { TAE_H_SLAB(a0, 0, 0) }
+    if (nslab & 1) { TAE_H_SLAB(a0, 0, 0) }
 #undef TAE_H_SLAB
 }
 

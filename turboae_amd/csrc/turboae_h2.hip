@@ -35,8 +35,25 @@ struct GeoH {
     static constexpr uint32_t TAILB = CP * 4u + 16u;    // bias + scale block after the fragments
 };
 
+// The same for a kernel size known at run time (5, 7, 9): the plain conv stacks take it from the launch parameters; the
+// dense stacks stay on the 5-tap constants above.
+struct TapGeo {
+    int pad, nsl_mid, nsl_l0;
+    uint32_t midb, l0b;
+};
+template <int U>
+__device__ __forceinline__ TapGeo tap_geo(int taps) {
+    TapGeo t;
+    t.pad = taps >> 1;
+    t.nsl_mid = (taps * U + 31) / 32;
+    t.nsl_l0 = (taps * 8 + 31) / 32;       // first layer: taps x 8 padded inputs
+    t.midb = (uint32_t)t.nsl_mid * GeoH<U>::SLB;
+    t.l0b = (uint32_t)t.nsl_l0 * GeoH<U>::SLB;
+    return t;
+}
+
 constexpr int kXRowB = 16;        // bytes per row of an X plane (8 halves)
-constexpr int kXSlack = 3;        // extra rows of the X planes: the first layer's second slab over-reads up to row + 5
+constexpr int kXSlack = 3;        // extra rows of the X planes: the first layer's last slab over-reads up to 4 * nsl_l0 - 2 * pad - 2 <= 2 rows past the panel
 
 // one stack-input panel = two fp16 planes
 struct XPlane {
@@ -94,6 +111,7 @@ struct TileH {
     uint32_t center;    // bit p: position whose stack output this workgroup owns (== valid for whole blocks)
     int m0;             // workgroup-relative position of tile 0 (tile p: m0 + 16 p)
     int L;
+    int pad;            // zero rows in front of every block (kernel size / 2)
     __device__ __forceinline__ int row(int p) const {
         const int* t = rowtab;
         asm volatile("" : "+v"(t));          // keep the load where it is used (it is loop-invariant: hoisted, it would be spilled)
@@ -103,7 +121,7 @@ struct TileH {
     __device__ __forceinline__ bool own(int p) const { return (center >> p) & 1u; }
     __device__ __forceinline__ int blk(int p) const { return (m0 + 16 * p) / L; }
     __device__ __forceinline__ int t(int p) const { const int m = m0 + 16 * p; return m - (m / L) * L; }
-    __device__ __forceinline__ int rowbase(int p) const { return blk(p) * (L + 2) + 2; }
+    __device__ __forceinline__ int rowbase(int p) const { return blk(p) * (L + pad) + pad; }
 };
 
 // Padding lanes (positions past the workgroup's blocks) compute on row 2 and store to the write-only dump row, so
@@ -134,18 +152,19 @@ __device__ __forceinline__ void dispatch_tiles(int live, F&& f) {
 }
 
 template <int PT>
-__device__ __forceinline__ void make_tiles_h(TileH<PT>& tc, int* rowtab, int gt0, int lane, int L, int npos) {
+__device__ __forceinline__ void make_tiles_h(TileH<PT>& tc, int* rowtab, int gt0, int lane, int L, int npos, int pad) {
     const int n = lane & 15;
     tc.valid = 0u;
     tc.m0 = gt0 * 16 + n;
     tc.L = L;
+    tc.pad = pad;
     tc.rowtab = rowtab + gt0 * 16 + n;
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
         const int m = tc.m0 + 16 * p;
         const bool v = m < npos;
         const int b = (v ? m : 0) / L;
-        if (lane < 16) rowtab[(gt0 + p) * 16 + n] = v ? b * (L + 2) + 2 + (m - b * L) : 2;    // both channel halves write the same values
+        if (lane < 16) rowtab[(gt0 + p) * 16 + n] = v ? b * (L + pad) + pad + (m - b * L) : pad;    // both channel halves write the same values
         tc.valid |= (v ? 1u : 0u) << p;
     }
     tc.center = tc.valid;
@@ -184,12 +203,13 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
     constexpr int CTT = G::CT;
     const int q = lane >> 4;
     const int dump_row = pn.dump;
+    const TapGeo tg = tap_geo<U>(tc.pad * 2 + 1);
     f32x4 acc[PT][NC];
     uint32_t lo = soff;
     float inv_scale = 1.0f;
     for (int l = 0; l < n_layer; ++l) {
         const bool first = (l == 0);
-        const uint32_t fragb = first ? G::L0B : G::MIDB;
+        const uint32_t fragb = first ? tg.l0b : tg.midb;
         const float* bias = reinterpret_cast<const float*>(wpack + lo + fragb);
         inv_scale = bias[G::CP];
         {
@@ -206,12 +226,11 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
         const uint32_t ph = (uint32_t)((first ? xin.h : pn.AH) - smem), pl = (uint32_t)((first ? xin.l : pn.AL) - smem);
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
-            const uint32_t o = (uint32_t)(tc.row(p) - 2) * stride + 16u * q;
+            const uint32_t o = (uint32_t)(tc.row(p) - tg.pad) * stride + 16u * q;
             bh[p] = ph + o;
             bl[p] = pl + o;
         }
-        if (first) conv_accumulate_h<CTT, C0, NC, PT, G::NSL_L0>(acc, ws.a, ws.rsrc, ws.voff, lo, smem, bh, bl);
-        else conv_accumulate_h<CTT, C0, NC, PT, G::NSL_MID>(acc, ws.a, ws.rsrc, ws.voff, lo, smem, bh, bl);
+        conv_accumulate_h<CTT, C0, NC, PT, 0>(acc, ws.a, ws.rsrc, ws.voff, lo, smem, bh, bl, first ? tg.nsl_l0 : tg.nsl_mid);
         lo += fragb + G::TAILB;
         {
             const uint32_t nxt = (l + 1 < n_layer) ? lo : snext;
@@ -480,7 +499,8 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = wave & (kGroups - 1), h = wave / kGroups;
     const int L = P.L, nb = P.nb;
-    const int rows = nb * (L + 2) + 2;
+    const int pad = P.taps >> 1;
+    const int rows = nb * (L + pad) + pad;
     const PanelsH pn = carve_h<U>(smem, rows, L);
     const int blk0 = blockIdx.x * nb;
     const int nblk = min(nb, P.B - blk0);
@@ -495,7 +515,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
     float vmax = 0.0f;
     for (int m = tid; m < npos; m += kThreads) {
         const int b = m / L, t = m - b * L;
-        const int row = b * (L + 2) + 2 + t;
+        const int row = b * (L + pad) + pad + t;
         const float* r = rx + (size_t)m * 3;
         const float r0 = r[0], r1 = r[1], r2 = r[2], ri = rx[((size_t)b * L + pn.PERM[t]) * 3 + 0];
         vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(r0), fabsf(r1))), fmaxf(fabsf(r2), fabsf(ri)));
@@ -516,7 +536,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
     auto run = [&](auto pt) {
         constexpr int T = decltype(pt)::value;
         TileH<T> tc;
-        make_tiles_h<T>(tc, pn.ROWT, gs.gt0, lane, L, npos);
+        make_tiles_h<T>(tc, pn.ROWT, gs.gt0, lane, L, npos, pad);
         __syncthreads();
         if (!upper) dec_body_h<U, T, 0, Split<U>::CTA>(P, smem, pn, tc, gs.gt0, lane, blk0);
         else dec_body_h<U, T, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, gs.gt0, lane, blk0);
@@ -559,7 +579,8 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = wave & (kGroups - 1), h = wave / kGroups;
     const int L = P.L, nb = P.nb;
-    const int rows = nb * (L + 2) + 2;
+    const int pad = P.taps >> 1;
+    const int rows = nb * (L + pad) + pad;
     const PanelsH pn = carve_h<U>(smem, rows, L);
     const int blk0 = blockIdx.x * nb;
     const int nblk = min(nb, P.B - blk0);
@@ -573,7 +594,7 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
     const float* u = P.in + (size_t)blk0 * L;
     for (int m = tid; m < npos; m += kThreads) {
         const int b = m / L, t = m - b * L;
-        const int row = b * (L + 2) + 2 + t;
+        const int row = b * (L + pad) + pad + t;
         pn.XA.write(row, 0, 2.0f * u[m] - 1.0f);
         pn.XB.write(row, 0, 2.0f * u[b * L + pn.PERM[t]] - 1.0f);
     }
@@ -585,7 +606,7 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
     auto run = [&](auto pt) {
         constexpr int T = decltype(pt)::value;
         TileH<T> tc;
-        make_tiles_h<T>(tc, pn.ROWT, gs.gt0, lane, L, npos);
+        make_tiles_h<T>(tc, pn.ROWT, gs.gt0, lane, L, npos, pad);
         __syncthreads();
         if (!upper) enc_body_h<U, T, 0, Split<U>::CTA>(P, smem, pn, tc, gs.gt0, lane, blk0, sum, sumsq);
         else enc_body_h<U, T, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, gs.gt0, lane, blk0, sum, sumsq);
@@ -668,7 +689,8 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = wave & (kGroups - 1), h = wave / kGroups;
-    const int L = P.L, H = 2 * P.n_layer;
+    const int pad = P.taps >> 1;                       // 2 for the dense stacks (5 taps)
+    const int L = P.L, H = pad * P.n_layer;
     int bid = blockIdx.x;
     int stack = P.stack;
     if (P.mode == 0) { stack = bid % 3; bid /= 3; }
@@ -677,7 +699,7 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
     const int tlen = min(P.T, L - s0);
     const int tstart = (s0 - H) - ((s0 - H) & 3);      // same panel origin as the fp32 kernel (floored to a multiple of 4)
     const int NP = s0 + P.T + H - tstart;
-    const int rows = P.T + 2 * H + 3 + 4;
+    const int rows = P.T + 2 * H + 3 + 2 * pad;
     const PanelsH pn = carve_seg_h<U>(smem, rows, P.dense ? (P.n_layer > 1 ? P.n_layer - 1 : 1) : 1);
     const bool odd = (stack & 1) != 0;
 
@@ -687,7 +709,7 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
     for (int m = tid; m < NP; m += kThreads) {
         const int t = tstart + m;
         if (t < 0 || t >= L) continue;
-        const int row = 2 + m;
+        const int row = pad + m;
         if (P.mode == 0) {
             const int src = (stack == 2) ? P.perm[t] : t;                           // encoders.py:369
             pn.XA.write(row, 0, 2.0f * P.in[(size_t)b * L + src] - 1.0f);           // encoders.py:362
@@ -716,13 +738,14 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
         tc.center = 0u;
         tc.m0 = gt0 * 16 + n;
         tc.L = L;
+        tc.pad = pad;
         tc.rowtab = pn.ROWT + gt0 * 16 + n;
 #pragma unroll
         for (int p = 0; p < TC::kTiles; ++p) {
             const int m = tc.m0 + 16 * p;
             const int t = tstart + m;
             const bool v = (m < NP) && (t >= 0) && (t < L);
-            if (lane < 16) pn.ROWT[(gt0 + p) * 16 + n] = v ? 2 + m : 2;
+            if (lane < 16) pn.ROWT[(gt0 + p) * 16 + n] = v ? pad + m : pad;
             tc.valid |= (v ? 1u : 0u) << p;
             tc.center |= ((v && t >= s0 && t < s0 + tlen) ? 1u : 0u) << p;
         }
@@ -795,8 +818,8 @@ hipError_t launch_seg_h(int U, const SegParams& P, int grid, hipStream_t st) {
     }
 }
 
-int seg_lds_bytes_h(int U, int T, int n_layer) {
-    const int rows = T + 4 * n_layer + 3 + 4;
+int seg_lds_bytes_h(int U, int T, int n_layer, int taps) {
+    const int pad = taps / 2, rows = T + 2 * pad * n_layer + 3 + 2 * pad;
     size_t b = 2 * (size_t)(rows + 2) * U * 2 + 2 * (size_t)(rows + 1 + kXSlack) * kXRowB + (size_t)kHeadSlots * 4;
     b = (b + 15) & ~(size_t)15;
     b += (size_t)kHeadSlots * 8 * 4;
@@ -814,8 +837,8 @@ int seg_lds_bytes_h_dense(int U, int T, int n_layer) {
     return (int)b;
 }
 
-int fused_lds_bytes_h(int U, int L, int nb) {
-    const int rows = nb * (L + 2) + 2;
+int fused_lds_bytes_h(int U, int L, int nb, int taps) {
+    const int pad = taps / 2, rows = nb * (L + pad) + pad;
     size_t b = 2 * (size_t)(rows + 2) * U * 2 + 4 * (size_t)(rows + 1 + kXSlack) * kXRowB + 2 * (size_t)L * 4 + (size_t)kHeadSlots * 4;
     b = (b + 15) & ~(size_t)15;
     b += (size_t)kHeadSlots * 8 * 4;

@@ -21,6 +21,7 @@ struct FusedParams {
     int32_t F;              // num_iter_ft
     int32_t extrinsic;
     int32_t act;            // encoder output activation (act_apply codes: 0 elu, 1 linear, 2 tanh, 3 relu, 4 selu, 5 sigmoid)
+    int32_t taps;           // f16x2 kernels: conv kernel size of this side (5, 7 or 9; 1 and 3 arrive embedded in 5)
     uint32_t stack_stride;  // floats between consecutive stacks in wpack
     uint32_t wpack_bytes;   // size of the packed weight buffer (buffer-resource bound)
     int32_t lds_bytes;
@@ -43,6 +44,7 @@ struct SegParams {
     int32_t last;           // decoder: final half-iteration
     int32_t B, L, T, nseg;  // T = centre positions per segment, nseg = segments per block
     int32_t n_layer, F, extrinsic, act;
+    int32_t taps;           // f16x2 kernel: conv kernel size (see FusedParams)
     uint32_t stack_stride;
     uint32_t wpack_bytes;
     int32_t lds_bytes;
@@ -97,9 +99,9 @@ hipError_t launch_seg(int U, const SegParams& P, int grid, hipStream_t st);
 int seg_lds_bytes(int U, int T, int n_layer);
 hipError_t launch_fused(int U, bool decoder, const FusedParams& P, int grid, hipStream_t st);
 hipError_t launch_fused_h(int U, bool decoder, const FusedParams& P, int grid, hipStream_t st);
-int fused_lds_bytes_h(int U, int L, int nb);
+int fused_lds_bytes_h(int U, int L, int nb, int taps = 5);
 hipError_t launch_seg_h(int U, const SegParams& P, int grid, hipStream_t st);
-int seg_lds_bytes_h(int U, int T, int n_layer);
+int seg_lds_bytes_h(int U, int T, int n_layer, int taps = 5);
 int seg_lds_bytes_h_dense(int U, int T, int n_layer);
 hipError_t launch_reduce_partials(const double* partials, int n, double count, double* stats, hipStream_t st);
 struct NormOpts {          // device-side view of tae_channel_opts
