@@ -68,6 +68,9 @@ CASES = [
     ("var_kernel_e1_d3_L400", dict(enc_num_unit=64, dec_num_unit=32, num_iteration=1, block_len=400, enc_kernel_size=1, dec_kernel_size=3), 2, 30, 1.0, 2.0),
     ("var_kernel_e7_d9", dict(enc_num_unit=64, dec_num_unit=100, num_iteration=2, enc_kernel_size=7, dec_kernel_size=9), 4, 31, 1.0, 2.0),
     ("var_kernel_e9_d7_L500", dict(enc_num_unit=32, dec_num_unit=64, num_iteration=1, block_len=500, enc_kernel_size=9, dec_kernel_size=7), 2, 32, 1.0, 2.0),
+    # widths other than the instantiated 32 / 64 / 100 (run embedded in the next wider kernel)
+    ("var_width_e25_d50", dict(enc_num_unit=25, dec_num_unit=50, num_iteration=2), 5, 33, 1.0, 2.0),
+    ("var_width_e80_d10_k3", dict(enc_num_unit=80, dec_num_unit=10, num_iteration=2, dec_kernel_size=3, block_len=64), 4, 34, 1.0, 2.0),
     # -channel fading: the reference draws fading_h from the torch global stream inside forward (channel_ae.py:51-56);
     # seeded here and reproduced draw for draw, the coefficients travel in the fixture
     ("var_fading", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, channel="fading"), 5, 20, 1.0, 3.0),

@@ -20,8 +20,9 @@ def draw_cases(n, seed):
     rng = np.random.RandomState(seed)
     cases = []
     for i in range(n):
-        U = int(rng.choice([32, 64, 100], p=[0.25, 0.25, 0.5]))
-        Ud = U if rng.rand() < 0.5 else int(rng.choice([32, 64, 100]))        # encoder and decoder widths are independent
+        widths = [32, 64, 100, 100, int(rng.randint(1, 101))]                 # any width up to 100 (narrow ones run embedded)
+        U = int(rng.choice(widths))
+        Ud = U if rng.rand() < 0.5 else int(rng.choice(widths))               # encoder and decoder widths are independent
         L = int(rng.choice(EDGE_LENS)) if rng.rand() < 0.6 else int(rng.randint(1, 420))
         nb_guess = max(1, 320 // L)
         B = int(rng.choice([1, 2, nb_guess, nb_guess + 1, 2 * nb_guess + 1, int(rng.randint(1, 48))]))

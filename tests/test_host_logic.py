@@ -98,8 +98,9 @@ def test_config_validation():
         TurboAEConfig(enc_kernel_size=7, precision="f32").validate()
     with pytest.raises(ValueError):
         TurboAEConfig(enc_kernel_size=4).validate()
+    TurboAEConfig(enc_num_unit=48, dec_num_unit=7).validate()
     with pytest.raises(ValueError):
-        TurboAEConfig(enc_num_unit=48, dec_num_unit=48).validate()
+        TurboAEConfig(enc_num_unit=128, dec_num_unit=128).validate()
     with pytest.raises(ValueError):
         TurboAEConfig(code_rate_n=2).validate()
 

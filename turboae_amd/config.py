@@ -68,8 +68,11 @@ class TurboAEConfig:
         acts = ("tanh", "selu", "relu", "elu", "sigmoid", "linear")
         if self.enc_act not in acts or self.dec_act not in acts:
             raise ValueError("enc_act / dec_act must be one of tanh, selu, relu, elu, sigmoid, linear (get_args.py:100-101)")
-        if self.enc_num_unit not in (32, 64, 100) or self.dec_num_unit not in (32, 64, 100):
-            raise ValueError("channel widths (enc_num_unit, dec_num_unit) must each be one of 32, 64, 100 (instantiated kernel widths)")
+        if not (1 <= self.enc_num_unit <= 100 and 1 <= self.dec_num_unit <= 100):
+            raise ValueError("channel widths (enc_num_unit, dec_num_unit) must be in 1..100 (kernels exist for 32 / 64 / 100; a "
+                             "narrower stack is embedded exactly into the next wider one)")
+        if self.dense and (self.enc_num_unit not in (32, 64, 100) or self.dec_num_unit not in (32, 64, 100)):
+            raise ValueError("dense stacks need channel widths of 32, 64 or 100")
         if not (1 <= self.num_iter_ft <= 6):
             raise ValueError("num_iter_ft must be in 1..6 (7-channel decoder input is padded to 8)")
         if self.num_iteration < 1 or self.enc_num_layer < 1 or self.dec_num_layer < 1:

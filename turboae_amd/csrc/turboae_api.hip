@@ -279,6 +279,9 @@ struct tae_handle {
 
 namespace {
 
+// Instantiated kernel widths / the width a configured one runs at (0: too wide)
+inline int kernel_width(int u) { return u <= 32 ? 32 : (u <= 64 ? 64 : (u <= 100 ? 100 : 0)); }
+
 int check_cfg(const tae_config* c) {
     if (!c) return fail(TAE_EINVAL, "config is NULL");
     if (c->struct_size != (int32_t)sizeof(tae_config)) return fail(TAE_EINVAL, "tae_config.struct_size mismatch (ABI)");
@@ -287,9 +290,10 @@ int check_cfg(const tae_config* c) {
         if (ks > 5 && (c->precision != TAE_PREC_AUTO || c->dense))
             return fail(TAE_EINVAL, "kernel sizes 7 and 9 are built in the fp16-split kernels only (precision = TAE_PREC_AUTO, no dense stacks)");
     }
-    if ((c->enc_num_unit != 100 && c->enc_num_unit != 64 && c->enc_num_unit != 32) ||
-        (c->dec_num_unit != 100 && c->dec_num_unit != 64 && c->dec_num_unit != 32))
-        return fail(TAE_EINVAL, "channel width (enc_num_unit, dec_num_unit) must be 32, 64 or 100");
+    if (c->enc_num_unit < 1 || c->enc_num_unit > 100 || c->dec_num_unit < 1 || c->dec_num_unit > 100)
+        return fail(TAE_EINVAL, "channel width (enc_num_unit, dec_num_unit) must be in 1..100 (kernels exist for 32 / 64 / 100; narrower stacks are embedded)");
+    if (c->dense && (kernel_width(c->enc_num_unit) != c->enc_num_unit || kernel_width(c->dec_num_unit) != c->dec_num_unit))
+        return fail(TAE_EINVAL, "dense stacks need a channel width of 32, 64 or 100");
     if (c->enc_num_layer < 1 || c->dec_num_layer < 1 || c->num_iteration < 1) return fail(TAE_EINVAL, "layer/iteration counts must be >= 1");
     if (c->num_iter_ft < 1 || c->num_iter_ft > 6) return fail(TAE_EINVAL, "num_iter_ft must be in 1..6");
     if (c->block_len < 1) return fail(TAE_EINVAL, "block_len must be >= 1");
@@ -650,18 +654,62 @@ size_t num_weights(const tae_config* c) {
     return n;
 }
 
-// The kernels contract 5 taps.  A SameShapeConv1d of kernel size 1 or 3 (padding ks / 2) is the 5-tap convolution whose
-// outer taps are zero, so smaller kernels are embedded - exactly - into the 5-tap layout before packing.
-std::vector<float> embed_in_5_taps(const tae_config* c, const float* w) {
+// The conv kernels exist for 32 / 64 / 100 channels and contract >= 5 taps.  Any narrower stack is the next wider one
+// with zero weights and biases for the extra channels (ELU(0) = 0: they stay zero and feed nothing), and a SameShapeConv1d
+// of kernel size 1 or 3 (padding ks / 2) is the 5-tap convolution whose outer taps are zero - so such configurations
+// are embedded, exactly, into the instantiated geometry before packing.  `out_cfg` receives that geometry.
+std::vector<float> embed_weights(const tae_config* c, const float* w, tae_config* out_cfg) {
     std::vector<float> out;
-    walk_weights(c, [&](bool conv, size_t a, size_t b, size_t ks) {
-        if (!conv || ks >= 5) { const size_t n = conv ? a * b * ks : a; out.insert(out.end(), w, w + n); w += n; return; }
-        const size_t off = (5 - ks) / 2;
-        for (size_t i = 0; i < a * b; ++i)
-            for (size_t j = 0; j < 5; ++j) out.push_back(j >= off && j < off + ks ? w[i * ks + (j - off)] : 0.0f);
-        w += a * b * ks;
-    });
+    *out_cfg = *c;
+    const size_t F = c->num_iter_ft;
+    auto conv = [&](size_t U, size_t U2, size_t cin, bool cin_is_u, size_t ks, size_t ks2) {     // weight (U, cin, ks) + bias (U)
+        const size_t cin2 = cin_is_u ? U2 : cin, off = (ks2 - ks) / 2;
+        for (size_t co = 0; co < U2; ++co)
+            for (size_t ci = 0; ci < cin2; ++ci)
+                for (size_t j = 0; j < ks2; ++j)
+                    out.push_back(co < U && ci < cin && j >= off && j < off + ks ? w[(co * cin + ci) * ks + (j - off)] : 0.0f);
+        w += U * cin * ks;
+        for (size_t co = 0; co < U2; ++co) out.push_back(co < U ? w[co] : 0.0f);
+        w += U;
+    };
+    auto linear = [&](size_t nout, size_t U, size_t U2) {                                          // weight (nout, U) + bias (nout)
+        for (size_t f = 0; f < nout; ++f)
+            for (size_t ci = 0; ci < U2; ++ci) out.push_back(ci < U ? w[f * U + ci] : 0.0f);
+        w += nout * U;
+        out.insert(out.end(), w, w + nout);
+        w += nout;
+    };
+    auto copy = [&](size_t n) { out.insert(out.end(), w, w + n); w += n; };
+    {
+        const size_t U = c->enc_num_unit, U2 = c->enc_type == 1 ? U : (size_t)kernel_width((int)U);
+        const size_t ks = c->enc_kernel_size, ks2 = ks < 5 ? 5 : ks;
+        out_cfg->enc_num_unit = (int32_t)U2;
+        out_cfg->enc_kernel_size = (int32_t)ks2;
+        for (int s = 0; s < 3; ++s) {
+            if (c->enc_type == 1) { copy(rnn_stack_floats(U, 1, 1)); continue; }
+            for (int l = 0; l < c->enc_num_layer; ++l) conv(U, U2, l == 0 ? 1 : U, l != 0, ks, ks2);
+            linear(1, U, U2);
+        }
+    }
+    {
+        const size_t U = c->dec_num_unit, U2 = c->dec_type == 1 ? U : (size_t)kernel_width((int)U);
+        const size_t ks = c->dec_kernel_size, ks2 = ks < 5 ? 5 : ks;
+        out_cfg->dec_num_unit = (int32_t)U2;
+        out_cfg->dec_kernel_size = (int32_t)ks2;
+        for (int it = 0; it < c->num_iteration; ++it)
+            for (int half = 0; half < 2; ++half) {
+                const size_t nout = (half == 1 && it == c->num_iteration - 1) ? 1 : F;
+                if (c->dec_type == 1) { copy(rnn_stack_floats(U, 2 + F, nout)); continue; }
+                for (int l = 0; l < c->dec_num_layer; ++l) conv(U, U2, l == 0 ? 2 + F : U, l != 0, ks, ks2);
+                linear(nout, U, U2);
+            }
+    }
     return out;
+}
+
+bool needs_embedding(const tae_config* c) {
+    return c->enc_kernel_size < 5 || c->dec_kernel_size < 5 || (c->enc_type == 0 && kernel_width(c->enc_num_unit) != c->enc_num_unit) ||
+           (c->dec_type == 0 && kernel_width(c->dec_num_unit) != c->dec_num_unit);
 }
 
 // `h2`: size for the f16x2 kernels' panels (the arithmetic that will run); `taps` > 5 exists there only
@@ -1041,10 +1089,8 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         return fail(TAE_EHIP, "no HIP device available: libturboae_hip needs an AMD GPU (no CPU fallback)");
     std::vector<float> w5;
     tae_config cfg5 = *cfg;
-    if (cfg->enc_kernel_size < 5 || cfg->dec_kernel_size < 5) {
-        w5 = embed_in_5_taps(cfg, weights);
-        if (cfg5.enc_kernel_size < 5) cfg5.enc_kernel_size = 5;
-        if (cfg5.dec_kernel_size < 5) cfg5.dec_kernel_size = 5;
+    if (needs_embedding(cfg)) {          // narrower stacks / kernel sizes 1, 3: run, exactly, in the next instantiated geometry
+        w5 = embed_weights(cfg, weights, &cfg5);
         cfg = &cfg5;
         weights = w5.data();
         n_weights = w5.size();
