@@ -61,9 +61,9 @@ typedef struct tae_config {
     int32_t enc_act;          /* -enc_act (get_args.py:100, encoders.py:86-100): TAE_ACT_* below; 0 = elu, the reference default */
     int32_t max_batch;        /* blocks per call the workspace is sized for (grown by tae_reserve) */
     int32_t dec_type;         /* -decoder: 0 = TurboAE_rate3_cnn (DEC_LargeCNN, decoders.py:157),
-                                 1 = TurboAE_rate3_rnn (DEC_LargeRNN with dec_rnn=gru, decoders.py:16; needs dec_num_unit=100)  main.py:75-88 */
+                                 1 = TurboAE_rate3_rnn (DEC_LargeRNN with dec_rnn=gru, decoders.py:16; dec_num_unit <= 100, runs in the 100-unit kernels)  main.py:75-88 */
     int32_t enc_type;         /* -encoder: 0 = TurboAE_rate3_cnn (ENC_interCNN, encoders.py:304), 1 = TurboAE_rate3_rnn (ENC_interRNN with
-                                 enc_rnn=gru, encoders.py:231-298; needs dec_type = 1, enc_num_unit = 100, enc_num_layer = 2)  main.py:32-36 */
+                                 enc_rnn=gru, encoders.py:231-298; needs dec_type = 1, enc_num_layer = 2; enc_num_unit <= 100)  main.py:32-36 */
     int32_t dense;            /* 1: -encoder TurboAE_rate3_cnn_dense: DenseSameShapeConv1d stacks in encoder AND decoder (cnn_utils.py:49-82; the
                                  reference keys both on the encoder name, encoders.py:312-330, decoders.py:173-176); needs enc_type =
                                  dec_type = 0 and precision = TAE_PREC_AUTO */

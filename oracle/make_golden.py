@@ -71,6 +71,8 @@ CASES = [
     # widths other than the instantiated 32 / 64 / 100 (run embedded in the next wider kernel)
     ("var_width_e25_d50", dict(enc_num_unit=25, dec_num_unit=50, num_iteration=2), 5, 33, 1.0, 2.0),
     ("var_width_e80_d10_k3", dict(enc_num_unit=80, dec_num_unit=10, num_iteration=2, dec_kernel_size=3, block_len=64), 4, 34, 1.0, 2.0),
+    ("fwd_rnn_width_e40_d25", dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_num_unit=40, dec_num_unit=25, num_iteration=2,
+                                   block_len=40), 3, 35, 1.0, 2.0),
     # -channel fading: the reference draws fading_h from the torch global stream inside forward (channel_ae.py:51-56);
     # seeded here and reproduced draw for draw, the coefficients travel in the fixture
     ("var_fading", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, channel="fading"), 5, 20, 1.0, 3.0),

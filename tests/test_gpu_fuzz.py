@@ -88,9 +88,11 @@ def draw_variant_cases(n, seed):
         acts = ["linear", "elu", "tanh", "relu", "selu", "sigmoid"]
         if kind == "dec_rnn":
             c.update(decoder="TurboAE_rate3_rnn", enc_num_layer=int(rng.randint(1, 4)), dec_act=str(rng.choice(acts)),
-                     enc_num_unit=int(rng.choice([32, 64, 100])))
+                     enc_num_unit=int(rng.choice([32, 64, 100, int(rng.randint(1, 101))])),
+                     dec_num_unit=int(rng.choice([100, 100, int(rng.randint(1, 101))])))       # GRU widths below 100 run embedded
         elif kind == "enc_rnn":
-            c.update(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_act=str(rng.choice(acts)), dec_act=str(rng.choice(acts)))
+            c.update(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_act=str(rng.choice(acts)), dec_act=str(rng.choice(acts)),
+                     enc_num_unit=int(rng.choice([100, int(rng.randint(1, 101))])), dec_num_unit=int(rng.choice([100, int(rng.randint(1, 101))])))
         else:
             U = int(rng.choice([32, 64]))
             c.update(encoder="TurboAE_rate3_cnn_dense", decoder="TurboAE_rate3_cnn_dense", enc_num_unit=U, dec_num_unit=int(rng.choice([32, 64])),
@@ -102,7 +104,7 @@ def draw_variant_cases(n, seed):
 VARIANT_CASES = draw_variant_cases(int(os.environ.get("TAE_FUZZ_CASES", "15")), int(os.environ.get("TAE_FUZZ_SEED", "77001")))
 
 
-@pytest.mark.parametrize("case", VARIANT_CASES, ids=lambda c: "{kind}_L{block_len}_B{B}_F{num_iter_ft}_it{num_iteration}".format(**c))
+@pytest.mark.parametrize("case", VARIANT_CASES, ids=lambda c: "{kind}_U{0}x{1}_L{block_len}_B{B}_F{num_iter_ft}_it{num_iteration}".format(c.get("enc_num_unit", 100), c.get("dec_num_unit", 100), **c))
 def test_random_shape_variants_match_oracle(gpu_device, case):
     from turboae_amd import Channel_AE_HIP
     case = dict(case)

@@ -111,6 +111,7 @@ def test_variant_configs_and_param_counts():
     assert sum(int(np.prod(s)) for k, s in W.canonical_entries(rnn) if k.startswith("dec.")) == 2970456
     # GRU encoder needs the GRU decoder; dense stacks need the fp16-split kernels and are keyed on the ENCODER name
     TurboAEConfig(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn").validate()
+    TurboAEConfig(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_num_unit=40, dec_num_unit=25).validate()
     with pytest.raises(ValueError):
         TurboAEConfig(encoder="TurboAE_rate3_rnn").validate()
     dense = TurboAEConfig(encoder="TurboAE_rate3_cnn_dense", decoder="TurboAE_rate3_cnn_dense")

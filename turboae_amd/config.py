@@ -88,16 +88,14 @@ class TurboAEConfig:
                 raise ValueError("the dense encoder pairs with the (then also dense) CNN decoder")
             if self.precision != "auto":
                 raise ValueError("DenseSameShapeConv1d is built on the fp16-split long-block kernels only (precision='auto')")
-        if self.encoder == "TurboAE_rate3_rnn" and (self.enc_num_unit != 100 or self.enc_num_layer != 2 or self.decoder != "TurboAE_rate3_rnn"):
-            raise ValueError("the GRU encoder runs on the GRU decoder's kernels: enc_num_unit = 100, enc_num_layer = 2, decoder = 'TurboAE_rate3_rnn' "
+        if self.encoder == "TurboAE_rate3_rnn" and (self.enc_num_layer != 2 or self.decoder != "TurboAE_rate3_rnn"):
+            raise ValueError("the GRU encoder runs on the GRU decoder's kernels: enc_num_layer = 2, decoder = 'TurboAE_rate3_rnn' "
                              "(with any other decoder the reference switches the decoder to DenseSameShapeConv1d, decoders.py:173-176)")
         if self.decoder not in ("TurboAE_rate3_cnn", "TurboAE_rate3_cnn_dense", "TurboAE_rate3_rnn"):
             raise ValueError("decoder must be 'TurboAE_rate3_cnn', 'TurboAE_rate3_cnn_dense' or 'TurboAE_rate3_rnn'")
         if self.decoder == "TurboAE_rate3_cnn_dense" and not self.dense:
             raise ValueError("the reference builds DenseSameShapeConv1d decoders from the ENCODER name (decoders.py:173-176): "
                              "use encoder='TurboAE_rate3_cnn_dense'")
-        if self.decoder == "TurboAE_rate3_rnn" and self.dec_num_unit != 100:
-            raise ValueError("the GRU decoder kernels are instantiated for dec_num_unit = 100")
 
     @staticmethod
     def from_args(args) -> "TurboAEConfig":

@@ -301,13 +301,12 @@ int check_cfg(const tae_config* c) {
     if (c->dec_act < 0 || c->dec_act > 5) return fail(TAE_EINVAL, "dec_act must be 0 (elu), 1 (linear), 2 (tanh), 3 (relu), 4 (selu) or 5 (sigmoid)");
     if (c->dec_type != 0 && c->dec_type != 1) return fail(TAE_EINVAL, "dec_type must be 0 (cnn) or 1 (rnn/gru)");
     if (c->precision != TAE_PREC_AUTO && c->precision != TAE_PREC_F32) return fail(TAE_EINVAL, "precision must be TAE_PREC_AUTO (0) or TAE_PREC_F32 (1)");
-    if (c->dec_type == 1 && c->dec_num_unit != 100) return fail(TAE_EINVAL, "the GRU decoder kernels are instantiated for dec_num_unit = 100");
     if (c->enc_type != 0 && c->enc_type != 1) return fail(TAE_EINVAL, "enc_type must be 0 (cnn) or 1 (rnn/gru)");
     if (c->dense != 0 && c->dense != 1) return fail(TAE_EINVAL, "dense must be 0 or 1");
     if (c->dense && (c->enc_type != 0 || c->dec_type != 0 || c->precision != TAE_PREC_AUTO))
         return fail(TAE_EINVAL, "DenseSameShapeConv1d stacks need the CNN encoder / decoder and precision = TAE_PREC_AUTO (fp16-split long-block kernels)");
-    if (c->enc_type == 1 && (c->dec_type != 1 || c->enc_num_unit != 100 || c->enc_num_layer != 2))
-        return fail(TAE_EINVAL, "the GRU encoder needs the GRU decoder (dec_type = 1), enc_num_unit = 100 and enc_num_layer = 2");
+    if (c->enc_type == 1 && (c->dec_type != 1 || c->enc_num_layer != 2))
+        return fail(TAE_EINVAL, "the GRU encoder needs the GRU decoder (dec_type = 1) and enc_num_layer = 2");
     return TAE_OK;
 }
 
@@ -679,27 +678,58 @@ std::vector<float> embed_weights(const tae_config* c, const float* w, tae_config
         out.insert(out.end(), w, w + nout);
         w += nout;
     };
-    auto copy = [&](size_t n) { out.insert(out.end(), w, w + n); w += n; };
+    // 2-layer bidirectional GRU(cin0 -> H) + Linear(2H -> nout) widened to H2 = 100 units: gate rows g*H + u -> g*H2 + u, the
+    // layer-1 / Linear input columns (forward | backward halves) likewise.  A unit with zero weights and biases has
+    // r = z = 1/2, n = tanh(0) = 0, so h' = (1 - z) n + z h stays at its initial 0 and feeds nothing.
+    auto rnn = [&](size_t H, size_t H2, size_t cin0, size_t nout) {
+        auto col2 = [&](size_t c2) -> long { const size_t half = c2 / H2, u = c2 % H2; return u < H ? (long)(half * H + u) : -1; };
+        for (int l = 0; l < 2; ++l) {
+            const size_t cin = l == 0 ? cin0 : 2 * H, cin2 = l == 0 ? cin0 : 2 * H2;
+            for (int d = 0; d < 2; ++d) {
+                for (size_t g = 0; g < 3; ++g)                        // weight_ih (3H, cin)
+                    for (size_t u = 0; u < H2; ++u)
+                        for (size_t c2 = 0; c2 < cin2; ++c2) {
+                            const long cc = l == 0 ? (long)c2 : col2(c2);
+                            out.push_back(u < H && cc >= 0 ? w[(g * H + u) * cin + (size_t)cc] : 0.0f);
+                        }
+                w += 3 * H * cin;
+                for (size_t g = 0; g < 3; ++g)                        // weight_hh (3H, H)
+                    for (size_t u = 0; u < H2; ++u)
+                        for (size_t c2 = 0; c2 < H2; ++c2) out.push_back(u < H && c2 < H ? w[(g * H + u) * H + c2] : 0.0f);
+                w += 3 * H * H;
+                for (int b = 0; b < 2; ++b) {                         // bias_ih, bias_hh (3H)
+                    for (size_t g = 0; g < 3; ++g)
+                        for (size_t u = 0; u < H2; ++u) out.push_back(u < H ? w[g * H + u] : 0.0f);
+                    w += 3 * H;
+                }
+            }
+        }
+        for (size_t f = 0; f < nout; ++f)                             // Linear (nout, 2H) + bias
+            for (size_t c2 = 0; c2 < 2 * H2; ++c2) { const long cc = col2(c2); out.push_back(cc >= 0 ? w[f * 2 * H + (size_t)cc] : 0.0f); }
+        w += nout * 2 * H;
+        out.insert(out.end(), w, w + nout);
+        w += nout;
+    };
     {
-        const size_t U = c->enc_num_unit, U2 = c->enc_type == 1 ? U : (size_t)kernel_width((int)U);
+        const size_t U = c->enc_num_unit, U2 = c->enc_type == 1 ? 100 : (size_t)kernel_width((int)U);
         const size_t ks = c->enc_kernel_size, ks2 = ks < 5 ? 5 : ks;
         out_cfg->enc_num_unit = (int32_t)U2;
         out_cfg->enc_kernel_size = (int32_t)ks2;
         for (int s = 0; s < 3; ++s) {
-            if (c->enc_type == 1) { copy(rnn_stack_floats(U, 1, 1)); continue; }
+            if (c->enc_type == 1) { rnn(U, U2, 1, 1); continue; }
             for (int l = 0; l < c->enc_num_layer; ++l) conv(U, U2, l == 0 ? 1 : U, l != 0, ks, ks2);
             linear(1, U, U2);
         }
     }
     {
-        const size_t U = c->dec_num_unit, U2 = c->dec_type == 1 ? U : (size_t)kernel_width((int)U);
+        const size_t U = c->dec_num_unit, U2 = c->dec_type == 1 ? 100 : (size_t)kernel_width((int)U);
         const size_t ks = c->dec_kernel_size, ks2 = ks < 5 ? 5 : ks;
         out_cfg->dec_num_unit = (int32_t)U2;
         out_cfg->dec_kernel_size = (int32_t)ks2;
         for (int it = 0; it < c->num_iteration; ++it)
             for (int half = 0; half < 2; ++half) {
                 const size_t nout = (half == 1 && it == c->num_iteration - 1) ? 1 : F;
-                if (c->dec_type == 1) { copy(rnn_stack_floats(U, 2 + F, nout)); continue; }
+                if (c->dec_type == 1) { rnn(U, U2, 2 + F, nout); continue; }
                 for (int l = 0; l < c->dec_num_layer; ++l) conv(U, U2, l == 0 ? 2 + F : U, l != 0, ks, ks2);
                 linear(nout, U, U2);
             }
@@ -708,8 +738,9 @@ std::vector<float> embed_weights(const tae_config* c, const float* w, tae_config
 }
 
 bool needs_embedding(const tae_config* c) {
-    return c->enc_kernel_size < 5 || c->dec_kernel_size < 5 || (c->enc_type == 0 && kernel_width(c->enc_num_unit) != c->enc_num_unit) ||
-           (c->dec_type == 0 && kernel_width(c->dec_num_unit) != c->dec_num_unit);
+    return c->enc_kernel_size < 5 || c->dec_kernel_size < 5 ||
+           (c->enc_type == 0 ? kernel_width(c->enc_num_unit) : 100) != c->enc_num_unit ||
+           (c->dec_type == 0 ? kernel_width(c->dec_num_unit) : 100) != c->dec_num_unit;
 }
 
 // `h2`: size for the f16x2 kernels' panels (the arithmetic that will run); `taps` > 5 exists there only
