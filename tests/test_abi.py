@@ -102,3 +102,15 @@ def test_header_is_plain_c_and_a_c_host_links(tmp_path):
     first, second = out.stdout.splitlines()
     assert first.split() == [str(_lib.TAE_ABI_VERSION), str(W.num_params(TurboAEConfig()))]
     assert second.startswith("0 ") and "channel width" in second
+
+
+def test_config_struct_is_the_same_everywhere():
+    """tae_config in the header, the ctypes mirror and the binding stub printed in INTEGRATION.md list the same int32 fields."""
+    with open(os.path.join(ROOT, "include", "turboae_hip.h")) as fh:
+        body = re.search(r"typedef struct tae_config \{(.*?)\} tae_config;", fh.read(), re.S).group(1)
+    header = re.findall(r"^\s*int32_t\s+(\w+);", body, re.M)
+    mirror = [n for n, _ in _lib.TaeConfig._fields_]
+    with open(os.path.join(ROOT, "INTEGRATION.md")) as fh:
+        stub = re.search(r"_fields_ = \[\(n, C\.c_int32\) for n in \((.*?)\)\]", fh.read(), re.S).group(1)
+    assert header == mirror == re.findall(r'"(\w+)"', stub)
+    assert C.sizeof(_lib.TaeConfig) == 4 * len(header)
