@@ -83,13 +83,21 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    # TAE_BENCH_BACKEND=gloo is a test hook: it lets N ranks share the GPUs that exist (rank % device_count) so the N > 1
+    # code path can be exercised on a 1-GPU box (tests/test_gpu_sharded.py); the contract run uses RCCL, one GPU per rank.
+    backend = os.environ.get("TAE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
 
     cfg = TurboAEConfig(enc_num_layer=args.enc_layers, precision=args.precision)
     sd = W.generate_state_dict(cfg, seed=20190001, gain=1.0)

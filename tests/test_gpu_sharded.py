@@ -71,3 +71,25 @@ def test_sharded_eval_sweep_equals_single_process(gpu_device, world):
             assert abs(res["ber"][si] - single["ber"][si]) <= 1e-4
         assert abs(res["enc_power"] - single["enc_power"]) <= 1e-6
     assert single["bit_errors"][0] > single["bit_errors"][1] > 0
+
+
+def test_bench_runs_with_two_ranks(gpu_device):
+    """bench.py's N > 1 path (stats all-reduce per step, barrier + max-over-ranks timing, error-count reduce, one JSON line
+    from rank 0) launched exactly as the driver launches it, with the gloo test hook so both ranks can share this box's GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TAE_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "3000"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["warmup"] == 1 and res["scaling"] == "weak"
+    assert res["config"]["global_blocks"] == 6000 and res["config"]["blocks_per_gpu"] == 3000
+    assert res["value"] > 0 and abs(res["value"] - 6000 * 100 * 2 / (res["ms_per_step"] * 2e-3)) <= 1e-3 * res["value"]
+    assert "cpu_baseline" not in res and res["roofline"]["frac"] > 0
