@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=50000, help="blocks per GPU per step (BASELINE configs[1]: 50000)")
+    ap.add_argument("--block-len", type=int, default=100, help="BASELINE configs[3] is block_len 1000 (long-block kernels)")
     ap.add_argument("--snr", type=float, default=2.0)
     ap.add_argument("--enc-layers", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -99,7 +100,7 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    cfg = TurboAEConfig(enc_num_layer=args.enc_layers, precision=args.precision)
+    cfg = TurboAEConfig(block_len=args.block_len, enc_num_layer=args.enc_layers, precision=args.precision)
     sd = W.generate_state_dict(cfg, seed=20190001, gain=1.0)
     B, L = args.batch, cfg.block_len
     model = Channel_AE_HIP(cfg, sd, device=dev, max_batch=B)
@@ -159,6 +160,8 @@ def main():
         # dense fp16 MFMA peak / 3; `mfma_tflops_executed` = 3 x achieved is what the matrix pipes actually ran.
         peak = PEAK_F16_MFMA_TFLOPS / F16X2_PRODUCTS if f16x2 else PEAK_FP32_MFMA_TFLOPS
         kname = "tae::dec_kernel_h<100,5> (fused 6-iteration decoder, fp16-split MFMA)" if f16x2 else "tae::dec_kernel<100,5> (fused 6-iteration decoder, fp32 MFMA)"
+        if nb == 0:        # long blocks: the decoder is 2 * num_iteration launches of the segment kernel; `kernel_ms` covers all of them
+            kname = ("tae::seg_kernel_h<100,5>" if f16x2 else "tae::seg_kernel<100,5>") + f" x {2 * cfg.num_iteration} launches (one conv stack each, long-block decoder)"
         pmc_dir = "r01_pmc_f16x2" if f16x2 else "r01_pmc"
         # HBM-side traffic of the decoder kernel from the committed PMC passes (rocprofv3 cannot run inside
         # this process): bytes per block measured at the same workload, scaled to this launch's blocks
@@ -168,13 +171,13 @@ def main():
             with open(tpath) as fh:
                 traffic = json.load(fh)["bytes_per_block"] * B / 1e9
         out = {
-            "metric": "decoded info bits/sec @ block_len=100, 6-iter rate-1/3 CNN; BER match",
+            "metric": f"decoded info bits/sec @ block_len={L}, 6-iter rate-1/3 CNN; BER match",      # BASELINE.json's metric at the default L = 100
             "value": value, "unit": "bits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": ("f16x2: fp32 operands as fp16 hi+lo halves, 3 x v_mfma_f32_16x16x32_f16 per 32 k, fp32 accumulate (fp32-grade, "
                       "DESIGN.md 3.7)") if f16x2 else "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: TurboAE_rate3_cnn enc{cfg.enc_num_layer}/dec{cfg.dec_num_layer}, "
+            "config": {"workload": f"BASELINE configs[{1 if L == 100 else 3}]: TurboAE_rate3_cnn enc{cfg.enc_num_layer}/dec{cfg.dec_num_layer}, "
                                    f"block_len={L}, batch={B} blocks per GPU, {cfg.num_iteration} iters, AWGN SNR={args.snr} dB, "
                                    "random-init weights (portable generator), inputs resident in HBM",
                        "blocks_per_gpu": B, "global_blocks": world * B, "block_len": L,
