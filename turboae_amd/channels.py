@@ -28,16 +28,20 @@ def snr_sigma2db(sigma: float) -> float:
 
 
 def _markov_good_state(shape, p_gg: float, p_bb: float, gen: Optional[torch.Generator], device) -> torch.Tensor:
-    """Gilbert-Elliott state sequence along dim 1 (channels.py:60-78 / 87-105): starts good, stays good with p_gg,
-    stays bad with p_bb; independent chains per (block, code symbol).  Returns a bool tensor (True = good)."""
+    """Gilbert-Elliott state sequence along dim 1 (channels.py:60-82 / 87-107), independent chains per (block, code
+    symbol), every chain starts good.  The transitions are the reference's as written: from the good state the next
+    state is good with probability p_gg (``good = np.random.random() < p_gg``, channels.py:73,100), and from the BAD state
+    the next state is good with probability p_bb as well (``good = np.random.random() < p_bb``, channels.py:79,105 - the
+    comment there says "stay in bad state", the code returns to good).  With p_gg = p_bb = 0.8 the state is therefore
+    good with probability 0.8 at every step after the first, independent of the previous state.  Returns a bool tensor
+    (True = good)."""
     B, L, C = shape
     u = torch.rand((B, L, C), generator=gen, device=device)
     good = torch.ones((B, C), dtype=torch.bool, device=device)
     out = torch.empty((B, L, C), dtype=torch.bool, device=device)
     for t in range(L):
         out[:, t, :] = good
-        stay = torch.where(good, u[:, t, :] < p_gg, ~(u[:, t, :] < p_bb))
-        good = stay
+        good = torch.where(good, u[:, t, :] < p_gg, u[:, t, :] < p_bb)
     return out
 
 
