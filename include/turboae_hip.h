@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TAE_ABI_VERSION 7
+#define TAE_ABI_VERSION 8
 
 #if defined(__GNUC__)
 #define TAE_API __attribute__((visibility("default")))
@@ -153,6 +153,14 @@ TAE_API int tae_normalize(tae_handle* h, const float* x_tx, const double* stats3
 /* Replaces model.dec(received) = DEC_LargeCNN.forward (decoders.py:206-269) or, with dec_type = 1,
  * DEC_LargeRNN.forward (decoders.py:84-149). */
 TAE_API int tae_decode(tae_handle* h, const float* received, float* x_dec, int32_t B, void* stream);
+
+/* tae_decode plus a debug export of what every half-iteration hands to the next one (no reference counterpart: the reference keeps
+ * `x_plr` / `prior` as locals of DEC_LargeCNN.forward, decoders.py:229-249): taps (device, (2*num_iteration - 1) * B * L * num_iter_ft
+ * floats) receives, for stack s = 2*it (dec1) the extrinsic output x_plr = dec1_outputs[it](...) - prior in natural order, and for
+ * s = 2*it + 1 (dec2, it < num_iteration - 1) x_plr = dec2_outputs[it](...) - x_plr_int in INTERLEAVED order (prior = its
+ * deinterleave), as [s][b][position][f].  Same results in x_dec as tae_decode; runs a separate instantiation of the decoder kernel
+ * (the production kernel carries no tap code).  Used by tests/ to localise a regression to one stack.  CNN decoder only. */
+TAE_API int tae_decode_taps(tae_handle* h, const float* received, float* x_dec, float* taps, int32_t B, void* stream);
 
 /* Replaces errors_ber / errors_bler (utils.py:6-18,49-66) as integer counts ACCUMULATED into
  * counts2 (device, 2 x uint64): [0] += bit errors, [1] += blocks with >= 1 bit error. */

@@ -47,6 +47,9 @@ CASES = [
     ("fwd_encrnn_decrnn_u100_L100_b4", dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", num_iteration=2), 4, 21, 1.0, 2.0),
     # DenseSameShapeConv1d stacks in encoder and decoder (cnn_utils.py:49-82; -encoder / -decoder TurboAE_rate3_cnn_dense)
     ("fwd_dense_u100_L100_b3_it2", dict(encoder="TurboAE_rate3_cnn_dense", decoder="TurboAE_rate3_cnn_dense", num_iteration=2), 3, 22, 1.0, 2.0),
+    # dense stacks with kernel sizes below 5 (embedded into 5 taps; ADVICE r01: the embedding must keep the dense input widths)
+    ("fwd_dense_k3_k1_u32_L64", dict(encoder="TurboAE_rate3_cnn_dense", decoder="TurboAE_rate3_cnn_dense", enc_num_unit=32, dec_num_unit=32,
+                                     num_iteration=2, enc_kernel_size=3, dec_kernel_size=1, block_len=64, dec_num_layer=3), 4, 36, 1.0, 2.0),
     # encoder-output / channel variants on the same kernels; small nets keep them cheap
     ("var_ste2_bsc", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, train_channel_mode="block_norm_ste", channel="bsc"), 5, 16, 1.0, 0.1),
     ("var_ste4_trunc_recq", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, train_channel_mode="block_norm_ste",
@@ -80,6 +83,38 @@ CASES = [
 
 FADING_SEED = 20190020
 
+# cases whose fixture also carries what every decoder half-iteration hands to the next one (`prior` after each
+# iteration), captured from the REAL reference with forward hooks on its dec1_outputs / dec2_outputs Linear modules
+TAP_CASES = ("fwd_enc2dec5_u100_L100_b4", "fwd_u32_L100_b8", "fwd_u32_L64_b6_ft3_noext", "fwd_u100_L1000_b2", "fwd_u100_L150_b3_it2")
+
+
+def reference_taps(model, cfg, u, noise):
+    """Run the reference forward with hooks on dec.dec{1,2}_outputs[it] (decoders.py:187-192; the Linear heads whose outputs
+    DEC_LargeCNN.forward turns into x_plr / prior, decoders.py:233-249) and rebuild the locals of that forward from them with the
+    same fp32 tensor operations: taps[2 it] = x_plr after dec1 (natural order), taps[2 it + 1] = x_plr after dec2 (interleaved
+    order; prior = its deinterleave).  Layout = tae_decode_taps (include/turboae_hip.h)."""
+    outs = {}
+    hooks = []
+    for half, mods in ((1, model.dec.dec1_outputs), (2, model.dec.dec2_outputs)):
+        for it, m in enumerate(mods):
+            hooks.append(m.register_forward_hook(lambda mod, inp, out, key=(half, it): outs.__setitem__(key, out.detach().clone())))
+    x_ref, c_ref = R.reference_forward(model, u, noise)
+    for h in hooks:
+        h.remove()
+    p = torch.from_numpy(O.rand_interleaver(cfg.block_len, 0))
+    B, L, F = u.shape[0], cfg.block_len, cfg.num_iter_ft
+    prior = torch.zeros((B, L, F))
+    taps = []
+    for it in range(cfg.num_iteration):
+        x_plr = outs[(1, it)] - prior if cfg.extrinsic else outs[(1, it)]
+        taps.append(x_plr)
+        x_plr_int = O.interleave(x_plr, p)
+        if it < cfg.num_iteration - 1:
+            x2 = outs[(2, it)] - x_plr_int if cfg.extrinsic else outs[(2, it)]
+            taps.append(x2)
+            prior = O.deinterleave(x2, p)
+    return x_ref, c_ref, torch.stack(taps).numpy()
+
 
 def make_inputs(B, L, snr_db, seed, channel="awgn", offset=0):
     """bits + channel 'noise': Gaussian for the additive channels; for bec / bsc the 0/1 keep-mask of
@@ -105,13 +140,23 @@ def run_case(name, over, B, wseed, gain, snr_db, manifest):
         a, b = torch.randn(noise.shape), torch.randn(noise.shape)          # the two draws of channel_ae.py:53, in order
         fading = (torch.sqrt(a ** 2 + b ** 2) / torch.sqrt(torch.tensor(3.14 / 2.0))).type(torch.FloatTensor)
         torch.manual_seed(FADING_SEED)                                      # the reference now makes the same draws
-    x_ref, c_ref = R.reference_forward(model, u, noise)
+    ref_taps = None
+    if name in TAP_CASES:
+        x_ref, c_ref, ref_taps = reference_taps(model, cfg, u, noise)
+    else:
+        x_ref, c_ref = R.reference_forward(model, u, noise)
     taps, state = {}, {}
     x_or, c_or = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict(), taps, state, fading)
     dx = float(np.abs(x_ref - x_or.numpy()).max())
     dc = float(np.abs(c_ref - c_or.numpy()).max())
     assert dc <= 2e-6 and dx <= 5e-6, (name, dc, dx)
     extra = {}
+    if ref_taps is not None:
+        p = torch.from_numpy(O.rand_interleaver(cfg.block_len, 0))
+        for it in range(cfg.num_iteration - 1):      # the oracle's own `prior` after every iteration against the reference's
+            d = float((O.deinterleave(torch.from_numpy(ref_taps[2 * it + 1]), p) - taps[f"prior_{it}"]).abs().max())
+            assert d <= 5e-6, (name, it, d)
+        extra["dec_taps"] = ref_taps
     if fading is not None:
         extra["fading"] = fading.numpy()
     if cfg.precompute_norm_stats:

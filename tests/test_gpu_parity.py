@@ -107,6 +107,45 @@ def test_forward_matches_reference_golden(gpu_device, name):
         _check_against_golden(xd2, codes2, g["codes2"], g["x_dec2"], None, quantised)
 
 
+TAP_CASES = [n for n in sorted(MANIFEST["cases"]) if "dec_taps" in np.load(os.path.join(GOLD, n + ".npz")).files]
+
+
+@pytest.mark.parametrize("precision", ["auto", "f32"])
+@pytest.mark.parametrize("name", TAP_CASES)
+def test_decoder_stage_taps_match_reference(gpu_device, name, precision):
+    """What every decoder half-iteration hands to the next one (x_plr after dec1, x_plr after dec2 = the next prior before
+    deinterleaving) against the values captured from the REAL reference with hooks: a decoder
+    regression is localised to the first stack that differs.  Whole-block kernels (L <= 150) and the long-block kernels
+    (L = 1000), both arithmetics."""
+    from dataclasses import replace
+    from turboae_amd import Channel_AE_HIP
+    meta = MANIFEST["cases"][name]
+    cfg = replace(TurboAEConfig(**meta["config"]), precision=precision)
+    sd = W.generate_state_dict(cfg, seed=meta["weight_seed"], gain=meta["gain"])
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=meta["B"])
+    rx = torch.from_numpy(g["codes"] + g["noise"]).to(gpu_device)          # channel_ae.py:42 on the reference's own codes
+    xd, taps = model.decode_taps(rx)
+    torch.cuda.synchronize()
+    assert torch.equal(xd, model.dec(rx))                                  # the tap instantiation computes the same decoder
+    ref = g["dec_taps"]
+    taps = taps.cpu().numpy()
+    assert taps.shape == ref.shape
+    for s in range(ref.shape[0]):
+        d = np.abs(taps[s] - ref[s]).max()
+        assert d <= 2e-5 * max(1.0, np.abs(ref[s]).max()), (s, d)
+    assert np.abs(xd.cpu().numpy() - g["x_dec"]).max() <= ATOL_XDEC
+
+
+def test_decoder_taps_rejected_for_gru(gpu_device):
+    from turboae_amd import Channel_AE_HIP
+    from turboae_amd._lib import TurboAEError
+    cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", num_iteration=1, block_len=16)
+    model = Channel_AE_HIP(cfg, W.generate_state_dict(cfg, seed=1, gain=1.0), device=gpu_device, max_batch=2)
+    with pytest.raises(TurboAEError, match="no tap export"):
+        model.decode_taps(torch.zeros((2, 16, 3), device=gpu_device))
+
+
 def test_enc_dec_views_and_split_path(gpu_device):
     from turboae_amd import Channel_AE_HIP
     cfg = TurboAEConfig()

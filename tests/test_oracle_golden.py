@@ -37,6 +37,19 @@ def test_oracle_matches_reference_fixture(name):
         x2, c2 = O.channel_ae_forward(torch.from_numpy(g["u2"]), torch.from_numpy(g["noise2"]), O.to_torch(sd), cfg.to_dict(), None, state)
         assert np.abs(c2.numpy() - g["codes2"]).max() <= 2e-6
         assert np.abs(x2.numpy() - g["x_dec2"]).max() <= 5e-6
+    if "dec_taps" in g.files:
+        # per-stage taps captured from the REAL reference (hooks on dec{1,2}_outputs, oracle/make_golden.py::reference_taps):
+        # `prior` after every iteration = deinterleave of the dec2 tap (decoders.py:244-249)
+        p = torch.from_numpy(O.rand_interleaver(cfg.block_len, 0))
+        assert g["dec_taps"].shape == (2 * cfg.num_iteration - 1, meta["B"], cfg.block_len, cfg.num_iter_ft)
+        for it in range(cfg.num_iteration - 1):
+            ref_prior = O.deinterleave(torch.from_numpy(g["dec_taps"][2 * it + 1]), p)
+            assert float((ref_prior - taps[f"prior_{it}"]).abs().max()) <= 5e-6, it
+
+
+def test_some_fixtures_carry_per_stage_taps():
+    with_taps = [n for n in CASES if "dec_taps" in np.load(os.path.join(GOLD, n + ".npz")).files]
+    assert len(with_taps) >= 4 and "fwd_enc2dec5_u100_L100_b4" in with_taps and "fwd_u100_L1000_b2" in with_taps
 
 
 @pytest.mark.parametrize("L", [40, 64, 100, 150, 1000])

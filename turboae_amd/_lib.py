@@ -12,7 +12,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TAE_LIB", os.path.join(_HERE, "lib", "libturboae_hip.so"))   # TAE_LIB: kernel-variant experiments
 
-TAE_ABI_VERSION = 7
+TAE_ABI_VERSION = 8
 
 
 class TaeConfig(C.Structure):
@@ -45,6 +45,7 @@ SIGNATURES = {
     "tae_encode_prenorm": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P]),
     "tae_normalize": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "tae_decode": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
+    "tae_decode_taps": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P]),
     "tae_count_errors": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
     "tae_generate_inputs": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64, C.c_float, _P]),
     "tae_eval_snr": (C.c_int, [_P, C.c_float, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64, _P, _P]),

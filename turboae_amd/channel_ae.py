@@ -274,6 +274,9 @@ class Channel_AE_HIP:
         self.enc._e = self._eng
         self.dec._e = self._eng
         old.close()
+        for e in self._by_len.values():        # per-length engines (is_variable_block_len) hold the OLD weights: rebuild on demand
+            e.close()
+        self._by_len.clear()
         return self
 
     def kernel_info(self):
@@ -299,7 +302,10 @@ class Channel_AE_HIP:
                              "(pass is_variable_block_len=True to allow other lengths)")
         if L not in self._by_len:
             from dataclasses import replace
-            self._by_len[L] = _Engine(replace(self.cfg, block_len=L), self._eng._state, self._eng.device, self._eng.cap)
+            e = _Engine(replace(self.cfg, block_len=L), self._eng._state, self._eng.device, self._eng.cap)
+            if self.is_interleave == 0:        # no interleaver (main.py:129-131): forward() never installs one, so do it here
+                e.set_interleaver(np.arange(L))
+            self._by_len[L] = e
         return self._by_len[L]
 
     def _channel_input(self, e, fwd_noise: torch.Tensor, fading: Optional[torch.Tensor]) -> torch.Tensor:
@@ -371,6 +377,21 @@ class Channel_AE_HIP:
         with torch.cuda.device(e.device):
             _lib.check(e.lib.tae_normalize(e.h, _ptr(x), _ptr(st), _ptr(noise), _ptr(codes), _ptr(rx), B, _stream()))
         return codes, rx
+
+    def decode_taps(self, received: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """model.dec(received) plus what every half-iteration hands to the next one (tae_decode_taps, a debug
+        instantiation of the decoder kernel): returns (x_dec, taps) with taps of shape (2 * num_iteration - 1, B, L, num_iter_ft):
+        taps[2 * it] = x_plr after dec1 of iteration `it` (natural order, decoders.py:233-236), taps[2 * it + 1] = x_plr after
+        dec2 (interleaved order; `prior` of the next iteration is its deinterleave, decoders.py:244-249)."""
+        e = self._eng
+        rx = e._in(received, 3, "received")
+        B = rx.shape[0]
+        e.reserve(B)
+        x_dec = e._out(B, 1)
+        taps = torch.zeros((2 * e.cfg.num_iteration - 1, B, e.cfg.block_len, e.cfg.num_iter_ft), dtype=torch.float32, device=e.device)
+        with torch.cuda.device(e.device):
+            _lib.check(e.lib.tae_decode_taps(e.h, _ptr(rx), _ptr(x_dec), _ptr(taps), B, _stream()))
+        return x_dec, taps
 
     def count_errors(self, x_dec: torch.Tensor, u: torch.Tensor, counts: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Accumulate (bit errors, block errors) (utils.py:6-18,49-66) into a device int64[2] tensor."""

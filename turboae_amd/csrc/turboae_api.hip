@@ -717,7 +717,11 @@ std::vector<float> embed_weights(const tae_config* c, const float* w, tae_config
         out_cfg->enc_kernel_size = (int32_t)ks2;
         for (int s = 0; s < 3; ++s) {
             if (c->enc_type == 1) { rnn(U, U2, 1, 1); continue; }
-            for (int l = 0; l < c->enc_num_layer; ++l) conv(U, U2, l == 0 ? 1 : U, l != 0, ks, ks2);
+            // dense stacks (widths are exact there, check_cfg): layer l sees cat(input, out_0 .. out_{l-1}) = 1 + l * U channels
+            for (int l = 0; l < c->enc_num_layer; ++l) {
+                if (c->dense) conv(U, U2, 1 + l * U, false, ks, ks2);
+                else conv(U, U2, l == 0 ? 1 : U, l != 0, ks, ks2);
+            }
             linear(1, U, U2);
         }
     }
@@ -730,7 +734,10 @@ std::vector<float> embed_weights(const tae_config* c, const float* w, tae_config
             for (int half = 0; half < 2; ++half) {
                 const size_t nout = (half == 1 && it == c->num_iteration - 1) ? 1 : F;
                 if (c->dec_type == 1) { rnn(U, U2, 2 + F, nout); continue; }
-                for (int l = 0; l < c->dec_num_layer; ++l) conv(U, U2, l == 0 ? 2 + F : U, l != 0, ks, ks2);
+                for (int l = 0; l < c->dec_num_layer; ++l) {
+                    if (c->dense) conv(U, U2, 2 + F + l * U, false, ks, ks2);
+                    else conv(U, U2, l == 0 ? 2 + F : U, l != 0, ks, ks2);
+                }
                 linear(nout, U, U2);
             }
     }
@@ -879,7 +886,7 @@ int run_encoder_long(tae_handle* h, const float* u, float* xtx, double* stats, i
     return TAE_OK;
 }
 
-int run_decoder_long(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st) {
+int run_decoder_long(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st, float* tap_out = nullptr) {
     tae::SegParams P = seg_params(h, B, true);
     P.wpack = h->d_wdec;
     P.in = rx;
@@ -907,6 +914,11 @@ int run_decoder_long(tae_handle* h, const float* rx, float* xdec, int32_t B, hip
         P.ecur = (s & 1) ? h->d_e1 : h->d_e0;
         if (h->prec == 1) TAE_HIP(tae::launch_seg_h(h->Ud, P, grid, st));
         else TAE_HIP(tae::launch_seg(h->Ud, P, grid, st));
+        if (tap_out && !P.last) {       // (B, L, 8) exchange rows -> compact (B, L, F)
+            const size_t F = (size_t)h->cfg.num_iter_ft, rows = (size_t)B * h->cfg.block_len;
+            TAE_HIP(hipMemcpy2DAsync(tap_out + (size_t)s * rows * F, F * sizeof(float), P.ecur, 8 * sizeof(float), F * sizeof(float), rows,
+                                     hipMemcpyDeviceToDevice, st));
+        }
     }
     return TAE_OK;
 }
@@ -945,6 +957,15 @@ int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_
 int run_encoder_rnn(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st) {
     const int L = h->cfg.block_len, H = 100;
     int slot = 0;
+    {   // every head launch writes gru_head_grid(npos) partial-sum slots: check the whole call BEFORE anything is launched
+        long need = 0;
+        for (int32_t c0 = 0; c0 < B; c0 += h->rnn_chunk) {
+            const int32_t Bc = (B - c0 < h->rnn_chunk) ? B - c0 : h->rnn_chunk;
+            const size_t npos = h->prec == 1 ? (size_t)((Bc + 15) / 16) * 16 * L : (size_t)Bc * L;
+            need += 3L * tae::gru_head_grid(npos);
+        }
+        if (need > h->rnn_partial_slots) return fail(TAE_ESTATE, "internal: GRU-encoder partial-sum slots exceeded");
+    }
     for (int32_t c0 = 0; c0 < B; c0 += h->rnn_chunk) {
         const int32_t Bc = (B - c0 < h->rnn_chunk) ? B - c0 : h->rnn_chunk;
         const size_t np = (size_t)Bc * L, npg = (size_t)((Bc + 15) / 16) * 16 * L;
@@ -989,7 +1010,6 @@ int run_encoder_rnn(tae_handle* h, const float* u, float* xtx, double* stats, in
             slot += tae::gru_head_grid(HP.npos);
         }
     }
-    if (slot > h->rnn_partial_slots) return fail(TAE_ESTATE, "internal: GRU-encoder partial-sum slots exceeded");
     TAE_HIP(tae::launch_reduce_partials(h->d_rnn_partials, slot, (double)B * L * 3.0, stats, st));
     return TAE_OK;
 }
@@ -1066,10 +1086,14 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
     return TAE_OK;
 }
 
-int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st) {
-    if (h->cfg.dec_type == 1) return run_decoder_rnn(h, rx, xdec, B, st);
-    if (h->nbd < 1) return run_decoder_long(h, rx, xdec, B, st);
+int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st, float* tap_out = nullptr) {
+    if (h->cfg.dec_type == 1) {
+        if (tap_out) return fail(TAE_EINVAL, "tae_decode_taps: the GRU decoder has no tap export");
+        return run_decoder_rnn(h, rx, xdec, B, st);
+    }
+    if (h->nbd < 1) return run_decoder_long(h, rx, xdec, B, st, tap_out);
     tae::FusedParams P = base_params(h, B, true);
+    P.tap_out = tap_out;
     P.wpack = h->d_wdec;
     P.in = rx;
     P.out = xdec;
@@ -1436,6 +1460,14 @@ int tae_decode(tae_handle* h, const float* received, float* x_dec, int32_t B, vo
     return run_decoder(h, received, x_dec, B, (hipStream_t)stream);
 }
 
+int tae_decode_taps(tae_handle* h, const float* received, float* x_dec, float* taps, int32_t B, void* stream) {
+    int rc = check_batch(h, B);
+    if (rc != TAE_OK) return rc;
+    if (!received || !x_dec || !taps) return fail(TAE_EINVAL, "NULL tensor");
+    if (h->cfg.dense) return fail(TAE_EINVAL, "tae_decode_taps: not built for DenseSameShapeConv1d stacks");
+    return run_decoder(h, received, x_dec, B, (hipStream_t)stream, taps);
+}
+
 int tae_forward(tae_handle* h, const float* u, const float* noise, float* x_dec, float* codes, int32_t B, void* stream) {
     int rc = check_batch(h, B);
     if (rc != TAE_OK) return rc;
@@ -1535,6 +1567,9 @@ int tae_range_status(tae_handle* h, int32_t* precision, int32_t* overflow) {
     if (precision) *precision = h->prec;
     if (overflow) {
         uint32_t f = 0;
+        // the launches whose flag is read may sit on any stream (torch side streams are non-blocking: the null-stream copy
+        // below does not order behind them) - wait for the whole device first
+        TAE_HIP(hipDeviceSynchronize());
         TAE_HIP(hipMemcpy(&f, h->d_flags, sizeof(f), hipMemcpyDeviceToHost));
         if (f) TAE_HIP(hipMemset(h->d_flags, 0, sizeof(f)));
         *overflow = (int32_t)(f & 1u);

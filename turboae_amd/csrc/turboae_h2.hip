@@ -451,13 +451,19 @@ __device__ __forceinline__ void run_stack_h_dense(const char* __restrict__ wpack
     __syncthreads();
 }
 
+// Range tracking outside the K loops (stack inputs, head outputs): max |x| where a NaN counts as +inf - fmaxf alone would
+// drop it.  Inside the layers (elu_split4) a NaN can only descend from a NaN input (tracked here) or from an activation
+// that overflowed one layer earlier (inf halves; already reported through vmax by then).
+__device__ __forceinline__ float track_abs(float vmax, float x) {
+    return (x == x) ? fmaxf(vmax, fabsf(x)) : __builtin_inff();
+}
 __device__ __forceinline__ void report_range(float vmax, uint32_t* flags) {
-    if (flags != nullptr && !(vmax <= kH2Limit)) atomicOr(flags, 1u);     // also catches NaN
+    if (flags != nullptr && !(vmax <= kH2Limit)) atomicOr(flags, 1u);
 }
 
 // =============================================================================================
 // Decoder: DEC_LargeCNN.forward (decoders.py:206-269)
-template <int U, int PT, int C0, int NC>
+template <int U, int PT, int C0, int NC, bool TAPS>
 __device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, const PanelsH& pn, const TileH<PT>& tc, int g, int lane, int blk0) {
     const int L = P.L;
     const int n_stack = 2 * P.n_iter;
@@ -479,7 +485,8 @@ __device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, con
                                        [&](int p, int f, float v) {
                 if (f < F) {
                     if (extrinsic) v -= Xin.read(tc.row(p), 2 + f);            // decoders.py:235-236,246-247
-                    vmax = fmaxf(vmax, fabsf(v));
+                    vmax = track_abs(vmax, v);
+                    if constexpr (TAPS) P.tap_out[(((size_t)s * P.B + blk0 + tc.blk(p)) * L + tc.t(p)) * F + f] = v;
                     Xout.write(tc.rowbase(p) + ptab[tc.t(p)], 2 + f, v);       // interleave / deinterleave (decoders.py:238,249)
                 }
             });
@@ -493,7 +500,7 @@ __device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, con
     report_range(vmax, P.flags);
 }
 
-template <int U, int PT>
+template <int U, int PT, bool TAPS = false>
 __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
         const int row = b * (L + pad) + pad + t;
         const float* r = rx + (size_t)m * 3;
         const float r0 = r[0], r1 = r[1], r2 = r[2], ri = rx[((size_t)b * L + pn.PERM[t]) * 3 + 0];
-        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(r0), fabsf(r1))), fmaxf(fabsf(r2), fabsf(ri)));
+        vmax = track_abs(track_abs(track_abs(vmax, r0), r1), r2);       // ri is some position's r0: covered
         pn.XA.write(row, 0, r0);
         pn.XA.write(row, 1, r1);
         pn.XB.write(row, 0, ri);
@@ -538,8 +545,8 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
         TileH<T> tc;
         make_tiles_h<T>(tc, pn.ROWT, gs.gt0, lane, L, npos, pad);
         __syncthreads();
-        if (!upper) dec_body_h<U, T, 0, Split<U>::CTA>(P, smem, pn, tc, gs.gt0, lane, blk0);
-        else dec_body_h<U, T, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, gs.gt0, lane, blk0);
+        if (!upper) dec_body_h<U, T, 0, Split<U>::CTA, TAPS>(P, smem, pn, tc, gs.gt0, lane, blk0);
+        else dec_body_h<U, T, Split<U>::CTA, Split<U>::CTB, TAPS>(P, smem, pn, tc, gs.gt0, lane, blk0);
     };
     dispatch_tiles<PT>(gs.live, run);
 }
@@ -653,7 +660,7 @@ __device__ __forceinline__ void seg_body_h(const SegParams& P, char* smem, const
         run([&](int p, int f, float v) {
             if (f < F) {
                 if (extrinsic) v -= X.read(tc.row(p), 2 + f);
-                vmax = fmaxf(vmax, fabsf(v));
+                vmax = track_abs(vmax, v);
                 ecur[(size_t)(tstart + tc.m0 + 16 * p) * 8 + f] = v;
             }
         });
@@ -717,7 +724,7 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
             const float* rx = P.in + (size_t)b * L * 3;
             const float r0 = odd ? rx[(size_t)P.perm[t] * 3] : rx[(size_t)t * 3];   // r_sys_int / r_sys
             const float r1 = rx[(size_t)t * 3 + (odd ? 2 : 1)];                     // r_par2 / r_par1
-            vmax = fmaxf(vmax, fmaxf(fabsf(r0), fabsf(r1)));
+            vmax = track_abs(track_abs(vmax, r0), r1);
             pn.XA.write(row, 0, r0);
             pn.XA.write(row, 1, r1);
             if (stack > 0) {
@@ -781,11 +788,14 @@ template <int U>
 static hipError_t launch_fused_h_u(bool decoder, const FusedParams& P, int grid, hipStream_t st) {
     constexpr int PT = 5;
     auto kd = dec_kernel_h<U, PT>;
+    auto kt = dec_kernel_h<U, PT, true>;       // debug instantiation exporting every stack's extrinsic outputs (tae_decode_taps)
     auto ke = enc_kernel_h<U, PT>;
-    const void* fn = decoder ? reinterpret_cast<const void*>(kd) : reinterpret_cast<const void*>(ke);
+    const bool taps = decoder && P.tap_out != nullptr;
+    const void* fn = decoder ? (taps ? reinterpret_cast<const void*>(kt) : reinterpret_cast<const void*>(kd)) : reinterpret_cast<const void*>(ke);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes);
     if (e != hipSuccess) return e;
-    if (decoder) hipLaunchKernelGGL(kd, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
+    if (taps) hipLaunchKernelGGL(kt, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
+    else if (decoder) hipLaunchKernelGGL(kd, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
     else hipLaunchKernelGGL(ke, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
     return hipGetLastError();
 }

@@ -27,6 +27,8 @@ struct FusedParams {
     int32_t lds_bytes;
     int32_t super;          // 1: remainder channels via super-tiles (needs U % 16 == 4 and block_len % 4 == 0)
     uint32_t* flags;        // f16x2 kernels: bit 0 set when an activation left the fp16 range (stack_stride is in BYTES there)
+    float* tap_out;         // decoder, debug instantiation only (tae_decode_taps): [2*n_iter-1][B][L][F] extrinsic outputs of every
+                            // non-final stack in the producing stack's own position order (before the (de)interleave scatter)
 };
 
 // Arguments of the per-stack segmented kernel used when a block does not fit one workgroup.
@@ -97,7 +99,7 @@ hipError_t launch_gru_head(const GruHeadParams& P, hipStream_t st);
 
 hipError_t launch_seg(int U, const SegParams& P, int grid, hipStream_t st);
 int seg_lds_bytes(int U, int T, int n_layer);
-hipError_t launch_fused(int U, bool decoder, const FusedParams& P, int grid, hipStream_t st);
+hipError_t launch_fused(int U, bool decoder, const FusedParams& P, int grid, hipStream_t st);       // P.tap_out != nullptr: tap-exporting decoder
 hipError_t launch_fused_h(int U, bool decoder, const FusedParams& P, int grid, hipStream_t st);
 int fused_lds_bytes_h(int U, int L, int nb, int taps = 5);
 hipError_t launch_seg_h(int U, const SegParams& P, int grid, hipStream_t st);

@@ -249,7 +249,7 @@ __device__ __forceinline__ Panels carve(char* smem, int rows, int L) {
 
 // =============================================================================================
 // Decoder: DEC_LargeCNN.forward (decoders.py:206-269) for nb blocks per workgroup.
-template <int U, int PT, int C0, int NC, bool SUPER>
+template <int U, int PT, int C0, int NC, bool SUPER, bool TAPS>
 __device__ __forceinline__ void dec_body(const FusedParams& P, char* smem, const Panels& pn, const TileCtx<PT>& tc,
                                          const SuperCtx& sc, int g, int lane, int blk0) {
     const int L = P.L;
@@ -272,6 +272,7 @@ __device__ __forceinline__ void dec_body(const FusedParams& P, char* smem, const
                                      [&](int p, int f, float v) {
                 if (f < F) {
                     if (extrinsic) v -= Xin[tc.row[p] * kXW + 2 + f];   // decoders.py:235-236,246-247
+                    if constexpr (TAPS) P.tap_out[(((size_t)s * P.B + blk0 + tc.blk[p]) * L + tc.t[p]) * F + f] = v;
                     Xout[(tc.rowbase[p] + ptab[tc.t[p]]) * kXW + 2 + f] = v;
                 }
             });
@@ -285,7 +286,7 @@ __device__ __forceinline__ void dec_body(const FusedParams& P, char* smem, const
     }
 }
 
-template <int U, int PT>
+template <int U, int PT, bool TAPS = false>
 __global__ __launch_bounds__(kThreads, 2) void dec_kernel(FusedParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -321,13 +322,13 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel(FusedParams P) {
     const bool upper = __builtin_amdgcn_readfirstlane(h) != 0;
     if constexpr (Geo<U>::SUP) {
         if (P.super) {
-            if (!upper) dec_body<U, PT, 0, Split<U>::SA, true>(P, smem, pn, tc, sc, g, lane, blk0);
-            else dec_body<U, PT, Split<U>::SA, Split<U>::SB, true>(P, smem, pn, tc, sc, g, lane, blk0);
+            if (!upper) dec_body<U, PT, 0, Split<U>::SA, true, TAPS>(P, smem, pn, tc, sc, g, lane, blk0);
+            else dec_body<U, PT, Split<U>::SA, Split<U>::SB, true, TAPS>(P, smem, pn, tc, sc, g, lane, blk0);
             return;
         }
     }
-    if (!upper) dec_body<U, PT, 0, Split<U>::CTA, false>(P, smem, pn, tc, sc, g, lane, blk0);
-    else dec_body<U, PT, Split<U>::CTA, Split<U>::CTB, false>(P, smem, pn, tc, sc, g, lane, blk0);
+    if (!upper) dec_body<U, PT, 0, Split<U>::CTA, false, TAPS>(P, smem, pn, tc, sc, g, lane, blk0);
+    else dec_body<U, PT, Split<U>::CTA, Split<U>::CTB, false, TAPS>(P, smem, pn, tc, sc, g, lane, blk0);
 }
 
 // =============================================================================================
@@ -663,11 +664,14 @@ template <int U>
 static hipError_t launch_fused_u(bool decoder, const FusedParams& P, int grid, hipStream_t st) {
     constexpr int PT = 5;
     auto kd = dec_kernel<U, PT>;
+    auto kt = dec_kernel<U, PT, true>;         // debug instantiation exporting every stack's extrinsic outputs (tae_decode_taps)
     auto ke = enc_kernel<U, PT>;
-    const void* fn = decoder ? reinterpret_cast<const void*>(kd) : reinterpret_cast<const void*>(ke);
+    const bool taps = decoder && P.tap_out != nullptr;
+    const void* fn = decoder ? (taps ? reinterpret_cast<const void*>(kt) : reinterpret_cast<const void*>(kd)) : reinterpret_cast<const void*>(ke);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes);
     if (e != hipSuccess) return e;
-    if (decoder) hipLaunchKernelGGL(kd, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
+    if (taps) hipLaunchKernelGGL(kt, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
+    else if (decoder) hipLaunchKernelGGL(kd, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
     else hipLaunchKernelGGL(ke, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
     return hipGetLastError();
 }
