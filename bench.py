@@ -9,13 +9,24 @@ A "step" is one pass of Channel_AE.forward (encoder + power normalisation + AWGN
 CNN turbo decoder + hard-decision error count) over one batch of synthetic blocks that is already
 resident in HBM: BASELINE.json configs[1] = enc2/dec5, block_len=100, batch=50000 blocks per GPU at
 SNR 2 dB.  With N GPUs every rank processes its own 50000-block shard of one global batch (weak
-scaling); the only exchange is the 24-byte all-reduce of the power-constraint statistics
-(encoders.py:107-108 take mean/std over the WHOLE batch) and the final error-count all-reduce.
+scaling; --strong splits ONE 50000-block batch over the ranks instead); the only exchange is the 24-byte
+all-reduce of the power-constraint statistics (encoders.py:107-108 take mean/std over the WHOLE batch)
+and the final error-count all-reduce.  BASELINE.json configs[3] (block_len 1000, 200 000 blocks over 8
+GPUs) is `bench.py --gpus 8 --block-len 1000 --batch 25000`.
+
+Weights: the reference-trained enc2/dec5 network of tests/golden/trained_enc2dec5_u100_fp32.npz (full
+fp32 precision; BER-meaningful), so `ber` in the line is a real operating point; other shapes
+(--enc-layers != 2) fall back to the portable random-init generator.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement) including
-  roofline     - fp32-MFMA roofline of the dominant kernel (the fused decoder), timed with HIP events
-  cpu_baseline - oracle/turboae_oracle.py (PyTorch-CPU restatement of the reference path) timed on
-                 the host cores of this box on a bounded sample (rank 0, N=1 only).
+  roofline      - MFMA roofline of the dominant kernel (the fused decoder) in the default fp16-split
+                  arithmetic, kernel time from HIP events on the launch stream
+  roofline_f32  - the same for a second timed pass in precision='f32' (v_mfma_f32_16x16x4_f32 on the
+                  fp32 operands: the reference's own arithmetic) against the fp32-MFMA peak
+  parity        - "BER match": GPU (both arithmetics) vs the CPU oracle on the FIRST 500 BLOCKS OF THE SAME
+                  Philox stream, same weights: BER of each, decision flips, max |codes| / |x_dec| deviation
+  cpu_baseline  - oracle/turboae_oracle.py (PyTorch-CPU restatement of the reference path) timed on
+                  the host cores of this box (rank 0, N=1 only): thread sweep, best + 1-thread figures
 """
 from __future__ import annotations
 
@@ -37,28 +48,108 @@ from turboae_amd import TurboAEConfig, Channel_AE_HIP, weights as W   # noqa: E4
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0     # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 F16X2_PRODUCTS = 3                # MFMA products per fp32-equivalent multiply-accumulate in the fp16-split contraction
+SEED = 20190001
+PARITY_BLOCKS = 500               # BASELINE configs[0]: the reference's own CPU-runnable batch
+TRAINED = os.path.join(ROOT, "tests", "golden", "trained_enc2dec5_u100_fp32.npz")
 
 
-def cpu_baseline(cfg: TurboAEConfig, sd, budget_s: float = 12.0):
-    """Oracle (CPU port of the reference path) on a bounded sample: B=500 blocks (BASELINE configs[0])."""
+def host_cpu_info():
+    """CPU model string, physical cores (unique (physical id, core id) pairs) and logical CPUs from /proc/cpuinfo."""
+    model, pairs, logical = "?", set(), 0
+    phys = core = None
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "processor":
+                    logical += 1
+                elif k == "model name":
+                    model = v
+                elif k == "physical id":
+                    phys = v
+                elif k == "core id":
+                    core = v
+                    pairs.add((phys, core))
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = logical or (os.cpu_count() or 1)
+    physical = len(pairs) if pairs else usable
+    return {"model": model, "physical_cores": physical, "logical_cpus": logical or usable, "usable_cpus": usable}
+
+
+def _time_forwards(fwd, warmups: int, runs: int):
+    for _ in range(warmups):
+        fwd()
+    ts = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        fwd()
+        ts.append(time.perf_counter() - t0)
+    return ts
+
+
+def cpu_baseline_and_parity(cfg: TurboAEConfig, sd, u500: np.ndarray, noise500: np.ndarray, budget_s: float):
+    """Oracle (CPU port of the reference path) on the first 500 blocks of the benchmark's own Philox stream.
+
+    Timing protocol: per thread count 1 warm-up + up to 5 forwards to pick the best setting among
+    {8, 16, 32, physical cores (capped at the usable CPUs)}; at the best setting 3 warm-ups and the MEDIAN of 10
+    forwards is `value`; plus a larger batch (B=2000) at the same setting and a 1-thread figure (B=100).  Bounded by
+    `budget_s` of wall time: on a slow host the run counts shrink (reported in `sample`), later stages are dropped first."""
     from oracle import turboae_oracle as O          # checker / baseline only
-    from turboae_amd import philox
-    B, L = 500, cfg.block_len
-    u = torch.from_numpy(philox.random_bits(1, 0, B * L).reshape(B, L, 1))
-    noise = torch.from_numpy((np.float32(O.snr_db2sigma(2.0)) * philox.random_normal(1, 0, B * L * 3)).reshape(B, L, 3))
+    t_start = time.perf_counter()
+    info = host_cpu_info()
+    L = cfg.block_len
     w = O.to_torch(sd)
-    O.channel_ae_forward(u, noise, w, cfg.to_dict())     # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        O.channel_ae_forward(u, noise, w, cfg.to_dict())
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= 50:
-            break
-    return {"value": B * L * n / dt, "unit": "bits/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} forwards of B=500 blocks (L={L}, enc{cfg.enc_num_layer}/dec{cfg.dec_num_layer}, "
-                      f"{cfg.num_iteration} iters) through oracle/turboae_oracle.py (PyTorch-CPU fp32, "
-                      f"{torch.get_num_threads()} threads), {dt:.1f} s"}
+    cd = cfg.to_dict()
+    ut, nt = torch.from_numpy(u500), torch.from_numpy(noise500)
+    B = ut.shape[0]
+    fwd = lambda: O.channel_ae_forward(ut, nt, w, cd)       # noqa: E731
+    old_threads = torch.get_num_threads()
+    cap = max(1, min(info["usable_cpus"], info["physical_cores"]))
+    cands = sorted({min(t, cap) for t in (8, 16, 32, cap)})
+    sweep = {}
+    torch.set_num_threads(cands[0])
+    t_est = _time_forwards(fwd, 1, 1)[0]                     # first touch (page-in, oneDNN primitive creation) + one timed forward
+    n_sweep = int(max(2, min(5, 0.35 * budget_s / (len(cands) * t_est) - 1)))
+    for t in cands:
+        torch.set_num_threads(t)
+        ts = _time_forwards(fwd, 1, n_sweep)
+        sweep[t] = B * L / float(np.median(ts))
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    t_best = B * L / sweep[best]
+    n_warm = 3
+    n_runs = int(max(3, min(10, 0.4 * budget_s / t_best - n_warm)))      # 10 (SURVEY.md section 8d) unless this host is too slow for the budget
+    ts = _time_forwards(fwd, n_warm, n_runs)
+    med, mn = float(np.median(ts)), float(np.min(ts))
+    x_cpu, c_cpu = fwd()
+    out = {"value": B * L / med, "unit": "bits/s", "cores": best, "kind": "port",
+           "value_at_min": B * L / mn, "run_to_run_spread": (float(np.max(ts)) - mn) / med,
+           "seconds_per_forward_median": med, "thread_sweep_bits_per_s": {str(k): v for k, v in sweep.items()},
+           "cpu_model": info["model"], "physical_cores": info["physical_cores"], "logical_cpus": info["logical_cpus"],
+           "usable_cpus": info["usable_cpus"], "torch": torch.__version__}
+    # larger batch at the best setting, then 1 thread on a smaller one - only while the budget lasts
+    if time.perf_counter() - t_start < 0.55 * budget_s:
+        big = 4
+        ub, nb_ = ut.repeat(big, 1, 1), nt.repeat(big, 1, 1)
+        tb = _time_forwards(lambda: O.channel_ae_forward(ub, nb_, w, cd), 1, 3)
+        out["value_B2000"] = big * B * L / float(np.median(tb))
+    if time.perf_counter() - t_start < 0.8 * budget_s:
+        torch.set_num_threads(1)
+        u1, n1 = ut[:100], nt[:100]
+        t1 = _time_forwards(lambda: O.channel_ae_forward(u1, n1, w, cd), 1, 3)
+        out["value_1_thread"] = 100 * L / float(np.median(t1))
+    torch.set_num_threads(old_threads)
+    out["sample"] = (f"median of {n_runs} forwards ({n_warm} warm-ups; thread sweep: {n_sweep} forwards per setting) of the first B={B} blocks of the benchmark's Philox stream (L={L}, "
+                     f"enc{cfg.enc_num_layer}/dec{cfg.dec_num_layer}, {cfg.num_iteration} iters, trained weights) through "
+                     f"oracle/turboae_oracle.py (PyTorch-CPU fp32) at {best} threads - best of the sweep {cands} on {info['model']} "
+                     f"({info['physical_cores']} physical cores); value_B2000: 4x that batch; value_1_thread: B=100 on one thread; "
+                     f"{time.perf_counter() - t_start:.0f} s of CPU work in total")
+    return out, x_cpu.numpy(), c_cpu.numpy()
 
 
 def main():
@@ -66,11 +157,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=50000, help="blocks per GPU per step (BASELINE configs[1]: 50000)")
+    ap.add_argument("--batch", type=int, default=50000, help="blocks per GPU per step (BASELINE configs[1]: 50000); with --strong: global blocks per step")
     ap.add_argument("--block-len", type=int, default=100, help="BASELINE configs[3] is block_len 1000 (long-block kernels)")
     ap.add_argument("--snr", type=float, default=2.0)
     ap.add_argument("--enc-layers", type=int, default=2)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --batch is the GLOBAL batch, split evenly over the ranks")
+    ap.add_argument("--random-weights", action="store_true", help="portable random-init weights instead of the trained fixture")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (cpu_baseline and the CPU side of parity)")
+    ap.add_argument("--no-f32-pass", action="store_true", help="skip the second timed pass in precision='f32'")
+    ap.add_argument("--cpu-budget", type=float, default=75.0, help="wall-time bound of the CPU leg in seconds")
     ap.add_argument("--precision", choices=("auto", "f32"), default="auto",
                     help="auto: fp16-split MFMA contraction (fp32-grade, DESIGN.md 3.7); f32: v_mfma_f32_16x16x4_f32")
     args = ap.parse_args()
@@ -92,7 +187,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("TAE_BENCH_FORCE_DIST") == "1":      # FORCE_DIST: run the RCCL init + collectives at world size 1 (test hook)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -100,103 +195,182 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    cfg = TurboAEConfig(block_len=args.block_len, enc_num_layer=args.enc_layers, precision=args.precision)
-    sd = W.generate_state_dict(cfg, seed=20190001, gain=1.0)
-    B, L = args.batch, cfg.block_len
-    model = Channel_AE_HIP(cfg, sd, device=dev, max_batch=B)
-    # synthetic inputs generated on device, keyed by the GLOBAL block index (identical to the 1-GPU stream)
-    u, noise = model.generate_inputs(B, args.snr, seed=20190001, first_block=rank * B)
-    counts = torch.zeros(2, dtype=torch.int64, device=dev)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    L = args.block_len
+    cfg = TurboAEConfig(block_len=L, enc_num_layer=args.enc_layers, precision=args.precision)
+    trained = (not args.random_weights) and args.enc_layers == 2 and os.path.isfile(TRAINED)
+    if trained:
+        # conv weights do not depend on the block length: the L=100-trained network also runs the L=1000 shape
+        sd = W.unpack_blob(TurboAEConfig(), np.load(TRAINED)["weights_fp32"])
+    else:
+        sd = W.generate_state_dict(cfg, seed=SEED, gain=1.0)
+    if args.strong:
+        lo, hi = (args.batch * rank) // world, (args.batch * (rank + 1)) // world
+        B, first = hi - lo, lo
+        global_blocks = args.batch
+    else:
+        B, first = args.batch, rank * args.batch
+        global_blocks = world * args.batch
+    if B < 1:
+        raise SystemExit("--strong: fewer blocks than ranks")
 
-    def step(i_timed=None):
-        x_tx, stats = model.encode_prenorm(u)                 # ENC_interCNN before power_constraint
+    def timed_pass(precision: str):
+        """W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize; returns the measurements."""
+        from dataclasses import replace
+        model = Channel_AE_HIP(replace(cfg, precision=precision), sd, device=dev, max_batch=max(B, PARITY_BLOCKS))
+        # synthetic inputs generated on device, keyed by the GLOBAL block index (identical to the 1-GPU stream); excluded from the
+        # timed region (inputs resident in HBM) but reported
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        model.generate_inputs(8, args.snr, seed=SEED)         # warm the generator kernel
+        g0.record()
+        u, noise = model.generate_inputs(B, args.snr, seed=SEED, first_block=first)
+        g1.record()
+        counts = torch.zeros(2, dtype=torch.int64, device=dev)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+
+        def step(i=None):
+            if i is not None:
+                ev[i][0].record()
+            x_tx, stats = model.encode_prenorm(u)                 # ENC_interCNN before power_constraint
+            if dist is not None:
+                dist.all_reduce(stats)                            # global-batch mean/std (encoders.py:107-108)
+            _, rx = model.normalize(x_tx, stats, noise, want_codes=False)     # power_constraint + AWGN add
+            if i is not None:
+                ev[i][1].record()
+            x_dec = model.dec(rx)                                 # DEC_LargeCNN, one fused kernel
+            if i is not None:
+                ev[i][2].record()
+            model.count_errors(x_dec, u, counts)                  # errors_ber / errors_bler as counts
+            if i is not None:
+                ev[i][3].record()
+
+        def barrier():
+            if dist is not None:
+                dist.barrier()
+
+        for _ in range(args.warmup):
+            step()
+        counts.zero_()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if dist is not None:
-            dist.all_reduce(stats)                            # global-batch mean/std (encoders.py:107-108)
-        _, rx = model.normalize(x_tx, stats, noise, want_codes=False)     # power_constraint + AWGN add
-        if i_timed is not None:
-            ev[i_timed][0].record()
-        x_dec = model.dec(rx)                                 # DEC_LargeCNN, one fused kernel
-        if i_timed is not None:
-            ev[i_timed][1].record()
-        model.count_errors(x_dec, u, counts)                  # errors_ber / errors_bler as counts
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    counts.zero_()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(counts)                               # final RCCL reduce of the error counts
-    elapsed = float(tmax.item())
-    dec_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-
-    if rank == 0:
-        bits_total = float(world) * B * L * args.steps
-        value = bits_total / elapsed
-        macs = cfg.macs_per_bit()
-        dec_flops_per_launch = 2.0 * macs["dec"] * B * L
-        achieved = dec_flops_per_launch / (dec_ms * 1e-3) / 1e12
-        nb, lds = model.kernel_info()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(counts)                               # final RCCL reduce of the error counts
         mode, overflow = model.range_status()
         if overflow:
             raise SystemExit("activation range overflow reported by the fp16-split kernels: results invalid")
-        f16x2 = mode == "f16x2"
-        # Roofline of the dominant kernel (the fused decoder).  fp32 mode: algorithmic FLOPs against the fp32 MFMA peak.
-        # fp16-split mode: every fp32-equivalent MAC costs 3 fp16 MFMA MACs, so the ceiling for ALGORITHMIC FLOPs is the
-        # dense fp16 MFMA peak / 3; `mfma_tflops_executed` = 3 x achieved is what the matrix pipes actually ran.
-        peak = PEAK_F16_MFMA_TFLOPS / F16X2_PRODUCTS if f16x2 else PEAK_FP32_MFMA_TFLOPS
-        kname = "tae::dec_kernel_h<100,5> (fused 6-iteration decoder, fp16-split MFMA)" if f16x2 else "tae::dec_kernel<100,5> (fused 6-iteration decoder, fp32 MFMA)"
-        if nb == 0:        # long blocks: the decoder is 2 * num_iteration launches of the segment kernel; `kernel_ms` covers all of them
-            kname = ("tae::seg_kernel_h<100,5>" if f16x2 else "tae::seg_kernel<100,5>") + f" x {2 * cfg.num_iteration} launches (one conv stack each, long-block decoder)"
-        pmc_dir = "r01_pmc_f16x2" if f16x2 else "r01_pmc"
-        # HBM-side traffic of the decoder kernel from the committed PMC passes (rocprofv3 cannot run inside
-        # this process): bytes per block measured at the same workload, scaled to this launch's blocks
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", pmc_dir, "traffic.json")
-        if os.path.isfile(tpath) and cfg.enc_num_layer == 2 and L == 100:
-            with open(tpath) as fh:
-                traffic = json.load(fh)["bytes_per_block"] * B / 1e9
+        dec = [e[1].elapsed_time(e[2]) for e in ev]
+        stepms = [e[0].elapsed_time(e[3]) for e in ev]
+        res = {"elapsed": float(tmax.item()), "dec_ms": float(np.mean(dec)), "dec_ms_median": float(np.median(dec)), "dec_ms_min": float(np.min(dec)),
+               "step_ms_median": float(np.median(stepms)), "step_ms_min": float(np.min(stepms)), "gen_ms": g0.elapsed_time(g1),
+               "counts": [int(counts[0].item()), int(counts[1].item())], "mode": mode, "kernel_info": model.kernel_info()}
+        # "BER match" sample: the first PARITY_BLOCKS blocks of the same Philox stream as ONE batch of their own (the power
+        # constraint takes its statistics over the batch it is handed, encoders.py:107-108), compared with the CPU oracle below
+        par = None
+        if rank == 0 and world == 1:
+            up, npar = model.generate_inputs(PARITY_BLOCKS, args.snr, seed=SEED, first_block=0)
+            xd, codes = model(up, npar)
+            torch.cuda.synchronize()
+            par = {"u": up.cpu().numpy(), "noise": npar.cpu().numpy(), "x_dec": xd.cpu().numpy(), "codes": codes.cpu().numpy()}
+        return res, par
+
+    main_res, main_par = timed_pass(args.precision)
+    f32_res = f32_par = None
+    if args.precision == "auto" and not args.no_f32_pass and main_res["mode"] == "f16x2":
+        f32_res, f32_par = timed_pass("f32")
+
+    if rank == 0:
+        steps = args.steps
+        elapsed = main_res["elapsed"]
+        bits_total = float(global_blocks) * L * steps
+        value = bits_total / elapsed
+        macs = cfg.macs_per_bit()
+        dec_flops_per_launch = 2.0 * macs["dec"] * B * L
+        nb, lds = main_res["kernel_info"]
+        f16x2 = main_res["mode"] == "f16x2"
+
+        def roofline(res, is_h2):
+            # Roofline of the dominant kernel (the fused decoder).  fp32 mode: algorithmic FLOPs against the fp32 MFMA peak.
+            # fp16-split mode: every fp32-equivalent MAC costs 3 fp16 MFMA MACs, so the ceiling for ALGORITHMIC FLOPs is the
+            # dense fp16 MFMA peak / 3; `mfma_tflops_executed` = 3 x achieved is what the matrix pipes actually ran.
+            achieved = dec_flops_per_launch / (res["dec_ms"] * 1e-3) / 1e12
+            peak = PEAK_F16_MFMA_TFLOPS / F16X2_PRODUCTS if is_h2 else PEAK_FP32_MFMA_TFLOPS
+            kname = "tae::dec_kernel_h<100,5> (fused 6-iteration decoder, fp16-split MFMA)" if is_h2 else "tae::dec_kernel<100,5> (fused 6-iteration decoder, fp32 MFMA)"
+            if nb == 0:        # long blocks: the decoder is 2 * num_iteration launches of the segment kernel; `kernel_ms` covers all of them
+                kname = ("tae::seg_kernel_h<100,5>" if is_h2 else "tae::seg_kernel<100,5>") + f" x {2 * cfg.num_iteration} launches (one conv stack each, long-block decoder)"
+            pmc_dir = "r01_pmc_f16x2" if is_h2 else "r01_pmc"
+            # HBM-side traffic of the decoder kernel from the committed PMC passes (rocprofv3 cannot run inside
+            # this process): bytes per block measured at the same workload, scaled to this launch's blocks
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", pmc_dir, "traffic.json")
+            if os.path.isfile(tpath) and cfg.enc_num_layer == 2 and L == 100:
+                with open(tpath) as fh:
+                    traffic = json.load(fh)["bytes_per_block"] * B / 1e9
+            return {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                    "frac": achieved / peak, "traffic": traffic,
+                    "traffic_unit": f"GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{pmc_dir}/traffic.json)",
+                    "peak_basis": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 products per fp32-equivalent MAC" if is_h2
+                                   else "dense fp32 MFMA peak"),
+                    "mfma_tflops_executed": achieved * (F16X2_PRODUCTS if is_h2 else 1),
+                    "vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                    "kernel_ms": res["dec_ms"], "kernel_ms_median": res["dec_ms_median"], "kernel_ms_min": res["dec_ms_min"],
+                    "flops_per_launch": dec_flops_per_launch}
+
         out = {
             "metric": f"decoded info bits/sec @ block_len={L}, 6-iter rate-1/3 CNN; BER match",      # BASELINE.json's metric at the default L = 100
-            "value": value, "unit": "bits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": value, "unit": "bits/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / steps * 1e3, "ms_per_step_median": main_res["step_ms_median"], "ms_per_step_min": main_res["step_ms_min"],
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": ("f16x2: fp32 operands as fp16 hi+lo halves, 3 x v_mfma_f32_16x16x32_f16 per 32 k, fp32 accumulate (fp32-grade, "
                       "DESIGN.md 3.7)") if f16x2 else "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{1 if L == 100 else 3}]: TurboAE_rate3_cnn enc{cfg.enc_num_layer}/dec{cfg.dec_num_layer}, "
                                    f"block_len={L}, batch={B} blocks per GPU, {cfg.num_iteration} iters, AWGN SNR={args.snr} dB, "
-                                   "random-init weights (portable generator), inputs resident in HBM",
-                       "blocks_per_gpu": B, "global_blocks": world * B, "block_len": L,
+                                   + ("reference-trained weights (tests/golden/trained_enc2dec5_u100_fp32.npz, full fp32)" if trained
+                                      else "random-init weights (portable generator)") + ", inputs resident in HBM",
+                       "blocks_per_gpu": B, "global_blocks": global_blocks, "block_len": L,
                        "parallelism": f"dp{world} (blocks sharded, 24-byte all-reduce of power-norm stats per step)",
-                       "blocks_per_workgroup": nb, "lds_bytes_per_workgroup": lds},
+                       "blocks_per_workgroup": nb, "lds_bytes_per_workgroup": lds,
+                       "weights": "trained" if trained else "random-init"},
             "total_tflops": value * cfg.flops_per_bit() / 1e12,
-            "ber": float(counts[0].item()) / bits_total, "bler": float(counts[1].item()) / (world * B * args.steps),
-            "roofline": {"bound": "mfma", "kernel": kname,
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
-                         "traffic_unit": f"GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{pmc_dir}/traffic.json)",
-                         "peak_basis": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 products per fp32-equivalent MAC" if f16x2
-                                        else "dense fp32 MFMA peak"),
-                         "mfma_tflops_executed": achieved * (F16X2_PRODUCTS if f16x2 else 1),
-                         "vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "kernel_ms": dec_ms, "flops_per_launch": dec_flops_per_launch},
+            "ber": main_res["counts"][0] / bits_total, "bler": main_res["counts"][1] / (float(global_blocks) * steps),
+            "input_generation_ms_excluded": main_res["gen_ms"],
+            "roofline": roofline(main_res, f16x2),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd)
+        if f32_res is not None:
+            r32 = roofline(f32_res, False)
+            r32["value_bits_per_s"] = bits_total / f32_res["elapsed"]
+            r32["ms_per_step"] = f32_res["elapsed"] / steps * 1e3
+            r32["ber"] = f32_res["counts"][0] / bits_total
+            out["roofline_f32"] = r32
+        if world == 1 and main_par is not None:
+            u500, n500 = main_par["u"], main_par["noise"]
+            hard = lambda x: (x[:, :, 0] > 0.5)                                  # noqa: E731  utils.py:9 (round half to even)
+            errs = lambda x: int((hard(x) != (u500[:, :, 0] > 0.5)).sum())       # noqa: E731
+            nbits = float(PARITY_BLOCKS * L)
+            parity = {"blocks": PARITY_BLOCKS, "sample": f"first {PARITY_BLOCKS} blocks of the benchmark's Philox stream (seed {SEED}), one batch, SNR {args.snr} dB",
+                      "ber_gpu_first500": errs(main_par["x_dec"]) / nbits, "arithmetic_gpu": main_res["mode"]}
+            if f32_par is not None:
+                parity["ber_gpu_f32_first500"] = errs(f32_par["x_dec"]) / nbits
+                parity["decision_flips_f16x2_vs_f32"] = int((hard(main_par["x_dec"]) != hard(f32_par["x_dec"])).sum())
+            if not args.no_cpu_baseline:
+                cpu, x_cpu, c_cpu = cpu_baseline_and_parity(cfg, sd, u500, n500, args.cpu_budget)
+                out["cpu_baseline"] = cpu
+                parity["ber_cpu_first500"] = errs(x_cpu) / nbits
+                parity["decision_flips"] = int((hard(main_par["x_dec"]) != hard(x_cpu)).sum())
+                parity["max_abs_codes_gpu_vs_cpu"] = float(np.abs(main_par["codes"] - c_cpu).max())
+                parity["max_abs_x_dec_gpu_vs_cpu"] = float(np.abs(main_par["x_dec"] - x_cpu).max())
+                parity["ber_abs_diff"] = abs(parity["ber_gpu_first500"] - parity["ber_cpu_first500"])
+                if f32_par is not None:
+                    parity["decision_flips_f32"] = int((hard(f32_par["x_dec"]) != hard(x_cpu)).sum())
+                    parity["max_abs_x_dec_gpu_f32_vs_cpu"] = float(np.abs(f32_par["x_dec"] - x_cpu).max())
+            out["parity"] = parity
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -216,6 +216,59 @@ def trained(manifest, pt_path):
     print(f"trained: BER@2dB={bit_err / (B * 100.0):.4e} blocks_in_error={blk_err}/{B} dx={dx:.2e} dc={dc:.2e}")
 
 
+TRAINED_FP32_SNRS = (2.0, 4.0, 6.0)
+TRAINED_FP32_SEED = 515151
+
+
+def trained_fp32(manifest, pt_path):
+    """Full-precision twin of trained(): the checkpoint's fp32 weights as they are (no fp16 rounding, so the hi/lo split of the
+    fp16-split kernels has non-zero lo halves for every weight and the per-layer 2^S scales see a trained network's dynamic
+    range), 4 batches of 500 blocks per SNR point at 2 / 4 / 6 dB (200 000 bits per point: a BER difference of 1e-4 is 20 bit
+    errors), hard decisions of the REAL reference for all of them, its x_dec for batch 0 of each point, and the per-stage
+    decoder taps of 4 blocks (reference_taps)."""
+    cfg = TurboAEConfig()
+    obj = torch.load(pt_path, map_location="cpu", weights_only=False)
+    sd = obj.state_dict() if hasattr(obj, "state_dict") else obj
+    sd = W.check_state_dict(cfg, sd)
+    blob = W.pack_blob(cfg, sd).astype(np.float32)
+    B, NB, L = 500, 4, 100
+    model, _ = R.build_reference_model(cfg.to_dict(), B)
+    R.load_weights(model, sd)
+    out = {"weights_fp32": blob}
+    info = {"config": cfg.to_dict(), "batch": B, "n_batches": NB, "input_seed": TRAINED_FP32_SEED, "snrs": list(TRAINED_FP32_SNRS),
+            "bit_errors": {}, "block_errors": {}, "ber": {}, "oracle_vs_reference_max_abs": {},
+            "note": "reference main.py trained in the build container (oracle/train_fixture.py, " + os.path.basename(pt_path) + "); "
+                    "inputs: Philox seed, blocks [i*500, (i+1)*500) of batch i, noise = sigma(snr) * N(0,1) of the same stream for every SNR"}
+    w = O.to_torch(sd)
+    for snr in TRAINED_FP32_SNRS:
+        key = f"{snr:g}dB"
+        hard, be, ble, dmax = [], [], [], [0.0, 0.0]
+        for i in range(NB):
+            u, noise = make_inputs(B, L, snr, seed=TRAINED_FP32_SEED, offset=i * B)
+            if i == 0 and snr == TRAINED_FP32_SNRS[0]:
+                x_ref, c_ref, taps = reference_taps(model, cfg, u, noise)
+                out["dec_taps_first4"] = taps[:, :4]
+                out["codes_batch0"] = c_ref
+            else:
+                x_ref, c_ref = R.reference_forward(model, u, noise)
+            if i == 0:
+                x_or, c_or = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), w, cfg.to_dict())
+                dmax = [float(np.abs(x_ref - x_or.numpy()).max()), float(np.abs(c_ref - c_or.numpy()).max())]
+                assert dmax[1] <= 2e-6 and dmax[0] <= 5e-6, (snr, dmax)
+                out[f"x_dec_batch0_{key}"] = x_ref
+            a, b = O.error_counts(torch.from_numpy(u), torch.from_numpy(x_ref))
+            be.append(a)
+            ble.append(b)
+            hard.append((x_ref > 0.5).astype(np.uint8).reshape(-1))
+        out[f"hard_bits_{key}"] = np.packbits(np.concatenate(hard))
+        info["bit_errors"][key], info["block_errors"][key] = be, ble
+        info["ber"][key] = float(np.mean([a / (B * L) for a in be]))          # mean of batch means (trainer.py:176-177,215-216)
+        info["oracle_vs_reference_max_abs"][key] = {"x_dec": dmax[0], "codes": dmax[1]}
+        print(f"trained_fp32 {key}: bit errors per batch {be}, blocks in error {ble}, BER {info['ber'][key]:.3e}, oracle dx={dmax[0]:.2e} dc={dmax[1]:.2e}")
+    np.savez_compressed(os.path.join(GOLD, "trained_enc2dec5_u100_fp32.npz"), **out)
+    manifest["trained_fp32"] = info
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     mpath = os.path.join(GOLD, "MANIFEST.json")
@@ -225,6 +278,11 @@ def main():
             manifest = json.load(fh)
         manifest.setdefault("cases", {})
     only_trained = len(sys.argv) > 2 and sys.argv[1] == "--trained"
+    if len(sys.argv) > 2 and sys.argv[1] == "--trained-fp32":      # python oracle/make_golden.py --trained-fp32 <checkpoint.pt>
+        trained_fp32(manifest, sys.argv[2])
+        with open(mpath, "w") as fh:
+            json.dump(manifest, fh, indent=1, sort_keys=True)
+        return
     if len(sys.argv) > 2 and sys.argv[1] == "--only":       # python oracle/make_golden.py --only encact,decact : just the matching cases
         keys = sys.argv[2].split(",")
         for case in CASES:

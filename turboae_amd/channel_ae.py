@@ -311,6 +311,10 @@ class Channel_AE_HIP:
     def _channel_input(self, e, fwd_noise: torch.Tensor, fading: Optional[torch.Tensor]) -> torch.Tensor:
         """The tensor handed to the library as `noise`: for channel='fading' the fading coefficients followed by the
         additive noise (include/turboae_hip.h, tae_channel_opts.channel = 3); otherwise the noise itself."""
+        if fwd_noise.dim() == 3 and fwd_noise.shape[2] == 1:
+            # the reference's punctured test pass hands a (B, L, 1) noise tensor (generate_noise(X_test.shape, ...),
+            # trainer.py:198-201) and `codes + fwd_noise` (channel_ae.py:42) broadcasts it over the three code symbols
+            fwd_noise = fwd_noise.expand(-1, -1, 3)
         noise = e._in(fwd_noise, 3, "fwd_noise")
         if e.cfg.channel != "fading":
             if fading is not None:

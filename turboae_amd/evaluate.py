@@ -24,6 +24,7 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional
 
+import numpy as np
 import torch
 
 from . import channels
@@ -120,6 +121,9 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
             stats = torch.zeros(3, dtype=torch.float64, device=dev)
             if nloc > 0:
                 u, noise, fading = make_batch(first, snr)
+                # the reference draws this pass's noise with X_test.shape = (B, L, 1) (trainer.py:198) and codes + fwd_noise
+                # (channel_ae.py:42) broadcasts it: all three code symbols of a position see the SAME noise value here
+                noise = noise[:, :, 0:1].expand(-1, -1, 3).contiguous()
                 x_tx, stats = model.encode_prenorm(u)
             all_reduce_sum_(stats)
             if precomp:
@@ -192,23 +196,27 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
         test_ber /= num_test_batch
         test_bler /= num_test_batch
         tot = per_batch.sum(dim=0)
+        # printed objects have the reference's types (numpy fp32 array / torch fp32 tensor), so the lines read the same
         if print_pos_power:
             pos_power_res.append((pos_pow / float(batch_size * num_test_batch)).cpu().tolist())
-            say("code power", pos_power_res[-1])
+            say("code power", np.asarray(pos_power_res[-1], dtype=np.float32))            # code_power returns numpy (utils.py:42-48)
         if print_pos_ber:
             res_pos = pos_err / float(batch_size * num_test_batch)
             pos_ber_res.append(res_pos.cpu().tolist())
-            say("positional ber", pos_ber_res[-1])
+            say("positional ber", res_pos.float().cpu())
             res_pos_arg = torch.argsort(res_pos, descending=True, stable=True).cpu().tolist()
             say("positional argmax", res_pos_arg)
-        say("Test SNR", snr, "with ber ", float(test_ber), "with bler", float(test_bler))
+        ber_p, bler_p = 0.0, 0.0
         if print_pos_ber:
             ber_p, bler_p = punctured_point(si, snr, res_pos_arg[:num_ber_puncture])
-            say("Punctured Test SNR", snr, "with ber ", float(ber_p), "with bler", float(bler_p))
-            ber_punc_res.append(float(ber_p))
-            bler_punc_res.append(float(bler_p))
         else:
-            say("No puncturation is there.")
+            # trainer.py:194-213 without --print_pos_ber: the second pass dies in its bare `except` on the first batch (NameError on
+            # res_pos_arg - after one forward the reference spends for nothing; skipped here), test_ber_punc stays .0
+            say("no pos BER specified.")
+        say("Test SNR", snr, "with ber ", float(test_ber), "with bler", float(test_bler))
+        say("Punctured Test SNR", snr, "with ber ", float(ber_p), "with bler", float(bler_p))     # trainer.py:220-225 (0.0 / 0.0 without the ranking)
+        ber_punc_res.append(float(ber_p))
+        bler_punc_res.append(float(bler_p))
         ber_res.append(float(test_ber))
         bler_res.append(float(test_bler))
         t = tot.cpu().tolist()
@@ -248,7 +256,7 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
             s, ss, n = loc.cpu().tolist()
             enc_power += math.sqrt(max((ss - s * s / n) / (n - 1.0), 0.0))
         enc_power /= float(num_test_batch)
-        say("encoder power is", enc_power)
+        say("encoder power is", torch.tensor(enc_power, dtype=torch.float32))      # the reference prints the 0-dim tensor (trainer.py:246)
         adj = [snr_sigma2db(snr_db2sigma(item) / enc_power) for item in snrs]
         say("adjusted SNR should be", adj)
         out["enc_power"] = enc_power
