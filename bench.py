@@ -36,6 +36,17 @@ import os
 import sys
 import time
 
+# CPU-baseline hygiene (single-process runs only - with N ranks every main thread would land on core 0): bind the OpenMP
+# pool of the oracle leg to cores, packed (threads 0..n-1 on the first n physical cores = one socket / NUMA node for the
+# thread counts swept); must be in the environment before libgomp initialises, i.e. before torch is imported.
+try:
+    _USABLE_CPUS = len(os.sched_getaffinity(0))      # before libgomp binds this (the initial) thread to its first place
+except (AttributeError, OSError):
+    _USABLE_CPUS = os.cpu_count() or 1
+if os.environ.get("WORLD_SIZE", "1") == "1":
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+
 import numpy as np
 import torch
 
@@ -73,10 +84,7 @@ def host_cpu_info():
                     pairs.add((phys, core))
     except OSError:
         pass
-    try:
-        usable = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        usable = logical or (os.cpu_count() or 1)
+    usable = _USABLE_CPUS
     physical = len(pairs) if pairs else usable
     return {"model": model, "physical_cores": physical, "logical_cpus": logical or usable, "usable_cpus": usable}
 
@@ -131,7 +139,8 @@ def cpu_baseline_and_parity(cfg: TurboAEConfig, sd, u500: np.ndarray, noise500: 
            "value_at_min": B * L / mn, "run_to_run_spread": (float(np.max(ts)) - mn) / med,
            "seconds_per_forward_median": med, "thread_sweep_bits_per_s": {str(k): v for k, v in sweep.items()},
            "cpu_model": info["model"], "physical_cores": info["physical_cores"], "logical_cpus": info["logical_cpus"],
-           "usable_cpus": info["usable_cpus"], "torch": torch.__version__}
+           "usable_cpus": info["usable_cpus"], "torch": torch.__version__,
+           "omp_binding": f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND', '-')} OMP_PLACES={os.environ.get('OMP_PLACES', '-')}"}
     # larger batch at the best setting, then 1 thread on a smaller one - only while the budget lasts
     if time.perf_counter() - t_start < 0.55 * budget_s:
         big = 4

@@ -1,0 +1,31 @@
+#!/bin/bash
+# One GPU-box visit of the build loop: [tests] + other-config timings + bench + rocprofv3 kernel trace (+ PMC passes with PMC=1).
+# usage (through gpurun): bash tools/gpu_round.sh <tag> [pytest -k expression | all | none]
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+TAG=${1:-cur}
+SEL=${2:-all}
+mkdir -p $OUT
+cd $R
+if [ "$SEL" = "all" ]; then python -m pytest tests -m gpu -q 2>&1 | tail -40 > $OUT/pytest_$TAG.log
+elif [ "$SEL" != "none" ]; then python -m pytest tests -m gpu -q -k "$SEL" 2>&1 | tail -40 > $OUT/pytest_$TAG.log; fi
+[ -f $OUT/pytest_$TAG.log ] && tail -8 $OUT/pytest_$TAG.log
+{ python tools/quick_bench_cfg.py 1000 25000 2; python tools/quick_bench_cfg.py 100 100000 5; python tools/quick_bench_cfg.py 100 500 2;
+  python tools/quick_bench_cfg.py 100 16384 2 TurboAE_rate3_rnn; } 2>&1 | grep -v amdgpu.ids | tee $OUT/cfg_$TAG.log
+python bench.py --steps 10 --warmup 2 ${BENCH_FLAGS:-} > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err
+python - $OUT/bench_$TAG.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+r, c, p = d["roofline"], d.get("cpu_baseline", {}), d.get("parity", {})
+print(f"bench: {d['value']/1e6:.2f} Mbit/s  ms/step {d['ms_per_step']:.2f} (median {d['ms_per_step_median']:.2f})  dec {r['kernel_ms']:.2f} ms frac {r['frac']:.4f}"
+      + (f"  f32 frac {d['roofline_f32']['frac']:.4f}" if 'roofline_f32' in d else "") + f"  ber {d['ber']:.5f}")
+print("cpu:", {k: c.get(k) for k in ("value", "cores", "run_to_run_spread", "value_B2000", "value_1_thread", "thread_sweep_bits_per_s")})
+print("parity:", p)
+PY
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/prof_$TAG.log 2>&1
+f=$(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && head -14 "$f"
+if [ "${PMC:-0}" = "1" ]; then cd $R; bash tools/gpu_pmc.sh $TAG; fi

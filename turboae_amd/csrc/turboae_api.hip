@@ -233,6 +233,7 @@ struct tae_handle {
     bool fixed_nb = false;   // TAE_FIXED_NB=1: always nb blocks per workgroup (testing knob)
     // long-block (segmented) path, used when a whole block does not fit one workgroup (nb == 0)
     int enc_T = 0, enc_nseg = 0, enc_lds = 0, dec_T = 0, dec_nseg = 0, dec_lds = 0;
+    int enc_T0 = 0, dec_T0 = 0;      // centre length of segment 0 (no left halo: up to H + 3 more than the others)
     uint32_t enc_stride = 0, dec_stride = 0;
     uint32_t enc_bytes = 0, dec_bytes = 0;
     int super = 0, super_d = 0;   // remainder channels via super-tiles (U % 16 == 4 and block_len % 4 == 0), encoder / decoder
@@ -761,8 +762,15 @@ int choose_nb(int U, int L, int* lds_out, bool h2 = false, int taps = 5) {
     return nb;
 }
 
-// Segment geometry of the long-block path: T centre positions + 2*H halo positions <= max positions.
-bool choose_seg(int U, int L, int n_layer, int* T, int* nseg, int* lds, bool dense = false, bool h2 = false, int taps = 5) {
+// Segment geometry of the long-block path.  A workgroup holds at most fused_max_positions() panel positions: T centre
+// positions + H halo positions per side (+ up to 3 alignment rows); halos that would lie outside the block are not walked
+// (the kernels clip the panel to [0, L)).  Segments are BALANCED (block_len 1000, H = 10: 4 x 250, 17 / 18 / 18 / 17 position
+// tiles).  Measured on MI355X (tools/seg_ab.sh, 25 000 blocks of 1000): balanced 4 x 250 412-419 ms per forward; panel-filling
+// segments with a short last one (310 + 297 + 297 + 96, T0 = T + H + 3) 434-441 ms although they walk 7 % fewer tile rows
+// (full 20-tile workgroups run every SIMD at 5 tiles and clock lower; the short workgroup still pays the fixed prologue);
+// 5 x 200 445 ms, 6 x 167 440 ms, 8 x 125 (two workgroups per CU) 545 ms.  T0 (segment 0 may own more centre positions, it
+// has no left halo) is kept in the kernel interface and set to T.
+bool choose_seg(int U, int L, int n_layer, int* T, int* T0, int* nseg, int* lds, bool dense = false, bool h2 = false, int taps = 5) {
     const int H = (taps / 2) * n_layer;
     auto seg_bytes = [&](int t) { return h2 ? tae::seg_lds_bytes_h(U, t, n_layer, taps) : tae::seg_lds_bytes(U, t, n_layer); };
     int tmax = tae::fused_max_positions() - 2 * H - 3;    // 3 alignment rows: panel origin floored to a multiple of 4
@@ -773,15 +781,24 @@ bool choose_seg(int U, int L, int n_layer, int* T, int* nseg, int* lds, bool den
         if (tmax < 8) return false;
         *nseg = (L + tmax - 1) / tmax;
         *T = (L + *nseg - 1) / *nseg;
+        *T0 = *T;
         *lds = tae::seg_lds_bytes_h_dense(U, *T, n_layer);
         return true;
     }
     while (tmax >= 16 && seg_bytes(tmax) > 160 * 1024) tmax -= 16;
     if (tmax < 16) return false;
     const char* cap = getenv("TAE_SEG_T");
-    if (cap && atoi(cap) >= 1 && atoi(cap) < tmax) tmax = atoi(cap);
+    if (cap && atoi(cap) >= 1 && atoi(cap) < tmax) {      // testing knob: equal segments of at most this many centre positions
+        tmax = atoi(cap);
+        *nseg = (L + tmax - 1) / tmax;
+        *T = (L + *nseg - 1) / *nseg;
+        *T0 = *T;
+        *lds = seg_bytes(*T);
+        return true;
+    }
     *nseg = (L + tmax - 1) / tmax;
     *T = (L + *nseg - 1) / *nseg;      // balanced segments
+    *T0 = *T;
     *lds = seg_bytes(*T);
     return true;
 }
@@ -867,6 +884,7 @@ int run_encoder_long(tae_handle* h, const float* u, float* xtx, double* stats, i
     P.partials = h->d_partials;
     P.mode = 0;
     P.T = h->enc_T;
+    P.T0 = h->enc_T0;
     P.nseg = h->enc_nseg;
     P.n_layer = h->cfg.enc_num_layer;
     P.stack_stride = h->enc_stride;
@@ -893,6 +911,7 @@ int run_decoder_long(tae_handle* h, const float* rx, float* xdec, int32_t B, hip
     P.out = xdec;
     P.mode = 1;
     P.T = h->dec_T;
+    P.T0 = h->dec_T0;
     P.nseg = h->dec_nseg;
     P.n_layer = h->cfg.dec_num_layer;
     P.stack_stride = h->dec_stride;
@@ -1176,8 +1195,8 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     if (cfg->dense) h->nb = h->nbd = 0;   // dense stacks run on the long-block kernels (one stack per launch)
     if (h->nb < 1 || h->nbd < 1) {
         h->nb = h->nbd = 0;               // one path for both sides (the exchange buffers and the workspace follow it)
-        if (!choose_seg(h->U, cfg->block_len, cfg->enc_num_layer, &h->enc_T, &h->enc_nseg, &h->enc_lds, cfg->dense != 0, want_h2 != 0, taps_e) ||
-            !choose_seg(h->Ud, cfg->block_len, cfg->dec_num_layer, &h->dec_T, &h->dec_nseg, &h->dec_lds, cfg->dense != 0, want_h2 != 0, taps_d)) {
+        if (!choose_seg(h->U, cfg->block_len, cfg->enc_num_layer, &h->enc_T, &h->enc_T0, &h->enc_nseg, &h->enc_lds, cfg->dense != 0, want_h2 != 0, taps_e) ||
+            !choose_seg(h->Ud, cfg->block_len, cfg->dec_num_layer, &h->dec_T, &h->dec_T0, &h->dec_nseg, &h->dec_lds, cfg->dense != 0, want_h2 != 0, taps_d)) {
             delete h;
             return fail(TAE_EINVAL, "too many conv layers for the segmented long-block kernels (halo exceeds the panel)");
         }

@@ -702,10 +702,12 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
     int stack = P.stack;
     if (P.mode == 0) { stack = bid % 3; bid /= 3; }
     const int seg = bid % P.nseg, b = bid / P.nseg;
-    const int s0 = seg * P.T;
-    const int tlen = min(P.T, L - s0);
-    const int tstart = (s0 - H) - ((s0 - H) & 3);      // same panel origin as the fp32 kernel (floored to a multiple of 4)
-    const int NP = s0 + P.T + H - tstart;
+    // segment 0 owns T0 centre positions, the others T (the last one what is left); only positions inside the block are
+    // walked (group_span deals NP): no halo in front of position 0 or behind position L - 1
+    const int s0 = seg == 0 ? 0 : P.T0 + (seg - 1) * P.T;
+    const int tlen = min(seg == 0 ? P.T0 : P.T, L - s0);
+    const int tstart = max(s0 - H, 0) & ~3;            // same panel origin as the fp32 kernel (floored to a multiple of 4)
+    const int NP = min(s0 + tlen + H, L) - tstart;
     const int rows = P.T + 2 * H + 3 + 2 * pad;
     const PanelsH pn = carve_seg_h<U>(smem, rows, P.dense ? (P.n_layer > 1 ? P.n_layer - 1 : 1) : 1);
     const bool odd = (stack & 1) != 0;

@@ -45,6 +45,7 @@ struct SegParams {
     int32_t stack;          // decoder stack index 0..2*n_iter-1
     int32_t last;           // decoder: final half-iteration
     int32_t B, L, T, nseg;  // T = centre positions per segment, nseg = segments per block
+    int32_t T0;             // centre positions of segment 0 (it needs no left halo, so it may own up to H + 3 more than the others)
     int32_t n_layer, F, extrinsic, act;
     int32_t taps;           // f16x2 kernel: conv kernel size (see FusedParams)
     uint32_t stack_stride;

@@ -461,12 +461,14 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel(SegParams P) {
     int stack = P.stack;
     if (P.mode == 0) { stack = bid % 3; bid /= 3; }
     const int seg = bid % P.nseg, b = bid / P.nseg;
-    const int s0 = seg * P.T;
-    const int tlen = min(P.T, L - s0);
+    // segment 0 owns T0 centre positions, the others T (the last one what is left); only positions inside the block are
+    // walked: no halo in front of position 0 or behind position L - 1 (those rows are the Conv1d zero padding)
+    const int s0 = seg == 0 ? 0 : P.T0 + (seg - 1) * P.T;
+    const int tlen = min(seg == 0 ? P.T0 : P.T, L - s0);
     // panel position m <-> block index t = tstart + m; tstart is floored to a multiple of 4 so that the
     // super-tile's shift index (m mod 4) equals t mod 4, exactly as in the whole-block kernels
-    const int tstart = (s0 - H) - ((s0 - H) & 3);
-    const int NP = s0 + P.T + H - tstart;              // <= T + 2H + 3
+    const int tstart = max(s0 - H, 0) & ~3;
+    const int NP = min(s0 + tlen + H, L) - tstart;     // <= T + 2H + 3
     const int rows = P.T + 2 * H + 3 + 4;              // allocation-independent of the segment
     float* ACT = reinterpret_cast<float*>(smem);
     float* X = ACT + (size_t)(rows + 1) * U;
@@ -624,6 +626,45 @@ __global__ void count_errors_kernel(const float* __restrict__ xdec, const float*
     }
 }
 
+// The same for block lengths that are a multiple of 4 (rows of both tensors 16-byte aligned): G = 2^k >= L / 4 lanes (at most a
+// wave) share one block, every lane compares four positions per 16-byte load of each tensor, 64 / G blocks per wave and
+// iteration.  The counts are reduced per WORKGROUP before they touch the two global counters: same-address atomics serialise
+// (~12 ns each on MI355X), and one pair per wave - 8 192 waves at 50 000 blocks - was all of the old kernel's 203 us.
+__global__ __launch_bounds__(256) void count_errors_vec4_kernel(const float4* __restrict__ xdec, const float4* __restrict__ u, int B, int L4, int G,
+                                                                unsigned long long* __restrict__ counts) {
+    __shared__ unsigned long long red[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & (G - 1), slot = lane / G, per_wave = 64 / G;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    unsigned long long bit_err = 0, blk_err = 0;
+    for (long b0 = (long)wave_global * per_wave; b0 < B; b0 += (long)nwaves * per_wave) {
+        const long b = b0 + slot;
+        int e = 0;
+        if (b < B) {
+            for (int t = sub; t < L4; t += G) {
+                const float4 x = xdec[(size_t)b * L4 + t], y = u[(size_t)b * L4 + t];
+                e += ((x.x > 0.5f) != (y.x > 0.5f)) + ((x.y > 0.5f) != (y.y > 0.5f)) + ((x.z > 0.5f) != (y.z > 0.5f)) + ((x.w > 0.5f) != (y.w > 0.5f));
+            }
+        }
+        for (int off = G >> 1; off > 0; off >>= 1) e += __shfl_xor(e, off);
+        if (sub == 0) { bit_err += e; blk_err += (e > 0); }
+    }
+    for (int off = 32; off > 0; off >>= 1) {       // sum the 64 / G sub-group leaders of the wave
+        bit_err += __shfl_xor(bit_err, off);
+        blk_err += __shfl_xor(blk_err, off);
+    }
+    if (lane == 0) { red[0][wave] = bit_err; red[1][wave] = blk_err; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long a = red[0][0] + red[0][1] + red[0][2] + red[0][3], c = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        if (a | c) {
+            atomicAdd(&counts[0], a);
+            atomicAdd(&counts[1], c);
+        }
+    }
+}
+
 // Test inputs on device (replaces trainer.py:167-169): u ~ Bernoulli(0.5), noise = sigma * N(0,1),
 // element e of block-major tensors keyed by the GLOBAL element index so any shard matches the
 // single-device stream.  Box-Muller in fp64 (see turboae_amd/philox.py).
@@ -727,6 +768,16 @@ hipError_t launch_normalize(const float* xtx, const double* stats, const float* 
 }
 
 hipError_t launch_count_errors(const float* xdec, const float* u, int B, int L, unsigned long long* counts, hipStream_t st) {
+    if (L % 4 == 0 && ((reinterpret_cast<uintptr_t>(xdec) | reinterpret_cast<uintptr_t>(u)) & 15) == 0) {
+        const int L4 = L / 4;
+        int G = 1;
+        while (G < L4 && G < 64) G <<= 1;
+        const long waves = ((long)B * G + 63) / 64;
+        const int grid = (int)std::min<long>((waves + 3) / 4, 1024);       // 4 workgroups per CU, grid-stride over the blocks
+        hipLaunchKernelGGL(count_errors_vec4_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const float4*>(xdec),
+                           reinterpret_cast<const float4*>(u), B, L4, G, counts);
+        return hipGetLastError();
+    }
     const int grid = std::min((B + 3) / 4, 2048);
     hipLaunchKernelGGL(count_errors_kernel, dim3(grid), dim3(256), 0, st, xdec, u, B, L, counts);
     return hipGetLastError();
