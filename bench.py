@@ -137,6 +137,7 @@ def cpu_baseline_and_parity(cfg: TurboAEConfig, sd, u500: np.ndarray, noise500: 
     x_cpu, c_cpu = fwd()
     out = {"value": B * L / med, "unit": "bits/s", "cores": best, "kind": "port",
            "value_at_min": B * L / mn, "run_to_run_spread": (float(np.max(ts)) - mn) / med,
+           "interquartile_spread": float(np.percentile(ts, 75) - np.percentile(ts, 25)) / med, "forward_seconds": [round(float(t), 4) for t in ts],
            "seconds_per_forward_median": med, "thread_sweep_bits_per_s": {str(k): v for k, v in sweep.items()},
            "cpu_model": info["model"], "physical_cores": info["physical_cores"], "logical_cpus": info["logical_cpus"],
            "usable_cpus": info["usable_cpus"], "torch": torch.__version__,
@@ -174,6 +175,7 @@ def main():
     ap.add_argument("--random-weights", action="store_true", help="portable random-init weights instead of the trained fixture")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (cpu_baseline and the CPU side of parity)")
     ap.add_argument("--no-f32-pass", action="store_true", help="skip the second timed pass in precision='f32'")
+    ap.add_argument("--no-parity", action="store_true", help="skip the 500-block BER-match sample (profiling runs: only full-size launches)")
     ap.add_argument("--cpu-budget", type=float, default=75.0, help="wall-time bound of the CPU leg in seconds")
     ap.add_argument("--precision", choices=("auto", "f32"), default="auto",
                     help="auto: fp16-split MFMA contraction (fp32-grade, DESIGN.md 3.7); f32: v_mfma_f32_16x16x4_f32")
@@ -282,7 +284,7 @@ def main():
         # "BER match" sample: the first PARITY_BLOCKS blocks of the same Philox stream as ONE batch of their own (the power
         # constraint takes its statistics over the batch it is handed, encoders.py:107-108), compared with the CPU oracle below
         par = None
-        if rank == 0 and world == 1:
+        if rank == 0 and world == 1 and not args.no_parity:
             up, npar = model.generate_inputs(PARITY_BLOCKS, args.snr, seed=SEED, first_block=0)
             xd, codes = model(up, npar)
             torch.cuda.synchronize()
@@ -313,7 +315,7 @@ def main():
             kname = "tae::dec_kernel_h<100,5> (fused 6-iteration decoder, fp16-split MFMA)" if is_h2 else "tae::dec_kernel<100,5> (fused 6-iteration decoder, fp32 MFMA)"
             if nb == 0:        # long blocks: the decoder is 2 * num_iteration launches of the segment kernel; `kernel_ms` covers all of them
                 kname = ("tae::seg_kernel_h<100,5>" if is_h2 else "tae::seg_kernel<100,5>") + f" x {2 * cfg.num_iteration} launches (one conv stack each, long-block decoder)"
-            pmc_dir = "r01_pmc_f16x2" if is_h2 else "r01_pmc"
+            pmc_dir = "r02_pmc_f16x2" if is_h2 else "r01_pmc"
             # HBM-side traffic of the decoder kernel from the committed PMC passes (rocprofv3 cannot run inside
             # this process): bytes per block measured at the same workload, scaled to this launch's blocks
             traffic = None

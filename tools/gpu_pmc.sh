@@ -11,7 +11,7 @@ cd /tmp
 B=${PMC_BATCH:-50000}
 run() {  # name, counters...
   name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_${TAG}_$name -o pmc -- python $R/bench.py --steps 2 --warmup 1 --batch $B --no-cpu-baseline --no-f32-pass > $OUT/pmc_${TAG}_$name.log 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_${TAG}_$name -o pmc -- python $R/bench.py --steps 2 --warmup 1 --batch $B --no-cpu-baseline --no-f32-pass --no-parity > $OUT/pmc_${TAG}_$name.log 2>&1
   f=$(find $OUT/pmc_${TAG}_$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" $OUT/pmc_${TAG}_$name.txt $B <<'PY'
 import csv, sys, collections

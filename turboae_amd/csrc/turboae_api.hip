@@ -824,6 +824,33 @@ int nb_for_batch(const tae_handle* h, int32_t B, int nb_max) {
     return best;
 }
 
+// Grid of one call of the whole-block f16x2 kernels: full rounds of ncu workgroups with nb blocks each, and the blocks that are
+// left (less than one round's worth) dealt nb_tail per workgroup with nb_tail chosen like nb_for_batch does: the last, partial
+// round then costs 5 + 2 * ceil(tiles(nb_tail) / 4) instead of a full workgroup time (50 000 blocks on 256 CUs: 65 rounds of
+// 256 x 3 blocks + 80 single-block workgroups instead of 27 three-block ones).  Returns the grid size.
+int tail_geometry(const tae_handle* h, int32_t B, int nb, tae::FusedParams* P) {
+    P->n_full = -1;
+    P->nb_tail = nb;
+    const int grid = (B + nb - 1) / nb;
+    if (h->fixed_nb || nb <= 1 || grid <= h->ncu) return grid;       // a single round is nb_for_batch's business
+    const int n_full = (B / nb) / h->ncu * h->ncu;                    // whole rounds of full workgroups
+    const int rest = B - n_full * nb;                                 // < ncu * nb + nb blocks
+    if (rest <= 0) return grid;
+    const int L = h->cfg.block_len;
+    int best = nb;
+    long best_cost = -1;
+    for (int t = nb; t >= 1; --t) {
+        const long g = ((long)rest + t - 1) / t, rounds = (g + h->ncu - 1) / h->ncu;
+        const long ntile = ((long)t * L + 15) / 16;
+        const long cost = rounds * (5 + 2 * ((ntile + 3) / 4));
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = t; }
+    }
+    if (best == nb) return grid;
+    P->n_full = n_full;
+    P->nb_tail = best;
+    return n_full + (rest + best - 1) / best;
+}
+
 int check_batch(tae_handle* h, int32_t B) {
     if (!h) return fail(TAE_EINVAL, "handle is NULL");
     if (B < 1) return fail(TAE_EINVAL, "batch must be >= 1");
@@ -956,8 +983,10 @@ int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_
     P.stack_stride = h->enc_stride;
     P.wpack_bytes = h->enc_bytes;
     P.nb = nb_for_batch(h, B, h->nb);
-    const int grid = (B + P.nb - 1) / P.nb;
+    P.n_full = -1;
+    int grid = (B + P.nb - 1) / P.nb;
     if (h->prec == 1) {
+        grid = tail_geometry(h, B, P.nb, &P);
         P.wpack = reinterpret_cast<const float*>(h->d_wenc_h);
         P.stack_stride = h->enc_stride_h;
         P.wpack_bytes = h->enc_bytes_h;
@@ -1120,8 +1149,10 @@ int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStrea
     P.stack_stride = h->dec_stride;
     P.wpack_bytes = h->dec_bytes;
     P.nb = nb_for_batch(h, B, h->nbd);
-    const int grid = (B + P.nb - 1) / P.nb;
+    P.n_full = -1;
+    int grid = (B + P.nb - 1) / P.nb;
     if (h->prec == 1) {
+        grid = tail_geometry(h, B, P.nb, &P);
         P.wpack = reinterpret_cast<const float*>(h->d_wdec_h);
         P.stack_stride = h->dec_stride_h;
         P.wpack_bytes = h->dec_bytes_h;

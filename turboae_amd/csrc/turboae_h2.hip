@@ -509,8 +509,10 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
     const int pad = P.taps >> 1;
     const int rows = nb * (L + pad) + pad;
     const PanelsH pn = carve_h<U>(smem, rows, L);
-    const int blk0 = blockIdx.x * nb;
-    const int nblk = min(nb, P.B - blk0);
+    // workgroups [0, n_full) own nb blocks, the tail workgroups nb_tail (fewer position tiles: a cheaper last round)
+    const bool tail = P.n_full >= 0 && (int)blockIdx.x >= P.n_full;
+    const int blk0 = tail ? P.n_full * nb + ((int)blockIdx.x - P.n_full) * P.nb_tail : (int)blockIdx.x * nb;
+    const int nblk = min(tail ? P.nb_tail : nb, P.B - blk0);
     const int npos = nblk * L;
 
     zero_lds(smem, P.lds_bytes, tid);
@@ -589,8 +591,10 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
     const int pad = P.taps >> 1;
     const int rows = nb * (L + pad) + pad;
     const PanelsH pn = carve_h<U>(smem, rows, L);
-    const int blk0 = blockIdx.x * nb;
-    const int nblk = min(nb, P.B - blk0);
+    // workgroups [0, n_full) own nb blocks, the tail workgroups nb_tail (fewer position tiles: a cheaper last round)
+    const bool tail = P.n_full >= 0 && (int)blockIdx.x >= P.n_full;
+    const int blk0 = tail ? P.n_full * nb + ((int)blockIdx.x - P.n_full) * P.nb_tail : (int)blockIdx.x * nb;
+    const int nblk = min(tail ? P.nb_tail : nb, P.B - blk0);
     const int npos = nblk * L;
 
     zero_lds(smem, P.lds_bytes, tid);

@@ -27,6 +27,8 @@ struct FusedParams {
     int32_t lds_bytes;
     int32_t super;          // 1: remainder channels via super-tiles (needs U % 16 == 4 and block_len % 4 == 0)
     uint32_t* flags;        // f16x2 kernels: bit 0 set when an activation left the fp16 range (stack_stride is in BYTES there)
+    int32_t n_full, nb_tail; // f16x2 whole-block kernels: workgroups [0, n_full) own nb blocks each, the rest nb_tail each (the last
+                            // partial round of workgroups runs thinner, see tail_geometry in turboae_api.hip); n_full < 0: all own nb
     float* tap_out;         // decoder, debug instantiation only (tae_decode_taps): [2*n_iter-1][B][L][F] extrinsic outputs of every
                             // non-final stack in the producing stack's own position order (before the (de)interleave scatter)
 };
