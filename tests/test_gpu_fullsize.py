@@ -102,3 +102,32 @@ def test_configs3_per_gpu_shape_25000_blocks_of_1000(gpu_device):
     # (no round-trip BER bound here: the network was trained with the 100-position interleaver)
     ber = _check_full_size(gpu_device, cfg, _trained_sd(), 25000, 8.0, 12, trained=False)
     print("configs[3] 25 000 x 1000 @ 8 dB: BER", ber)
+
+
+def test_configs4_gru_decoder_16384_blocks(gpu_device):
+    """BASELINE configs[4] (DeepTurbo GRU decoder) at one full wave of recurrent workgroups: 16 384 blocks (256 CUs x 8 waves x
+    16 blocks / 2 directions), the GRU path's internal chunk size - so this also runs the chunk boundary when 16 400 are given."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn")
+    sd = W.generate_state_dict(cfg, seed=14, gain=1.0)
+    B, L = 16400, cfg.block_len
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    u, noise = model.generate_inputs(B, 2.0, seed=78)
+    x_dec, codes = model(u, noise)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(x_dec).all())
+    m, s = float(codes.double().mean()), float(codes.double().std())
+    assert abs(m) < 1e-6 and abs(s - 1.0) < 1e-6
+    rx = codes + noise
+    for lo, hi in ((0, 5), (16380, 16390), (B - 7, B)):          # inside chunk 0, across the chunk boundary, the tail of chunk 1
+        assert torch.equal(model.dec(rx[lo:hi].contiguous()), x_dec[lo:hi]), (lo, hi)
+    idx = np.array([0, 1, 8191, 16383, 16384, B - 1])
+    w = O.to_torch(sd)
+    p = torch.from_numpy(O.rand_interleaver(L, 0))
+    with torch.no_grad():
+        xd_o = O.decode_rnn(rx[torch.from_numpy(idx).to(gpu_device)].cpu(), w, p, cfg.dec_num_unit, cfg.num_iteration, cfg.num_iter_ft)
+    d = float((x_dec[torch.from_numpy(idx).to(gpu_device)].cpu() - xd_o).abs().max())
+    assert d <= 5e-5, d                                          # the GRU golden tests' tolerance (100 sequential steps x 12 stacks)
+    counts = model.count_errors(x_dec, u).cpu().tolist()
+    err = (x_dec > 0.5) != (u > 0.5)
+    assert counts == [int(err.sum()), int(err.any(dim=1).sum())]
