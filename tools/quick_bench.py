@@ -25,3 +25,8 @@ for _ in range(3):
     a.record(); xd, codes = model(u, noise); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
 ms = float(np.median(ts))
 print(f"B={B} forward {ms:.3f} ms  {B*100/ms/1e3:.2f} Mbit/s", flush=True)
+ts = []
+for _ in range(5):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); c = model.enc(u); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+print(f"B={B} encoder + power constraint {float(np.median(ts)):.3f} ms", flush=True)

@@ -202,6 +202,18 @@ size_t pack_stack_h(const float* src, const LayoutH& lo, int n_layer, int cin0, 
         if (S > 60) S = 60;
         if (S < -60) S = -60;
         const float scale = ldexpf(1.0f, S), inv = ldexpf(1.0f, -S);
+        if (l == 0 && cin0 == 1) {
+            // encoder stacks: all taps folded into ONE slab (turboae_h2.hip::fold_enc_input): k = 8 q + a holds tap q + 4 a.  The
+            // region keeps its nsl_l0 slabs (offsets unchanged); the kernel walks the first one only.
+            std::vector<float> wf((size_t)lo.U * 32, 0.0f);            // as a (U, cin = 4 taps-of-8 ..) tensor: W'[co][k], k < 32
+            for (int co = 0; co < lo.U; ++co)
+                for (int tap = 0; tap < lo.taps; ++tap) wf[(size_t)co * 32 + 8 * (tap % 4) + tap / 4] = s[(size_t)co * lo.taps + tap];
+            // pack_conv_h reads W[(co * cin + ci) * taps + j] with k = j * cin_pad + ci: taps = 1, cin = cin_pad = 32 gives k = ci
+            std::vector<uint16_t> one((size_t)lo.CT * 2 * 512);
+            pack_conv_h(wf.data(), lo.U, 32, 32, 1, lo.CT, scale, one.data(), 1);
+            memset(d, 0, lo.l0b);
+            memcpy(d, one.data(), one.size() * sizeof(uint16_t));
+        } else
         pack_conv_h(s, lo.U, cin, l == 0 ? 8 : lo.U, l == 0 ? lo.nsl_l0 : lo.nsl_mid, lo.CT, scale, reinterpret_cast<uint16_t*>(d), lo.taps);
         d += l == 0 ? lo.l0b : lo.midb;
         const float* b = s + nw;

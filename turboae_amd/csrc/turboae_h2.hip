@@ -70,6 +70,18 @@ struct XPlane {
     }
 };
 
+// Encoder stacks have ONE input channel, so the first layer's K = taps: instead of one 8-wide k chunk per tap (taps x 8 padded
+// inputs = 2..3 slabs, 5/64 real at 5 taps) the taps are folded into one 32-k slab: chunk q of an output position reads input row
+// (t - pad + q), and channel a of that row holds the input 4a positions further on, X[row][a] = x[row + 4a], so k = 8q + a is tap
+// q + 4a (pack_stack_h packs the weights to match).  Called by the thread that stages input position t (panel row `row`) with value
+// v: scatters v into channel a of the row 4a positions back.  `t` = index inside the block (rows before t = -pad belong to the
+// previous block's tail and are never written), `row_min` = first row of the panel this workgroup may write.
+__device__ __forceinline__ void fold_enc_input(const XPlane& X, int row, int t, int pad, int row_min, float v) {
+#pragma unroll
+    for (int a = 1; a <= 2; ++a)
+        if (4 * a <= 2 * pad && t - 4 * a >= -pad && row - 4 * a >= row_min) X.write(row - 4 * a, a, v);
+}
+
 struct PanelsH {
     int dump;        // write-only row after the slack row (index rows + 1): where padding lanes / padding channels store
     uint32_t panel_bytes;   // dense stacks: bytes between consecutive layer panels (hi plane | lo plane); AH / AL = panel 0
@@ -195,10 +207,12 @@ __device__ __forceinline__ void elu_split4(f32x4 a, float inv_scale, float& vmax
 
 // One SameShapeConv1d stack (cnn_utils.py:36-46) + Linear head; same contract as run_stack in
 // turboae_kernels.hip, except that `g` is the first position TILE of the wave's group (not the group index).  `vmax` collects max |activation| before the fp16-range clamp (overflow report).
+// `l0_slabs` > 0: the first layer walks that many K slabs instead of the tap_geo count (encoder stacks: C_in = 1 folds all taps
+// into ONE slab, see fold_enc_input).
 template <int U, int PT, int C0, int NC, class Epi>
 __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint32_t soff, uint32_t snext, int n_layer, char* smem,
                                             const PanelsH& pn, const XPlane& xin, const TileH<PT>& tc, int g, int lane,
-                                            WeightStreamH<U, C0, NC>& ws, float& vmax, Epi epi) {
+                                            WeightStreamH<U, C0, NC>& ws, float& vmax, Epi epi, int l0_slabs = 0) {
     using G = GeoH<U>;
     constexpr int CTT = G::CT;
     const int q = lane >> 4;
@@ -230,7 +244,8 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
             bh[p] = ph + o;
             bl[p] = pl + o;
         }
-        conv_accumulate_h<CTT, C0, NC, PT, 0>(acc, ws.a, ws.rsrc, ws.voff, lo, smem, bh, bl, first ? tg.nsl_l0 : tg.nsl_mid);
+        conv_accumulate_h<CTT, C0, NC, PT, 0>(acc, ws.a, ws.rsrc, ws.voff, lo, smem, bh, bl,
+                                              first ? (l0_slabs > 0 ? l0_slabs : tg.nsl_l0) : tg.nsl_mid);
         lo += fragb + G::TAILB;
         {
             const uint32_t nxt = (l + 1 < n_layer) ? lo : snext;
@@ -577,7 +592,7 @@ __device__ __forceinline__ void enc_body_h(const FusedParams& P, char* smem, con
                 sum += (double)v;
                 sumsq += (double)v * (double)v;
             }
-        });
+        }, 1);
     }
     report_range(vmax, P.flags);
 }
@@ -606,8 +621,11 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
     for (int m = tid; m < npos; m += kThreads) {
         const int b = m / L, t = m - b * L;
         const int row = b * (L + pad) + pad + t;
-        pn.XA.write(row, 0, 2.0f * u[m] - 1.0f);
-        pn.XB.write(row, 0, 2.0f * u[b * L + pn.PERM[t]] - 1.0f);
+        const float va = 2.0f * u[m] - 1.0f, vb = 2.0f * u[b * L + pn.PERM[t]] - 1.0f;
+        pn.XA.write(row, 0, va);
+        pn.XB.write(row, 0, vb);
+        fold_enc_input(pn.XA, row, t, pad, 0, va);
+        fold_enc_input(pn.XB, row, t, pad, 0, vb);
     }
     __syncthreads();
 
@@ -644,7 +662,7 @@ __device__ __forceinline__ void seg_body_h(const SegParams& P, char* smem, const
     float vmax = 0.0f;
     auto run = [&](auto epi) {
         if constexpr (DENSE) run_stack_h_dense<U, PT, C0, NC>(wpack, soff, P.n_layer, smem, pn, X, tc, g, lane, ws, vmax, active, epi);
-        else run_stack_h<U, PT, C0, NC>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, vmax, epi);
+        else run_stack_h<U, PT, C0, NC>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, vmax, epi, P.mode == 0 ? 1 : 0);
     };
     if (P.mode == 0) {
         const int act = P.act;
@@ -725,7 +743,9 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
         const int row = pad + m;
         if (P.mode == 0) {
             const int src = (stack == 2) ? P.perm[t] : t;                           // encoders.py:369
-            pn.XA.write(row, 0, 2.0f * P.in[(size_t)b * L + src] - 1.0f);           // encoders.py:362
+            const float v = 2.0f * P.in[(size_t)b * L + src] - 1.0f;                // encoders.py:362
+            pn.XA.write(row, 0, v);
+            if (!P.dense) fold_enc_input(pn.XA, row, t, pad, 0, v);
         } else {
             const float* rx = P.in + (size_t)b * L * 3;
             const float r0 = odd ? rx[(size_t)P.perm[t] * 3] : rx[(size_t)t * 3];   // r_sys_int / r_sys
