@@ -216,7 +216,8 @@ def trained(manifest, pt_path):
     print(f"trained: BER@2dB={bit_err / (B * 100.0):.4e} blocks_in_error={blk_err}/{B} dx={dx:.2e} dc={dc:.2e}")
 
 
-TRAINED_FP32_SNRS = (2.0, 4.0, 6.0)
+TRAINED_FP32_SNRS = (2.0, 4.0, 6.0, 8.0)
+TRAINED_FP32_BATCHES = {2.0: 4, 4.0: 4, 6.0: 4, 8.0: 20}      # batches of 500 blocks per point: 2e5 bits, 1e6 bits at the low-BER point
 TRAINED_FP32_SEED = 515151
 
 
@@ -224,24 +225,26 @@ def trained_fp32(manifest, pt_path):
     """Full-precision twin of trained(): the checkpoint's fp32 weights as they are (no fp16 rounding, so the hi/lo split of the
     fp16-split kernels has non-zero lo halves for every weight and the per-layer 2^S scales see a trained network's dynamic
     range), 4 batches of 500 blocks per SNR point at 2 / 4 / 6 dB (200 000 bits per point: a BER difference of 1e-4 is 20 bit
-    errors), hard decisions of the REAL reference for all of them, its x_dec for batch 0 of each point, and the per-stage
+    errors) and 20 batches at 8 dB (10^6 bits at the low-BER end), hard decisions of the REAL reference for all of them, its x_dec for batch 0 of each point, and the per-stage
     decoder taps of 4 blocks (reference_taps)."""
     cfg = TurboAEConfig()
     obj = torch.load(pt_path, map_location="cpu", weights_only=False)
     sd = obj.state_dict() if hasattr(obj, "state_dict") else obj
     sd = W.check_state_dict(cfg, sd)
     blob = W.pack_blob(cfg, sd).astype(np.float32)
-    B, NB, L = 500, 4, 100
+    B, L = 500, 100
     model, _ = R.build_reference_model(cfg.to_dict(), B)
     R.load_weights(model, sd)
     out = {"weights_fp32": blob}
-    info = {"config": cfg.to_dict(), "batch": B, "n_batches": NB, "input_seed": TRAINED_FP32_SEED, "snrs": list(TRAINED_FP32_SNRS),
+    info = {"config": cfg.to_dict(), "batch": B, "n_batches": {f"{k:g}dB": v for k, v in TRAINED_FP32_BATCHES.items()},
+            "input_seed": TRAINED_FP32_SEED, "snrs": list(TRAINED_FP32_SNRS),
             "bit_errors": {}, "block_errors": {}, "ber": {}, "oracle_vs_reference_max_abs": {},
             "note": "reference main.py trained in the build container (oracle/train_fixture.py, " + os.path.basename(pt_path) + "); "
                     "inputs: Philox seed, blocks [i*500, (i+1)*500) of batch i, noise = sigma(snr) * N(0,1) of the same stream for every SNR"}
     w = O.to_torch(sd)
     for snr in TRAINED_FP32_SNRS:
         key = f"{snr:g}dB"
+        NB = TRAINED_FP32_BATCHES[snr]
         hard, be, ble, dmax = [], [], [], [0.0, 0.0]
         for i in range(NB):
             u, noise = make_inputs(B, L, snr, seed=TRAINED_FP32_SEED, offset=i * B)

@@ -112,7 +112,7 @@ def test_bench_rccl_backend_at_world_size_1(gpu_device):
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert res["n_gpus"] == 1 and res["scaling"] == "strong" and res["config"]["global_blocks"] == 3000
-    assert res["value"] > 0 and 0.005 < res["ber"] < 0.03           # trained weights at 2 dB
+    assert res["value"] > 0 and 1e-4 < res["ber"] < 0.03            # trained weights at 2 dB (chance level would be 0.45)
     assert res["parity"]["ber_gpu_first500"] > 0
 
 

@@ -28,4 +28,9 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/prof_$TAG.log 2>&1
 f=$(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -14 "$f"
+if [ "${PROF_CFG:-0}" = "1" ]; then     # kernel traces of the long-block (cfg 4 shape) and GRU (cfg 5) configurations
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_cfg4 -o cfg4 -- python $R/tools/quick_bench_cfg.py 1000 25000 2 > $OUT/prof_${TAG}_cfg4.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_cfg5 -o cfg5 -- python $R/tools/quick_bench_cfg.py 100 16384 2 TurboAE_rate3_rnn > $OUT/prof_${TAG}_cfg5.log 2>&1
+  for c in cfg4 cfg5; do f=$(find $OUT/prof_${TAG}_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { echo "== $c"; head -6 "$f"; }; done
+fi
 if [ "${PMC:-0}" = "1" ]; then cd $R; bash tools/gpu_pmc.sh $TAG; fi

@@ -363,17 +363,23 @@ struct Split {
 };
 
 __device__ __forceinline__ void block_reduce_stats(char* smem, int tid, double sum, double sumsq, double* partials) {
-    // deterministic fixed-order tree; the panels are dead after the last stack's closing barrier, so the
-    // reduction scratch aliases them (no static LDS: guide G17)
-    double* red = reinterpret_cast<double*>(smem);
-    red[tid] = sum;
-    red[kThreads + tid] = sumsq;
-    __syncthreads();
-    for (int off = kThreads / 2; off > 0; off >>= 1) {
-        if (tid < off) { red[tid] += red[tid + off]; red[kThreads + tid] += red[kThreads + tid + off]; }
-        __syncthreads();
+    // deterministic fixed-order tree: xor butterfly inside each wave (registers), then the 8 wave totals in wave order; the
+    // panels are dead after the last stack's closing barrier, so the scratch aliases them (no static LDS: guide G17)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off);
+        sumsq += __shfl_xor(sumsq, off);
     }
-    if (tid == 0) { partials[2 * blockIdx.x] = red[0]; partials[2 * blockIdx.x + 1] = red[kThreads]; }
+    double* red = reinterpret_cast<double*>(smem);
+    if ((tid & 63) == 0) { red[tid >> 6] = sum; red[kWaves + (tid >> 6)] = sumsq; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = red[0], b = red[kWaves];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) { a += red[w]; b += red[kWaves + w]; }
+        partials[2 * blockIdx.x] = a;
+        partials[2 * blockIdx.x + 1] = b;
+    }
 }
 
 
