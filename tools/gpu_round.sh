@@ -20,7 +20,7 @@ d = json.load(open(sys.argv[1]))
 r, c, p = d["roofline"], d.get("cpu_baseline", {}), d.get("parity", {})
 print(f"bench: {d['value']/1e6:.2f} Mbit/s  ms/step {d['ms_per_step']:.2f} (median {d['ms_per_step_median']:.2f})  dec {r['kernel_ms']:.2f} ms frac {r['frac']:.4f}"
       + (f"  f32 frac {d['roofline_f32']['frac']:.4f}" if 'roofline_f32' in d else "") + f"  ber {d['ber']:.5f}")
-print("cpu:", {k: c.get(k) for k in ("value", "cores", "run_to_run_spread", "value_B2000", "value_1_thread", "thread_sweep_bits_per_s")})
+print("cpu:", {k: c.get(k) for k in ("value", "cores", "run_to_run_spread", "min_max_spread", "value_B2000", "value_1_thread", "thread_sweep_bits_per_s")})
 print("parity:", p)
 PY
 export TMPDIR=/tmp
