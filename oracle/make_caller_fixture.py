@@ -11,7 +11,7 @@ tests/golden/trained_enc2dec5_u100_fp32.npz), runs the reference's unmodified ``
   * caller_trainer_test.npz  - the actual tensors of every model call (bits packed, noise, x_dec, codes), so that a drop-in
     can be REPLAYED call by call on the GPU box and must print the same numbers.
 
-Two runs: the default flags (the punctured second pass dies in its bare ``except`` on the first batch - after one extra
+Three runs: ``--precompute_norm_stats`` (pre-pass over ``model.enc``, running statistics), the default flags (the punctured second pass dies in its bare ``except`` on the first batch - after one extra
 forward with a (B, L, 1) noise tensor, trainer.py:198-201 - and prints 'no pos BER specified.'), and ``--print_pos_ber
 --print_pos_power`` (the punctured pass runs; its noise is (B, L, 1), broadcast over the three code symbols by
 ``codes + fwd_noise``, channel_ae.py:42).  Data only: no reference source is stored.
@@ -85,9 +85,9 @@ class Recorder:
         return out
 
 
-def run(name, extra_flags, tensors):
-    cfg = TurboAEConfig()
-    sd = W.unpack_blob(cfg, np.load(os.path.join(GOLD, "trained_enc2dec5_u100_fp32.npz"))["weights_fp32"])
+def run(name, extra_flags, tensors, cfg_over=None):
+    cfg = TurboAEConfig(**(cfg_over or {}))
+    sd = W.unpack_blob(TurboAEConfig(), np.load(os.path.join(GOLD, "trained_enc2dec5_u100_fp32.npz"))["weights_fp32"])
     B = 50
     model, args = R.build_reference_model(cfg.to_dict(), B)
     R.load_weights(model, sd)
@@ -116,6 +116,8 @@ def main():
            "weights": "tests/golden/trained_enc2dec5_u100_fp32.npz", "torch": torch.__version__, "runs": {}}
     out["runs"]["default"] = run("default", {}, tensors)
     out["runs"]["pos_ber"] = run("pos_ber", {"print_pos_ber": True, "print_pos_power": True, "num_ber_puncture": 5}, tensors)
+    # --precompute_norm_stats: the pre-pass over model.enc and the read of model.enc.mean_scalar / std_scalar (trainer.py:145-153)
+    out["runs"]["precomp"] = run("precomp", {}, tensors, cfg_over={"precompute_norm_stats": True})
     with open(os.path.join(GOLD, "caller_trainer_test.json"), "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
     np.savez_compressed(os.path.join(GOLD, "caller_trainer_test.npz"), **tensors)

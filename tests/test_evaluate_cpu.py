@@ -82,7 +82,7 @@ def _model():
     return OracleModel(cfg, sd), cfg
 
 
-@pytest.mark.parametrize("run", sorted(FIX["runs"]))
+@pytest.mark.parametrize("run", [r for r in sorted(FIX["runs"]) if not FIX["runs"][r]["args"]["precompute_norm_stats"]])
 def test_transcript_shape_and_sweep_arithmetic(run):
     torch.set_num_threads(4)
     rec = FIX["runs"][run]

@@ -175,6 +175,23 @@ class _EncView:
     def set_parallel(self) -> None:                    # encoders.py:343-349: DataParallel wrappers; nothing to do
         pass
 
+    # --precompute_norm_stats state of ENCBase (encoders.py:82-87,110-114); trainer.test prints mean_scalar / std_scalar (trainer.py:153)
+    @property
+    def mean_scalar(self) -> float:
+        return self._e.mean_scalar
+
+    @property
+    def std_scalar(self) -> float:
+        return self._e.std_scalar
+
+    @property
+    def num_test_block(self) -> float:
+        return self._e.num_test_block
+
+    def reset_precomp(self) -> None:                   # encoders.py:84-87
+        self._e.reset_precomp()
+        self._e.apply_channel_opts()
+
     def __call__(self, inputs: torch.Tensor) -> torch.Tensor:
         e = self._e
         u = e._in(inputs, 1, "inputs")

@@ -60,7 +60,6 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
     else:
         step = 0.0
     snrs = [step * i + snr_test_start for i in range(snr_points)]
-    say("SNRS", snrs)
     num_test_batch = int(num_block / batch_size)
     lo, hi = shard_bounds(batch_size, rank, world)
     nloc = hi - lo
@@ -84,7 +83,10 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
                 _, stats = model.encode_prenorm(u)
             all_reduce_sum_(stats)
             model.update_precomp(stats)
-        say("Pre-computed norm statistics mean ", model._eng.mean_scalar, "std ", model._eng.std_scalar)
+        # the reference prints its (1,)-shaped running-statistics tensors (trainer.py:153)
+        say("Pre-computed norm statistics mean ", torch.tensor([model._eng.mean_scalar], dtype=torch.float32),
+            "std ", torch.tensor([model._eng.std_scalar], dtype=torch.float32))
+    say("SNRS", snrs)                      # after the pre-pass line, as trainer.py:153-160 prints them
     if hip_graph and world > 1 and dist.get_backend() != "nccl":
         raise ValueError("hip_graph=True with torch.distributed needs the nccl (RCCL) backend")
     ber_res, bler_res, bit_res, blk_res = [], [], [], []
