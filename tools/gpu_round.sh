@@ -25,7 +25,7 @@ print("parity:", p)
 PY
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity > $OUT/prof_$TAG.log 2>&1
 f=$(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -14 "$f"
 if [ "${PROF_CFG:-0}" = "1" ]; then     # kernel traces of the long-block (cfg 4 shape) and GRU (cfg 5) configurations
