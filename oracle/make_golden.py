@@ -40,6 +40,12 @@ CASES = [
                                        extrinsic=0, dec_num_layer=3), 6, 11, 1.0, -1.5),
     ("fwd_u100_L1000_b2", dict(block_len=1000), 2, 12, 1.0, 2.0),
     ("fwd_u100_L150_b3_it2", dict(block_len=150, num_iteration=2), 3, 13, 1.0, 2.0),
+    # edges of the kernel geometry and of the feature ranges, against the REAL reference (the fuzz tests cover them against the oracle)
+    ("edge_ft6_noext_u100", dict(num_iter_ft=6, extrinsic=0, num_iteration=3), 4, 40, 1.0, 2.0),          # widest stack input (2 + 6), no extrinsic subtraction
+    ("edge_ft1_u100", dict(num_iter_ft=1, num_iteration=3), 3, 41, 1.0, 1.0),                               # narrowest
+    ("edge_L37_u64", dict(enc_num_unit=64, dec_num_unit=64, block_len=37, num_iteration=2), 9, 42, 1.0, 2.0),      # odd length: 8 blocks per workgroup + 1
+    ("edge_L320_u100", dict(block_len=320, num_iteration=2, dec_num_layer=3), 2, 43, 1.0, 2.0),              # the longest block that still fits one workgroup
+    ("edge_L321_u100", dict(block_len=321, num_iteration=2, dec_num_layer=3), 2, 44, 1.0, 2.0),              # one more: long-block path, two segments
     # BASELINE configs[4]: DeepTurbo GRU decoder (DEC_LargeRNN) behind the CNN encoder
     ("fwd_rnn_u100_L100_b4", dict(decoder="TurboAE_rate3_rnn"), 4, 14, 1.0, 2.0),
     ("fwd_rnn_u100_L40_b3_it2_ft3", dict(decoder="TurboAE_rate3_rnn", block_len=40, num_iteration=2, num_iter_ft=3), 3, 15, 1.0, 1.0),
