@@ -46,6 +46,8 @@ CASES = [
     ("edge_L37_u64", dict(enc_num_unit=64, dec_num_unit=64, block_len=37, num_iteration=2), 9, 42, 1.0, 2.0),      # odd length: 8 blocks per workgroup + 1
     ("edge_L320_u100", dict(block_len=320, num_iteration=2, dec_num_layer=3), 2, 43, 1.0, 2.0),              # the longest block that still fits one workgroup
     ("edge_L321_u100", dict(block_len=321, num_iteration=2, dec_num_layer=3), 2, 44, 1.0, 2.0),              # one more: long-block path, two segments
+    # -is_interleave 0 (main.py:129-131, channel_ae.py:22-23): identity permutation, forward leaves it alone
+    ("var_no_interleaver", dict(enc_num_unit=64, dec_num_unit=64, num_iteration=3, block_len=48), 5, 45, 1.0, 2.0),
     # BASELINE configs[4]: DeepTurbo GRU decoder (DEC_LargeRNN) behind the CNN encoder
     ("fwd_rnn_u100_L100_b4", dict(decoder="TurboAE_rate3_rnn"), 4, 14, 1.0, 2.0),
     ("fwd_rnn_u100_L40_b3_it2_ft3", dict(decoder="TurboAE_rate3_rnn", block_len=40, num_iteration=2, num_iter_ft=3), 3, 15, 1.0, 1.0),
@@ -138,7 +140,8 @@ def run_case(name, over, B, wseed, gain, snr_db, manifest):
     cfg = TurboAEConfig(**over)
     sd = W.generate_state_dict(cfg, seed=wseed, gain=gain)
     u, noise = make_inputs(B, cfg.block_len, snr_db, seed=100 + wseed, channel=cfg.channel)
-    model, _ = R.build_reference_model(cfg.to_dict(), B)
+    no_int = name == "var_no_interleaver"
+    model, _ = R.build_reference_model(cfg.to_dict(), B, is_interleave=0 if no_int else 1)
     R.load_weights(model, sd)
     fading = None
     if cfg.channel == "fading":
@@ -152,7 +155,10 @@ def run_case(name, over, B, wseed, gain, snr_db, manifest):
     else:
         x_ref, c_ref = R.reference_forward(model, u, noise)
     taps, state = {}, {}
-    x_or, c_or = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict(), taps, state, fading)
+    ocfg = cfg.to_dict()
+    if no_int:
+        ocfg["p_array"] = np.arange(cfg.block_len)
+    x_or, c_or = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), ocfg, taps, state, fading)
     dx = float(np.abs(x_ref - x_or.numpy()).max())
     dc = float(np.abs(c_ref - c_or.numpy()).max())
     assert dc <= 2e-6 and dx <= 5e-6, (name, dc, dx)
@@ -176,7 +182,8 @@ def run_case(name, over, B, wseed, gain, snr_db, manifest):
                         logits=taps["logits"].numpy(), x_tx=taps["x_tx"].numpy(),
                         mean=taps["mean"].numpy(), std=taps["std"].numpy(), **extra)
     manifest["cases"][name] = {"config": cfg.to_dict(), "B": B, "weight_seed": wseed, "gain": gain, "snr_db": snr_db,
-                               "input_seed": 100 + wseed, "oracle_vs_reference_max_abs": {"x_dec": dx, "codes": dc},
+                               "input_seed": 100 + wseed, "is_interleave": 0 if no_int else 1,
+                               "oracle_vs_reference_max_abs": {"x_dec": dx, "codes": dc},
                                "ber_reference": O.errors_ber(torch.from_numpy(u), torch.from_numpy(x_ref))}
     print(f"{name}: oracle-vs-reference max|dx|={dx:.2e} max|dc|={dc:.2e}")
 

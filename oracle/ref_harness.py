@@ -38,7 +38,7 @@ def _import_reference():
         fractions.gcd = math.gcd        # commpy/channelcoding/gfields.py:8, algcode.py:6
 
 
-def build_reference_model(cfg: dict, batch_size: int, is_parallel: int = 1):
+def build_reference_model(cfg: dict, batch_size: int, is_parallel: int = 1, is_interleave: int = 1):
     """Channel_AE(ENC_interCNN, DEC_LargeCNN) built exactly as main.py:109-159 does."""
     _import_reference()
     enc_name = cfg.get("encoder", "TurboAE_rate3_cnn")
@@ -51,7 +51,7 @@ def build_reference_model(cfg: dict, batch_size: int, is_parallel: int = 1):
             "-num_iteration", str(cfg["num_iteration"]), "-num_iter_ft", str(cfg["num_iter_ft"]),
             "-extrinsic", str(cfg.get("extrinsic", 1)), "-enc_act", cfg.get("enc_act", "elu"), "-dec_act", cfg.get("dec_act", "linear"),
             "-enc_kernel_size", str(cfg.get("enc_kernel_size", 5)), "-dec_kernel_size", str(cfg.get("dec_kernel_size", 5)),
-            "-is_parallel", str(is_parallel), "-batch_size", str(batch_size),
+            "-is_parallel", str(is_parallel), "-is_interleave", str(is_interleave), "-batch_size", str(batch_size),
             "-block_len", str(cfg["block_len"]), "--no-cuda",
             "-channel", cfg.get("channel", "awgn"), "-train_channel_mode", cfg.get("train_channel_mode", "block_norm"),
             "-enc_truncate_limit", str(cfg.get("enc_truncate_limit", 0.0)),
@@ -77,7 +77,10 @@ def build_reference_model(cfg: dict, batch_size: int, is_parallel: int = 1):
     from numpy import arange
     from numpy.random import mtrand
     ENC, DEC = import_enc(args), import_dec(args)
-    p_array = mtrand.RandomState(0).permutation(arange(args.block_len))     # main.py:123-127
+    if is_interleave == 0:
+        p_array = range(args.block_len)                                     # main.py:129-131: no interleaver
+    else:
+        p_array = mtrand.RandomState(0).permutation(arange(args.block_len)) # main.py:123-127
     model = Channel_AE(args, ENC(args, p_array), DEC(args, p_array))
     if is_parallel:
         model.enc.set_parallel()

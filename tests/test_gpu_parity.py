@@ -97,7 +97,7 @@ def test_forward_matches_reference_golden(gpu_device, name):
     cfg = TurboAEConfig(**meta["config"])
     sd = W.generate_state_dict(cfg, seed=meta["weight_seed"], gain=meta["gain"])
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=meta["B"])
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=meta["B"], is_interleave=meta.get("is_interleave", 1))
     quantised = cfg.train_channel_mode == "block_norm_ste"
     fading = torch.from_numpy(g["fading"]).to(gpu_device) if "fading" in g.files else None
     xd, codes = model(torch.from_numpy(g["u"]).to(gpu_device), torch.from_numpy(g["noise"]).to(gpu_device), fading)

@@ -26,7 +26,10 @@ def test_oracle_matches_reference_fixture(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     taps, state = {}, {}
     fading = torch.from_numpy(g["fading"]) if "fading" in g.files else None
-    x, c = O.channel_ae_forward(torch.from_numpy(g["u"]), torch.from_numpy(g["noise"]), O.to_torch(sd), cfg.to_dict(), taps, state, fading)
+    ocfg = cfg.to_dict()
+    if meta.get("is_interleave", 1) == 0:          # -is_interleave 0: the identity permutation (main.py:129-131)
+        ocfg["p_array"] = np.arange(cfg.block_len)
+    x, c = O.channel_ae_forward(torch.from_numpy(g["u"]), torch.from_numpy(g["noise"]), O.to_torch(sd), ocfg, taps, state, fading)
     # the reference itself is not bit-deterministic across thread counts: <= 5e-7 / 6e-8
     assert np.abs(c.numpy() - g["codes"]).max() <= 2e-6
     assert np.abs(x.numpy() - g["x_dec"]).max() <= 5e-6
