@@ -14,7 +14,9 @@
  *    the reference's own layouts: u (B,L,1), noise / codes / received (B,L,3), x_dec (B,L,1);
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream); all calls are asynchronous
  *    on it, allocate nothing and never synchronise, so a caller may capture them in a hipGraph;
- *  - a handle is single-owner (not thread-safe), bound to the device current at tae_create;
+ *  - a handle is single-owner (not thread-safe), bound to the device current at tae_create: one handle per GPU, and
+ *    every call that touches the device returns TAE_ESTATE unless that device is the calling thread's current one
+ *    (a process driving several GPUs does hipSetDevice first; nothing is ever launched on foreign pointers);
  *  - every function returns 0 on success or a negative TAE_E* code; tae_last_error() gives the
  *    message for the calling thread.  Shape mismatches are rejected, never silently re-viewed
  *    (the reference hard-codes args.batch_size views, decoders.py:221).

@@ -625,3 +625,24 @@ def test_eval_sweep_positional_outputs(gpu_device):
         bler_p += (err.sum(axis=1) > 0).mean() / 3
     assert abs(res["ber_punc"][0] - ber_p) <= 1e-12 and abs(res["bler_punc"][0] - bler_p) <= 1e-12
     assert 0.0 < res["ber_punc"][0] < res["ber"][0] * 2.0
+
+
+def test_handle_is_bound_to_its_device(gpu_device):
+    """A handle's calls are refused (TAE_ESTATE, nothing launched) while another device is current; Channel_AE_HIP makes its own
+    device current around every call, so it works from any current device.  Needs two GPUs for the refusal half."""
+    import ctypes as C
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(enc_num_unit=32, dec_num_unit=32, num_iteration=2, block_len=40)
+    sd = W.generate_state_dict(cfg, seed=3)
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4)
+    u, noise = model.generate_inputs(4, 1.0, seed=9)
+    want, _ = model(u, noise)
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU: the refusal needs a second device to be current")
+    other = (gpu_device.index or 0) ^ 1
+    with torch.cuda.device(other):
+        got, _ = model(u, noise)                     # the mirror switches to the handle's device itself
+        assert torch.equal(got, want)
+        e = model._engine_for(cfg.block_len)
+        rc = e.lib.tae_decode(e.h, C.c_void_p(u.data_ptr()), C.c_void_p(u.data_ptr()), 4, None)
+        assert rc == -4 and b"current device" in e.lib.tae_last_error()      # TAE_ESTATE

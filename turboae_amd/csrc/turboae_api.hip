@@ -863,8 +863,21 @@ int tail_geometry(const tae_handle* h, int32_t B, int nb, tae::FusedParams* P) {
     return n_full + (rest + best - 1) / best;
 }
 
-int check_batch(tae_handle* h, int32_t B) {
+// A handle's weights, workspace and kernel launches live on the device that was current at tae_create: a call made with another
+// current device would launch there on foreign pointers (a fault, or silent peer traffic over xGMI).  One handle per GPU; a process
+// that drives several GPUs makes the handle's device current before calling (hipSetDevice / torch.cuda.device).
+int check_handle(tae_handle* h) {
     if (!h) return fail(TAE_EINVAL, "handle is NULL");
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != h->device)
+        return fail(TAE_ESTATE, "handle belongs to device " + std::to_string(h->device) + " but the calling thread's current device is " +
+                                    std::to_string(cur) + " (make the handle's device current first)");
+    return TAE_OK;
+}
+
+int check_batch(tae_handle* h, int32_t B) {
+    const int rc = check_handle(h);
+    if (rc != TAE_OK) return rc;
     if (B < 1) return fail(TAE_EINVAL, "batch must be >= 1");
     if (B > h->cap) return fail(TAE_ESTATE, "batch exceeds reserved workspace; call tae_reserve first");
     return TAE_OK;
@@ -1409,7 +1422,7 @@ int tae_destroy(tae_handle* h) {
 }
 
 int tae_reserve(tae_handle* h, int32_t max_batch) {
-    if (!h) return fail(TAE_EINVAL, "handle is NULL");
+    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
     if (max_batch < 1) return fail(TAE_EINVAL, "max_batch must be >= 1");
     if (max_batch <= h->cap) return TAE_OK;
     TAE_HIP(hipDeviceSynchronize());
@@ -1457,6 +1470,7 @@ int tae_reserve(tae_handle* h, int32_t max_batch) {
 
 int tae_set_interleaver(tae_handle* h, const int32_t* p, int32_t L) {
     if (!h || !p) return fail(TAE_EINVAL, "NULL argument");
+    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
     if (L != h->cfg.block_len) return fail(TAE_EINVAL, "interleaver length must equal block_len");
     std::vector<int32_t> inv(L, -1);
     for (int i = 0; i < L; ++i) {
@@ -1548,6 +1562,7 @@ int tae_forward(tae_handle* h, const float* u, const float* noise, float* x_dec,
 int tae_eval_snr(tae_handle* h, float snr_db, int32_t batch, int32_t n_batches, int64_t first_block, uint64_t seed_bits,
                  uint64_t seed_noise, uint64_t* counts, void* stream) {
     if (!h || !counts) return fail(TAE_EINVAL, "NULL argument");
+    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
     if (batch < 1 || n_batches < 1 || first_block < 0) return fail(TAE_EINVAL, "bad batch geometry");
     if (h->nopts.channel != 0) return fail(TAE_EINVAL, "tae_eval_snr generates AWGN inputs: the configured channel must be additive (channel = 0)");
     hipStream_t st = (hipStream_t)stream;
@@ -1591,6 +1606,7 @@ int tae_eval_snr(tae_handle* h, float snr_db, int32_t batch, int32_t n_batches, 
 
 int tae_count_errors(tae_handle* h, const float* x_dec, const float* u, int32_t B, uint64_t* counts2, void* stream) {
     if (!h || !x_dec || !u || !counts2) return fail(TAE_EINVAL, "NULL argument");
+    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
     if (B < 1) return fail(TAE_EINVAL, "batch must be >= 1");
     TAE_HIP(tae::launch_count_errors(x_dec, u, B, h->cfg.block_len, (unsigned long long*)counts2, (hipStream_t)stream));
     return TAE_OK;
@@ -1598,7 +1614,7 @@ int tae_count_errors(tae_handle* h, const float* x_dec, const float* u, int32_t 
 
 int tae_generate_inputs(tae_handle* h, float* u, float* noise, int32_t B, int64_t first_block, uint64_t seed_bits,
                         uint64_t seed_noise, float snr_db, void* stream) {
-    if (!h) return fail(TAE_EINVAL, "handle is NULL");
+    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
     if (B < 1 || first_block < 0) return fail(TAE_EINVAL, "bad block range");
     if (!u && !noise) return fail(TAE_EINVAL, "nothing to write");
     const float sigma = (float)pow(10.0, -(double)snr_db / 20.0);   // utils.py:69-70
@@ -1625,7 +1641,7 @@ int tae_debug_split_f16(const float* x, size_t n, float scale, uint16_t* hi, uin
 }
 
 int tae_range_status(tae_handle* h, int32_t* precision, int32_t* overflow) {
-    if (!h) return fail(TAE_EINVAL, "handle is NULL");
+    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
     if (precision) *precision = h->prec;
     if (overflow) {
         uint32_t f = 0;
