@@ -4,9 +4,9 @@ parity bound?  DESIGN.md section 7 names it as the one lever left for the decode
 the reference-trained enc2/dec5 model of tests/golden, every 5-tap Conv1d replaced by F(m,5) evaluated in fp32 (transforms and the
 per-point channel contractions in fp32, like an fp32-grade kernel would), against a float64 evaluation of the direct form.
 
-    python tools/winograd_numerics_probe.py [blocks]
+    python tests/probes/winograd_numerics_probe.py [blocks]
 
-Uses the oracle as the network definition (a tool, not the product path)."""
+Uses the oracle as the network definition; lives under tests/ because only test infrastructure may import oracle/."""
 import os
 import sys
 
@@ -14,11 +14,12 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 from oracle import turboae_oracle as O                                   # noqa: E402
 from turboae_amd import TurboAEConfig, philox, weights as W             # noqa: E402
 
-GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def cook_toom(m, r, points):
