@@ -131,3 +131,77 @@ def test_configs4_gru_decoder_16384_blocks(gpu_device):
     counts = model.count_errors(x_dec, u).cpu().tolist()
     err = (x_dec > 0.5) != (u > 0.5)
     assert counts == [int(err.sum()), int(err.any(dim=1).sum())]
+
+
+def test_configs1_twelve_point_ber_sweep(gpu_device):
+    """BASELINE configs[1] as it is quoted: the BER sweep -1.5 .. 4 dB in 12 points with 50 000-block batches, reference-trained
+    network, through evaluate.test (trainer.test restated) in both arithmetics, eager and as one hipGraph per SNR point.
+      * the sweep's error counts equal a forward + count of the same Philox blocks made by hand (per point, exactly);
+      * the fp16-split and the fp32-MFMA sweeps differ by a handful of decisions out of 5e6 per point;
+      * an ORACLE SUBSAMPLE per point (blocks strided over the batch; batch statistics from the full-size run) has the GPU's
+        hard decisions;
+      * BER falls monotonically and sits at the reference-measured values of this network where the fixture has them.
+    TAE_SWEEP_OUT=<file>: also write the table (profiles/r02_sweep_cfg1.json comes from this)."""
+    import json
+    import time
+    from dataclasses import replace
+    from turboae_amd import Channel_AE_HIP, evaluate
+    from turboae_amd.distributed import mean_std_from_stats
+    cfg, sd = TurboAEConfig(), _trained_sd()
+    B, L, SEED, NP = 50000, 100, 20190928, 12
+    sweep = dict(snr_test_start=-1.5, snr_test_end=4.0, snr_points=NP, num_block=B, batch_size=B, seed=SEED, verbose=False,
+                 enc_power_epilogue=False)
+    res, secs = {}, {}
+    for name, prec, graph in (("f16x2", "auto", False), ("f16x2_hipgraph", "auto", True), ("f32", "f32", False)):
+        model = Channel_AE_HIP(replace(cfg, precision=prec), sd, device=gpu_device, max_batch=B)
+        evaluate.test(model, **{**sweep, "snr_points": 1, "snr_test_end": -1.5}, hip_graph=graph)      # warm-up (workspace, graph pools)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res[name] = evaluate.test(model, **sweep, hip_graph=graph)
+        torch.cuda.synchronize()
+        secs[name] = time.perf_counter() - t0
+        model.check_range()
+    a, g, f = res["f16x2"], res["f16x2_hipgraph"], res["f32"]
+    assert g["bit_errors"] == a["bit_errors"] and g["block_errors"] == a["block_errors"]
+    gaps = [abs(x - y) for x, y in zip(a["bit_errors"], f["bit_errors"])]
+    assert max(gaps) <= 8, gaps                                             # of 5e6 decisions per point
+    assert all(x > y for x, y in zip(a["ber"], a["ber"][1:])), a["ber"]
+    with open(os.path.join(GOLD, "MANIFEST.json")) as fh:
+        ref = json.load(fh)["trained_fp32"]["ber"]
+    for snr, key in ((2.0, "2dB"), (4.0, "4dB")):                           # the reference's own BER of this network (2e5 bits each)
+        mine = a["ber"][a["snrs"].index(snr)]
+        assert abs(mine - ref[key]) <= 5.0 * (ref[key] * 20.0 / 2e5) ** 0.5, (snr, mine, ref[key])      # ~20 errors per bad block
+    # by hand + oracle subsample, point by point
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    w, p = O.to_torch(sd), torch.from_numpy(O.rand_interleaver(L, 0))
+    idx = torch.from_numpy(np.unique(np.concatenate([np.linspace(0, B - 1, 160).astype(np.int64), [1, B - 2]])))
+    flips, worst = [], 0.0
+    for si, snr in enumerate(a["snrs"]):
+        u, noise = model.generate_inputs(B, snr, seed=SEED, first_block=si * B)
+        x_tx, stats = model.encode_prenorm(u)
+        _, rx = model.normalize(x_tx, stats, noise, want_codes=False)
+        x_dec = model.dec(rx)
+        assert model.count_errors(x_dec, u).cpu().tolist() == [a["bit_errors"][si], a["block_errors"][si]], snr
+        mean, std = mean_std_from_stats(stats)
+        ti = idx.to(gpu_device)
+        with torch.no_grad():
+            xo = O.encode_prenorm(u[ti].cpu(), w, p, cfg.enc_num_layer)
+            rxo = (xo - np.float32(mean)) / np.float32(std) + noise[ti].cpu()
+            xd_o = O.decode(rxo, w, p, cfg.dec_num_layer, cfg.num_iteration, cfg.num_iter_ft)
+        worst = max(worst, float((x_dec[ti].cpu() - xd_o).abs().max()))
+        flips.append(int(((x_dec[ti].cpu() > 0.5) != (xd_o > 0.5)).sum()))
+    assert worst <= 2e-5 and sum(flips) == 0, (worst, flips)
+    out = os.environ.get("TAE_SWEEP_OUT")
+    if out:
+        bits = float(NP) * B * L
+        table = {"workload": "BASELINE configs[1]: enc2/dec5 reference-trained (tests/golden/trained_enc2dec5_u100_fp32.npz), block_len 100, "
+                             "12 SNR points -1.5 .. 4 dB, one 50 000-block batch per point, evaluate.test (device Philox inputs, seed %d)" % SEED,
+                 "snr_db": a["snrs"],
+                 "f16x2": {k: a[k] for k in ("ber", "bler", "bit_errors", "block_errors")},
+                 "f32": {k: f[k] for k in ("ber", "bler", "bit_errors", "block_errors")},
+                 "bit_error_count_gap_f16x2_vs_f32": gaps,
+                 "oracle_subsample": {"blocks_per_point": int(idx.numel()), "decision_flips_per_point": flips, "max_abs_x_dec": worst},
+                 "sweep_seconds": secs, "info_bits_per_second": {k: bits / v for k, v in secs.items()},
+                 "reference_ber_of_this_network": ref, "device": torch.cuda.get_device_name(0)}
+        with open(out, "w") as fh:
+            json.dump(table, fh, indent=1)
