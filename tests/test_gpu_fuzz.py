@@ -115,16 +115,19 @@ def test_random_shape_variants_match_oracle(gpu_device, case):
     u = philox.random_bits(wseed, 0, B * L).reshape(B, L, 1)
     noise = (np.float32(O.snr_db2sigma(1.0)) * philox.random_normal(wseed, 0, B * L * 3)).reshape(B, L, 3).astype(np.float32)
     ut, nt = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
-    xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict())
+    taps = {}
+    xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict(), taps)
     xo, co = xo.numpy(), co.numpy()
     if not (np.isfinite(xo).all() and np.isfinite(co).all()):
         pytest.skip("degenerate draw: constant encoder output, the power constraint divides by 0")
+    # as above: an encoder output that barely varies (relu / sigmoid of a random GRU: std 2e-3 has been drawn) is divided by its std
+    amplify = max(1.0, 0.25 / float(taps["std"]))
     for prec in (("auto",) if kind == "dense" else ("auto", "f32")):      # dense stacks exist in f16x2 only
         model = Channel_AE_HIP(TurboAEConfig(precision=prec, **case), sd, device=gpu_device, max_batch=B)
         xd, codes = model(ut, nt)
         model.check_range()
         xd, codes = xd.cpu().numpy(), codes.cpu().numpy()
         assert np.isfinite(xd).all() and np.isfinite(codes).all(), prec
-        tol_c, tol_x = (2e-5, 6e-5) if B * L >= 8 else (2e-4, 2e-4)       # GRU recurrences: the golden-vector tests' x_dec tolerance
+        tol_c, tol_x = (2e-5 * amplify, 6e-5 * amplify) if B * L >= 8 else (2e-4 * amplify, 2e-4 * amplify)   # GRU recurrences: the golden-vector tests' x_dec tolerance
         assert np.abs(codes - co).max() <= tol_c, (prec, np.abs(codes - co).max())
         assert np.abs(xd - xo).max() <= tol_x, (prec, np.abs(xd - xo).max())
