@@ -1217,6 +1217,14 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(TAE_EHIP, "no HIP device available: libturboae_hip needs an AMD GPU (no CPU fallback)");
+    {   // the library carries gfx950 code objects only (MFMA shapes, 160 KB LDS per workgroup): say so instead of a launch error later
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return fail(TAE_EHIP, "cannot query the current HIP device");
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(TAE_EHIP, std::string("libturboae_hip is built for gfx950 (MI355X) only; the current device is ") + prop.gcnArchName);
+    }
     std::vector<float> w5;
     tae_config cfg5 = *cfg;
     if (needs_embedding(cfg)) {          // narrower stacks / kernel sizes 1, 3: run, exactly, in the next instantiated geometry
