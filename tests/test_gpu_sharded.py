@@ -95,6 +95,34 @@ def test_bench_runs_with_two_ranks(gpu_device):
     assert "cpu_baseline" not in res and res["roofline"]["frac"] > 0
 
 
+def test_bench_runs_with_eight_ranks_strong_and_ragged(gpu_device):
+    """The driver's widest launch shape - 8 ranks - on this box's one GPU (gloo hook): a global batch that does not divide by 8
+    (--strong 4003 -> shards of 500 / 501 blocks) decodes to the same BER as ONE process decoding the same 4003 blocks, and the
+    line's throughput is the global block count over the max-over-ranks time."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = [os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4003", "--strong", "--no-f32-pass",
+              "--no-cpu-baseline", "--no-parity"]
+    env = dict(os.environ, TAE_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + common[:1] + ["--gpus", "8"] + common[1:]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["scaling"] == "strong" and res["config"]["global_blocks"] == 4003
+    assert abs(res["value"] - 4003 * 100 / (res["ms_per_step"] * 1e-3)) <= 1e-3 * res["value"]
+    one = subprocess.run([sys.executable] + common[:1] + ["--gpus", "1"] + common[1:], capture_output=True, text=True, timeout=600, cwd=root,
+                         env={k: v for k, v in os.environ.items() if k not in ("TAE_BENCH_BACKEND", "TAE_BENCH_FORCE_DIST")})
+    assert one.returncode == 0, one.stderr[-2000:]
+    ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert ref["config"]["global_blocks"] == 4003
+    assert res["ber"] == ref["ber"] and res["bler"] == ref["bler"]          # same blocks, same global statistics, whatever the sharding
+
+
 def test_bench_rccl_backend_at_world_size_1(gpu_device):
     """The RCCL ("nccl") branch of bench.py - process-group init bound to the device, stats all-reduce per step, barrier,
     max-over-ranks and error-count all-reduces - executed for real under torch.distributed.run (TAE_BENCH_FORCE_DIST=1 keeps the
