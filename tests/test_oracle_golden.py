@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import turboae_oracle as O
-from turboae_amd import TurboAEConfig, weights as W, rand_interleaver
+from turboae_amd import TurboAEConfig, philox, weights as W, rand_interleaver
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 with open(os.path.join(GOLD, "MANIFEST.json")) as fh:
@@ -153,3 +153,57 @@ def test_oracle_matches_reference_on_full_precision_trained_weights():
                 ref_prior = O.deinterleave(torch.from_numpy(g["dec_taps_first4"][2 * it + 1]), p)
                 assert float((ref_prior - taps[f"prior_{it}"][:4]).abs().max()) <= 5e-6
     assert meta["ber"]["6dB"] < 0.1 * meta["ber"]["2dB"]
+
+
+# ---- randomised pin: oracle == REAL reference on the configuration space the GPU fuzz walks (oracle/fuzz_vs_reference.py)
+with open(os.path.join(GOLD, "oracle_fuzz_vs_reference.json")) as _fh:
+    FUZZ_REF = json.load(_fh)
+
+
+def test_recorded_random_configurations_matched_the_reference():
+    cases = FUZZ_REF["cases"]
+    assert len(cases) >= 90
+    live = [c for c in cases if not c["degenerate"]]
+    assert len(live) >= 0.8 * len(cases)
+    for c in cases:
+        if c["degenerate"]:
+            assert c["same_nonfinite_pattern"], c["config"]        # std = 0: the reference and the oracle produce the same non-finite outputs
+            continue
+        assert c["max_abs_codes"] <= 3e-6 * c["amplify"] and c["max_abs_x_dec"] <= 2e-6 * c["amplify"], c
+        assert c["decision_flips"] == 0, c
+    # the draw really covered the space
+    cfgs = [c["config"] for c in cases]
+    assert {k for c in cfgs for k in (c.get("enc_kernel_size", 5), c.get("dec_kernel_size", 5))} == {1, 3, 5, 7, 9}
+    assert {c.get("enc_act", "elu") for c in cfgs} == {"elu", "linear", "tanh", "relu", "selu", "sigmoid"}
+    assert {"TurboAE_rate3_rnn", "TurboAE_rate3_cnn_dense"} <= {c.get("decoder", "TurboAE_rate3_cnn") for c in cfgs}
+    assert any(c.get("encoder") == "TurboAE_rate3_rnn" for c in cfgs)
+    assert min(c["block_len"] for c in cfgs) == 1 and max(c["block_len"] for c in cfgs) > 320
+    assert any(c.get("extrinsic") == 0 for c in cfgs) and {c["num_iter_ft"] for c in cfgs} == {1, 2, 3, 4, 5, 6}
+
+
+def _digest(a):
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    sign = 1.0 - 2.0 * philox.random_bits(424242, 0, a.size).astype(np.float64)
+    return float(a.sum()), float((a * sign).sum()), float(np.abs(a).max())
+
+
+_SMALL = [c for c in FUZZ_REF["cases"] if not c["degenerate"] and c["bits"] <= 3000][:40]
+
+
+@pytest.mark.parametrize("case", _SMALL, ids=lambda c: "L{}_B{}_w{}".format(c["config"]["block_len"], c["B"], c["weight_seed"]))
+def test_oracle_reproduces_the_reference_digest_of_a_random_configuration(case):
+    """Re-run, without the reference: same generated weights, same Philox inputs; the oracle's outputs must land on the three-number
+    digest (sum, +-1 projection, max |.|) the reference's outputs had in the build container."""
+    torch.set_num_threads(4)
+    cfg = TurboAEConfig(**case["config"])
+    B, L, wseed = case["B"], cfg.block_len, case["weight_seed"]
+    sd = W.generate_state_dict(cfg, seed=wseed, gain=1.0)
+    u = philox.random_bits(wseed, 0, B * L).reshape(B, L, 1)
+    noise = (np.float32(O.snr_db2sigma(1.0)) * philox.random_normal(wseed, 0, B * L * 3)).reshape(B, L, 3).astype(np.float32)
+    x, c = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict())
+    for name, got, tol in (("x_dec", x.numpy(), 2e-6), ("codes", c.numpy(), 3e-6)):
+        ref = case["reference_digest"][name]
+        s, pr, mx = _digest(got)
+        n, e = ref["n"], tol * case["amplify"]
+        assert got.size == n
+        assert abs(s - ref["sum"]) <= n * e and abs(pr - ref["proj"]) <= n * e and abs(mx - ref["max_abs"]) <= e + 1e-6 * ref["max_abs"], (name, s, pr, mx, ref)
