@@ -11,7 +11,9 @@ pin is the reference itself imported in the build container: ``oracle/make_golde
 real ``Channel_AE`` (``oracle/ref_harness.py``) and this restatement on identical weights/inputs,
 asserts equality (<= 2e-6) and commits the reference's outputs as fixtures under
 ``tests/golden/``; ``tests/test_oracle_golden.py`` re-checks this module against those fixtures
-everywhere (no reference needed).
+everywhere (no reference needed).  ``oracle/fuzz_vs_reference.py`` adds a randomised pin: 90 random
+configurations from the GPU fuzz's own generators, reference vs this module <= 2.5e-6, with digests of
+the reference's outputs re-checked by the same test file.
 
 The arithmetic lives in PyTorch ATen (oneDNN conv / elu / addmm / std), a third-party dependency of
 the reference (README.md:16 "PyTorch 1.0", no lockfile); semantics restated here are the
