@@ -5,7 +5,9 @@
 The golden vectors (oracle/make_golden.py) pin the oracle on hand-picked configurations.  This script draws the SAME kind of random
 configurations that tests/test_gpu_fuzz.py later runs through the HIP kernels (widths 1..100 chosen independently for encoder and
 decoder, 1-5 layers, kernel sizes 1 / 3 / 5 / 7 / 9, block lengths 1..420 clustered at the tile / workgroup / long-block edges,
-num_iter_ft 1..6, 1-3 iterations, extrinsic on / off, every enc_act; GRU decoder, GRU encoder and dense stacks with every dec_act),
+num_iter_ft 1..6, 1-3 iterations, extrinsic on / off, every enc_act; GRU decoder, GRU encoder and dense stacks with every dec_act;
+and 40 random combinations of the encoder-output / channel options: block_norm_ste levels, truncation, --no_code_norm, every channel
+branch of channel_ae.py:40-69, --rec_quantize),
 builds the reference's own Channel_AE for each (oracle/ref_harness.py: the reference's argument parser, module classes and
 forward), loads the same generated weights with strict=True and compares the reference's forward with the oracle's on the same
 Philox inputs.  Only the summary travels (configuration, deviations and a three-number digest of the reference's outputs per case: data, no
@@ -78,6 +80,39 @@ def run(case):
     return rec
 
 
+def run_channel(fz, case):
+    """A random combination of encoder-output / channel options: the quantisers make the forward discontinuous, so a code symbol
+    within fp32 noise of a threshold may take the neighbouring level in one of the two implementations; such symbols are counted,
+    and x_dec is compared on the blocks whose codes agree."""
+    cfg, sd, B, u, noise, fading = fz.channel_case_inputs(case)
+    model, _ = R.build_reference_model(cfg.to_dict(), B)
+    R.load_weights(model, sd)
+    ft = None
+    if cfg.channel == "fading":      # the reference draws the coefficients itself (channel_ae.py:51-56): reproduce its two randn draws
+        torch.manual_seed(case["wseed"])
+        a, b = torch.randn(noise.shape), torch.randn(noise.shape)
+        ft = (torch.sqrt(a ** 2 + b ** 2) / torch.sqrt(torch.tensor(3.14 / 2.0))).type(torch.FloatTensor)
+        torch.manual_seed(case["wseed"])     # the reference's forward now makes the same two draws
+    x_ref, c_ref = R.reference_forward(model, u, noise)
+    taps = {}
+    x_or, c_or = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict(), taps, {}, ft)
+    x_or, c_or = x_or.numpy(), c_or.numpy()
+    rec = {"config": {k: v for k, v in case.items() if k not in ("B", "wseed")}, "B": B, "weight_seed": case["wseed"]}
+    if not (np.isfinite(x_ref).all() and np.isfinite(c_ref).all()):
+        rec["degenerate"] = True
+        rec["same_nonfinite_pattern"] = bool((np.isfinite(x_ref) == np.isfinite(x_or)).all() and (np.isfinite(c_ref) == np.isfinite(c_or)).all())
+        return rec
+    amplify = 1.0 if cfg.no_code_norm else max(1.0, 0.25 / float(taps["std"]))
+    bad_c = np.abs(c_ref - c_or) > 3e-6 * amplify
+    blocks_c = bad_c.reshape(B, -1).any(axis=1)
+    bad_x = (np.abs(x_ref - x_or) > 5e-6 * amplify).reshape(B, -1).any(axis=1)
+    rec.update(degenerate=False, amplify=amplify, code_symbols=int(bad_c.size), code_symbols_off=int(bad_c.sum()),
+               blocks_with_code_mismatch=int(blocks_c.sum()), blocks_with_x_dec_mismatch=int(bad_x.sum()),
+               x_dec_mismatch_outside_those_blocks=int((bad_x & ~blocks_c).sum()),
+               max_abs_x_dec_on_agreeing_blocks=float(np.abs(x_ref - x_or).reshape(B, -1)[~blocks_c].max()) if (~blocks_c).any() else 0.0)
+    return rec
+
+
 def main():
     n_cnn = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     n_var = int(sys.argv[2]) if len(sys.argv) > 2 else 30
@@ -98,6 +133,12 @@ def main():
         else:
             print(f"{i:3d} degenerate (std = 0), same non-finite pattern: {rec['same_nonfinite_pattern']} {rec['config']}")
     out["worst_over_amplify"] = worst
+    out["channel_cases"] = []
+    for i, c in enumerate(fz.draw_channel_cases(40, seed + 2)):
+        rec = run_channel(fz, c)
+        out["channel_cases"].append(rec)
+        print(f"ch {i:2d}", {k: v for k, v in rec.items() if k not in ("config",)}, rec["config"]["channel"], rec["config"]["train_channel_mode"],
+              "recq" if rec["config"]["rec_quantize"] else "")
     with open(os.path.join(GOLD, "oracle_fuzz_vs_reference.json"), "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
     print("worst (divided by the 1/std amplification):", worst)

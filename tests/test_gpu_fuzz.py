@@ -131,3 +131,79 @@ def test_random_shape_variants_match_oracle(gpu_device, case):
         tol_c, tol_x = (2e-5 * amplify, 6e-5 * amplify) if B * L >= 8 else (2e-4 * amplify, 2e-4 * amplify)   # GRU recurrences: the golden-vector tests' x_dec tolerance
         assert np.abs(codes - co).max() <= tol_c, (prec, np.abs(codes - co).max())
         assert np.abs(xd - xo).max() <= tol_x, (prec, np.abs(xd - xo).max())
+
+
+def draw_channel_cases(n, seed):
+    """Random combinations of the encoder-output / channel options (power_constraint variants encoders.py:102-125, channel
+    branches channel_ae.py:40-69) on small CNN networks."""
+    rng = np.random.RandomState(seed)
+    cases = []
+    for i in range(n):
+        U = int(rng.choice([32, 64, 100]))
+        c = dict(block_len=int(rng.choice([16, 40, 64, 100, 101])), enc_num_unit=U, dec_num_unit=U, enc_num_layer=int(rng.randint(1, 3)),
+                 dec_num_layer=int(rng.randint(1, 4)), num_iteration=int(rng.randint(1, 3)), num_iter_ft=int(rng.randint(1, 6)),
+                 train_channel_mode=str(rng.choice(["block_norm", "block_norm_ste", "block_norm_ste"])),
+                 enc_value_limit=float(rng.choice([1.0, 1.5])), enc_quantize_level=float(rng.choice([2.0, 4.0, 8.0])),
+                 enc_truncate_limit=float(rng.choice([0.0, 0.0, 1.2, 2.0])), no_code_norm=bool(rng.rand() < 0.15),
+                 channel=str(rng.choice(["awgn", "bec", "bsc", "fading", "t-dist", "ge_awgn", "radar", "ge"])),
+                 rec_quantize=bool(rng.rand() < 0.4), rec_quantize_level=int(rng.choice([2, 4])),
+                 B=int(rng.choice([1, 3, 8, 17])), wseed=int(rng.randint(1, 1 << 30)))
+        cases.append(c)
+    return cases
+
+
+def channel_case_inputs(case):
+    """(cfg, state_dict, u, noise, fading) of a channel case - shared with oracle/fuzz_vs_reference.py."""
+    case = dict(case)
+    B, wseed = case.pop("B"), case.pop("wseed")
+    cfg = TurboAEConfig(**case)
+    L = cfg.block_len
+    sd = W.generate_state_dict(cfg, seed=wseed, gain=1.0)
+    u = philox.random_bits(wseed, 0, B * L).reshape(B, L, 1)
+    if cfg.channel in ("bec", "bsc", "ge"):       # 0 / 1 keep masks (channels.py:48-54), erase / flip probability 0.1
+        w = philox.random_u32(wseed, philox.STREAM_NOISE, 0, B * L * 3).astype(np.float64) / 2.0 ** 32
+        noise = (w >= 0.1).astype(np.float32).reshape(B, L, 3)
+    else:
+        noise = (np.float32(O.snr_db2sigma(1.0)) * philox.random_normal(wseed, 0, B * L * 3)).reshape(B, L, 3).astype(np.float32)
+    fading = None
+    if cfg.channel == "fading":
+        a, b = philox.random_normal(wseed + 1, 0, B * L * 3), philox.random_normal(wseed + 2, 0, B * L * 3)
+        fading = (np.sqrt(a.astype(np.float64) ** 2 + b.astype(np.float64) ** 2) / np.sqrt(3.14 / 2.0)).astype(np.float32).reshape(B, L, 3)
+    return cfg, sd, B, u, noise, fading
+
+
+CHANNEL_CASES = draw_channel_cases(int(os.environ.get("TAE_FUZZ_CASES", "24")), int(os.environ.get("TAE_FUZZ_SEED", "55021")))
+
+
+@pytest.mark.parametrize("case", CHANNEL_CASES, ids=lambda c: "{channel}_{train_channel_mode}_q{enc_quantize_level}_t{enc_truncate_limit}_rq{rec_quantize}_L{block_len}_B{B}".format(**c))
+def test_random_channel_options_match_oracle_stage_by_stage(gpu_device, case):
+    """Quantisers make the forward discontinuous, so the stages are checked one at a time, each fed with the GPU's own previous
+    stage: encoder output; power constraint + quantiser + truncation; channel + receive quantiser; decoder."""
+    from turboae_amd import Channel_AE_HIP
+    cfg, sd, B, u, noise, fading = channel_case_inputs(case)
+    dev = gpu_device
+    w = O.to_torch(sd)
+    p = torch.from_numpy(O.rand_interleaver(cfg.block_len, 0))
+    model = Channel_AE_HIP(cfg, sd, device=dev, max_batch=B)
+    ut, nt = torch.from_numpy(u).to(dev), torch.from_numpy(noise).to(dev)
+    ft = None if fading is None else torch.from_numpy(fading).to(dev)
+    x_tx, stats = model.encode_prenorm(ut)
+    codes, rx = model.normalize(x_tx, stats, nt, fading=ft)
+    x_dec = model.dec(rx)
+    xd_fused, codes_fused = model(ut, nt, ft)
+    assert torch.equal(codes_fused, codes) and torch.equal(xd_fused, x_dec)              # fused call == split calls
+    model.check_range()
+    with torch.no_grad():
+        xo = O.encode_prenorm(torch.from_numpy(u), w, p, cfg.enc_num_layer, cfg.enc_act)
+        if float(xo.std()) == 0.0 and not cfg.no_code_norm:
+            pytest.skip("degenerate draw: constant encoder output")
+        assert float((x_tx.cpu() - xo).abs().max()) <= 1e-5
+        co, _, std = O.power_constraint(x_tx.cpu(), cfg.to_dict(), {})
+        amplify = 1.0 if cfg.no_code_norm else max(1.0, 0.25 / float(std))
+        bad = (codes.cpu() - co).abs() > 1e-5 * amplify
+        assert float(bad.float().mean()) <= 2e-3, float(bad.float().mean())            # a value on a quantiser threshold may take the other level
+        ro = O.apply_channel(codes.cpu(), torch.from_numpy(noise), cfg.to_dict(), None if fading is None else torch.from_numpy(fading))
+        bad = (rx.cpu() - ro).abs() > 1e-5
+        assert float(bad.float().mean()) <= (2e-3 if cfg.rec_quantize else 0.0)
+        xd_o = O.decode(rx.cpu(), w, p, cfg.dec_num_layer, cfg.num_iteration, cfg.num_iter_ft)
+    assert float((x_dec.cpu() - xd_o).abs().max()) <= 2e-5

@@ -181,6 +181,23 @@ def test_recorded_random_configurations_matched_the_reference():
     assert any(c.get("extrinsic") == 0 for c in cfgs) and {c["num_iter_ft"] for c in cfgs} == {1, 2, 3, 4, 5, 6}
 
 
+def test_recorded_random_channel_option_combinations_matched_the_reference():
+    """40 random combinations of block_norm_ste levels / truncation / --no_code_norm / channel branch / --rec_quantize: a code symbol
+    on a quantiser threshold may differ (counted); wherever a block's codes agree its decoder output must."""
+    cases = FUZZ_REF["channel_cases"]
+    assert len(cases) >= 40
+    for c in cases:
+        if c["degenerate"]:
+            assert c["same_nonfinite_pattern"]
+            continue
+        assert c["code_symbols_off"] <= 2e-3 * c["code_symbols"] + 1e-9, c
+        assert c["x_dec_mismatch_outside_those_blocks"] == 0 and c["max_abs_x_dec_on_agreeing_blocks"] <= 5e-6 * c["amplify"], c
+    cfgs = [c["config"] for c in cases]
+    assert {c["channel"] for c in cfgs} == {"awgn", "bec", "bsc", "fading", "t-dist", "ge_awgn", "radar", "ge"}
+    assert any(c["rec_quantize"] for c in cfgs) and any(c["no_code_norm"] for c in cfgs) and any(c["enc_truncate_limit"] > 0 for c in cfgs)
+    assert {c["enc_quantize_level"] for c in cfgs if c["train_channel_mode"] == "block_norm_ste"} == {2.0, 4.0, 8.0}
+
+
 def _digest(a):
     a = np.asarray(a, dtype=np.float64).reshape(-1)
     sign = 1.0 - 2.0 * philox.random_bits(424242, 0, a.size).astype(np.float64)
