@@ -36,8 +36,9 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def _fuzz_module():
-    """the case generators of the GPU fuzz test (so both fuzzers walk the same configuration space)"""
-    spec = importlib.util.spec_from_file_location("_tae_gpu_fuzz", os.path.join(ROOT, "tests", "test_gpu_fuzz.py"))
+    """the case generators shared with the GPU fuzz test (tests/_fuzz_cases.py: a helper, not a test file), so both fuzzers
+    walk the same configuration space"""
+    spec = importlib.util.spec_from_file_location("_tae_fuzz_cases", os.path.join(ROOT, "tests", "_fuzz_cases.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod

@@ -49,7 +49,8 @@ def deinterleave(x: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
 
 # cnn_utils.py:36-46 (SameShapeConv1d.forward; ctor :6-34): x (B,L,C) -> transpose -> for each layer
 # ELU(conv1d(pad=k//2)) -> transpose back.  ELU on every layer, alpha=1.
-DENSE = {"on": False}      # set by channel_ae_forward from cfg["encoder"] (the reference keys encoder AND decoder stacks on it)
+# The reference keys encoder AND decoder stacks on args.encoder == 'TurboAE_rate3_cnn_dense' (encoders.py:312-330,
+# decoders.py:173-176): every function below takes that as an explicit ``dense`` argument - this module holds NO state.
 
 
 # cnn_utils.py:49-82 (DenseSameShapeConv1d): layer l convolves cat(inputs, out_0 .. out_{l-1}); the stack returns out_{n-1}
@@ -64,8 +65,9 @@ def dense_same_shape_conv1d(x: torch.Tensor, w: Dict[str, torch.Tensor], prefix:
     return out.transpose(1, 2)
 
 
-def same_shape_conv1d(x: torch.Tensor, w: Dict[str, torch.Tensor], prefix: str, num_layer: int) -> torch.Tensor:
-    if DENSE["on"]:
+def same_shape_conv1d(x: torch.Tensor, w: Dict[str, torch.Tensor], prefix: str, num_layer: int,
+                      dense: bool = False) -> torch.Tensor:
+    if dense:
         return dense_same_shape_conv1d(x, w, prefix, num_layer)
     h = x.transpose(1, 2)
     for l in range(num_layer):
@@ -142,13 +144,13 @@ def _enc_act(x: torch.Tensor, enc_act: str) -> torch.Tensor:
 
 # encoders.py:351-377 (ENC_interCNN.forward), non-Dense branch.
 def encode_prenorm(u: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor, enc_num_layer: int,
-                   enc_act: str = "elu") -> torch.Tensor:
+                   enc_act: str = "elu", dense: bool = False) -> torch.Tensor:
     s = 2.0 * u - 1.0
-    b1 = _enc_act(F.linear(same_shape_conv1d(s, w, "enc.enc_cnn_1", enc_num_layer),
+    b1 = _enc_act(F.linear(same_shape_conv1d(s, w, "enc.enc_cnn_1", enc_num_layer, dense),
                            w["enc.enc_linear_1.weight"], w["enc.enc_linear_1.bias"]), enc_act)
-    b2 = _enc_act(F.linear(same_shape_conv1d(s, w, "enc.enc_cnn_2", enc_num_layer),
+    b2 = _enc_act(F.linear(same_shape_conv1d(s, w, "enc.enc_cnn_2", enc_num_layer, dense),
                            w["enc.enc_linear_2.weight"], w["enc.enc_linear_2.bias"]), enc_act)
-    b3 = _enc_act(F.linear(same_shape_conv1d(interleave(s, p), w, "enc.enc_cnn_3", enc_num_layer),
+    b3 = _enc_act(F.linear(same_shape_conv1d(interleave(s, p), w, "enc.enc_cnn_3", enc_num_layer, dense),
                            w["enc.enc_linear_3.weight"], w["enc.enc_linear_3.bias"]), enc_act)
     return torch.cat([b1, b2, b3], dim=2)
 
@@ -162,15 +164,15 @@ def encode_prenorm_rnn(u: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Ten
     return torch.cat([branch(u, 1), branch(u, 2), branch(interleave(u, p), 3)], dim=2)
 
 
-def encode(u, w, p, enc_num_layer, enc_act="elu", cfg=None, state=None):
-    codes, _, _ = power_constraint(encode_prenorm(u, w, p, enc_num_layer, enc_act), cfg, state)
+def encode(u, w, p, enc_num_layer, enc_act="elu", cfg=None, state=None, dense=False):
+    codes, _, _ = power_constraint(encode_prenorm(u, w, p, enc_num_layer, enc_act, dense), cfg, state)
     return codes
 
 
 # decoders.py:206-269 (DEC_LargeCNN.forward), extrinsic per decoders.py:235-236,246-247.
 def decode(received: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor, dec_num_layer: int,
            num_iteration: int, num_iter_ft: int, extrinsic: int = 1,
-           taps: Optional[dict] = None) -> torch.Tensor:
+           taps: Optional[dict] = None, dense: bool = False) -> torch.Tensor:
     B, L, _ = received.shape
     r_sys = received[:, :, 0:1]
     r_sys_int = interleave(r_sys, p)
@@ -178,12 +180,12 @@ def decode(received: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor, 
     r_par2 = received[:, :, 2:3]
     prior = torch.zeros((B, L, num_iter_ft), dtype=received.dtype)
     for it in range(num_iteration - 1):
-        h = same_shape_conv1d(torch.cat([r_sys, r_par1, prior], dim=2), w, f"dec.dec1_cnns.{it}", dec_num_layer)
+        h = same_shape_conv1d(torch.cat([r_sys, r_par1, prior], dim=2), w, f"dec.dec1_cnns.{it}", dec_num_layer, dense)
         x_plr = F.linear(h, w[f"dec.dec1_outputs.{it}.weight"], w[f"dec.dec1_outputs.{it}.bias"])
         if extrinsic:
             x_plr = x_plr - prior
         x_plr_int = interleave(x_plr, p)
-        h = same_shape_conv1d(torch.cat([r_sys_int, r_par2, x_plr_int], dim=2), w, f"dec.dec2_cnns.{it}", dec_num_layer)
+        h = same_shape_conv1d(torch.cat([r_sys_int, r_par2, x_plr_int], dim=2), w, f"dec.dec2_cnns.{it}", dec_num_layer, dense)
         x_plr = F.linear(h, w[f"dec.dec2_outputs.{it}.weight"], w[f"dec.dec2_outputs.{it}.bias"])
         if extrinsic:
             x_plr = x_plr - x_plr_int
@@ -191,12 +193,12 @@ def decode(received: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor, 
         if taps is not None:
             taps[f"prior_{it}"] = prior.clone()
     it = num_iteration - 1
-    h = same_shape_conv1d(torch.cat([r_sys, r_par1, prior], dim=2), w, f"dec.dec1_cnns.{it}", dec_num_layer)
+    h = same_shape_conv1d(torch.cat([r_sys, r_par1, prior], dim=2), w, f"dec.dec1_cnns.{it}", dec_num_layer, dense)
     x_plr = F.linear(h, w[f"dec.dec1_outputs.{it}.weight"], w[f"dec.dec1_outputs.{it}.bias"])
     if extrinsic:
         x_plr = x_plr - prior
     x_plr_int = interleave(x_plr, p)
-    h = same_shape_conv1d(torch.cat([r_sys_int, r_par2, x_plr_int], dim=2), w, f"dec.dec2_cnns.{it}", dec_num_layer)
+    h = same_shape_conv1d(torch.cat([r_sys_int, r_par2, x_plr_int], dim=2), w, f"dec.dec2_cnns.{it}", dec_num_layer, dense)
     logit_int = F.linear(h, w[f"dec.dec2_outputs.{it}.weight"], w[f"dec.dec2_outputs.{it}.bias"])
     logits = deinterleave(logit_int, p)
     if taps is not None:
@@ -249,13 +251,20 @@ def decode_rnn(received: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tens
     return torch.sigmoid(logits)
 
 
+# encoders.py:312-330, decoders.py:173-176: DenseSameShapeConv1d replaces SameShapeConv1d in BOTH halves when the
+# encoder name says so.  Accepts a cfg dict or anything with an ``encoder`` attribute (turboae_amd.config.TurboAEConfig).
+def is_dense(cfg) -> bool:
+    enc = cfg.get("encoder", "TurboAE_rate3_cnn") if isinstance(cfg, dict) else getattr(cfg, "encoder", "TurboAE_rate3_cnn")
+    return enc == "TurboAE_rate3_cnn_dense"
+
+
 # channel_ae.py:20-73 (Channel_AE.forward), AWGN branch (:41-42), rec_quantize off.
 def channel_ae_forward(u: torch.Tensor, fwd_noise: torch.Tensor, w: Dict[str, torch.Tensor], cfg: dict,
                        taps: Optional[dict] = None, state: Optional[dict] = None,
                        fading: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """cfg keys: block_len, enc_num_layer, dec_num_layer, num_iteration, num_iter_ft, extrinsic, enc_act (+ the
     variant flags of power_constraint / apply_channel).  `state` = running norm statistics across calls."""
-    DENSE["on"] = cfg.get("encoder", "TurboAE_rate3_cnn") == "TurboAE_rate3_cnn_dense"     # encoders.py:312-330, decoders.py:173-176
+    dense = is_dense(cfg)
     with torch.no_grad():
         if cfg.get("p_array") is not None:      # enc/dec.set_interleaver(p) (channel_ae.py:35-36)
             p = torch.from_numpy(np.asarray(cfg["p_array"], dtype=np.int64))
@@ -264,7 +273,7 @@ def channel_ae_forward(u: torch.Tensor, fwd_noise: torch.Tensor, w: Dict[str, to
         if cfg.get("encoder", "TurboAE_rate3_cnn") == "TurboAE_rate3_rnn":
             x_tx = encode_prenorm_rnn(u, w, p, cfg["enc_num_unit"], cfg.get("enc_act", "elu"))
         else:
-            x_tx = encode_prenorm(u, w, p, cfg["enc_num_layer"], cfg.get("enc_act", "elu"))
+            x_tx = encode_prenorm(u, w, p, cfg["enc_num_layer"], cfg.get("enc_act", "elu"), dense)
         codes, mean, std = power_constraint(x_tx, cfg, state if state is not None else {})
         received = apply_channel(codes, fwd_noise, cfg, fading)
         if cfg.get("decoder", "TurboAE_rate3_cnn") == "TurboAE_rate3_rnn":
@@ -272,7 +281,7 @@ def channel_ae_forward(u: torch.Tensor, fwd_noise: torch.Tensor, w: Dict[str, to
                                cfg.get("extrinsic", 1), taps, cfg.get("dec_act", "linear"))
         else:
             x_dec = decode(received, w, p, cfg["dec_num_layer"], cfg["num_iteration"], cfg["num_iter_ft"],
-                           cfg.get("extrinsic", 1), taps)
+                           cfg.get("extrinsic", 1), taps, dense)
         if taps is not None:
             taps["x_tx"] = x_tx.clone()
             taps["mean"] = mean.clone()

@@ -1,0 +1,97 @@
+"""Case generators shared by the GPU fuzz (tests/test_gpu_fuzz.py) and the build-container pin of the oracle against the real
+reference (oracle/fuzz_vs_reference.py), so that both walk the same configuration space.  No tests live here: editing a test file
+cannot change what the pin script draws."""
+import numpy as np
+
+from turboae_amd import TurboAEConfig, philox, weights as W
+
+
+def _sigma(snr_db):           # utils.py:69-70 (snr_db2sigma), restated to keep this helper free of oracle imports
+    return 10 ** (-snr_db * 1.0 / 20)
+
+
+EDGE_LENS = [1, 2, 3, 4, 5, 7, 15, 16, 17, 31, 32, 33, 48, 63, 79, 80, 81, 99, 101, 106, 107, 159, 160, 161,
+             318, 319, 320, 321, 322, 323, 400]
+
+
+def draw_cases(n, seed):
+    rng = np.random.RandomState(seed)
+    cases = []
+    for i in range(n):
+        widths = [32, 64, 100, 100, int(rng.randint(1, 101))]                 # any width up to 100 (narrow ones run embedded)
+        U = int(rng.choice(widths))
+        Ud = U if rng.rand() < 0.5 else int(rng.choice(widths))               # encoder and decoder widths are independent
+        L = int(rng.choice(EDGE_LENS)) if rng.rand() < 0.6 else int(rng.randint(1, 420))
+        nb_guess = max(1, 320 // L)
+        B = int(rng.choice([1, 2, nb_guess, nb_guess + 1, 2 * nb_guess + 1, int(rng.randint(1, 48))]))
+        cases.append(dict(block_len=L, enc_num_unit=U, dec_num_unit=Ud, enc_num_layer=int(rng.randint(1, 6)),
+                          dec_num_layer=int(rng.randint(1, 6)), num_iter_ft=int(rng.randint(1, 7)),
+                          num_iteration=int(rng.randint(1, 4)), extrinsic=int(rng.randint(0, 2)),
+                          enc_kernel_size=int(rng.choice([5, 5, 3, 1, 7, 9])), dec_kernel_size=int(rng.choice([5, 5, 3, 1, 7, 9])),
+                          enc_act=str(rng.choice(["elu", "linear", "elu", "tanh", "relu", "selu", "sigmoid"])), B=B, fixed_nb=str(int(rng.randint(0, 2))), wseed=int(rng.randint(1, 1 << 30))))
+    return cases
+
+
+def draw_variant_cases(n, seed):
+    """GRU decoder (CNN or GRU encoder) and DenseSameShapeConv1d stacks: fixed widths, random lengths / batches."""
+    rng = np.random.RandomState(seed)
+    cases = []
+    for i in range(n):
+        kind = ["dec_rnn", "enc_rnn", "dense"][i % 3]
+        L = int(rng.choice([1, 2, 5, 15, 16, 17, 33, 64, 100, 127])) if rng.rand() < 0.6 else int(rng.randint(1, 140))
+        B = int(rng.choice([1, 2, 15, 16, 17, 31, 33, int(rng.randint(1, 70))]))
+        c = dict(block_len=L, num_iter_ft=int(rng.randint(1, 7)), num_iteration=int(rng.randint(1, 3)), extrinsic=int(rng.randint(0, 2)),
+                 B=B, wseed=int(rng.randint(1, 1 << 30)), kind=kind)
+        acts = ["linear", "elu", "tanh", "relu", "selu", "sigmoid"]
+        if kind == "dec_rnn":
+            c.update(decoder="TurboAE_rate3_rnn", enc_num_layer=int(rng.randint(1, 4)), dec_act=str(rng.choice(acts)),
+                     enc_num_unit=int(rng.choice([32, 64, 100, int(rng.randint(1, 101))])),
+                     dec_num_unit=int(rng.choice([100, 100, int(rng.randint(1, 101))])))       # GRU widths below 100 run embedded
+        elif kind == "enc_rnn":
+            c.update(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_act=str(rng.choice(acts)), dec_act=str(rng.choice(acts)),
+                     enc_num_unit=int(rng.choice([100, int(rng.randint(1, 101))])), dec_num_unit=int(rng.choice([100, int(rng.randint(1, 101))])))
+        else:
+            U = int(rng.choice([32, 64]))
+            c.update(encoder="TurboAE_rate3_cnn_dense", decoder="TurboAE_rate3_cnn_dense", enc_num_unit=U, dec_num_unit=int(rng.choice([32, 64])),
+                     enc_num_layer=int(rng.randint(1, 4)), dec_num_layer=int(rng.randint(1, 4)))
+        cases.append(c)
+    return cases
+
+
+def draw_channel_cases(n, seed):
+    """Random combinations of the encoder-output / channel options (power_constraint variants encoders.py:102-125, channel
+    branches channel_ae.py:40-69) on small CNN networks."""
+    rng = np.random.RandomState(seed)
+    cases = []
+    for i in range(n):
+        U = int(rng.choice([32, 64, 100]))
+        c = dict(block_len=int(rng.choice([16, 40, 64, 100, 101])), enc_num_unit=U, dec_num_unit=U, enc_num_layer=int(rng.randint(1, 3)),
+                 dec_num_layer=int(rng.randint(1, 4)), num_iteration=int(rng.randint(1, 3)), num_iter_ft=int(rng.randint(1, 6)),
+                 train_channel_mode=str(rng.choice(["block_norm", "block_norm_ste", "block_norm_ste"])),
+                 enc_value_limit=float(rng.choice([1.0, 1.5])), enc_quantize_level=float(rng.choice([2.0, 4.0, 8.0])),
+                 enc_truncate_limit=float(rng.choice([0.0, 0.0, 1.2, 2.0])), no_code_norm=bool(rng.rand() < 0.15),
+                 channel=str(rng.choice(["awgn", "bec", "bsc", "fading", "t-dist", "ge_awgn", "radar", "ge"])),
+                 rec_quantize=bool(rng.rand() < 0.4), rec_quantize_level=int(rng.choice([2, 4])),
+                 B=int(rng.choice([1, 3, 8, 17])), wseed=int(rng.randint(1, 1 << 30)))
+        cases.append(c)
+    return cases
+
+
+def channel_case_inputs(case):
+    """(cfg, state_dict, u, noise, fading) of a channel case - shared with oracle/fuzz_vs_reference.py."""
+    case = dict(case)
+    B, wseed = case.pop("B"), case.pop("wseed")
+    cfg = TurboAEConfig(**case)
+    L = cfg.block_len
+    sd = W.generate_state_dict(cfg, seed=wseed, gain=1.0)
+    u = philox.random_bits(wseed, 0, B * L).reshape(B, L, 1)
+    if cfg.channel in ("bec", "bsc", "ge"):       # 0 / 1 keep masks (channels.py:48-54), erase / flip probability 0.1
+        w = philox.random_u32(wseed, philox.STREAM_NOISE, 0, B * L * 3).astype(np.float64) / 2.0 ** 32
+        noise = (w >= 0.1).astype(np.float32).reshape(B, L, 3)
+    else:
+        noise = (np.float32(_sigma(1.0)) * philox.random_normal(wseed, 0, B * L * 3)).reshape(B, L, 3).astype(np.float32)
+    fading = None
+    if cfg.channel == "fading":
+        a, b = philox.random_normal(wseed + 1, 0, B * L * 3), philox.random_normal(wseed + 2, 0, B * L * 3)
+        fading = (np.sqrt(a.astype(np.float64) ** 2 + b.astype(np.float64) ** 2) / np.sqrt(3.14 / 2.0)).astype(np.float32).reshape(B, L, 3)
+    return cfg, sd, B, u, noise, fading
