@@ -25,6 +25,11 @@ Prints ONE JSON line on rank 0 (see the driver contract in the task statement) i
                   fp32 operands: the reference's own arithmetic) against the fp32-MFMA peak
   parity        - "BER match": GPU (both arithmetics) vs the CPU oracle on the FIRST 500 BLOCKS OF THE SAME
                   Philox stream, same weights: BER of each, decision flips, max |codes| / |x_dec| deviation
+                  + roofline.sustained_probe_tflops / frac_of_sustained: what a pure v_mfma_f32_16x16x32_f16 stream sustains on
+                  THIS device on N(0,1) operands, measured by the library (tae_probe_mfma_f16, ~150 ms) right before the timed
+                  pass, and the decoder's executed f16 MFMA rate as a fraction of it (the spec-peak `frac` stays the headline)
+                  + roofline.other_configs: BASELINE configs[2], [3] (per-GPU shape), [0] (B = 500) and [4] (GRU decoder), each
+                  timed here with HIP events (median of 5 forwards) with its decoder's roofline fraction
   cpu_baseline  - oracle/turboae_oracle.py (PyTorch-CPU restatement of the reference path) timed on
                   the host cores of this box (rank 0, N=1 only): thread sweep, best + 1-thread figures
 """
@@ -163,6 +168,93 @@ def cpu_baseline_and_parity(cfg: TurboAEConfig, sd, u500: np.ndarray, noise500: 
     return out, x_cpu.numpy(), c_cpu.numpy()
 
 
+def mfma_sustained_probe(min_ms: int = 150):
+    """TFLOP/s a pure f16 MFMA stream sustains on the current device on non-zero data (library probe)."""
+    import ctypes as C
+    from turboae_amd import _lib
+    lib = _lib.load()
+    tf, ms = C.c_double(), C.c_double()
+    _lib.check(lib.tae_probe_mfma_f16(0, int(min_ms), C.byref(tf), C.byref(ms)))
+    return float(tf.value), float(ms.value)
+
+
+def time_other_config(name: str, cfg: TurboAEConfig, sd, B: int, dev, snr: float, weights: str, runs: int = 5):
+    """One of the other BASELINE configs: `runs` forwards (after 2 warm-ups) of encoder -> power constraint + AWGN -> decoder ->
+    error count on B resident blocks, HIP events around the forward and around the decoder; medians."""
+    model = Channel_AE_HIP(cfg, sd, device=dev, max_batch=B)
+    u, noise = model.generate_inputs(B, snr, seed=SEED)
+    counts = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def fwd(ev=None):
+        if ev:
+            ev[0].record()
+        x_tx, stats = model.encode_prenorm(u)
+        _, rx = model.normalize(x_tx, stats, noise, want_codes=False)
+        if ev:
+            ev[1].record()
+        x_dec = model.dec(rx)
+        if ev:
+            ev[2].record()
+        model.count_errors(x_dec, u, counts)
+        if ev:
+            ev[3].record()
+
+    for _ in range(2):
+        fwd()
+    counts.zero_()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(runs)]
+    for e in evs:
+        fwd(e)
+    torch.cuda.synchronize()
+    mode, overflow = model.range_status()
+    if overflow:
+        raise SystemExit(f"{name}: activation range overflow reported by the fp16-split kernels")
+    L = cfg.block_len
+    fwd_ms = float(np.median([e[0].elapsed_time(e[3]) for e in evs]))
+    dec_ms = float(np.median([e[1].elapsed_time(e[2]) for e in evs]))
+    enc_ms = float(np.median([e[0].elapsed_time(e[1]) for e in evs]))
+    macs = cfg.macs_per_bit()
+    is_h2 = mode == "f16x2"
+    peak = PEAK_F16_MFMA_TFLOPS / F16X2_PRODUCTS if is_h2 else PEAK_FP32_MFMA_TFLOPS
+    dec_tf = 2.0 * macs["dec"] * B * L / (dec_ms * 1e-3) / 1e12
+    enc_tf = 2.0 * macs["enc"] * B * L / (enc_ms * 1e-3) / 1e12
+    nb, lds = model.kernel_info()
+    if cfg.decoder == "TurboAE_rate3_rnn":
+        kern = ("gru_rec_h / gru_proj_h / gru_head" if is_h2 else "gru_rec / gru_proj / gru_head") + f" x {2 * cfg.num_iteration} stacks (GRU decoder)"
+    elif nb == 0:
+        kern = ("tae::seg_kernel_h<100,5>" if is_h2 else "tae::seg_kernel<100,5>") + f" x {2 * cfg.num_iteration} launches (long-block decoder)"
+    else:
+        kern = "tae::dec_kernel_h<100,5>" if is_h2 else "tae::dec_kernel<100,5>"
+    out = {"config": name, "blocks": B, "block_len": L, "weights": weights, "arithmetic": mode, "ms_per_forward": fwd_ms,
+           "bits_per_s": B * L / (fwd_ms * 1e-3), "dominant_kernel": kern, "decoder_ms": dec_ms, "decoder_tflops": dec_tf,
+           "decoder_frac": dec_tf / peak, "encoder_plus_norm_ms": enc_ms, "encoder_frac": enc_tf / peak, "peak": peak,
+           "ber": int(counts[0].item()) / (float(B) * L * runs), "blocks_per_workgroup": nb}
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+def other_configs(dev, snr: float, sd_trained):
+    """BASELINE.json configs[2], [3] (its per-GPU shape), [0] (B = 500) and [4] (GRU decoder at one full wave of recurrent
+    workgroups).  The enc2/dec5 shapes run the reference-trained network; enc5/dec5 and the GRU decoder have no trained fixture
+    (random-init weights, so their BER is not an operating point)."""
+    res = []
+    c2 = TurboAEConfig(enc_num_layer=5)
+    res.append(time_other_config("configs[2]: enc5/dec5, block_len=100, batch=100000", c2, W.generate_state_dict(c2, seed=SEED, gain=1.0),
+                                 100000, dev, snr, "random-init"))
+    c3 = TurboAEConfig(block_len=1000)
+    sd3, w3 = (sd_trained, "trained") if sd_trained is not None else (W.generate_state_dict(c3, seed=SEED, gain=1.0), "random-init")
+    res.append(time_other_config("configs[3] per-GPU shape: enc2/dec5, block_len=1000, batch=25000 (200000 over 8 GPUs)", c3, sd3,
+                                 25000, dev, snr, w3))
+    c0 = TurboAEConfig()
+    sd0, w0 = (sd_trained, "trained") if sd_trained is not None else (W.generate_state_dict(c0, seed=SEED, gain=1.0), "random-init")
+    res.append(time_other_config("configs[0] shape: enc2/dec5, block_len=100, batch=500", c0, sd0, 500, dev, snr, w0, runs=9))
+    c4 = TurboAEConfig(decoder="TurboAE_rate3_rnn")
+    res.append(time_other_config("configs[4]: TurboAE_rate3_rnn (GRU decoder), block_len=100, batch=16384", c4,
+                                 W.generate_state_dict(c4, seed=SEED, gain=1.0), 16384, dev, snr, "random-init"))
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +269,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (cpu_baseline and the CPU side of parity)")
     ap.add_argument("--no-f32-pass", action="store_true", help="skip the second timed pass in precision='f32'")
     ap.add_argument("--no-parity", action="store_true", help="skip the 500-block BER-match sample (profiling runs: only full-size launches)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the timings of BASELINE configs[0], [2], [3], [4] (roofline.other_configs)")
+    ap.add_argument("--no-probe", action="store_true", help="skip the sustained-MFMA probe (roofline.sustained_probe_tflops)")
     ap.add_argument("--cpu-budget", type=float, default=75.0, help="wall-time bound of the CPU leg in seconds")
     ap.add_argument("--precision", choices=("auto", "f32"), default="auto",
                     help="auto: fp16-split MFMA contraction (fp32-grade, DESIGN.md 3.7); f32: v_mfma_f32_16x16x4_f32")
@@ -271,15 +365,25 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        per_rank = [elapsed]
+        ranks_seen = 1
         if dist is not None:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(counts)                               # final RCCL reduce of the error counts
+            # diagnostics for the first real multi-GPU run: every rank's own clock (a straggler shows as one large entry, a
+            # collective stall as all entries large) and the number of ranks the collectives actually reached
+            gathered = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(gathered, torch.tensor([elapsed], dtype=torch.float64, device=dev))
+            per_rank = [float(t.item()) for t in gathered]
+            ones = torch.ones(1, dtype=torch.int64, device=dev)
+            dist.all_reduce(ones)
+            ranks_seen = int(ones.item())
         mode, overflow = model.range_status()
         if overflow:
             raise SystemExit("activation range overflow reported by the fp16-split kernels: results invalid")
         dec = [e[1].elapsed_time(e[2]) for e in ev]
         stepms = [e[0].elapsed_time(e[3]) for e in ev]
-        res = {"elapsed": float(tmax.item()), "dec_ms": float(np.mean(dec)), "dec_ms_median": float(np.median(dec)), "dec_ms_min": float(np.min(dec)),
+        res = {"per_rank_elapsed": per_rank, "ranks_seen": ranks_seen, "elapsed": float(tmax.item()), "dec_ms": float(np.mean(dec)), "dec_ms_median": float(np.median(dec)), "dec_ms_min": float(np.min(dec)),
                "step_ms_median": float(np.median(stepms)), "step_ms_min": float(np.min(stepms)), "gen_ms": g0.elapsed_time(g1),
                "counts": [int(counts[0].item()), int(counts[1].item())], "mode": mode, "kernel_info": model.kernel_info()}
         # "BER match" sample: the first PARITY_BLOCKS blocks of the same Philox stream as ONE batch of their own (the power
@@ -292,6 +396,12 @@ def main():
             par = {"u": up.cpu().numpy(), "noise": npar.cpu().numpy(), "x_dec": xd.cpu().numpy(), "codes": codes.cpu().numpy()}
         return res, par
 
+    probe = None
+    if rank == 0 and not args.no_probe:
+        torch.cuda.synchronize()
+        probe = mfma_sustained_probe(150)              # same device, right before the timed pass
+    if dist is not None:
+        dist.barrier()
     main_res, main_par = timed_pass(args.precision)
     f32_res = f32_par = None
     if args.precision == "auto" and not args.no_f32_pass and main_res["mode"] == "f16x2":
@@ -355,6 +465,20 @@ def main():
             "input_generation_ms_excluded": main_res["gen_ms"],
             "roofline": roofline(main_res, f16x2),
         }
+        pr = [t / steps * 1e3 for t in main_res["per_rank_elapsed"]]
+        out["config"]["rccl_ranks_seen"] = main_res["ranks_seen"]
+        out["config"]["per_rank_ms_per_step"] = {"min": min(pr), "max": max(pr), "all": [round(t, 3) for t in pr]}
+        out["config"]["collective_backend"] = (backend if dist is not None else None)
+        if probe is not None:
+            rf = out["roofline"]
+            rf["sustained_probe_tflops"] = probe[0]
+            rf["sustained_probe"] = (f"tae_probe_mfma_f16: pure v_mfma_f32_16x16x32_f16 stream, N(0,1) fp16 operands refreshed from LDS, one 8-wave "
+                                     f"workgroup per CU, {probe[1]:.0f} ms on this device right before the timed pass (spec peak {PEAK_F16_MFMA_TFLOPS:.0f})")
+            rf["sustained_over_spec"] = probe[0] / PEAK_F16_MFMA_TFLOPS
+            if f16x2:
+                rf["frac_of_sustained"] = rf["mfma_tflops_executed"] / probe[0]
+        if world == 1 and not args.no_other_configs and L == 100 and cfg.enc_num_layer == 2:
+            out["roofline"]["other_configs"] = other_configs(dev, args.snr, sd if trained else None)
         if f32_res is not None:
             r32 = roofline(f32_res, False)
             r32["value_bits_per_s"] = bits_total / f32_res["elapsed"]

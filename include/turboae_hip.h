@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TAE_ABI_VERSION 8
+#define TAE_ABI_VERSION 9
 
 #if defined(__GNUC__)
 #define TAE_API __attribute__((visibility("default")))
@@ -175,19 +175,59 @@ TAE_API int tae_count_errors(tae_handle* h, const float* x_dec, const float* u, 
 TAE_API int tae_generate_inputs(tae_handle* h, float* u, float* noise, int32_t B, int64_t first_block, uint64_t seed_bits,
                         uint64_t seed_noise, float snr_db, void* stream);
 
-/* Blocks per workgroup and dynamic LDS bytes of the fused kernels (for DESIGN / bench reporting). */
+/* Test-time channel noise of every channel of the reference on the device: replaces generate_noise(noise_shape, args, test_sigma=...)
+ * (channels.py:7-109, the test_sigma != 'default' branches trainer.test uses, trainer.py:167-169) and, for -channel fading, the
+ * Rayleigh coefficients Channel_AE.forward draws itself (channel_ae.py:51-56).  Counter-based: every value is a function of
+ * (seed, global element index ((first_block + b) * L + t) * 3 + c) on named Philox streams (turboae_amd/philox.py; the numpy mirror
+ * turboae_amd/channels.py::generate_noise_host reproduces the draws), so any shard of any batch can be drawn on any rank. */
+#define TAE_NOISE_AWGN 0      /* sigma * N(0,1)                                                     channels.py:37-38 (== tae_generate_inputs' noise) */
+#define TAE_NOISE_TDIST 1     /* sigma * sqrt((vv-2)/vv) * standard_t(vv)                           channels.py:40-41 */
+#define TAE_NOISE_RADAR 2     /* sigma * N(0,1) + radar_power * N(0,1) * Bernoulli(radar_prob)      channels.py:43-49 */
+#define TAE_NOISE_GE_AWGN 3   /* Gilbert-Elliott chain per (block, code symbol) along time: good state sigma(snr + 1 dB), bad state
+                                 sigma(snr - 1 dB), times N(0,1)                                    channels.py:58-82 */
+#define TAE_NOISE_BEC 4       /* keep mask: 0 with probability test_sigma, else 1                   channels.py:51-53 */
+#define TAE_NOISE_BSC 5       /* the same mask (applied as a sign flip by the channel)              channels.py:55-57 */
+#define TAE_NOISE_GE 6        /* the chain; good state: 1, bad state: 1 with probability test_sigma channels.py:84-107 */
+#define TAE_NOISE_FADING 7    /* noise = sigma * N(0,1), fading_h = sqrt(N^2 + N^2) / sqrt(3.14/2)  channels.py:37-38, channel_ae.py:53 */
+typedef struct tae_noise_opts {
+    int32_t struct_size;      /* = sizeof(tae_noise_opts) */
+    int32_t kind;             /* TAE_NOISE_* (-channel, get_args.py:43) */
+    float   vv;               /* -vv (get_args.py:53): t-dist degrees of freedom, > 2 */
+    float   radar_prob;       /* -radar_prob (get_args.py:55) */
+    float   radar_power;      /* -radar_power (get_args.py:56) */
+    float   p_gg, p_bb;       /* Gilbert-Elliott: P(next good | good), P(next GOOD | bad) - the reference hard-codes 0.8 / 0.8 and, as
+                                 written, returns to the good state with p_bb (channels.py:73,79,100,105) */
+} tae_noise_opts;
+/* test_sigma: SNR in dB for the additive kinds, erase / flip probability for BEC / BSC / GE (channels.py:28-31).  noise (device,
+ * B*L*3 floats); fading_h (device, B*L*3 floats) is written for TAE_NOISE_FADING only and may be NULL otherwise - pass
+ * fading_h = buf and noise = buf + B*L*3 to obtain the layout tae_channel_opts.channel = 3 consumes. */
+TAE_API int tae_generate_noise(tae_handle* h, const tae_noise_opts* opts, float test_sigma, float* noise, float* fading_h, int32_t B,
+                               int64_t first_block, uint64_t seed, void* stream);
+/* The generator tae_eval_snr draws its noise from (NULL: AWGN, the default); with a non-AWGN generator tae_eval_snr's `snr_db`
+ * argument is the test_sigma above, exactly as trainer.test hands its loop variable to generate_noise (trainer.py:160-169). */
+TAE_API int tae_set_noise_opts(tae_handle* h, const tae_noise_opts* opts);
+
 /* One SNR point of the reference's eval sweep (trainer.test, trainer.py:160-217; the entry point SURVEY.md section 8b sketches as
  * tae_eval_snr) entirely on the device: n_batches batches of `batch` blocks.  Batch i (global blocks first_block + i*batch ...) gets
  * the Philox inputs of tae_generate_inputs, runs encoder -> power constraint with ITS OWN statistics -> additive noise; the
  * received blocks of a group of batches (about 24 576 blocks) are decoded in one call - the decoder never mixes blocks - and
  * the errors are counted per batch: counts (device, 2*n_batches uint64, zeroed by the call) = (bit errors, block errors) of
  * batch i at [2i], [2i+1], so BER = mean_i counts[2i] / (batch * block_len) exactly as trainer.py:176-177,215-216 average it.
- * Needs an additive channel (tae_channel_opts.channel = 0).  The first call for a geometry grows the workspace (allocates,
+ * The noise comes from the generator installed with tae_set_noise_opts (default AWGN) and is applied by the channel of
+ * tae_set_channel_opts (additive, bec, bsc / ge sign flips, fading with device-drawn coefficients).  The first call for a geometry grows the workspace (allocates,
  * synchronises); after that the call only enqueues work on `stream`. */
 TAE_API int tae_eval_snr(tae_handle* h, float snr_db, int32_t batch, int32_t n_batches, int64_t first_block, uint64_t seed_bits,
                          uint64_t seed_noise, uint64_t* counts, void* stream);
 
+/* Blocks per workgroup and dynamic LDS bytes of the fused kernels (for DESIGN / bench reporting). */
 TAE_API int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_t* lds_bytes);
+
+/* Measurement support (no reference counterpart; needs no handle): the rate a pure stream of v_mfma_f32_16x16x32_f16 sustains on
+ * the current device for at least `min_ms` milliseconds - one 8-wave workgroup per CU (the decoder's residency), 16 independent
+ * accumulator tiles per wave, operands refreshed from LDS every iteration; N(0,1) fp16 operands, or all-zero ones with zero_data = 1
+ * (zeros clock higher: the limit on real data is power).  *tflops = dense f16 MFMA TFLOP/s executed.  bench.py reports the decoder
+ * against this next to the spec-peak fraction.  Allocates, launches on the null stream and SYNCHRONISES. */
+TAE_API int tae_probe_mfma_f16(int32_t zero_data, int32_t min_ms, double* tflops, double* ms_measured);
 
 /* Arithmetic actually in use (*precision = 0: fp32 MFMA, 1: fp16-split MFMA) and its sticky range flag:
  * *overflow = 1 if, since the last call, an activation exceeded the fp16 range (65504) in the fp16-split

@@ -1,4 +1,5 @@
-"""turboae_amd/channels.py (generate_noise restated, channels.py:7-109) against statistics of the REFERENCE's own
+"""turboae_amd/channels.py (the numpy mirror of the library's device generator tae_generate_noise = generate_noise restated,
+channels.py:7-109) against statistics of the REFERENCE's own
 generate_noise (tests/golden/channel_stats.json, written by oracle/make_channel_stats.py in the build container).
 
 The draws cannot be compared (the reference uses the unseeded global numpy / torch streams); the distributions can:
@@ -11,7 +12,6 @@ import os
 
 import numpy as np
 import pytest
-import torch
 
 from turboae_amd import TurboAEConfig, channels
 
@@ -20,17 +20,11 @@ with open(os.path.join(GOLD, "channel_stats.json")) as _fh:
     REF = json.load(_fh)["cases"]
 
 
-def _gen(seed=3):
-    g = torch.Generator()
-    g.manual_seed(seed)
-    return g
-
-
 def _draw(case, seed=3):
     cfg = TurboAEConfig(channel=case["channel"], **case["args"])
-    x = channels.generate_noise(tuple(case["shape"]), cfg, case["test_sigma"], generator=_gen(seed))
-    assert tuple(x.shape) == tuple(case["shape"]) and x.dtype == torch.float32
-    return x.double().numpy()
+    x = channels.generate_noise(tuple(case["shape"]), cfg, case["test_sigma"], seed=seed)
+    assert tuple(x.shape) == tuple(case["shape"]) and x.dtype == np.float32
+    return x.astype(np.float64)
 
 
 def _lag1(s):
@@ -83,14 +77,14 @@ def test_gilbert_elliott_chain_is_the_reference_chain():
     returns to good with 0.8; it does not stay bad with 0.8), so with 0.8 / 0.8 the state is good 80 % of the time,
     memoryless after the start.  The numbers asserted are the reference's (fixture), not this derivation."""
     shape = (400, 100, 3)
-    good = channels._markov_good_state(shape, 0.8, 0.8, _gen(), "cpu")
+    good = channels._good_states(shape[0], shape[1], 3, 0, 0.8, 0.8)
     assert bool(good[:, 0, :].all())                              # every chain starts good (channels.py:64,91)
     ref = REF["ge_0p0"]["stats"]                                  # p = 0: the mask IS the state sequence
-    assert float(good[:, 1:, :].float().mean()) == pytest.approx(ref["rest_mean"], abs=0.008)
-    assert _lag1(good.double().numpy()) == pytest.approx(ref["lag1"], abs=0.02)
+    assert float(good[:, 1:, :].mean()) == pytest.approx(ref["rest_mean"], abs=0.008)
+    assert _lag1(good.astype(np.float64)) == pytest.approx(ref["lag1"], abs=0.02)
     # asymmetric chain: stationary good fraction = p_bb' / (1 - p_gg + p_bb') with p_bb' = P(bad -> good)
-    g2 = channels._markov_good_state((400, 200, 3), 0.9, 0.3, _gen(5), "cpu")
-    assert float(g2[:, 50:, :].float().mean()) == pytest.approx(0.3 / (0.1 + 0.3), abs=0.01)
+    g2 = channels._good_states(400, 200, 5, 0, 0.9, 0.3)
+    assert float(g2[:, 50:, :].mean()) == pytest.approx(0.3 / (0.1 + 0.3), abs=0.01)
 
 
 def test_fixture_is_the_reference_not_a_derivation():
@@ -101,14 +95,37 @@ def test_fixture_is_the_reference_not_a_derivation():
 
 
 def test_rayleigh_fading_constant_of_the_reference():
-    h = channels.rayleigh_fading((400, 100, 3), generator=_gen())
-    assert float(h.min()) >= 0.0
+    h = channels.rayleigh_fading((400, 100, 3), seed=3)
+    assert h.dtype == np.float32 and float(h.min()) >= 0.0
     # E[sqrt(a^2 + b^2)] = sqrt(pi / 2); the reference divides by sqrt(3.14 / 2) (channel_ae.py:53)
     assert float(h.mean()) == pytest.approx(math.sqrt(math.pi / 2) / math.sqrt(3.14 / 2), rel=0.01)
 
 
-def test_generators_are_reproducible():
-    cfg = TurboAEConfig(channel="radar")
-    a = channels.generate_noise((4, 100, 3), cfg, 1.0, generator=_gen(9))
-    b = channels.generate_noise((4, 100, 3), cfg, 1.0, generator=_gen(9))
-    assert torch.equal(a, b)
+def test_generators_are_counter_based():
+    """any shard of any batch reproduces the single-stream draw (keyed by seed and GLOBAL block index), for every channel"""
+    for ch, sig in (("radar", 1.0), ("t-dist", 0.5), ("ge_awgn", 2.0), ("ge", 0.3), ("bec", 0.2), ("bsc", 0.1), ("awgn", 0.0), ("fading", 1.0)):
+        cfg = TurboAEConfig(channel=ch, block_len=37)
+        full = channels.generate_noise((9, 37, 3), cfg, sig, seed=9)
+        assert np.array_equal(full, channels.generate_noise((9, 37, 3), cfg, sig, seed=9))
+        assert np.array_equal(full[4:7], channels.generate_noise((3, 37, 3), cfg, sig, seed=9, first_block=4)), ch
+        assert not np.array_equal(full, channels.generate_noise((9, 37, 3), cfg, sig, seed=10))
+    h = channels.rayleigh_fading((9, 37, 3), seed=9)
+    assert np.array_equal(h[2:5], channels.rayleigh_fading((3, 37, 3), seed=9, first_block=2))
+
+
+def test_awgn_mirror_is_the_benchmark_noise_stream():
+    """channel='awgn' of the mirror == the Philox noise tae_generate_inputs draws (philox.random_normal x sigma)"""
+    from turboae_amd import philox
+    cfg = TurboAEConfig(block_len=20)
+    x = channels.generate_noise((5, 20, 3), cfg, 2.0, seed=11, first_block=3)
+    ref = np.float32(channels.snr_db2sigma(2.0)) * philox.random_normal(11, 3 * 20 * 3, 5 * 20 * 3)
+    assert np.array_equal(x.reshape(-1), ref.astype(np.float32))
+
+
+def test_chi_square_sampler_moments():
+    from turboae_amd import philox
+    for vv in (3.0, 5.0, 12.5):
+        x = philox.chi_square(4, 0, 400000, vv)
+        assert x.min() > 0.0
+        assert float(x.mean()) == pytest.approx(vv, rel=0.01)
+        assert float(x.var()) == pytest.approx(2.0 * vv, rel=0.03)

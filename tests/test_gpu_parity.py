@@ -414,9 +414,10 @@ def test_eval_sweep_matches_oracle_on_trained_weights(gpu_device, capsys):
 
 
 @pytest.mark.parametrize("channel,lo,hi,benign", [("bec", 0.0, 0.4, 0.02), ("radar", 6.0, -2.0, 0.05), ("fading", 8.0, 0.0, 0.02),
-                                                  ("ge_awgn", 6.0, -2.0, 0.02), ("t-dist", 6.0, -2.0, 0.02)])
+                                                  ("ge_awgn", 6.0, -2.0, 0.02), ("t-dist", 6.0, -2.0, 0.02), ("bsc", 0.0, 0.2, 0.02),
+                                                  ("ge", 0.9, 0.2, 0.02)])
 def test_eval_sweep_other_channels(gpu_device, channel, lo, hi, benign):
-    """The sweep on the reference's other channels (noise from turboae_amd/channels.py): the short-trained model must be
+    """The sweep on the reference's other channels (noise from the library's device generator, tae_generate_noise): the short-trained model must be
     near error-free at the benign end and clearly worse at the harsh end (`lo`, `hi` are SNR dB or the erase probability)."""
     from dataclasses import replace
     from turboae_amd import Channel_AE_HIP, evaluate
@@ -429,6 +430,14 @@ def test_eval_sweep_other_channels(gpu_device, channel, lo, hi, benign):
     assert res["ber"][0] < res["ber"][1]
     assert res["ber"][0] < benign and res["ber"][1] > benign      # (5 % power-25 impulses leave ~3 % errors even at 6 dB)
     model.check_range()
+    # the noise is drawn by a device kernel keyed by Philox counters: one hipGraph per SNR point returns the same counts ...
+    gr = evaluate.test(model, snr_test_start=lo, snr_test_end=hi, snr_points=2, num_block=200, batch_size=100, seed=5,
+                       verbose=False, enc_power_epilogue=False, hip_graph=True)
+    assert gr["bit_errors"] == res["bit_errors"] and gr["block_errors"] == res["block_errors"]
+    # ... and so does the sweep point as ONE C call (tae_eval_snr with the generator installed by tae_set_noise_opts)
+    for si, snr in enumerate(res["snrs"]):
+        c = model.eval_snr(snr, 100, 2, seed=5, first_block=si * 200).sum(dim=0).cpu().tolist()
+        assert c == [res["bit_errors"][si], res["block_errors"][si]], (channel, snr)
 
 
 # ------------------------------------------------------------------------------------------------

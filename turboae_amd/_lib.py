@@ -12,7 +12,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TAE_LIB", os.path.join(_HERE, "lib", "libturboae_hip.so"))   # TAE_LIB: kernel-variant experiments
 
-TAE_ABI_VERSION = 8
+TAE_ABI_VERSION = 9
 
 
 class TaeConfig(C.Structure):
@@ -27,6 +27,14 @@ class TaeChannelOpts(C.Structure):
                 ("ste", C.c_int32), ("enc_value_limit", C.c_float), ("enc_quantize_level", C.c_float),
                 ("enc_truncate_limit", C.c_float), ("channel", C.c_int32), ("rec_quantize", C.c_int32),
                 ("rec_quantize_limit", C.c_float), ("rec_quantize_level", C.c_float)]
+
+
+class TaeNoiseOpts(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("kind", C.c_int32), ("vv", C.c_float), ("radar_prob", C.c_float),
+                ("radar_power", C.c_float), ("p_gg", C.c_float), ("p_bb", C.c_float)]
+
+
+NOISE_KIND = {"awgn": 0, "t-dist": 1, "radar": 2, "ge_awgn": 3, "bec": 4, "bsc": 5, "ge": 6, "fading": 7}      # TAE_NOISE_*
 
 
 # name -> (restype, argtypes); every symbol declared in include/turboae_hip.h
@@ -48,6 +56,9 @@ SIGNATURES = {
     "tae_decode_taps": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P]),
     "tae_count_errors": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P]),
     "tae_generate_inputs": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64, C.c_float, _P]),
+    "tae_generate_noise": (C.c_int, [_P, C.POINTER(TaeNoiseOpts), C.c_float, _P, _P, C.c_int32, C.c_int64, C.c_uint64, _P]),
+    "tae_set_noise_opts": (C.c_int, [_P, C.POINTER(TaeNoiseOpts)]),
+    "tae_probe_mfma_f16": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "tae_eval_snr": (C.c_int, [_P, C.c_float, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64, _P, _P]),
     "tae_kernel_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tae_range_status": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -94,6 +94,17 @@ class _Engine:
         o.rec_quantize_limit = float(cfg.rec_quantize_level)
         o.rec_quantize_level = float(cfg.rec_quantize_level)
         _lib.check(self.lib.tae_set_channel_opts(self.h, C.byref(o)))
+        _lib.check(self.lib.tae_set_noise_opts(self.h, C.byref(self.noise_opts())))      # the generator tae_eval_snr draws from
+
+    def noise_opts(self) -> "_lib.TaeNoiseOpts":
+        """tae_noise_opts of the configured channel (-channel, -vv, -radar_prob, -radar_power; get_args.py:43,53-56)."""
+        cfg = self.cfg
+        o = _lib.TaeNoiseOpts()
+        o.struct_size = C.sizeof(_lib.TaeNoiseOpts)
+        o.kind = _lib.NOISE_KIND[cfg.channel]
+        o.vv, o.radar_prob, o.radar_power = float(cfg.vv), float(cfg.radar_prob), float(cfg.radar_power)
+        o.p_gg, o.p_bb = 0.8, 0.8                                       # channels.py:60-61,86-87
+        return o
 
     def update_precomp(self, stats: torch.Tensor) -> None:
         """--precompute_norm_stats (encoders.py:110-114): running averages of the per-call mean / std."""
@@ -444,6 +455,22 @@ class Channel_AE_HIP:
                                           _ptr(counts), _stream()))
         e.cap = max(e.cap, min(n_batches, -(-24576 // batch)) * batch)      # the library grew its workspace to one decode group
         return counts
+
+    def generate_noise(self, B: int, test_sigma: float, seed: int, first_block: int = 0):
+        """Device-side ``generate_noise(noise_shape, args, test_sigma=...)`` of the configured channel (channels.py:27-109) through
+        tae_generate_noise: returns (noise, fading) - `fading` is the Rayleigh coefficient tensor the reference draws inside forward
+        for -channel fading (channel_ae.py:51-56), None for every other channel.  `test_sigma` is the SNR in dB for the additive
+        channels and the erase / flip probability for bec / bsc / ge.  turboae_amd/channels.py is the numpy mirror of the draw."""
+        e = self._eng
+        n = B * e.cfg.block_len * 3
+        is_fading = e.cfg.channel == "fading"
+        buf = torch.empty(2 * n if is_fading else n, dtype=torch.float32, device=e.device)
+        noise = buf[n:] if is_fading else buf
+        with torch.cuda.device(e.device):
+            _lib.check(e.lib.tae_generate_noise(e.h, C.byref(e.noise_opts()), float(test_sigma), _ptr(noise), _ptr(buf) if is_fading else None,
+                                                B, int(first_block), int(seed), _stream()))
+        shape = (B, e.cfg.block_len, 3)
+        return noise.view(shape), (buf[:n].view(shape) if is_fading else None)
 
     def generate_inputs(self, B: int, snr_db: float, seed: int, first_block: int = 0,
                         seed_noise: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -22,6 +22,14 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
+}  // namespace
+
+namespace tae {
+int fail_msg(int code, const char* msg) { return fail(code, msg ? msg : "?"); }       // for the library's other translation units
+}
+
+namespace {
+
 #define TAE_HIP(expr)                                                                              \
     do {                                                                                           \
         hipError_t e__ = (expr);                                                                   \
@@ -279,6 +287,7 @@ struct tae_handle {
     float* d_eval_xdec = nullptr;    // decisions of one decode group
     int64_t eval_group_blocks = 0;
     int32_t eval_batch = 0;
+    bool eval_noise_x2 = false;      // d_eval_noise holds fading coefficients + noise
     double* d_rnn_partials = nullptr;   // GRU encoder: per (chunk, stack, head workgroup) partial sums
     int32_t rnn_partial_slots = 0;
     int32_t rnn_chunk = 0;   // blocks per internal chunk (bounds the workspace)
@@ -288,6 +297,7 @@ struct tae_handle {
     float* d_gy1 = nullptr;  // (chunk, L, 2H) layer-1 outputs
     float* d_ggi = nullptr;  // (chunk, L, 2, 19, 16) layer-1 input projections in gate-tile order
     tae::NormOpts nopts;       // encoder-output / channel variant (tae_set_channel_opts)
+    tae_noise_opts noise_opts; // generator tae_eval_snr draws from (tae_set_noise_opts; default AWGN)
 };
 
 namespace {
@@ -883,6 +893,41 @@ int check_batch(tae_handle* h, int32_t B) {
     return TAE_OK;
 }
 
+tae_noise_opts default_noise_opts() {
+    tae_noise_opts o;
+    o.struct_size = (int32_t)sizeof(tae_noise_opts);
+    o.kind = TAE_NOISE_AWGN;
+    o.vv = 5.0f; o.radar_prob = 0.05f; o.radar_power = 5.0f;      // get_args.py:53-56
+    o.p_gg = 0.8f; o.p_bb = 0.8f;                                  // channels.py:60-61,86-87
+    return o;
+}
+
+int check_noise_opts(const tae_noise_opts* o) {
+    if (o->struct_size != (int32_t)sizeof(tae_noise_opts)) return fail(TAE_EINVAL, "tae_noise_opts.struct_size mismatch (ABI)");
+    if (o->kind < TAE_NOISE_AWGN || o->kind > TAE_NOISE_FADING) return fail(TAE_EINVAL, "tae_noise_opts.kind must be one of TAE_NOISE_*");
+    if (o->kind == TAE_NOISE_TDIST && !(o->vv > 2.0f)) return fail(TAE_EINVAL, "t-dist needs vv > 2 (the reference scales by sqrt((vv - 2) / vv), channels.py:41)");
+    if (o->kind == TAE_NOISE_RADAR && !(o->radar_prob >= 0.0f && o->radar_prob <= 1.0f)) return fail(TAE_EINVAL, "radar_prob must be in [0, 1]");
+    if ((o->kind == TAE_NOISE_GE || o->kind == TAE_NOISE_GE_AWGN) && !(o->p_gg >= 0.0f && o->p_gg <= 1.0f && o->p_bb >= 0.0f && o->p_bb <= 1.0f))
+        return fail(TAE_EINVAL, "Gilbert-Elliott transition probabilities must be in [0, 1]");
+    return TAE_OK;
+}
+
+// host-side derivation of the generator's constants from test_sigma (channels.py:27-31,62-63,88-89; utils.py:69-76)
+int make_noise_gen(const tae_noise_opts* o, float test_sigma, tae::NoiseGen* g) {
+    const bool mask = o->kind == TAE_NOISE_BEC || o->kind == TAE_NOISE_BSC || o->kind == TAE_NOISE_GE;
+    if (mask && !(test_sigma >= 0.0f && test_sigma <= 1.0f)) return fail(TAE_EINVAL, "bec / bsc / ge: test_sigma is a probability in [0, 1]");
+    const double sigma = pow(10.0, -(double)test_sigma / 20.0);          // snr_db2sigma
+    const double snr_back = -20.0 * log10(sigma);                       // snr_sigma2db
+    g->kind = o->kind;
+    g->sigma = mask ? 0.0f : (float)sigma;
+    g->p = mask ? test_sigma : 0.0f;
+    g->s_good = (float)pow(10.0, -(snr_back + 1.0) / 20.0);
+    g->s_bad = (float)pow(10.0, -(snr_back - 1.0) / 20.0);
+    g->t_scale = 0.0f;
+    g->vv = o->vv; g->radar_prob = o->radar_prob; g->radar_power = o->radar_power; g->p_gg = o->p_gg; g->p_bb = o->p_bb;
+    return TAE_OK;
+}
+
 tae::NormOpts default_norm_opts() {
     tae::NormOpts o;
     memset(&o, 0, sizeof(o));
@@ -1236,6 +1281,7 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     tae_handle* h = new tae_handle();
     h->cfg = *cfg;
     h->nopts = default_norm_opts();
+    h->noise_opts = default_noise_opts();
     h->U = cfg->enc_num_unit;
     h->Ud = cfg->dec_num_unit;
     (void)hipGetDevice(&h->device);
@@ -1491,6 +1537,30 @@ int tae_set_interleaver(tae_handle* h, const int32_t* p, int32_t L) {
     return TAE_OK;
 }
 
+int tae_set_noise_opts(tae_handle* h, const tae_noise_opts* o) {
+    if (!h) return fail(TAE_EINVAL, "handle is NULL");
+    if (!o) { h->noise_opts = default_noise_opts(); return TAE_OK; }
+    const int rc = check_noise_opts(o);
+    if (rc != TAE_OK) return rc;
+    h->noise_opts = *o;
+    return TAE_OK;
+}
+
+int tae_generate_noise(tae_handle* h, const tae_noise_opts* opts, float test_sigma, float* noise, float* fading_h, int32_t B,
+                       int64_t first_block, uint64_t seed, void* stream) {
+    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
+    if (!opts || !noise) return fail(TAE_EINVAL, "NULL argument");
+    if (B < 1 || first_block < 0) return fail(TAE_EINVAL, "bad block range");
+    int rc = check_noise_opts(opts);
+    if (rc != TAE_OK) return rc;
+    if (opts->kind == TAE_NOISE_FADING && !fading_h) return fail(TAE_EINVAL, "TAE_NOISE_FADING writes the fading coefficients: fading_h is NULL");
+    tae::NoiseGen g;
+    rc = make_noise_gen(opts, test_sigma, &g);
+    if (rc != TAE_OK) return rc;
+    TAE_HIP(tae::launch_gen_noise(g, noise, fading_h, (size_t)B, (size_t)first_block, h->cfg.block_len, seed, (hipStream_t)stream));
+    return TAE_OK;
+}
+
 int tae_set_channel_opts(tae_handle* h, const tae_channel_opts* o) {
     if (!h) return fail(TAE_EINVAL, "handle is NULL");
     if (!o) { h->nopts = default_norm_opts(); return TAE_OK; }
@@ -1572,12 +1642,18 @@ int tae_eval_snr(tae_handle* h, float snr_db, int32_t batch, int32_t n_batches, 
     if (!h || !counts) return fail(TAE_EINVAL, "NULL argument");
     { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
     if (batch < 1 || n_batches < 1 || first_block < 0) return fail(TAE_EINVAL, "bad batch geometry");
-    if (h->nopts.channel != 0) return fail(TAE_EINVAL, "tae_eval_snr generates AWGN inputs: the configured channel must be additive (channel = 0)");
+    // the generator must produce what the configured channel consumes (channel_ae.py:41-56): masks for bec / bsc / ge, fading
+    // coefficients for fading, additive noise otherwise
+    const int nk = h->noise_opts.kind;
+    const bool mask_kind = nk == TAE_NOISE_BEC || nk == TAE_NOISE_BSC || nk == TAE_NOISE_GE;
+    if ((h->nopts.channel == 1 || h->nopts.channel == 2) != mask_kind || (h->nopts.channel == 3) != (nk == TAE_NOISE_FADING))
+        return fail(TAE_EINVAL, "tae_eval_snr: the noise generator (tae_set_noise_opts) does not match the channel (tae_set_channel_opts)");
+    const size_t noise_mult = nk == TAE_NOISE_FADING ? 2 : 1;      // fading: coefficients followed by the noise
     hipStream_t st = (hipStream_t)stream;
     const size_t L = h->cfg.block_len;
     int64_t group = (24576 + batch - 1) / batch;           // batches per decoder call: about 24 576 blocks
     if (group > n_batches) group = n_batches;
-    if (group * batch > h->cap || group * batch > h->eval_group_blocks || batch > h->eval_batch) {
+    if (group * batch > h->cap || group * batch > h->eval_group_blocks || batch > h->eval_batch || (noise_mult == 2 && !h->eval_noise_x2)) {
         // workspace growth: synchronises and allocates (first call for a geometry only - afterwards the call only enqueues work)
         int rc = tae_reserve(h, (int32_t)(group * batch));
         if (rc != TAE_OK) return rc;
@@ -1587,7 +1663,8 @@ int tae_eval_snr(tae_handle* h, float snr_db, int32_t batch, int32_t n_batches, 
         h->eval_group_blocks = 0; h->eval_batch = 0;
         TAE_HIP(hipMalloc(&h->d_eval_u, (size_t)group * batch * L * sizeof(float)));
         TAE_HIP(hipMalloc(&h->d_eval_xdec, (size_t)group * batch * L * sizeof(float)));
-        TAE_HIP(hipMalloc(&h->d_eval_noise, (size_t)batch * L * 3 * sizeof(float)));
+        TAE_HIP(hipMalloc(&h->d_eval_noise, noise_mult * (size_t)batch * L * 3 * sizeof(float)));
+        h->eval_noise_x2 = noise_mult == 2;
         h->eval_group_blocks = group * batch;
         h->eval_batch = batch;
     }
@@ -1596,8 +1673,14 @@ int tae_eval_snr(tae_handle* h, float snr_db, int32_t batch, int32_t n_batches, 
         const int64_t ng = g0 + group <= n_batches ? group : n_batches - g0;
         for (int64_t i = 0; i < ng; ++i) {
             float* u = h->d_eval_u + (size_t)i * batch * L;
-            int rc = tae_generate_inputs(h, u, h->d_eval_noise, batch, first_block + (g0 + i) * batch, seed_bits, seed_noise, snr_db, stream);
+            const int64_t fb = first_block + (g0 + i) * batch;
+            int rc = tae_generate_inputs(h, u, nk == TAE_NOISE_AWGN ? h->d_eval_noise : nullptr, batch, fb, seed_bits, seed_noise, snr_db, stream);
             if (rc != TAE_OK) return rc;
+            if (nk != TAE_NOISE_AWGN) {
+                float* nz = h->d_eval_noise + (noise_mult - 1) * (size_t)batch * L * 3;
+                rc = tae_generate_noise(h, &h->noise_opts, snr_db, nz, nk == TAE_NOISE_FADING ? h->d_eval_noise : nullptr, batch, fb, seed_noise, stream);
+                if (rc != TAE_OK) return rc;
+            }
             rc = run_encoder(h, u, h->d_xtx, h->d_stats, batch, st);
             if (rc != TAE_OK) return rc;
             rc = tae_normalize(h, h->d_xtx, h->d_stats, h->d_eval_noise, nullptr, h->d_rx + (size_t)i * batch * L * 3, batch, stream);

@@ -119,6 +119,18 @@ hipError_t launch_normalize(const float* xtx, const double* stats, const float* 
 hipError_t launch_count_errors(const float* xdec, const float* u, int B, int L, unsigned long long* counts, hipStream_t st);
 hipError_t launch_gen_inputs(float* u, float* noise, size_t n_bits, size_t bit_offset, unsigned long long seed_bits,
                              unsigned long long seed_noise, float sigma, hipStream_t st);
+// device-side view of tae_noise_opts (+ the values derived on the host from test_sigma)
+struct NoiseGen {
+    int32_t kind;              // TAE_NOISE_*
+    float sigma;               // additive kinds: 10^(-test_sigma / 20)
+    float p;                   // bec / bsc: erase / flip probability; ge: P(1) in the bad state
+    float s_good, s_bad;       // ge_awgn: sigma one dB up / one dB down
+    float t_scale;             // t-dist: sigma * sqrt((vv - 2) / vv)
+    float vv, radar_prob, radar_power, p_gg, p_bb;
+};
+hipError_t launch_gen_noise(const NoiseGen& g, float* noise, float* fading, size_t n_blocks, size_t first_block, int L,
+                            unsigned long long seed, hipStream_t st);
+int fail_msg(int code, const char* msg);          // turboae_api.hip: sets the calling thread's tae_last_error string
 int fused_lds_bytes(int U, int L, int nb);
 int fused_max_positions();
 

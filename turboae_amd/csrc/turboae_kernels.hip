@@ -31,6 +31,7 @@
 //    layer's epilogue straight from the accumulators (the last layer never touches the panel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/turboae_hip.h"      // TAE_NOISE_* kinds
 #include "turboae_internal.hpp"
 #include "turboae_device.hpp"
 #include "philox.hpp"
@@ -699,6 +700,69 @@ __global__ void gen_inputs_kernel(float* __restrict__ u, float* __restrict__ noi
     }
 }
 
+// Test-time noise of the reference's other channels on the device (replaces generate_noise, channels.py:37-109, and the fading
+// coefficients of channel_ae.py:51-56).  Every value is a function of (seed, global element index e = ((block * L) + t) * 3 + c) on
+// named Philox streams; turboae_amd/channels.py::generate_noise_host is the numpy mirror.  fp64 inside, one rounding to fp32.
+// chi-square with vv degrees of freedom = 2 * Gamma(vv / 2), Marsaglia-Tsang (shape >= 1 because vv > 2), attempt k of element e
+// draws Philox counter (e, STREAM_GAMMA, k): normal from words 0, 1, uniform from word 2.
+__device__ __forceinline__ double chi_square_at(unsigned long long seed, uint64_t e, double vv) {
+    const double d = 0.5 * vv - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (uint32_t k = 0; k < 32; ++k) {
+        const u32x4 w = philox4x32_10((uint32_t)e, (uint32_t)(e >> 32), STREAM_GAMMA, k, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const double x = sqrt(-2.0 * log(u32_to_unit_open(w.x))) * cos(6.283185307179586476925 * u32_to_unit_open(w.y));
+        const double t = 1.0 + c * x, v = t * t * t;
+        if (v > 0.0 && log(u32_to_unit_open(w.z)) < 0.5 * x * x + d - d * v + d * log(v)) return 2.0 * d * v;
+    }
+    return 2.0 * d;      // unreachable in practice (rejection probability per attempt < 5 %)
+}
+
+__device__ __forceinline__ float noise_value(const NoiseGen& g, unsigned long long seed, uint64_t e, bool good) {
+    switch (g.kind) {
+        case TAE_NOISE_TDIST: {
+            const double t = philox_normal(seed, STREAM_NOISE, e) / sqrt(chi_square_at(seed, e, (double)g.vv) / (double)g.vv);
+            return g.sigma * (float)(sqrt(((double)g.vv - 2.0) / (double)g.vv) * t);
+        }
+        case TAE_NOISE_RADAR: {
+            const float base = g.sigma * (float)philox_normal(seed, STREAM_NOISE, e);
+            const bool hit = philox_uniform(seed, STREAM_MASK, e) < (double)g.radar_prob;
+            return hit ? base + (float)((double)g.radar_power * philox_normal(seed, STREAM_AUX_A, e)) : base;
+        }
+        case TAE_NOISE_GE_AWGN: return (good ? g.s_good : g.s_bad) * (float)philox_normal(seed, STREAM_NOISE, e);
+        case TAE_NOISE_BEC:
+        case TAE_NOISE_BSC: return philox_uniform(seed, STREAM_MASK, e) >= (double)g.p ? 1.0f : 0.0f;
+        case TAE_NOISE_GE: return good ? 1.0f : (philox_uniform(seed, STREAM_MASK, e) < (double)g.p ? 1.0f : 0.0f);
+        default: return g.sigma * (float)philox_normal(seed, STREAM_NOISE, e);        // awgn, fading
+    }
+}
+
+// memoryless kinds: one element per thread and step
+__global__ void gen_noise_kernel(NoiseGen g, float* __restrict__ noise, float* __restrict__ fading, size_t n, size_t e0, unsigned long long seed) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t e = e0 + i;
+        noise[i] = noise_value(g, seed, e, true);
+        if (g.kind == TAE_NOISE_FADING) {      // channel_ae.py:53: sqrt(randn^2 + randn^2) / sqrt(3.14 / 2)
+            const double a = philox_normal(seed, STREAM_AUX_A, e), b = philox_normal(seed, STREAM_AUX_B, e);
+            fading[i] = (float)(sqrt(a * a + b * b) / sqrt(3.14 / 2.0));
+        }
+    }
+}
+
+// Gilbert-Elliott kinds: one thread walks the chain of one (block, code symbol) along time (channels.py:66-81 / 93-107): every
+// chain starts good; from the good state the next state is good with probability p_gg, from the bad state with probability p_bb
+__global__ void gen_noise_chain_kernel(NoiseGen g, float* __restrict__ noise, size_t n_chains, size_t first_block, int L, unsigned long long seed) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x; ch < n_chains; ch += stride) {
+        const size_t b = ch / 3, c = ch % 3;
+        bool good = true;
+        for (int t = 0; t < L; ++t) {
+            const uint64_t e = ((uint64_t)(first_block + b) * L + t) * 3 + c;
+            noise[(b * L + t) * 3 + c] = noise_value(g, seed, e, good);
+            good = philox_uniform(seed, STREAM_CHAIN, e) < (double)(good ? g.p_gg : g.p_bb);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launch helpers (called from turboae_api.cpp through turboae_internal.hpp)
 template <int U>
@@ -780,6 +844,20 @@ hipError_t launch_count_errors(const float* xdec, const float* u, int B, int L, 
     }
     const int grid = std::min((B + 3) / 4, 2048);
     hipLaunchKernelGGL(count_errors_kernel, dim3(grid), dim3(256), 0, st, xdec, u, B, L, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_gen_noise(const NoiseGen& g, float* noise, float* fading, size_t n_blocks, size_t first_block, int L,
+                            unsigned long long seed, hipStream_t st) {
+    if (g.kind == TAE_NOISE_GE || g.kind == TAE_NOISE_GE_AWGN) {
+        const size_t chains = n_blocks * 3;
+        const int grid = (int)((chains + 255) / 256 < 4096 ? (chains + 255) / 256 : 4096);
+        hipLaunchKernelGGL(gen_noise_chain_kernel, dim3(grid), dim3(256), 0, st, g, noise, chains, first_block, L, seed);
+    } else {
+        const size_t n = n_blocks * (size_t)L * 3;
+        const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(gen_noise_kernel, dim3(grid), dim3(256), 0, st, g, noise, fading, n, first_block * (size_t)L * 3, seed);
+    }
     return hipGetLastError();
 }
 

@@ -27,7 +27,6 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from . import channels
 from .distributed import all_reduce_sum_, shard_bounds
 
 
@@ -46,7 +45,7 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
     """model: turboae_amd.Channel_AE_HIP.  Returns {'snrs', 'ber', 'bler', 'bit_errors', 'block_errors', 'enc_power'}.
     decode_group: batches decoded per decoder call (None: enough for about 24 576 blocks per rank; 1: one call per batch).
     hip_graph: capture every SNR point (all of its launches, the all-reduces included) into one hipGraph and launch that
-    (AWGN only: the other channels draw their noise from a torch generator).  The sweep is GPU-bound either way; the
+    (every channel: all noise generators are device kernels keyed by Philox counters).  The sweep is GPU-bound either way; the
     option exists because the entry points are capturable (no allocation, no synchronisation) and a launch-bound caller
     (tiny batches) can use it."""
     import torch.distributed as dist
@@ -67,8 +66,6 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
     if decode_group is None:
         decode_group = max(1, -(-24576 // max(nloc, 1)))
     decode_group = max(1, min(int(decode_group), max(num_test_batch, 1)))
-    if hip_graph and model.cfg.channel != "awgn":
-        raise ValueError("hip_graph=True needs channel='awgn' (device-side Philox inputs)")
     precomp = bool(model.cfg.precompute_norm_stats) and not model.cfg.no_code_norm
     if hip_graph and precomp:
         raise ValueError("hip_graph=True cannot be combined with precompute_norm_stats (the running statistics live on the host)")
@@ -102,13 +99,10 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
         u, noise = model.generate_inputs(nloc, snr, seed=seed, first_block=first)
         fading = None
         if model.cfg.channel != "awgn":
-            # other channels: generate_noise restated on the device (turboae_amd/channels.py), one generator per
-            # (seed, global first block of the shard): shards of any world size draw independent streams
-            gen = torch.Generator(device=dev)
-            gen.manual_seed((seed * 1000003 + first) & 0x7FFFFFFFFFFFFFFF)
-            noise = channels.generate_noise((nloc, L, 3), model.cfg, snr, device=dev, generator=gen)
-            if model.cfg.channel == "fading":
-                fading = channels.rayleigh_fading((nloc, L, 3), device=dev, generator=gen)
+            # other channels: generate_noise restated as a device kernel (tae_generate_noise), keyed like the AWGN draw by
+            # (seed, global block index), so shards of any world size reproduce the single-device stream; `snr` is the
+            # reference's test_sigma (an SNR in dB, or the erase / flip probability of bec / bsc / ge: trainer.py:160-169)
+            noise, fading = model.generate_noise(nloc, snr, seed=seed, first_block=first)
         return u, noise, fading
 
     def punctured_point(si, snr, positions):

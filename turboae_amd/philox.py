@@ -25,6 +25,13 @@ _MASK32 = np.uint64(0xFFFFFFFF)
 STREAM_BITS = 1
 STREAM_NOISE = 2
 STREAM_WEIGHTS = 3
+# channel generators (tae_generate_noise / channels.py): keep and radar-position masks, Gilbert-Elliott state walk, second and third
+# normal streams (radar bursts, fading_h), chi-square draws of the t distribution (attempt index in counter word 3)
+STREAM_MASK = 4
+STREAM_CHAIN = 5
+STREAM_AUX_A = 6
+STREAM_AUX_B = 7
+STREAM_GAMMA = 8
 
 
 def philox4x32_10(c0, c1, c2, c3, k0, k1):
@@ -92,6 +99,49 @@ def random_normal(seed: int, start: int, count: int, stream: int = STREAM_NOISE)
     z = np.stack([r * np.cos(th), r * np.sin(th)], axis=1).reshape(-1)
     off = start - 2 * p0
     return z[off:off + count].astype(np.float32)
+
+
+def random_normal64(seed: int, start: int, count: int, stream: int = STREAM_NOISE) -> np.ndarray:
+    """The same normals before the rounding to float32 (the channel generators combine them in fp64 and round once)."""
+    if count <= 0:
+        return np.zeros((0,), dtype=np.float64)
+    p0 = start >> 1
+    p1 = (start + count - 1) >> 1
+    w = random_u32(seed, stream, 2 * p0, 2 * (p1 - p0 + 1)).reshape(-1, 2)
+    r = np.sqrt(-2.0 * np.log(_u32_to_unit_open(w[:, 0])))
+    th = 2.0 * np.pi * _u32_to_unit_open(w[:, 1])
+    z = np.stack([r * np.cos(th), r * np.sin(th)], axis=1).reshape(-1)
+    off = start - 2 * p0
+    return z[off:off + count]
+
+
+def random_unit(seed: int, stream: int, start: int, count: int) -> np.ndarray:
+    """Uniforms in (0, 1) as float64 with 24 random bits each: word e of the stream -> ((w >> 8) + 0.5) * 2^-24."""
+    return _u32_to_unit_open(random_u32(seed, stream, start, count))
+
+
+def chi_square(seed: int, start: int, count: int, vv: float) -> np.ndarray:
+    """chi-square(vv) = 2 * Gamma(vv / 2) by Marsaglia-Tsang (vv > 2, so the shape is >= 1), float64.  Attempt k of element e draws
+    the Philox counter (e_lo, e_hi, STREAM_GAMMA, k): a Box-Muller normal (cosine branch) from words 0, 1 and a uniform from word 2;
+    the first accepted attempt (of at most 32) counts.  Mirrors chi_square_at in csrc/turboae_kernels.hip."""
+    e = np.arange(start, start + count, dtype=np.uint64)
+    d = 0.5 * float(vv) - 1.0 / 3.0
+    c = 1.0 / np.sqrt(9.0 * d)
+    out = np.full(count, 2.0 * d, dtype=np.float64)
+    pending = np.arange(count)
+    for k in range(32):
+        if pending.size == 0:
+            break
+        ee = e[pending]
+        w = philox4x32_10(ee & _MASK32, ee >> np.uint64(32), np.uint64(STREAM_GAMMA), np.uint64(k), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+        x = np.sqrt(-2.0 * np.log(_u32_to_unit_open(w[0]))) * np.cos(2.0 * np.pi * _u32_to_unit_open(w[1]))
+        t = 1.0 + c * x
+        v = t * t * t
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ok = (v > 0.0) & (np.log(_u32_to_unit_open(w[2])) < 0.5 * x * x + d - d * v + d * np.log(np.where(v > 0.0, v, 1.0)))
+        out[pending[ok]] = 2.0 * d * v[ok]
+        pending = pending[~ok]
+    return out
 
 
 def random_uniform_pm1(seed: int, start: int, count: int, stream: int = STREAM_WEIGHTS) -> np.ndarray:
