@@ -525,7 +525,7 @@ std::vector<size_t> dec_rnn_nouts(size_t F, int n_iter) {
 
 // ---- GRU decoder, f16x2 representation (turboae_gru_h2.hip) -----------------------------------------------
 constexpr size_t kGHTileB = 3 * 2048 + 1024, kGHFragB = 19 * kGHTileB, kGHNiB = 6 * 1024;
-constexpr size_t kGHRec0B = kGHFragB + kGHNiB + 25 * 64 + 16, kGHRec1B = kGHFragB + 7 * 64 + 16;
+constexpr size_t kGHRec0B = kGHFragB + kGHNiB + 25 * 64 + 16, kGHRec1B = kGHFragB + kGHTileB + 7 * 64 + 16;
 constexpr size_t kGHProjDirB = 7 * 19 * 2048, kGHProjB = 2 * kGHProjDirB + 2 * 19 * 64 + 16;
 
 inline void put_split(char* dst, size_t hi_off, size_t lo_off, float w) {
@@ -561,6 +561,25 @@ void pack_gru_rec_h(const float* Whh, const float* Wih0, int cin, float scale, c
                 put_split(dst, o, o + 512, w);
             }
         }
+}
+// Linear head (nout, 2H): direction d's half as one more row tile in the recurrence's fragment order (rows >= nout zero), so the
+// layer-1 recurrence contracts h_t with it on the spot: 3 slabs x (hi | lo) x [lane][8 halves] + the K = 16 remainder (k0 = unit 96 + kq)
+void pack_gru_head_h(const float* Wlin, int nout, int d, float scale, char* dst) {
+    for (int lane = 0; lane < 64; ++lane) {
+        const int m = lane & 15, kq = lane >> 4;
+        for (int sl = 0; sl < 3; ++sl)
+            for (int j = 0; j < 8; ++j) {
+                const int unit = j < 4 ? 16 * (2 * sl) + 4 * kq + j : 16 * (2 * sl + 1) + 4 * kq + (j - 4);
+                const float w = m < nout ? Wlin[(size_t)m * 2 * kGH + d * kGH + unit] * scale : 0.0f;
+                const size_t o = (size_t)sl * 2048 + lane * 16 + j * 2;
+                put_split(dst, o, o + 1024, w);
+            }
+        for (int j = 0; j < 4; ++j) {
+            const float w = (j == 0 && m < nout) ? Wlin[(size_t)m * 2 * kGH + d * kGH + 96 + kq] * scale : 0.0f;
+            const size_t o = 6144 + lane * 8 + j * 2;
+            put_split(dst, o, o + 512, w);
+        }
+    }
 }
 // layer 0: n-gate input tiles (K = 16 fragments, x only)
 void pack_gru_ni_h(const float* Wih0, int cin, float scale, char* dst) {
@@ -630,10 +649,15 @@ void repack_rnn_h(const float* src, char* dst, size_t cin0, const std::vector<si
             const float scale = pow2_scale(max_abs(p + 3 * H * cin1, 3 * H * H));
             char* o = dst + d * kGHRec1B;
             pack_gru_rec_h(p + 3 * H * cin1, nullptr, 0, scale, o);
-            float* b = reinterpret_cast<float*>(o + kGHFragB);
+            const float* wlin = src + 2 * per1;                    // Linear(2H -> nout) follows the two directions of layer 1
+            const float scale_h = pow2_scale(max_abs(wlin, nout * 2 * H));
+            pack_gru_head_h(wlin, (int)nout, d, scale_h, o + kGHFragB);
+            float* b = reinterpret_cast<float*>(o + kGHFragB + kGHTileB);
             pack_gru_bias1(p + 3 * H * cin1 + 3 * H * H + 3 * H, b);
             for (int i = 0; i < 7 * 16; ++i) b[i] *= scale;
-            for (int i = 0; i < 4; ++i) b[7 * 16 + i] = 1.0f / scale;
+            b[7 * 16] = 1.0f / scale;
+            b[7 * 16 + 1] = 1.0f / scale_h;
+            b[7 * 16 + 2] = b[7 * 16 + 3] = 0.0f;
         }
         src += 2 * per1;
         dst += 2 * kGHRec1B;
@@ -1105,6 +1129,7 @@ int run_encoder_rnn(tae_handle* h, const float* u, float* xtx, double* stats, in
                 PP.w = reinterpret_cast<const float*>(w1); PP.npos = npg;
                 R1.w = reinterpret_cast<const float*>(w1 + kGHProjB); R1.w_dir_stride = (uint32_t)kGHRec1B;
                 wl = reinterpret_cast<const float*>(w1 + kGHProjB + 2 * kGHRec1B);
+                R1.hpart = h->d_gy1;          // per-direction head products (the layer-1 recurrence contracts Y1 away)
                 TAE_HIP(tae::launch_gru_rec_h(true, R0, st));
                 TAE_HIP(tae::launch_gru_proj_h(PP, st));
                 TAE_HIP(tae::launch_gru_rec_h(false, R1, st));
@@ -1124,7 +1149,8 @@ int run_encoder_rnn(tae_handle* h, const float* u, float* xtx, double* stats, in
             HP.grouped = h->prec == 1 ? 1 : 0; HP.B = Bc;
             HP.enc_stack = s; HP.act = h->cfg.enc_act; HP.xtx = xtx + (size_t)c0 * L * 3;
             HP.partials = h->d_rnn_partials + (size_t)slot * 2;
-            TAE_HIP(tae::launch_gru_head(HP, st));
+            if (h->prec == 1) TAE_HIP(tae::launch_gru_head_part(HP, st));
+            else TAE_HIP(tae::launch_gru_head(HP, st));
             slot += tae::gru_head_grid(HP.npos);
         }
     }
@@ -1157,7 +1183,7 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
                 TAE_HIP(tae::launch_gru_proj_h(PP, st));
                 tae::GruRecParams R1;
                 memset(&R1, 0, sizeof(R1));
-                R1.w = reinterpret_cast<const float*>(w1 + kGHProjB); R1.w_dir_stride = (uint32_t)kGHRec1B; R1.gi = h->d_ggi; R1.B = Bc; R1.L = L; R1.y = h->d_gy1;
+                R1.w = reinterpret_cast<const float*>(w1 + kGHProjB); R1.w_dir_stride = (uint32_t)kGHRec1B; R1.gi = h->d_ggi; R1.B = Bc; R1.L = L; R1.hpart = h->d_gy1;
                 TAE_HIP(tae::launch_gru_rec_h(false, R1, st));
                 const float* wl = reinterpret_cast<const float*>(w1 + kGHProjB + 2 * kGHRec1B);
                 tae::GruHeadParams HP;
@@ -1167,7 +1193,7 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
                 HP.ptab = odd ? h->d_perm : h->d_inv;
                 HP.npos = npg; HP.L = L; HP.F = F; HP.nout = nout; HP.extrinsic = h->cfg.extrinsic; HP.last = last ? 1 : 0;
                 HP.grouped = 1; HP.B = Bc; HP.enc_stack = -1; HP.act = h->cfg.dec_act;
-                TAE_HIP(tae::launch_gru_head(HP, st));
+                TAE_HIP(tae::launch_gru_head_part(HP, st));
                 wb += rnn_h_stack_bytes((size_t)nout);
             }
             continue;

@@ -34,7 +34,7 @@ constexpr int kRecTileB = 3 * 2048 + 1024;                 // bytes of A fragmen
 constexpr int kRecFragB = 19 * kRecTileB;                   // 136 192
 constexpr int kNiFragB = 6 * 1024;                          // layer 0: n-gate input tiles (K = 16, hi | lo)
 constexpr int kRec0B = kRecFragB + kNiFragB + 25 * 64 + 16; // + accumulator-init rows + 2^-S
-constexpr int kRec1B = kRecFragB + 7 * 64 + 16;             // + b_hn rows + 2^-S
+constexpr int kRec1B = kRecFragB + kRecTileB + 7 * 64 + 16; // + Linear-head tile (this direction's half of the head weights) + b_hn rows + (2^-S, 2^-S_head)
 
 __device__ __forceinline__ f32x4 mfma16x16x16h(h4 a, h4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
@@ -116,20 +116,24 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
     const bool valid = n < nb;
     const int nc = valid ? n : nb - 1;
     const lds_cptr lds3 = (lds_cptr)smem;
-    const lds_cptr bias = lds3 + kRecFragB + (LAYER0 ? kNiFragB : 0) + q * 16;
-    const float inv = *reinterpret_cast<const float*>(smem + kRecFragB + (LAYER0 ? kNiFragB + 25 * 64 : 7 * 64));
+    const lds_cptr bias = lds3 + kRecFragB + (LAYER0 ? kNiFragB : kRecTileB) + q * 16;
+    const float inv = *reinterpret_cast<const float*>(smem + kRecFragB + (LAYER0 ? kNiFragB + 25 * 64 : kRecTileB + 7 * 64));
+    const float inv_head = LAYER0 ? 0.0f : *reinterpret_cast<const float*>(smem + kRecFragB + kRecTileB + 7 * 64 + 4);
 
     const __amdgpu_buffer_rsrc_t rs_in = LAYER0
         ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x + (size_t)b0 * L * kGXW), 0, nb * L * kGXW * 4, 0x00020000)
         : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.gi), 0, -1, 0x00020000);
     const uint32_t v_in = LAYER0 ? (uint32_t)(nc * L * kGXW * 4) : (uint32_t)((n * 4 + q) * 16);
     const uint32_t gi_wave = (uint32_t)(b0 / 16) * (uint32_t)L * (2 * 19 * 1024u) + (uint32_t)dir * (19 * 1024u);
-    // outputs: layer 0 -> Y0 as halves [pos][hi 200 | lo 200] (the projection kernel's operand), layer 1 -> Y1 fp32 [pos][200]
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y + (size_t)b0 * L * 2 * kGH, 0, 16 * L * 2 * kGH * 4, 0x00020000);
+    // outputs: layer 0 -> Y0 as halves [pos][hi 200 | lo 200] (the projection kernel's operand); layer 1 -> this direction's
+    // share of the Linear head, W_lin[:, dir * H .. dir * H + H) * h_t, as [pos][dir][8] floats (Y1 itself is never written:
+    // the head contracts it away, 16 instead of 200 floats per position leave the kernel)
+    const __amdgpu_buffer_rsrc_t rs_y = LAYER0
+        ? __builtin_amdgcn_make_buffer_rsrc(P.y + (size_t)b0 * L * 2 * kGH, 0, 16 * L * 2 * kGH * 4, 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(P.hpart + (size_t)b0 * L * 16, 0, 16 * L * 16 * 4, 0x00020000);
     const uint32_t v_y = !valid ? 0x80000000u
-        : (LAYER0 ? (uint32_t)(n * 800 + (dir * kGH + 4 * q) * 2) : (uint32_t)(n * 800 + dir * kGH * 4 + q * 16));
-    const uint32_t v_yr = !valid ? 0x80000000u
-        : (LAYER0 ? (uint32_t)(n * 800 + (dir * kGH + 96 + q) * 2) : (uint32_t)(n * 800 + (dir * kGH + 96 + q) * 4));
+        : (LAYER0 ? (uint32_t)(n * 800 + (dir * kGH + 4 * q) * 2) : (q < 2 ? (uint32_t)(n * 64 + dir * 32 + q * 16) : 0x80000000u));
+    const uint32_t v_yr = !valid ? 0x80000000u : (uint32_t)(n * 800 + (dir * kGH + 96 + q) * 2);
 
     f32x4 h[6];
 #pragma unroll
@@ -234,8 +238,6 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
             if (LAYER0) {
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nhi[u]), rs_y, v_y + u * 32, yo, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nlo[u]), rs_y, v_y + u * 32 + 400, yo, 0);
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, hn), rs_y, v_y + u * 64, yo, 0);
             }
         }
         // remainder tile: rows 4qq + i = gate i of unit 96 + qq (i = 3: layer-0 n-gate input part)
@@ -274,9 +276,25 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
                 __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, hi), rs_y, v_yr, yo, 0);
                 __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, lo), rs_y, v_yr + 400, yo, 0);
                 set_x(xa, xb);
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, hr), rs_y, v_yr, yo, 0);
             }
+        }
+        if (!LAYER0) {
+            // Linear head on the new state (decoders.py:103,115,143; encoders.py:284-292): tile 19 = the <= 8 output rows of this
+            // direction's half of the head weights, B operand = the halves of h_t just formed for the next step - 12 MFMAs off the
+            // dependent chain (the next step's gate products do not wait for them)
+            f32x4 ah[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+            const lds_cptr fr = lds3 + 19 * kRecTileB + lane * 16;
+            FragS<1> fh0, fh1, fh2;
+            FragR<1> fhq;
+            load_slab<1>(fh0, fr);
+            load_slab<1>(fh1, fr + 2048);
+            load_slab<1>(fh2, fr + 4096);
+            load_rem<1, kRecTileB>(fhq, lds3 + 19 * kRecTileB + 6144 + lane * 8);
+            mma_slab<1>(ah, fh0, bh[0], bl[0]);
+            mma_slab<1>(ah, fh1, bh[1], bl[1]);
+            mma_slab<1>(ah, fh2, bh[2], bl[2]);
+            mma_rem<1>(ah, fhq, rh, rl);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, ah[0] * inv_head), rs_y, v_y, (uint32_t)t * 1024u, 0);
         }
     }
 }
@@ -352,6 +370,64 @@ __global__ __launch_bounds__(512, 2) void gru_proj_h_kernel(GruProjParams P) {
         proj_pass_h<10, 5>(P, smem, pg, dir, lane, p0);
         proj_pass_h<15, 4>(P, smem, pg, dir, lane, p0);
     }
+}
+
+// ---- head epilogue: the Linear products arrive from the layer-1 recurrence ---------------------------------------------
+// out[f] = fwd[f] + bwd[f] + b[f] -> dec_act -> extrinsic subtraction -> (de)interleave scatter into the other panel, or
+// sigmoid + deinterleave for the last half-iteration (decoders.py:103-147); encoder mode: enc_act -> x_tx + partial sums
+// (encoders.py:284-298).  One thread per position of the block-group-major workspace, pos' = ((b / 16) * L + t) * 16 + b % 16.
+constexpr int kHeadPartThreads = 256;
+__global__ __launch_bounds__(kHeadPartThreads) void gru_head_part_kernel(GruHeadParams P) {
+    double esum = 0.0, esq = 0.0;
+    for (size_t posy = (size_t)blockIdx.x * kHeadPartThreads + threadIdx.x; posy < P.npos; posy += (size_t)gridDim.x * kHeadPartThreads) {
+        const size_t row = posy >> 4, grp = row / P.L;
+        const int t = (int)(row - grp * P.L);
+        const size_t b = grp * 16 + (posy & 15);
+        if (b >= (size_t)P.B) continue;
+        const f32x4* hp = reinterpret_cast<const f32x4*>(P.y + posy * 16);
+        const f32x4 f0 = hp[0], b0 = hp[2];
+        float o[8] = {f0.x + b0.x, f0.y + b0.y, f0.z + b0.z, f0.w + b0.w, 0.f, 0.f, 0.f, 0.f};
+        if (P.nout > 4) {
+            const f32x4 f1 = hp[1], b1 = hp[3];
+            o[4] = f1.x + b1.x; o[5] = f1.y + b1.y; o[6] = f1.z + b1.z; o[7] = f1.w + b1.w;
+        }
+        const size_t pos = b * P.L + t;      // (block, t) order of the X panels
+        if (P.enc_stack >= 0) {              // ENC_interRNN: x = enc_act(Linear(2H -> 1)) (encoders.py:284,287,292)
+            float v = o[0] + P.b[0];
+            v = P.act == 0 ? (v > 0.0f ? v : expm1f(v)) : act_apply(v, P.act);
+            P.xtx[pos * 3 + P.enc_stack] = v;
+            esum += (double)v;
+            esq += (double)v * (double)v;
+        } else if (!P.last) {
+            const float* xc = P.xcur + pos * kGXW + 2;
+            float* xn = P.xnext + (b * P.L + P.ptab[t]) * kGXW + 2;
+#pragma unroll
+            for (int f = 0; f < 6; ++f)
+                if (f < P.F) xn[f] = act_apply(o[f] + P.b[f], P.act) - (P.extrinsic ? xc[f] : 0.0f);      // dec_act, then extrinsic (decoders.py:103-106)
+        } else {
+            const float v = act_apply(o[0] + P.b[0], P.act);
+            P.xdec[b * P.L + P.ptab[t]] = 1.0f / (1.0f + expf(-v));      // sigmoid(deinterleave(dec_act(x_plr))), decoders.py:143-147
+        }
+    }
+    if (P.enc_stack >= 0) {
+        // per-workgroup partial sums for power_constraint (encoders.py:107-108), fixed-order tree
+        __shared__ double red[2 * kHeadPartThreads];
+        const int tid = threadIdx.x;
+        red[tid] = esum;
+        red[kHeadPartThreads + tid] = esq;
+        __syncthreads();
+        for (int off = kHeadPartThreads / 2; off > 0; off >>= 1) {
+            if (tid < off) { red[tid] += red[tid + off]; red[kHeadPartThreads + tid] += red[kHeadPartThreads + tid + off]; }
+            __syncthreads();
+        }
+        if (tid == 0) { P.partials[2 * blockIdx.x] = red[0]; P.partials[2 * blockIdx.x + 1] = red[kHeadPartThreads]; }
+    }
+}
+
+hipError_t launch_gru_head_part(const GruHeadParams& P, hipStream_t st) {
+    // the same grid as launch_gru_head (the encoder's partial-sum slots are sized by gru_head_grid)
+    hipLaunchKernelGGL(gru_head_part_kernel, dim3(gru_head_grid(P.npos)), dim3(kHeadPartThreads), 0, st, P);
+    return hipGetLastError();
 }
 
 int gru_rec_h_lds_bytes(bool layer0) { return layer0 ? kRec0B : kRec1B; }

@@ -64,7 +64,8 @@ struct GruRecParams {
     uint32_t w_dir_stride; // floats between the two directions' blocks
     const float* x;        // layer 0: input panel (B,L,8)
     const float* gi;       // layer 1: input projections (B,L,2,19,16) in gate-tile order
-    float* y;              // (B,L,2H)
+    float* y;              // (B,L,2H); f16x2 kernels: layer 0 only (halves)
+    float* hpart;          // f16x2 layer 1: (npos', 2, 8) this direction's share of the Linear head (no Y1 is written)
     int32_t B, L;
 };
 struct GruProjParams {
@@ -75,7 +76,7 @@ struct GruProjParams {
     int32_t B, L;         // f16x2 kernels: blocks in this chunk and block length (npos = B * L)
 };
 struct GruHeadParams {
-    const float* y;       // (npos, 2H)
+    const float* y;       // (npos, 2H); launch_gru_head_part: the (npos', 2, 8) per-direction head products of the layer-1 recurrence
     const float* w;       // (nout, 2H)
     const float* b;       // (nout)
     const float* xcur;    // this stack's input panel (extrinsic subtraction)
@@ -98,6 +99,7 @@ hipError_t launch_gru_rec(bool layer0, const GruRecParams& P, hipStream_t st);
 hipError_t launch_gru_proj(const GruProjParams& P, hipStream_t st);
 hipError_t launch_gru_rec_h(bool layer0, const GruRecParams& P, hipStream_t st);      // f16x2: w / w_dir_stride in BYTES, layer-0 y as halves
 hipError_t launch_gru_proj_h(const GruProjParams& P, hipStream_t st);
+hipError_t launch_gru_head_part(const GruHeadParams& P, hipStream_t st);       // f16x2: bias + act + extrinsic + scatter on the fused head products
 hipError_t launch_gru_head(const GruHeadParams& P, hipStream_t st);
 
 hipError_t launch_seg(int U, const SegParams& P, int grid, hipStream_t st);
