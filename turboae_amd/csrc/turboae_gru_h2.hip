@@ -20,6 +20,7 @@
 // [pos][hi 200 | lo 200], so staging is a copy.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "turboae_internal.hpp"
 #include "turboae_device.hpp"
 
@@ -242,8 +243,9 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
         }
         // remainder tile: rows 4qq + i = gate i of unit 96 + qq (i = 3: layer-0 n-gate input part)
         {
-            f32x4 a1[1];
+            f32x4 a1[1], ar[1];
             a1[0] = *reinterpret_cast<lds_f4c*>(bias + (LAYER0 ? 18 : 6) * 64);
+            ar[0] = f32x4{0.f, 0.f, 0.f, 0.f};
             const lds_cptr fr = lds3 + 18 * kRecTileB + lane * 16;
             FragS<1> f2;
             FragR<1> fq;
@@ -254,8 +256,9 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
             load_rem<1, kRecTileB>(fq, lds3 + 18 * kRecTileB + 6144 + lane * 8);
             mma_slab<1>(a1, f1, bh[2], bl[2]);
             load_slab<3>(fa, lds3 + lane * 16);          // slab 0 of unit tile 0 for the next step
-            mma_rem<1>(a1, fq, rh, rl);
-            const f32x4 a = a1[0];
+            // K = 16 products into their own accumulator (single-tile chain: no 16x16x32 -> 16x16x16 srcC hand-over, see the head below)
+            mma_rem<1>(ar, fq, rh, rl);
+            const f32x4 a = a1[0] + ar[0];
             const float r = sigm_h(LAYER0 ? a[0] * inv : fmaf(a[0], inv, g[18][0]));
             const float z = sigm_h(LAYER0 ? a[1] * inv : fmaf(a[1], inv, g[18][1]));
             const float nn = tanh_h(fmaf(r, a[2] * inv, LAYER0 ? a[3] * inv : g[18][2]));
@@ -290,11 +293,15 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
             load_slab<1>(fh1, fr + 2048);
             load_slab<1>(fh2, fr + 4096);
             load_rem<1, kRecTileB>(fhq, lds3 + 19 * kRecTileB + 6144 + lane * 8);
+            // the K = 16 remainder product has its own accumulator: a v_mfma_f32_16x16x16_f16 that takes the result of a
+            // v_mfma_f32_16x16x32_f16 issued just before it as srcC read a stale accumulator on gfx950 when two waves shared the SIMD
+            // (r03: results differed run to run by one product term; the gate tiles interleave three chains and are spaced out)
+            f32x4 ar[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+            mma_rem<1>(ar, fhq, rh, rl);
             mma_slab<1>(ah, fh0, bh[0], bl[0]);
             mma_slab<1>(ah, fh1, bh[1], bl[1]);
             mma_slab<1>(ah, fh2, bh[2], bl[2]);
-            mma_rem<1>(ah, fhq, rh, rl);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, ah[0] * inv_head), rs_y, v_y, (uint32_t)t * 1024u, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, (ah[0] + ar[0]) * inv_head), rs_y, v_y, (uint32_t)t * 1024u, 0);
         }
     }
 }
@@ -436,6 +443,7 @@ hipError_t launch_gru_rec_h(bool layer0, const GruRecParams& P, hipStream_t st) 
     const int lds = gru_rec_h_lds_bytes(layer0);
     int nw = 8;
     while (nw > 1 && 2 * ((P.B + 16 * nw - 1) / (16 * nw)) < 256) nw >>= 1;
+    if (const char* e = getenv("TAE_GRU_NW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) nw = v; }   // experiments
     const dim3 grid((P.B + 16 * nw - 1) / (16 * nw), 2);
     const void* fn = layer0 ? reinterpret_cast<const void*>(gru_rec_h_kernel<true>) : reinterpret_cast<const void*>(gru_rec_h_kernel<false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
