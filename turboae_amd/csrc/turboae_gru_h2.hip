@@ -9,7 +9,7 @@
 //   * k-slab s (32 k) of the recurrent product = unit tiles 2s and 2s+1: lane (n, kq) supplies the units
 //     16(2s) + 4kq + j (j < 4) and 16(2s+1) + 4kq + (j-4) - exactly the 8 state values that lane holds in the
 //     D layout of those two unit tiles, re-split into halves after every step;
-//   * the 4 remainder units (96..99) as one K = 16 MFMA (v_mfma_f32_16x16x16_f16): lane kq supplies unit
+//   * the 4 remainder units (96..99) as one K = 16 product (a zero-extended v_mfma_f32_16x16x32_f16, see zext8): lane kq supplies unit
 //     96 + kq in k = 4kq, and - layer 0 - its three spare k slots carry the stack inputs x_t[3kq .. 3kq+2], so
 //     the K = 7 input projection costs no extra MFMAs for the r / z rows (the n-gate input part needs its own
 //     accumulators: 6 extra K = 16 tiles);
@@ -37,9 +37,12 @@ constexpr int kNiFragB = 6 * 1024;                          // layer 0: n-gate i
 constexpr int kRec0B = kRecFragB + kNiFragB + 25 * 64 + 16; // + accumulator-init rows + 2^-S
 constexpr int kRec1B = kRecFragB + kRecTileB + 7 * 64 + 16; // + Linear-head tile (this direction's half of the head weights) + b_hn rows + (2^-S, 2^-S_head)
 
-__device__ __forceinline__ f32x4 mfma16x16x16h(h4 a, h4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
-}
+// The K = 16 remainder products run as v_mfma_f32_16x16x32_f16 with the upper four k slots of every lane zero (the same lane
+// pairing: lane (i, kq) contracts its k = 0..3), NOT as v_mfma_f32_16x16x16_f16: mixed in one stream with 16x16x32, the K = 16
+// instruction read stale accumulators on gfx950 (a dependent 16x16x32 -> 16x16x16 pair through srcC, and - once the scheduler
+// moved the K = 16 products between other chains - whole tiles; the compiler inserts no wait states for these pairs).  Found in
+// r03 when the head tile was added: results changed from run to run with two waves per SIMD.  One MFMA shape per kernel.
+__device__ __forceinline__ h8 zext8(u32x2v v) { return __builtin_bit_cast(h8, u32x4w{v.x, v.y, 0u, 0u}); }
 __device__ __forceinline__ float sigm_h(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
 }
@@ -56,7 +59,7 @@ using lds_f4c = const f32x4 __attribute__((address_space(3)));
 // caller can issue the next slab's LDS reads before the current slab's MFMAs (pinned with sched_group_barrier: left to
 // the scheduler every read ends up right in front of its first use and the LDS latency is exposed 28 times per step).
 template <int NG> struct FragS { h8 ah[NG], al[NG]; };
-template <int NG> struct FragR { h4 ah[NG], al[NG]; };
+template <int NG> struct FragR { h8 ah[NG], al[NG]; };      // 4 halves from LDS, zero-extended
 
 template <int NG>
 __device__ __forceinline__ void load_slab(FragS<NG>& f, lds_cptr fr) {
@@ -79,18 +82,19 @@ template <int NG, int STRIDE>
 __device__ __forceinline__ void load_rem(FragR<NG>& f, lds_cptr fr) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        f.ah[g] = __builtin_bit_cast(h4, *reinterpret_cast<lds_q2*>(fr + g * STRIDE));
-        f.al[g] = __builtin_bit_cast(h4, *reinterpret_cast<lds_q2*>(fr + g * STRIDE + 512));
+        f.ah[g] = zext8(*reinterpret_cast<lds_q2*>(fr + g * STRIDE));
+        f.al[g] = zext8(*reinterpret_cast<lds_q2*>(fr + g * STRIDE + 512));
     }
 }
 template <int NG>
-__device__ __forceinline__ void mma_rem(f32x4 (&acc)[NG], const FragR<NG>& f, h4 bh, h4 bl) {
+__device__ __forceinline__ void mma_rem(f32x4 (&acc)[NG], const FragR<NG>& f, h4 bh4, h4 bl4) {
+    const h8 bh = zext8(__builtin_bit_cast(u32x2v, bh4)), bl = zext8(__builtin_bit_cast(u32x2v, bl4));
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x16h(f.ah[g], bl, acc[g]);
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(f.ah[g], bl, acc[g]);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x16h(f.al[g], bh, acc[g]);
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(f.al[g], bh, acc[g]);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x16h(f.ah[g], bh, acc[g]);
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(f.ah[g], bh, acc[g]);
 }
 // {ND LDS reads, then NM MFMAs}: the reads (for a LATER slab) go first, the MFMAs of the current slab cover their latency
 template <int ND, int NM>
@@ -243,9 +247,8 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
         }
         // remainder tile: rows 4qq + i = gate i of unit 96 + qq (i = 3: layer-0 n-gate input part)
         {
-            f32x4 a1[1], ar[1];
+            f32x4 a1[1];
             a1[0] = *reinterpret_cast<lds_f4c*>(bias + (LAYER0 ? 18 : 6) * 64);
-            ar[0] = f32x4{0.f, 0.f, 0.f, 0.f};
             const lds_cptr fr = lds3 + 18 * kRecTileB + lane * 16;
             FragS<1> f2;
             FragR<1> fq;
@@ -256,9 +259,8 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
             load_rem<1, kRecTileB>(fq, lds3 + 18 * kRecTileB + 6144 + lane * 8);
             mma_slab<1>(a1, f1, bh[2], bl[2]);
             load_slab<3>(fa, lds3 + lane * 16);          // slab 0 of unit tile 0 for the next step
-            // K = 16 products into their own accumulator (single-tile chain: no 16x16x32 -> 16x16x16 srcC hand-over, see the head below)
-            mma_rem<1>(ar, fq, rh, rl);
-            const f32x4 a = a1[0] + ar[0];
+            mma_rem<1>(a1, fq, rh, rl);
+            const f32x4 a = a1[0];
             const float r = sigm_h(LAYER0 ? a[0] * inv : fmaf(a[0], inv, g[18][0]));
             const float z = sigm_h(LAYER0 ? a[1] * inv : fmaf(a[1], inv, g[18][1]));
             const float nn = tanh_h(fmaf(r, a[2] * inv, LAYER0 ? a[3] * inv : g[18][2]));
@@ -293,15 +295,11 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
             load_slab<1>(fh1, fr + 2048);
             load_slab<1>(fh2, fr + 4096);
             load_rem<1, kRecTileB>(fhq, lds3 + 19 * kRecTileB + 6144 + lane * 8);
-            // the K = 16 remainder product has its own accumulator: a v_mfma_f32_16x16x16_f16 that takes the result of a
-            // v_mfma_f32_16x16x32_f16 issued just before it as srcC read a stale accumulator on gfx950 when two waves shared the SIMD
-            // (r03: results differed run to run by one product term; the gate tiles interleave three chains and are spaced out)
-            f32x4 ar[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-            mma_rem<1>(ar, fhq, rh, rl);
             mma_slab<1>(ah, fh0, bh[0], bl[0]);
             mma_slab<1>(ah, fh1, bh[1], bl[1]);
             mma_slab<1>(ah, fh2, bh[2], bl[2]);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, (ah[0] + ar[0]) * inv_head), rs_y, v_y, (uint32_t)t * 1024u, 0);
+            mma_rem<1>(ah, fhq, rh, rl);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, ah[0] * inv_head), rs_y, v_y, (uint32_t)t * 1024u, 0);
         }
     }
 }
