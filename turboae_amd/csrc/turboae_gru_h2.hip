@@ -308,13 +308,19 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
 // Workgroup = 8 waves, 160 positions staged in LDS (hi plane | lo plane, rows of 200 halves); wave (pg, rq):
 // position group pg (5 tiles), row quarter rq = (direction, half): gate tiles [0, 10) or [10, 19) of that
 // direction in two passes of <= 5 tiles (accumulators 5 x 5 tiles).
-constexpr int kProjHPos = 160;
-constexpr int kProjHPlaneB = kProjHPos * 400 + 512;          // + slack for the K padding over-read of the last row
-constexpr int kProjHLds = 2 * kProjHPlaneB;
+// Workgroup geometry: NPG position groups of 5 tiles (80 positions each) x 4 row quarters = 4 * NPG waves.  NPG = 1 (4 waves, 80
+// positions, 65 KB of LDS): two workgroups share a CU, one stages its Y0 rows while the other streams MFMAs; NPG = 2 (8 waves, 160
+// positions): one workgroup per CU (the r02 geometry; TAE_GRU_PROJ_PG=2).  The A-fragment stream per position is the same.
 constexpr int kProjHSlabs = 7;                                // K = 200 -> 224
 constexpr uint32_t kProjHDirB = kProjHSlabs * 19 * 2048u;     // A fragments of one direction
+template <int NPG> struct ProjGeo {
+    static constexpr int kPos = 80 * NPG;
+    static constexpr int kPlaneB = kPos * 400 + 512;          // + slack for the K padding over-read of the last row
+    static constexpr int kLds = 2 * kPlaneB;
+    static constexpr int kThreads = 256 * NPG;
+};
 
-template <int C0, int NC>
+template <int NPG, int C0, int NC, bool NT>
 __device__ __forceinline__ void proj_pass_h(const GruProjParams& P, const char* smem, int pg, int dir, int lane, size_t p0) {
     const int n = lane & 15, kq = lane >> 4;
     const char* wb = reinterpret_cast<const char*>(P.w);
@@ -327,7 +333,7 @@ __device__ __forceinline__ void proj_pass_h(const GruProjParams& P, const char* 
 #pragma unroll
     for (int p = 0; p < 5; ++p) {
         bh[p] = (uint32_t)(((pg * 5 + p) * 16 + n) * 400 + 16 * kq);
-        bl[p] = bh[p] + (uint32_t)kProjHPlaneB;
+        bl[p] = bh[p] + (uint32_t)ProjGeo<NPG>::kPlaneB;
     }
     OpsHA<NC> a0;
     load_wh<19, C0, NC>(a0, rsrc, voff, soff);
@@ -345,35 +351,42 @@ __device__ __forceinline__ void proj_pass_h(const GruProjParams& P, const char* 
         if (pos < P.npos) {
             float* dst = P.gi + ((pos >> 4) * 2 + dir) * (size_t)(19 * 256) + (size_t)C0 * 256 + (n * 4 + kq) * 4;
 #pragma unroll
-            for (int ct = 0; ct < NC; ++ct) *reinterpret_cast<f32x4*>(dst + ct * 256) = acc[p][ct] * inv;
+            for (int ct = 0; ct < NC; ++ct) {
+                // GI is written once and read once by the layer-1 recurrence (4 GB per stack): NT = streaming stores that do
+                // not displace the A fragments every workgroup re-reads from L2
+                if (NT) __builtin_nontemporal_store(acc[p][ct] * inv, reinterpret_cast<f32x4*>(dst + ct * 256));
+                else *reinterpret_cast<f32x4*>(dst + ct * 256) = acc[p][ct] * inv;
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(512, 2) void gru_proj_h_kernel(GruProjParams P) {
+template <int NPG, bool NT>
+__global__ __launch_bounds__(256 * NPG, 2) void gru_proj_h_kernel(GruProjParams P) {
+    using G = ProjGeo<NPG>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t p0 = (size_t)blockIdx.x * kProjHPos;
-    const int np = (int)min((size_t)kProjHPos, P.npos - p0);
+    const size_t p0 = (size_t)blockIdx.x * G::kPos;
+    const int np = (int)min((size_t)G::kPos, P.npos - p0);
     {
         // Y0 arrives as halves [pos][hi 200 | lo 200]: 50 16-byte pieces per position, 25 per plane
         const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(P.yin) + p0 * 800);
-        for (int i = tid; i < kProjHLds / 16; i += 512) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < G::kLds / 16; i += G::kThreads) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
-        for (int i = tid; i < np * 50; i += 512) {
+        for (int i = tid; i < np * 50; i += G::kThreads) {
             const int pos = i / 50, c = i - pos * 50, plane = c >= 25 ? 1 : 0, cc = c - plane * 25;
-            *reinterpret_cast<f32x4*>(smem + plane * kProjHPlaneB + pos * 400 + cc * 16) = src[i];
+            *reinterpret_cast<f32x4*>(smem + plane * G::kPlaneB + pos * 400 + cc * 16) = src[i];
         }
     }
     __syncthreads();
-    const int pg = wave & 1, rq = wave >> 1, dir = rq >> 1;
+    const int pg = NPG == 1 ? 0 : (wave & 1), rq = NPG == 1 ? wave : (wave >> 1), dir = rq >> 1;
     if ((rq & 1) == 0) {
-        proj_pass_h<0, 5>(P, smem, pg, dir, lane, p0);
-        proj_pass_h<5, 5>(P, smem, pg, dir, lane, p0);
+        proj_pass_h<NPG, 0, 5, NT>(P, smem, pg, dir, lane, p0);
+        proj_pass_h<NPG, 5, 5, NT>(P, smem, pg, dir, lane, p0);
     } else {
-        proj_pass_h<10, 5>(P, smem, pg, dir, lane, p0);
-        proj_pass_h<15, 4>(P, smem, pg, dir, lane, p0);
+        proj_pass_h<NPG, 10, 5, NT>(P, smem, pg, dir, lane, p0);
+        proj_pass_h<NPG, 15, 4, NT>(P, smem, pg, dir, lane, p0);
     }
 }
 
@@ -451,12 +464,21 @@ hipError_t launch_gru_rec_h(bool layer0, const GruRecParams& P, hipStream_t st) 
     return hipGetLastError();
 }
 
-hipError_t launch_gru_proj_h(const GruProjParams& P, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_proj_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kProjHLds);
+template <int NPG, bool NT>
+static hipError_t launch_gru_proj_h_t(const GruProjParams& P, hipStream_t st) {
+    using G = ProjGeo<NPG>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_proj_h_kernel<NPG, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, G::kLds);
     if (e != hipSuccess) return e;
-    const dim3 grid((unsigned)((P.npos + kProjHPos - 1) / kProjHPos));
-    hipLaunchKernelGGL(gru_proj_h_kernel, grid, dim3(512), kProjHLds, st, P);
+    const dim3 grid((unsigned)((P.npos + G::kPos - 1) / G::kPos));
+    hipLaunchKernelGGL((gru_proj_h_kernel<NPG, NT>), grid, dim3(G::kThreads), G::kLds, st, P);
     return hipGetLastError();
+}
+
+hipError_t launch_gru_proj_h(const GruProjParams& P, hipStream_t st) {
+    static const int npg = [] { const char* e = getenv("TAE_GRU_PROJ_PG"); return (e && atoi(e) == 2) ? 2 : 1; }();     // experiments
+    static const int nt = [] { const char* e = getenv("TAE_GRU_PROJ_NT"); return e ? atoi(e) : 1; }();
+    if (npg == 2) return nt ? launch_gru_proj_h_t<2, true>(P, st) : launch_gru_proj_h_t<2, false>(P, st);
+    return nt ? launch_gru_proj_h_t<1, true>(P, st) : launch_gru_proj_h_t<1, false>(P, st);
 }
 
 }  // namespace tae
