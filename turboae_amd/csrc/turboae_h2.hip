@@ -21,6 +21,10 @@
 #include "turboae_device.hpp"
 #include <type_traits>
 
+#ifndef TAE_PAIR_REVERSE
+#define TAE_PAIR_REVERSE 1
+#endif
+
 namespace tae {
 
 template <int U>
@@ -519,7 +523,10 @@ template <int U, int PT, bool TAPS = false>
 __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = wave & (kGroups - 1), h = wave / kGroups;
+    // wave w sits on SIMD w % 4; the lower channel half (4 of 7 channel tiles) of position group s runs on SIMD s, the upper half
+    // (3 tiles) of group 3 - s: group_span deals the extra position tiles to the low groups, so the SIMD that carries the heavier
+    // lower wave gets the lighter upper one (18 tiles: 32 / 32 / 31 / 31 tile pairs per SIMD instead of 35 / 35 / 28 / 28)
+    const int h = wave / kGroups, g = TAE_PAIR_REVERSE && h ? (kGroups - 1) - (wave & (kGroups - 1)) : (wave & (kGroups - 1));
     const int L = P.L, nb = P.nb;
     const int pad = P.taps >> 1;
     const int rows = nb * (L + pad) + pad;
@@ -601,7 +608,10 @@ template <int U, int PT>
 __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = wave & (kGroups - 1), h = wave / kGroups;
+    // wave w sits on SIMD w % 4; the lower channel half (4 of 7 channel tiles) of position group s runs on SIMD s, the upper half
+    // (3 tiles) of group 3 - s: group_span deals the extra position tiles to the low groups, so the SIMD that carries the heavier
+    // lower wave gets the lighter upper one (18 tiles: 32 / 32 / 31 / 31 tile pairs per SIMD instead of 35 / 35 / 28 / 28)
+    const int h = wave / kGroups, g = TAE_PAIR_REVERSE && h ? (kGroups - 1) - (wave & (kGroups - 1)) : (wave & (kGroups - 1));
     const int L = P.L, nb = P.nb;
     const int pad = P.taps >> 1;
     const int rows = nb * (L + pad) + pad;
@@ -717,7 +727,10 @@ template <int U, int PT>
 __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = wave & (kGroups - 1), h = wave / kGroups;
+    // wave w sits on SIMD w % 4; the lower channel half (4 of 7 channel tiles) of position group s runs on SIMD s, the upper half
+    // (3 tiles) of group 3 - s: group_span deals the extra position tiles to the low groups, so the SIMD that carries the heavier
+    // lower wave gets the lighter upper one (18 tiles: 32 / 32 / 31 / 31 tile pairs per SIMD instead of 35 / 35 / 28 / 28)
+    const int h = wave / kGroups, g = TAE_PAIR_REVERSE && h ? (kGroups - 1) - (wave & (kGroups - 1)) : (wave & (kGroups - 1));
     const int pad = P.taps >> 1;                       // 2 for the dense stacks (5 taps)
     const int L = P.L, H = pad * P.n_layer;
     int bid = blockIdx.x;
