@@ -52,7 +52,7 @@ typedef struct tae_config {
     int32_t struct_size;      /* = sizeof(tae_config), for ABI evolution */
     int32_t block_len;        /* -block_len        get_args.py:122 */
     int32_t enc_num_layer;    /* -enc_num_layer    get_args.py:93  */
-    int32_t enc_num_unit;     /* -enc_num_unit     get_args.py:98  (1..100, independent of dec_num_unit; kernels exist for 32 / 64 / 100, narrower stacks run embedded) */
+    int32_t enc_num_unit;     /* -enc_num_unit     get_args.py:98  (1..100 on the MFMA kernels, independent of dec_num_unit: instantiated for 32 / 64 / 100, narrower stacks run embedded; 101..1024: generic fp32 kernels) */
     int32_t enc_kernel_size;  /* -enc_kernel_size  get_args.py:89  (1, 3, 5, 7, 9; 1 and 3 are embedded into 5 taps; 7 and 9 need precision = TAE_PREC_AUTO, no dense) */
     int32_t dec_num_layer;    /* -dec_num_layer    get_args.py:94  */
     int32_t dec_num_unit;     /* -dec_num_unit     get_args.py:97  (1..100) */
@@ -75,7 +75,17 @@ typedef struct tae_config {
                                  TAE_PREC_F32 otherwise; TAE_PREC_F32 = 1: v_mfma_f32_16x16x4_f32 on the fp32 operands everywhere */
     int32_t dec_act;          /* -dec_act (get_args.py:101, decoders.py:59-73): TAE_ACT_* on the GRU decoder's Linear outputs (DEC_LargeCNN
                                  has no dec_act; ignored for dec_type = 0).  The reference default is TAE_ACT_LINEAR (= 1, NOT 0) */
+    int32_t enc_rnn;          /* -enc_rnn (get_args.py:79, encoders.py:242-247): TAE_RNN_GRU / LSTM / RNN cell of ENC_interRNN (enc_type = 1) */
+    int32_t dec_rnn;          /* -dec_rnn (get_args.py:80, decoders.py:27-32): the cell of DEC_LargeRNN (dec_type = 1) */
 } tae_config;
+
+/* Configurations the MFMA kernels do not instantiate run on generic fp32 kernels (one launch per layer, vector-ALU FMA chains:
+ * a coverage / parity path, far slower than the kernels above, same results): channel widths 101..1024, odd kernel sizes 11..63,
+ * num_iter_ft 7..64, LSTM / vanilla-RNN cells, ENC_interRNN with enc_num_layer != 2 or in front of a CNN decoder (which the
+ * reference then builds from DenseSameShapeConv1d, decoders.py:173-176), and TAE_PREC_F32 for dense stacks / kernel sizes 7, 9. */
+#define TAE_RNN_GRU 0
+#define TAE_RNN_LSTM 1
+#define TAE_RNN_RNN 2
 
 #define TAE_ACT_ELU 0
 #define TAE_ACT_LINEAR 1

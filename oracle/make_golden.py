@@ -87,6 +87,23 @@ CASES = [
     # -channel fading: the reference draws fading_h from the torch global stream inside forward (channel_ae.py:51-56);
     # seeded here and reproduced draw for draw, the coefficients travel in the fixture
     ("var_fading", dict(enc_num_unit=32, dec_num_unit=32, num_iteration=2, channel="fading"), 5, 20, 1.0, 3.0),
+    # r03: what the reference's argument parser accepts beyond the MFMA kernels' envelope (generic fp32 kernels, csrc/turboae_generic.hip)
+    ("gen_dec_lstm", dict(decoder="TurboAE_rate3_rnn", dec_rnn="lstm", enc_num_unit=32, dec_num_unit=24, num_iteration=2, block_len=40), 3, 50, 1.0, 2.0),
+    ("gen_dec_rnn_tanh", dict(decoder="TurboAE_rate3_rnn", dec_rnn="rnn", enc_num_unit=32, dec_num_unit=40, num_iteration=2, block_len=33,
+                              num_iter_ft=3, dec_act="tanh"), 4, 51, 1.0, 1.0),
+    ("gen_enc_lstm_l3_dec_gru", dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_rnn="lstm", enc_num_layer=3, enc_num_unit=20,
+                                     dec_num_unit=28, num_iteration=2, block_len=36), 3, 52, 1.0, 2.0),
+    ("gen_enc_rnn_l1_dec_lstm", dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_rnn="rnn", dec_rnn="lstm", enc_num_layer=1,
+                                     enc_num_unit=48, dec_num_unit=16, num_iteration=1, block_len=50, enc_act="tanh"), 3, 53, 1.0, 2.0),
+    # an RNN encoder in front of the CNN decoder: the reference then builds the decoder from DenseSameShapeConv1d (decoders.py:173-176)
+    ("gen_enc_gru_dec_cnn_dense", dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_cnn", enc_num_layer=1, enc_num_unit=24, dec_num_unit=20,
+                                       dec_num_layer=3, num_iteration=2, block_len=45), 3, 54, 1.0, 2.0),
+    ("gen_wide_e120_d136", dict(enc_num_unit=120, dec_num_unit=136, dec_num_layer=3, num_iteration=2, block_len=64), 3, 55, 1.0, 2.0),
+    ("gen_ft9", dict(enc_num_unit=32, dec_num_unit=32, num_iter_ft=9, num_iteration=2, dec_num_layer=2, block_len=70), 3, 56, 1.0, 2.0),
+    ("gen_kernel_e11_d13", dict(enc_num_unit=32, dec_num_unit=40, enc_kernel_size=11, dec_kernel_size=13, num_iteration=2, dec_num_layer=2,
+                                block_len=60), 3, 57, 1.0, 2.0),
+    ("gen_dense_enc_dec_rnn", dict(encoder="TurboAE_rate3_cnn_dense", decoder="TurboAE_rate3_rnn", enc_num_unit=24, dec_num_unit=20, num_iteration=1,
+                                   block_len=40, enc_num_layer=3), 3, 58, 1.0, 2.0),
 ]
 
 FADING_SEED = 20190020

@@ -57,7 +57,8 @@ def build_reference_model(cfg: dict, batch_size: int, is_parallel: int = 1, is_i
             "-enc_truncate_limit", str(cfg.get("enc_truncate_limit", 0.0)),
             "-enc_value_limit", str(cfg.get("enc_value_limit", 1.0)),
             "-enc_quantize_level", str(cfg.get("enc_quantize_level", 2.0)),
-            "-rec_quantize_level", str(cfg.get("rec_quantize_level", 2))]
+            "-rec_quantize_level", str(cfg.get("rec_quantize_level", 2)),
+            "-enc_rnn", cfg.get("enc_rnn", "gru"), "-dec_rnn", cfg.get("dec_rnn", "gru")]
     if cfg.get("no_code_norm", False):
         argv.append("--no_code_norm")
     if cfg.get("precompute_norm_stats", False):

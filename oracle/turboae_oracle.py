@@ -157,9 +157,10 @@ def encode_prenorm(u: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor,
 
 # encoders.py:281-298 (ENC_interRNN.forward): three 2-layer bidirectional GRU(1 -> U) + Linear(2U -> 1) + enc_act; the
 # input is the raw bit tensor (no 2u - 1 here, unlike ENC_interCNN), the third branch sees the interleaved bits.
-def encode_prenorm_rnn(u: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor, hidden: int, enc_act: str = "elu") -> torch.Tensor:
+def encode_prenorm_rnn(u: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor, hidden: int, enc_act: str = "elu",
+                       cell: str = "gru", num_layers: int = 2) -> torch.Tensor:
     def branch(x, i):
-        h = _gru_stack(x, w, f"enc.enc_rnn_{i}", hidden)
+        h = _gru_stack(x, w, f"enc.enc_rnn_{i}", hidden, cell, num_layers)       # RNN_MODEL(1, enc_num_unit, num_layers=enc_num_layer), encoders.py:251-263
         return _enc_act(F.linear(h, w[f"enc.enc_linear_{i}.weight"], w[f"enc.enc_linear_{i}.bias"]), enc_act)
     return torch.cat([branch(u, 1), branch(u, 2), branch(interleave(u, p), 3)], dim=2)
 
@@ -212,8 +213,12 @@ def decode(received: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor, 
 # The GRU arithmetic is PyTorch's (third-party to the reference); its documented cell is
 #   r = sigmoid(W_ir x + b_ir + W_hr h + b_hr); z = sigmoid(W_iz x + b_iz + W_hz h + b_hz)
 #   n = tanh(W_in x + b_in + r * (W_hn h + b_hn)); h' = (1 - z) * n + z * h        (gate order r, z, n)
-def _gru_stack(x: torch.Tensor, w: Dict[str, torch.Tensor], prefix: str, hidden: int) -> torch.Tensor:
-    gru = torch.nn.GRU(x.shape[2], hidden, num_layers=2, bias=True, batch_first=True, dropout=0.0, bidirectional=True)
+def _rnn_model(cell: str):          # decoders.py:27-32, encoders.py:242-247
+    return torch.nn.GRU if cell == "gru" else (torch.nn.LSTM if cell == "lstm" else torch.nn.RNN)
+
+
+def _gru_stack(x: torch.Tensor, w: Dict[str, torch.Tensor], prefix: str, hidden: int, cell: str = "gru", num_layers: int = 2) -> torch.Tensor:
+    gru = _rnn_model(cell)(x.shape[2], hidden, num_layers=num_layers, bias=True, batch_first=True, dropout=0.0, bidirectional=True)
     with torch.no_grad():
         for name, _ in gru.named_parameters():
             getattr(gru, name).copy_(w[f"{prefix}.{name}"])
@@ -223,7 +228,7 @@ def _gru_stack(x: torch.Tensor, w: Dict[str, torch.Tensor], prefix: str, hidden:
 
 
 def decode_rnn(received: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tensor, hidden: int, num_iteration: int,
-               num_iter_ft: int, extrinsic: int = 1, taps: Optional[dict] = None, dec_act: str = "linear") -> torch.Tensor:
+               num_iter_ft: int, extrinsic: int = 1, taps: Optional[dict] = None, dec_act: str = "linear", cell: str = "gru") -> torch.Tensor:
     B, L, _ = received.shape
     r_sys = received[:, :, 0:1]
     r_sys_int = interleave(r_sys, p)
@@ -232,12 +237,12 @@ def decode_rnn(received: torch.Tensor, w: Dict[str, torch.Tensor], p: torch.Tens
     prior = torch.zeros((B, L, num_iter_ft), dtype=received.dtype)
     x_plr = None
     for it in range(num_iteration):
-        h = _gru_stack(torch.cat([r_sys, r_par1, prior], dim=2), w, f"dec.dec1_rnns.{it}", hidden)
+        h = _gru_stack(torch.cat([r_sys, r_par1, prior], dim=2), w, f"dec.dec1_rnns.{it}", hidden, cell)       # num_layers=2 fixed, decoders.py:41-49
         x_plr = _enc_act(F.linear(h, w[f"dec.dec1_outputs.{it}.weight"], w[f"dec.dec1_outputs.{it}.bias"]), dec_act)   # decoders.py:103
         if extrinsic:
             x_plr = x_plr - prior
         x_plr_int = interleave(x_plr, p)
-        h = _gru_stack(torch.cat([r_sys_int, r_par2, x_plr_int], dim=2), w, f"dec.dec2_rnns.{it}", hidden)
+        h = _gru_stack(torch.cat([r_sys_int, r_par2, x_plr_int], dim=2), w, f"dec.dec2_rnns.{it}", hidden, cell)
         x_plr = _enc_act(F.linear(h, w[f"dec.dec2_outputs.{it}.weight"], w[f"dec.dec2_outputs.{it}.bias"]), dec_act)   # decoders.py:115,143
         if it < num_iteration - 1:
             if extrinsic:
@@ -258,6 +263,13 @@ def is_dense(cfg) -> bool:
     return enc == "TurboAE_rate3_cnn_dense"
 
 
+# decoders.py:173-176: `if args.encoder == 'TurboAE_rate3_cnn': SameShapeConv1d else: DenseSameShapeConv1d` - the CNN decoder is
+# dense behind ANY other encoder (the dense CNN encoder, and also the RNN encoder)
+def is_dec_dense(cfg) -> bool:
+    enc = cfg.get("encoder", "TurboAE_rate3_cnn") if isinstance(cfg, dict) else getattr(cfg, "encoder", "TurboAE_rate3_cnn")
+    return enc != "TurboAE_rate3_cnn"
+
+
 # channel_ae.py:20-73 (Channel_AE.forward), AWGN branch (:41-42), rec_quantize off.
 def channel_ae_forward(u: torch.Tensor, fwd_noise: torch.Tensor, w: Dict[str, torch.Tensor], cfg: dict,
                        taps: Optional[dict] = None, state: Optional[dict] = None,
@@ -271,17 +283,17 @@ def channel_ae_forward(u: torch.Tensor, fwd_noise: torch.Tensor, w: Dict[str, to
         else:
             p = torch.from_numpy(rand_interleaver(u.shape[1], cfg.get("interleaver_seed", 0)))
         if cfg.get("encoder", "TurboAE_rate3_cnn") == "TurboAE_rate3_rnn":
-            x_tx = encode_prenorm_rnn(u, w, p, cfg["enc_num_unit"], cfg.get("enc_act", "elu"))
+            x_tx = encode_prenorm_rnn(u, w, p, cfg["enc_num_unit"], cfg.get("enc_act", "elu"), cfg.get("enc_rnn", "gru"), cfg["enc_num_layer"])
         else:
             x_tx = encode_prenorm(u, w, p, cfg["enc_num_layer"], cfg.get("enc_act", "elu"), dense)
         codes, mean, std = power_constraint(x_tx, cfg, state if state is not None else {})
         received = apply_channel(codes, fwd_noise, cfg, fading)
         if cfg.get("decoder", "TurboAE_rate3_cnn") == "TurboAE_rate3_rnn":
             x_dec = decode_rnn(received, w, p, cfg["dec_num_unit"], cfg["num_iteration"], cfg["num_iter_ft"],
-                               cfg.get("extrinsic", 1), taps, cfg.get("dec_act", "linear"))
+                               cfg.get("extrinsic", 1), taps, cfg.get("dec_act", "linear"), cfg.get("dec_rnn", "gru"))
         else:
             x_dec = decode(received, w, p, cfg["dec_num_layer"], cfg["num_iteration"], cfg["num_iter_ft"],
-                           cfg.get("extrinsic", 1), taps, dense)
+                           cfg.get("extrinsic", 1), taps, is_dec_dense(cfg))
         if taps is not None:
             taps["x_tx"] = x_tx.clone()
             taps["mean"] = mean.clone()

@@ -45,9 +45,15 @@ def test_num_weights_matches_python_side():
 
 def test_bad_config_is_rejected_with_message():
     lib = _lib.load()
-    c = _lib.TaeConfig(C.sizeof(_lib.TaeConfig), 100, 2, 128, 5, 5, 128, 5, 6, 5, 1, 0, 1, 0)
+    c = _lib.TaeConfig(C.sizeof(_lib.TaeConfig), 100, 2, 2000, 5, 5, 2000, 5, 6, 5, 1, 0, 1, 0)
     assert lib.tae_num_weights(C.byref(c)) == 0
-    assert b"channel width" in lib.tae_last_error()
+    assert b"must be in 1..1024" in lib.tae_last_error()
+    c = _lib.TaeConfig(C.sizeof(_lib.TaeConfig), 100, 2, 100, 4, 5, 100, 5, 6, 5, 1, 0, 1, 0)      # even kernel size
+    assert lib.tae_num_weights(C.byref(c)) == 0
+    assert b"kernel_size" in lib.tae_last_error()
+    # widths above 100 are inside the generic fp32 kernels' envelope (r03)
+    c = _lib.TaeConfig(C.sizeof(_lib.TaeConfig), 100, 2, 128, 5, 5, 128, 5, 6, 5, 1, 0, 1, 0)
+    assert lib.tae_num_weights(C.byref(c)) == W.num_params(TurboAEConfig(enc_num_unit=128, dec_num_unit=128))
     c = _lib.TaeConfig(4, 100, 2, 100, 5, 5, 100, 5, 6, 5, 1, 0, 1, 0)
     assert lib.tae_num_weights(C.byref(c)) == 0
     assert b"struct_size" in lib.tae_last_error()
@@ -91,7 +97,7 @@ def test_header_is_plain_c_and_a_c_host_links(tmp_path):
                    "    c.block_len = 100; c.enc_num_layer = 2; c.enc_num_unit = 100; c.enc_kernel_size = 5; c.dec_num_layer = 5;\n"
                    "    c.dec_num_unit = 100; c.dec_kernel_size = 5; c.num_iteration = 6; c.num_iter_ft = 5; c.extrinsic = 1; c.max_batch = 1;\n"
                    '    printf("%d %zu\\n", tae_abi_version(), tae_num_weights(&c));\n'
-                   "    c.enc_num_unit = 128; c.dec_num_unit = 128;\n"
+                   "    c.enc_num_unit = 2000; c.dec_num_unit = 2000;\n"
                    '    { size_t n = tae_num_weights(&c); printf("%zu %s\\n", n, tae_last_error()); }\n'
                    "    return tae_abi_version() == TAE_ABI_VERSION ? 0 : 1;\n}\n")
     exe = tmp_path / "abi"
@@ -101,7 +107,7 @@ def test_header_is_plain_c_and_a_c_host_links(tmp_path):
     assert out.returncode == 0, out.stderr
     first, second = out.stdout.splitlines()
     assert first.split() == [str(_lib.TAE_ABI_VERSION), str(W.num_params(TurboAEConfig()))]
-    assert second.startswith("0 ") and "channel width" in second
+    assert second.startswith("0 ") and "must be in 1..1024" in second
 
 
 def test_config_struct_is_the_same_everywhere():

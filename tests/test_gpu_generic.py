@@ -1,0 +1,160 @@
+"""Configurations outside the MFMA kernels' envelope, through the C ABI on the library's generic fp32 kernels
+(csrc/turboae_generic.hip): golden vectors from the REAL reference for LSTM / vanilla-RNN cells, ENC_interRNN with 1 and 3 layers,
+an RNN encoder in front of the (then dense) CNN decoder, channel widths above 100, num_iter_ft above 6 and kernel sizes above 9;
+`precision='f32'` for the variants whose MFMA kernels exist in the fp16-split arithmetic only (dense stacks, kernel sizes 7 / 9)
+against the same reference vectors; random generic configurations against the oracle; the range fall-back."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from turboae_amd import TurboAEConfig, philox, weights as W
+from oracle import turboae_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+with open(os.path.join(GOLD, "MANIFEST.json")) as fh:
+    MANIFEST = json.load(fh)
+
+GEN = [n for n in sorted(MANIFEST["cases"]) if n.startswith("gen_")]
+
+
+def _run(gpu_device, cfg, meta, name):
+    from turboae_amd import Channel_AE_HIP
+    sd = W.generate_state_dict(cfg, seed=meta["weight_seed"], gain=meta["gain"])
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=meta["B"])
+    xd, codes = model(torch.from_numpy(g["u"]).to(gpu_device), torch.from_numpy(g["noise"]).to(gpu_device))
+    return model, g, xd.cpu().numpy(), codes.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", GEN)
+def test_generic_configurations_match_reference_golden(gpu_device, name):
+    assert len(GEN) >= 9
+    meta = MANIFEST["cases"][name]
+    cfg = TurboAEConfig(**meta["config"])
+    assert cfg.generic
+    model, g, xd, codes = _run(gpu_device, cfg, meta, name)
+    assert model.range_status() == ("f32", False) and model.kernel_info() == (0, 0)
+    assert np.abs(codes - g["codes"]).max() <= 1e-5, np.abs(codes - g["codes"]).max()
+    d = np.abs(xd - g["x_dec"]).max()
+    assert d <= 2e-5, d
+    flips = (xd > 0.5) != (g["x_dec"] > 0.5)
+    assert np.all(np.abs(g["logits"][flips]) < 2e-4)
+    # the split entry points agree with the fused forward on this path too
+    u = torch.from_numpy(g["u"]).to(gpu_device)
+    assert torch.equal(model.enc(u).cpu(), torch.from_numpy(codes))
+    assert torch.equal(model.dec(torch.from_numpy(codes + g["noise"]).to(gpu_device)).cpu(), torch.from_numpy(xd))
+
+
+@pytest.mark.parametrize("name", ["fwd_dense_u100_L100_b3_it2", "fwd_dense_k3_k1_u32_L64", "var_kernel_e7_d9", "var_kernel_e9_d7_L500"])
+def test_precision_f32_for_dense_stacks_and_kernel_sizes_7_9(gpu_device, name):
+    """the second arithmetic for the variants the fp32 MFMA kernels do not cover: the same reference vectors, fp32 end to end"""
+    from dataclasses import replace
+    meta = MANIFEST["cases"][name]
+    cfg = replace(TurboAEConfig(**meta["config"]), precision="f32")
+    assert cfg.generic
+    model, g, xd, codes = _run(gpu_device, cfg, meta, name)
+    assert model.range_status()[0] == "f32"
+    assert np.abs(codes - g["codes"]).max() <= 1e-5
+    assert np.abs(xd - g["x_dec"]).max() <= 2e-5
+    # and the fp16-split kernels' result for the same network is within the same bound of it
+    auto = replace(cfg, precision="auto")
+    assert not auto.generic
+    _, _, xd2, codes2 = _run(gpu_device, auto, meta, name)
+    assert np.abs(codes - codes2).max() <= 1e-5 and np.abs(xd - xd2).max() <= 2e-5
+
+
+def _draw(n, seed):
+    rng = np.random.RandomState(seed)
+    cases = []
+    for i in range(n):
+        kind = ["wide", "bigk", "ft", "lstm", "rnn", "enc_rnn", "rnn_cnn"][i % 7]
+        c = dict(block_len=int(rng.choice([1, 7, 31, 32, 33, 64, 90])), num_iteration=int(rng.randint(1, 3)), num_iter_ft=int(rng.randint(1, 6)),
+                 extrinsic=int(rng.randint(0, 2)), enc_num_unit=int(rng.randint(4, 40)), dec_num_unit=int(rng.randint(4, 40)),
+                 enc_num_layer=int(rng.randint(1, 4)), dec_num_layer=int(rng.randint(1, 4)),
+                 enc_act=str(rng.choice(["elu", "linear", "tanh"])), B=int(rng.choice([1, 2, 5])), wseed=int(rng.randint(1, 1 << 30)), kind=kind)
+        if kind == "wide":
+            c.update(enc_num_unit=int(rng.randint(101, 200)), dec_num_unit=int(rng.randint(101, 260)))
+        elif kind == "bigk":
+            c.update(enc_kernel_size=int(rng.choice([11, 15, 21])), dec_kernel_size=int(rng.choice([11, 13, 63])))
+        elif kind == "ft":
+            c.update(num_iter_ft=int(rng.randint(7, 20)))
+        elif kind in ("lstm", "rnn"):
+            c.update(decoder="TurboAE_rate3_rnn", dec_rnn=kind, dec_act=str(rng.choice(["linear", "tanh", "elu"])))
+        elif kind == "enc_rnn":
+            c.update(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_rnn=str(rng.choice(["gru", "lstm", "rnn"])),
+                     dec_rnn=str(rng.choice(["gru", "lstm", "rnn"])), enc_num_layer=int(rng.choice([1, 3, 4])))
+        else:
+            c.update(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_cnn", enc_rnn=str(rng.choice(["gru", "lstm"])))
+        cases.append(c)
+    return cases
+
+
+@pytest.mark.parametrize("case", _draw(21, 90210), ids=lambda c: "{kind}_L{block_len}_B{B}_e{enc_num_unit}x{enc_num_layer}_d{dec_num_unit}x{dec_num_layer}_F{num_iter_ft}".format(**c))
+def test_random_generic_configurations_match_oracle(gpu_device, case):
+    from turboae_amd import Channel_AE_HIP
+    case = dict(case)
+    B, wseed, kind = case.pop("B"), case.pop("wseed"), case.pop("kind")
+    cfg = TurboAEConfig(**case)
+    assert cfg.generic
+    L = cfg.block_len
+    sd = W.generate_state_dict(cfg, seed=wseed, gain=1.0)
+    u = philox.random_bits(wseed, 0, B * L).reshape(B, L, 1)
+    noise = (np.float32(O.snr_db2sigma(1.0)) * philox.random_normal(wseed, 0, B * L * 3)).reshape(B, L, 3).astype(np.float32)
+    taps = {}
+    xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict(), taps)
+    xo, co = xo.numpy(), co.numpy()
+    if not (np.isfinite(xo).all() and np.isfinite(co).all()):
+        pytest.skip("degenerate draw: constant encoder output")
+    amplify = max(1.0, 0.25 / float(taps["std"]))
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    xd, codes = model(torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device))
+    xd, codes = xd.cpu().numpy(), codes.cpu().numpy()
+    tol_c, tol_x = (2e-5 * amplify, 6e-5 * amplify) if B * L >= 8 else (2e-4 * amplify, 2e-4 * amplify)
+    assert np.abs(codes - co).max() <= tol_c, np.abs(codes - co).max()
+    assert np.abs(xd - xo).max() <= tol_x, np.abs(xd - xo).max()
+
+
+def test_generic_path_runs_the_eval_sweep_and_every_entry_point(gpu_device):
+    """evaluate.test, tae_eval_snr and the hipGraph form on an LSTM decoder (all launches are plain kernels on the caller's stream)"""
+    from turboae_amd import Channel_AE_HIP, evaluate
+    cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="lstm", enc_num_unit=16, dec_num_unit=12, num_iteration=1, block_len=20)
+    model = Channel_AE_HIP(cfg, W.generate_state_dict(cfg, seed=3, gain=1.0), device=gpu_device, max_batch=40)
+    res = evaluate.test(model, snr_test_start=0.0, snr_test_end=2.0, snr_points=2, num_block=80, batch_size=40, seed=4, verbose=False)
+    gr = evaluate.test(model, snr_test_start=0.0, snr_test_end=2.0, snr_points=2, num_block=80, batch_size=40, seed=4, verbose=False, hip_graph=True)
+    assert gr["bit_errors"] == res["bit_errors"] and gr["block_errors"] == res["block_errors"]
+    for si, snr in enumerate(res["snrs"]):
+        c = model.eval_snr(snr, 40, 2, seed=4, first_block=si * 80).sum(dim=0).cpu().tolist()
+        assert c == [res["bit_errors"][si], res["block_errors"][si]]
+    with pytest.raises(Exception, match="tap"):
+        model.decode_taps(torch.zeros(2, 20, 3, device=gpu_device))
+
+
+def test_range_fallback_reruns_on_fp32_kernels(gpu_device):
+    """Activations beyond the fp16 range make the fp16-split results invalid (sticky flag).  With range_fallback=True the mirror
+    notices, rebuilds its engine with precision='f32' and runs the call again: a correct result and a flag that says so."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(enc_num_unit=32, dec_num_unit=32, num_iteration=2, block_len=40)
+    sd = W.generate_state_dict(cfg, seed=11, gain=1.0)
+    big = {k: (v * np.float32(40.0) if ".cnns." in k and k.endswith("weight") and k.startswith("dec.") else v) for k, v in sd.items()}
+    B = 4
+    u = philox.random_bits(5, 0, B * 40).reshape(B, 40, 1)
+    noise = (np.float32(0.8) * philox.random_normal(5, 0, B * 40 * 3)).reshape(B, 40, 3).astype(np.float32)
+    xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(big), cfg.to_dict())
+    ut, nt = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
+    plain = Channel_AE_HIP(cfg, big, device=gpu_device, max_batch=B)
+    plain(ut, nt)
+    assert plain.range_status() == ("f16x2", True)                 # the fp16-split kernels report, the caller has to act
+    model = Channel_AE_HIP(cfg, big, device=gpu_device, max_batch=B, range_fallback=True)
+    xd, codes = model(ut, nt)
+    assert model.fell_back and model.range_status() == ("f32", False)
+    rel = float(np.abs(xd.cpu().numpy() - xo.numpy()).max())
+    assert rel <= 1e-3, rel                                        # logits of order 1e5: compare the saturated outputs
+    assert np.array_equal(xd.cpu().numpy() > 0.5, xo.numpy() > 0.5)
+    assert np.abs(codes.cpu().numpy() - co.numpy()).max() <= 1e-5
+    xd2, _ = model(ut, nt)                                          # stays on the fp32 kernels
+    assert torch.equal(xd2, xd)

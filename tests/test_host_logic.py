@@ -95,12 +95,19 @@ def test_config_validation():
     TurboAEConfig(enc_kernel_size=3, dec_kernel_size=1, enc_num_unit=32, dec_num_unit=64).validate()
     TurboAEConfig(enc_kernel_size=7, dec_kernel_size=9).validate()
     with pytest.raises(ValueError):
-        TurboAEConfig(enc_kernel_size=7, precision="f32").validate()
-    with pytest.raises(ValueError):
         TurboAEConfig(enc_kernel_size=4).validate()
     TurboAEConfig(enc_num_unit=48, dec_num_unit=7).validate()
-    with pytest.raises(ValueError):
-        TurboAEConfig(enc_num_unit=128, dec_num_unit=128).validate()
+    assert not TurboAEConfig(enc_num_unit=48, dec_num_unit=7).generic and not TurboAEConfig(enc_kernel_size=7, dec_kernel_size=9).generic
+    # outside the MFMA kernels' envelope: the generic fp32 kernels (r03) - still validated, with their own (wider) limits
+    for over in (dict(enc_kernel_size=7, precision="f32"), dict(enc_num_unit=128, dec_num_unit=128), dict(num_iter_ft=9), dict(dec_kernel_size=21),
+                 dict(decoder="TurboAE_rate3_rnn", dec_rnn="lstm"), dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_num_layer=3),
+                 dict(encoder="TurboAE_rate3_rnn"), dict(encoder="TurboAE_rate3_cnn_dense", precision="f32")):
+        cfg = TurboAEConfig(**over)
+        cfg.validate()
+        assert cfg.generic, over
+    for over in (dict(enc_num_unit=2000), dict(dec_kernel_size=12), dict(num_iter_ft=100), dict(dec_rnn="elman"), dict(dec_kernel_size=65)):
+        with pytest.raises(ValueError):
+            TurboAEConfig(**over).validate()
     with pytest.raises(ValueError):
         TurboAEConfig(code_rate_n=2).validate()
 
@@ -112,13 +119,15 @@ def test_variant_configs_and_param_counts():
     # GRU encoder needs the GRU decoder; dense stacks need the fp16-split kernels and are keyed on the ENCODER name
     TurboAEConfig(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn").validate()
     TurboAEConfig(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_num_unit=40, dec_num_unit=25).validate()
-    with pytest.raises(ValueError):
-        TurboAEConfig(encoder="TurboAE_rate3_rnn").validate()
+    # an RNN encoder in front of the CNN decoder: the reference then builds the decoder from DenseSameShapeConv1d (decoders.py:173-176)
+    mixed = TurboAEConfig(encoder="TurboAE_rate3_rnn")
+    mixed.validate()
+    assert mixed.dec_dense and not mixed.dense and dict(W.canonical_entries(mixed))["dec.dec1_cnns.0.cnns.2.weight"] == (100, 7 + 200, 5)
+    lstm = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="lstm")
+    assert dict(W.canonical_entries(lstm))["dec.dec2_rnns.3.weight_hh_l1_reverse"] == (400, 100)
     dense = TurboAEConfig(encoder="TurboAE_rate3_cnn_dense", decoder="TurboAE_rate3_cnn_dense")
     dense.validate()
     assert dense.dense and not TurboAEConfig().dense
-    with pytest.raises(ValueError):
-        TurboAEConfig(encoder="TurboAE_rate3_cnn_dense", precision="f32").validate()
     with pytest.raises(ValueError):
         TurboAEConfig(decoder="TurboAE_rate3_cnn_dense").validate()
     shapes = dict(W.canonical_entries(dense))

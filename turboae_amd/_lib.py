@@ -19,7 +19,7 @@ class TaeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "struct_size", "block_len", "enc_num_layer", "enc_num_unit", "enc_kernel_size",
         "dec_num_layer", "dec_num_unit", "dec_kernel_size", "num_iteration", "num_iter_ft",
-        "extrinsic", "enc_act", "max_batch", "dec_type", "enc_type", "dense", "precision", "dec_act")]
+        "extrinsic", "enc_act", "max_batch", "dec_type", "enc_type", "dense", "precision", "dec_act", "enc_rnn", "dec_rnn")]
 
 
 class TaeChannelOpts(C.Structure):

@@ -26,6 +26,7 @@ from .config import TurboAEConfig
 from .interleaver import rand_interleaver
 from . import weights as W
 
+_RNN = {"gru": 0, "lstm": 1, "rnn": 2}                                                # TAE_RNN_*
 _ACT = {"elu": 0, "linear": 1, "tanh": 2, "relu": 3, "selu": 4, "sigmoid": 5}      # TAE_ACT_* (include/turboae_hip.h)
 
 
@@ -61,7 +62,8 @@ class _Engine:
                            cfg.enc_kernel_size, cfg.dec_num_layer, cfg.dec_num_unit, cfg.dec_kernel_size,
                            cfg.num_iteration, cfg.num_iter_ft, cfg.extrinsic, _ACT[cfg.enc_act], max_batch,
                            1 if cfg.decoder == "TurboAE_rate3_rnn" else 0, 1 if cfg.encoder == "TurboAE_rate3_rnn" else 0,
-                           1 if cfg.dense else 0, 1 if cfg.precision == "f32" else 0, _ACT[cfg.dec_act])
+                           1 if cfg.dense else 0, 1 if cfg.precision == "f32" else 0, _ACT[cfg.dec_act],
+                           _RNN[cfg.enc_rnn], _RNN[cfg.dec_rnn])
         n = self.lib.tae_num_weights(C.byref(c))
         if n != blob.size:
             raise _lib.TurboAEError(f"weight count mismatch: library wants {n}, blob has {blob.size}")
@@ -253,7 +255,7 @@ class Channel_AE_HIP:
 
     def __init__(self, args_or_cfg, state_dict: Dict[str, object], device: Optional[torch.device] = None,
                  max_batch: int = 500, is_same_interleaver: Optional[int] = None, is_variable_block_len: Optional[bool] = None,
-                 is_interleave: Optional[int] = None):
+                 is_interleave: Optional[int] = None, range_fallback: bool = False):
         cfg = _as_cfg(args_or_cfg)
         # -is_interleave / -is_same_interleaver (get_args.py:85,87), taken from a reference-style namespace when not given:
         #   is_interleave == 0: the identity permutation set at construction (main.py:129-131) and forward leaves whatever
@@ -271,6 +273,11 @@ class Channel_AE_HIP:
             is_variable_block_len = bool(getattr(args_or_cfg, "is_variable_block_len", False))
         self.is_variable_block_len = is_variable_block_len
         self._by_len: Dict[int, _Engine] = {}
+        # range_fallback: after every forward the fp16-split kernels' range flag is read (one device synchronisation per call); if an
+        # activation left the fp16 range the engine is rebuilt with precision='f32' and the call runs again - `fell_back` says so.
+        # Off by default: the entry points stay asynchronous and capturable, the caller checks with check_range().
+        self.range_fallback = bool(range_fallback)
+        self.fell_back = False
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         self.cfg = cfg
@@ -357,6 +364,19 @@ class Channel_AE_HIP:
         return torch.cat([fh.reshape(-1), noise.reshape(-1)])
 
     def forward(self, input: torch.Tensor, fwd_noise: torch.Tensor, fading: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        out = self._forward_once(input, fwd_noise, fading)
+        if self.range_fallback and not self.fell_back and self.cfg.precision != "f32":
+            e = self._engine_for(input.shape[1]) if input.dim() == 3 else self._eng
+            mode, overflow = e.range_status()
+            if overflow:
+                from dataclasses import replace
+                self.cfg = replace(self.cfg, precision="f32")
+                self.fell_back = True
+                self.load_state_dict(self._eng._state)          # rebuilds the engine(s) with the fp32 kernels, keeps interleaver / statistics
+                out = self._forward_once(input, fwd_noise, fading)
+        return out
+
+    def _forward_once(self, input: torch.Tensor, fwd_noise: torch.Tensor, fading: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         e = self._engine_for(input.shape[1]) if input.dim() == 3 else self._eng
         if self.is_interleave == 0:      # channel_ae.py:22-23
             pass

@@ -31,6 +31,8 @@ class TurboAEConfig:
                                          # reference's own CLI cannot select it - its -encoder choice is spelled 'Turboae_rate3_rnn')
     decoder: str = "TurboAE_rate3_cnn"   # get_args.py:26 / main.py:75-76,87-88: 'TurboAE_rate3_cnn' (DEC_LargeCNN) or
                                          # 'TurboAE_rate3_rnn' (DEC_LargeRNN, 2-layer bidirectional GRU, dec_rnn='gru')
+    enc_rnn: str = "gru"          # get_args.py:79: cell of ENC_interRNN (encoders.py:242-247): 'gru' | 'lstm' | 'rnn'
+    dec_rnn: str = "gru"          # get_args.py:80: cell of DEC_LargeRNN (decoders.py:27-32)
     interleaver_seed: int = 0     # channel_ae.py:33 (RandInterlv(block_len, 0))
     precision: str = "auto"       # no reference counterpart: 'auto' = fp16-split MFMA contraction (fp32-grade)
                                   # where the whole-block kernels apply; 'f32' = fp32 MFMA everywhere
@@ -55,9 +57,35 @@ class TurboAEConfig:
         name (encoders.py:312-330, decoders.py:173-176)."""
         return self.encoder == "TurboAE_rate3_cnn_dense"
 
+    @property
+    def dec_dense(self) -> bool:
+        """The CNN decoder is built from DenseSameShapeConv1d whenever the encoder is NOT the plain CNN (decoders.py:173-176)."""
+        return self.decoder != "TurboAE_rate3_rnn" and self.encoder != "TurboAE_rate3_cnn"
+
+    @property
+    def generic(self) -> bool:
+        """True when the configuration lies outside the MFMA kernels' envelope and runs on the library's generic fp32 kernels
+        (csrc/turboae_generic.hip; mirrors tae::generic_needed): one launch per layer, same results, far slower."""
+        ks = (self.enc_kernel_size, self.dec_kernel_size)
+        enc_rnn, dec_rnn = self.encoder == "TurboAE_rate3_rnn", self.decoder == "TurboAE_rate3_rnn"
+        if max(ks) > 9 or self.enc_num_unit > 100 or self.dec_num_unit > 100 or self.num_iter_ft > 6:
+            return True
+        if (enc_rnn and self.enc_rnn != "gru") or (dec_rnn and self.dec_rnn != "gru"):
+            return True
+        if enc_rnn and (self.enc_num_layer != 2 or not dec_rnn):
+            return True
+        if self.dense and (dec_rnn or self.enc_num_unit not in (32, 64, 100) or self.dec_num_unit not in (32, 64, 100)):
+            return True
+        return self.precision == "f32" and (self.dense or max(ks) > 5)
+
     def validate(self) -> None:
         if self.code_rate_k != 1 or self.code_rate_n != 3:
             raise ValueError("only the rate-1/3 code (code_rate_k=1, code_rate_n=3) is on the hot path")
+        if self.enc_rnn not in ("gru", "lstm", "rnn") or self.dec_rnn not in ("gru", "lstm", "rnn"):
+            raise ValueError("enc_rnn / dec_rnn must be 'gru', 'lstm' or 'rnn' (get_args.py:79-80)")
+        if self.generic:
+            self._validate_generic()
+            return
         ks = (self.enc_kernel_size, self.dec_kernel_size)
         if any(k not in (1, 3, 5, 7, 9) for k in ks):
             raise ValueError("kernel sizes must be 1, 3, 5, 7 or 9 (odd: SameShapeConv1d pads with kernel_size // 2)")
@@ -97,6 +125,32 @@ class TurboAEConfig:
             raise ValueError("the reference builds DenseSameShapeConv1d decoders from the ENCODER name (decoders.py:173-176): "
                              "use encoder='TurboAE_rate3_cnn_dense'")
 
+    def _validate_generic(self) -> None:
+        """Limits of the generic fp32 kernels (tae::generic_check)."""
+        for k in (self.enc_kernel_size, self.dec_kernel_size):
+            if k < 1 or k > 63 or k % 2 == 0:
+                raise ValueError("kernel sizes must be odd and in 1..63 (SameShapeConv1d pads with kernel_size // 2: an even size changes the length)")
+        if not (1 <= self.enc_num_unit <= 1024 and 1 <= self.dec_num_unit <= 1024):
+            raise ValueError("enc_num_unit / dec_num_unit must be in 1..1024")
+        if not (1 <= self.num_iter_ft <= 64):
+            raise ValueError("num_iter_ft must be in 1..64")
+        if self.precision not in ("auto", "f32"):
+            raise ValueError("precision must be 'auto' or 'f32'")
+        acts = ("tanh", "selu", "relu", "elu", "sigmoid", "linear")
+        if self.enc_act not in acts or self.dec_act not in acts:
+            raise ValueError("enc_act / dec_act must be one of tanh, selu, relu, elu, sigmoid, linear (get_args.py:100-101)")
+        if self.num_iteration < 1 or self.enc_num_layer < 1 or self.dec_num_layer < 1 or self.block_len < 1:
+            raise ValueError("layer / iteration counts and block_len must be >= 1")
+        if self.channel not in ("awgn", "t-dist", "radar", "ge_awgn", "bec", "bsc", "ge", "fading"):
+            raise ValueError("channel must be one of awgn, t-dist, radar, ge_awgn, bec, bsc, ge, fading")
+        if self.encoder not in ("TurboAE_rate3_cnn", "TurboAE_rate3_cnn_dense", "TurboAE_rate3_rnn"):
+            raise ValueError("encoder must be 'TurboAE_rate3_cnn', 'TurboAE_rate3_cnn_dense' or 'TurboAE_rate3_rnn'")
+        if self.decoder not in ("TurboAE_rate3_cnn", "TurboAE_rate3_cnn_dense", "TurboAE_rate3_rnn"):
+            raise ValueError("decoder must be 'TurboAE_rate3_cnn', 'TurboAE_rate3_cnn_dense' or 'TurboAE_rate3_rnn'")
+        if self.decoder == "TurboAE_rate3_cnn_dense" and not self.dec_dense:
+            raise ValueError("the reference builds DenseSameShapeConv1d decoders from the ENCODER name (decoders.py:173-176): "
+                             "use a non-plain-CNN encoder")
+
     @staticmethod
     def from_args(args) -> "TurboAEConfig":
         """Build from a reference-style argparse namespace (get_args.py)."""
@@ -112,16 +166,19 @@ class TurboAEConfig:
     def macs_per_bit(self) -> dict:
         ke, kd = self.enc_kernel_size, self.dec_kernel_size
         ue, ud, f = self.enc_num_unit, self.dec_num_unit, self.num_iter_ft
+        gates = {"gru": 3, "lstm": 4, "rnn": 1}
         enc = 3 * (1 * ke * ue + (self.enc_num_layer - 1) * ue * ke * ue + ue)
         if self.encoder == "TurboAE_rate3_rnn":
-            enc = 3 * (2 * (3 * ue * (1 + ue) + 3 * ue * (2 * ue + ue)) + 2 * ue)
+            g = gates[self.enc_rnn]
+            enc = 3 * (2 * sum(g * ue * ((1 if l == 0 else 2 * ue) + ue) for l in range(self.enc_num_layer)) + 2 * ue)
         if self.decoder == "TurboAE_rate3_rnn":
             # 2-layer bidirectional GRU(2+F -> ud): per direction 3*ud*(in + ud) MAC per layer (244 200)
-            stack = 2 * (3 * ud * ((2 + f) + ud) + 3 * ud * (2 * ud + ud))
+            g = gates[self.dec_rnn]
+            stack = 2 * (g * ud * ((2 + f) + ud) + g * ud * (2 * ud + ud))
             dec = 2 * self.num_iteration * stack + (2 * self.num_iteration - 1) * 2 * ud * f + 2 * ud
         else:
             stack = (2 + f) * kd * ud + (self.dec_num_layer - 1) * ud * kd * ud
-            if self.dense:      # layer l convolves 2 + F + l * ud input channels (cnn_utils.py:59-62)
+            if self.dec_dense:      # layer l convolves 2 + F + l * ud input channels (cnn_utils.py:59-62)
                 stack = sum((2 + f + l * ud) * kd * ud for l in range(self.dec_num_layer))
             dec = 2 * self.num_iteration * stack + (2 * self.num_iteration - 1) * ud * f + ud
         if self.dense:

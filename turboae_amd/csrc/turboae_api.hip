@@ -298,6 +298,7 @@ struct tae_handle {
     float* d_ggi = nullptr;  // (chunk, L, 2, 19, 16) layer-1 input projections in gate-tile order
     tae::NormOpts nopts;       // encoder-output / channel variant (tae_set_channel_opts)
     tae_noise_opts noise_opts; // generator tae_eval_snr draws from (tae_set_noise_opts; default AWGN)
+    tae::GenericEngine* gen = nullptr;   // generic fp32 kernels (configurations outside the MFMA kernels' envelope)
 };
 
 namespace {
@@ -308,6 +309,16 @@ inline int kernel_width(int u) { return u <= 32 ? 32 : (u <= 64 ? 64 : (u <= 100
 int check_cfg(const tae_config* c) {
     if (!c) return fail(TAE_EINVAL, "config is NULL");
     if (c->struct_size != (int32_t)sizeof(tae_config)) return fail(TAE_EINVAL, "tae_config.struct_size mismatch (ABI)");
+    if (c->enc_rnn < 0 || c->enc_rnn > 2 || c->dec_rnn < 0 || c->dec_rnn > 2) return fail(TAE_EINVAL, "enc_rnn / dec_rnn must be TAE_RNN_GRU, TAE_RNN_LSTM or TAE_RNN_RNN");
+    if (tae::generic_needed(c)) {          // outside the MFMA kernels' envelope: the generic fp32 kernels' (wider) limits apply
+        if (const char* msg = tae::generic_check(c)) return fail(TAE_EINVAL, msg);
+        if (c->enc_num_layer < 1 || c->dec_num_layer < 1 || c->num_iteration < 1) return fail(TAE_EINVAL, "layer/iteration counts must be >= 1");
+        if (c->block_len < 1) return fail(TAE_EINVAL, "block_len must be >= 1");
+        if (c->enc_act < 0 || c->enc_act > 5 || c->dec_act < 0 || c->dec_act > 5) return fail(TAE_EINVAL, "enc_act / dec_act must be a TAE_ACT_* code");
+        if ((c->dec_type | 1) != 1 || (c->enc_type | 1) != 1 || (c->dense | 1) != 1) return fail(TAE_EINVAL, "dec_type / enc_type / dense must be 0 or 1");
+        if (c->precision != TAE_PREC_AUTO && c->precision != TAE_PREC_F32) return fail(TAE_EINVAL, "precision must be TAE_PREC_AUTO (0) or TAE_PREC_F32 (1)");
+        return TAE_OK;
+    }
     for (int ks : {c->enc_kernel_size, c->dec_kernel_size}) {
         if (ks != 1 && ks != 3 && ks != 5 && ks != 7 && ks != 9) return fail(TAE_EINVAL, "kernel_size must be 1, 3, 5, 7 or 9");
         if (ks > 5 && (c->precision != TAE_PREC_AUTO || c->dense))
@@ -695,6 +706,7 @@ void walk_weights(const tae_config* c, Fn&& f) {
 }
 
 size_t num_weights(const tae_config* c) {
+    if (tae::generic_needed(c)) return tae::generic_num_weights(c);
     size_t n = 0;
     walk_weights(c, [&](bool conv, size_t a, size_t b, size_t ks) { n += conv ? a * b * ks : a; });
     return n;
@@ -1066,6 +1078,7 @@ int run_decoder_long(tae_handle* h, const float* rx, float* xdec, int32_t B, hip
 int run_encoder_rnn(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st);
 
 int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st) {
+    if (h->gen) return tae::generic_encode(h->gen, u, xtx, stats, h->d_perm, B, st);
     if (h->cfg.enc_type == 1) return run_encoder_rnn(h, u, xtx, stats, B, st);
     if (h->nb < 1) return run_encoder_long(h, u, xtx, stats, B, st);
     tae::FusedParams P = base_params(h, B, false);
@@ -1231,6 +1244,10 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
 }
 
 int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st, float* tap_out = nullptr) {
+    if (h->gen) {
+        if (tap_out) return fail(TAE_EINVAL, "tae_decode_taps: no tap export on the generic fp32 kernels");
+        return tae::generic_decode(h->gen, rx, xdec, h->d_perm, h->d_inv, B, st);
+    }
     if (h->cfg.dec_type == 1) {
         if (tap_out) return fail(TAE_EINVAL, "tae_decode_taps: the GRU decoder has no tap export");
         return run_decoder_rnn(h, rx, xdec, B, st);
@@ -1295,6 +1312,35 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
             return fail(TAE_EHIP, "cannot query the current HIP device");
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(TAE_EHIP, std::string("libturboae_hip is built for gfx950 (MI355X) only; the current device is ") + prop.gcnArchName);
+    }
+    if (tae::generic_needed(cfg)) {
+        // outside the MFMA kernels' envelope: generic fp32 kernels, one launch per layer (turboae_generic.hip)
+        tae_handle* h = new tae_handle();
+        h->cfg = *cfg;
+        h->nopts = default_norm_opts();
+        h->noise_opts = default_noise_opts();
+        h->U = cfg->enc_num_unit;
+        h->Ud = cfg->dec_num_unit;
+        h->nb = h->nbd = 0;
+        h->prec = 0;
+        (void)hipGetDevice(&h->device);
+        rc = tae::generic_create(cfg, weights, n_weights, &h->gen);
+        if (rc != TAE_OK) { delete h; return rc; }
+        const int L = cfg->block_len;
+        std::vector<int32_t> ident(L);
+        for (int i = 0; i < L; ++i) ident[i] = i;
+        hipError_t e = hipMalloc(&h->d_perm, L * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc(&h->d_inv, L * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc(&h->d_stats, 4 * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc(&h->d_flags, 4 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(h->d_flags, 0, 4 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpy(h->d_perm, ident.data(), L * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(h->d_inv, ident.data(), L * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { tae_destroy(h); return fail(TAE_EHIP, hipGetErrorString(e)); }
+        rc = tae_reserve(h, cfg->max_batch > 0 ? cfg->max_batch : 1);
+        if (rc != TAE_OK) { tae_destroy(h); return rc; }
+        *out = h;
+        return TAE_OK;
     }
     std::vector<float> w5;
     tae_config cfg5 = *cfg;
@@ -1489,6 +1535,8 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
 
 int tae_destroy(tae_handle* h) {
     if (!h) return TAE_OK;
+    tae::generic_destroy(h->gen);
+    h->gen = nullptr;
     (void)hipFree(h->d_wenc); (void)hipFree(h->d_wdec); (void)hipFree(h->d_perm); (void)hipFree(h->d_inv);
     (void)hipFree(h->d_xtx); (void)hipFree(h->d_rx); (void)hipFree(h->d_partials); (void)hipFree(h->d_stats);
     (void)hipFree(h->d_e0); (void)hipFree(h->d_e1);
@@ -1509,6 +1557,14 @@ int tae_reserve(tae_handle* h, int32_t max_batch) {
     (void)hipFree(h->d_xtx); (void)hipFree(h->d_rx); (void)hipFree(h->d_partials); (void)hipFree(h->d_e0); (void)hipFree(h->d_e1);
     h->d_xtx = h->d_rx = h->d_e0 = h->d_e1 = nullptr; h->d_partials = nullptr; h->cap = 0;
     const size_t n3 = (size_t)max_batch * h->cfg.block_len * 3;
+    if (h->gen) {
+        const int rc_g = tae::generic_reserve(h->gen, max_batch);
+        if (rc_g != TAE_OK) return rc_g;
+        TAE_HIP(hipMalloc(&h->d_xtx, n3 * sizeof(float)));
+        TAE_HIP(hipMalloc(&h->d_rx, n3 * sizeof(float)));
+        h->cap = max_batch;
+        return TAE_OK;
+    }
     const size_t grid = h->nb >= 1 ? (size_t)max_batch : (size_t)3 * max_batch * h->enc_nseg;   // workgroups of the encoder at most (nb_for_batch may pick 1 block each)
     if (h->nbd < 1) {
         const size_t n8 = (size_t)max_batch * h->cfg.block_len * 8;
@@ -1742,6 +1798,11 @@ int tae_generate_inputs(tae_handle* h, float* u, float* noise, int32_t B, int64_
 
 int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_t* lds_bytes) {
     if (!h) return fail(TAE_EINVAL, "handle is NULL");
+    if (h->gen) {          // generic fp32 kernels: no fused geometry to report
+        if (blocks_per_workgroup) *blocks_per_workgroup = 0;
+        if (lds_bytes) *lds_bytes = 0;
+        return TAE_OK;
+    }
     if (blocks_per_workgroup) *blocks_per_workgroup = h->nbd;        // the decoder's (the dominant kernel)
     if (lds_bytes) *lds_bytes = h->nbd >= 1 ? (h->prec == 1 ? h->lds_bytes_hd : h->lds_bytes_d) : (h->prec == 1 ? h->dec_lds_h : h->dec_lds);
     return TAE_OK;

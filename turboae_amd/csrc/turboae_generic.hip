@@ -1,0 +1,521 @@
+// Generic fp32 kernels: the reference's layer arithmetic one layer at a time, for every configuration the reference's argument
+// parser accepts on this path but the MFMA kernels do not instantiate - channel widths above 100, kernel sizes above 9 (any odd
+// size), num_iter_ft above 6, LSTM / vanilla-RNN cells (decoders.py:27-32, encoders.py:242-253), ENC_interRNN with
+// enc_num_layer != 2, an RNN encoder in front of the (then dense, decoders.py:173-176) CNN decoder - and `precision = f32` for the
+// variants whose MFMA kernels exist in the fp16-split arithmetic only (DenseSameShapeConv1d, kernel sizes 7 / 9).
+//
+// These are parity / coverage kernels, not the benchmark path: plain fp32 FMA chains on the vector ALU (an input tile staged in
+// LDS, weights streamed transposed so a wave's loads coalesce over output channels), activations round-trip through HBM between
+// layers.  Every op follows the PyTorch definition the reference relies on:
+//   SameShapeConv1d / DenseSameShapeConv1d   cnn_utils.py:6-82       y[co,t] = b[co] + sum_ci sum_j W[co,ci,j] x[ci,t+j-k//2]; ELU
+//   torch.nn.GRU / LSTM / RNN (bidirectional, batch_first, n layers)   decoders.py:41-49, encoders.py:251-268
+//   Linear heads, enc_act / dec_act, extrinsic subtraction, (de)interleave, sigmoid    decoders.py:84-149,206-269, encoders.py:281-377
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/turboae_hip.h"
+#include "turboae_internal.hpp"
+#include "turboae_device.hpp"
+
+namespace tae {
+
+namespace {
+
+constexpr int kConvPos = 32;        // positions per workgroup
+constexpr int kConvCh = 64;         // output channels per workgroup
+constexpr int kConvCi = 128;        // input channels staged per pass
+
+// y[b, t, coff + co] = act(bias[co] + sum_{ci, j} wt[(ci * k + j) * cout + co] * x[b, t + j - k / 2, ci]), zero outside the block
+// (Conv1d padding = k // 2, cnn_utils.py:16,58).  act: 0 none (Linear, RNN input projections), 1 ELU (every conv layer).
+__global__ __launch_bounds__(256) void gen_conv_kernel(const float* __restrict__ x, int ldx, int cin, const float* __restrict__ wt,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int ldy, int coff, int cout,
+                                                       int k, int L, int act) {
+    extern __shared__ float xs[];                      // [(kConvPos + k - 1)][kConvCi]
+    const int tid = threadIdx.x, col = tid & 63, pg = tid >> 6;
+    const int t0 = blockIdx.x * kConvPos, co = blockIdx.z * kConvCh + col, pad = k / 2;
+    const size_t b = blockIdx.y;
+    const int rows = kConvPos + k - 1;
+    float acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) acc[p] = 0.0f;
+    for (int c0 = 0; c0 < cin; c0 += kConvCi) {
+        const int nc = min(kConvCi, cin - c0);
+        __syncthreads();
+        for (int i = tid; i < rows * nc; i += 256) {
+            const int r = i / nc, c = i - r * nc, t = t0 - pad + r;
+            xs[r * kConvCi + c] = (t >= 0 && t < L) ? x[(b * L + t) * (size_t)ldx + c0 + c] : 0.0f;
+        }
+        __syncthreads();
+        if (co < cout) {
+            for (int c = 0; c < nc; ++c)
+                for (int j = 0; j < k; ++j) {
+                    const float w = wt[((size_t)(c0 + c) * k + j) * cout + co];
+                    const float* xr = xs + (pg * 8 + j) * kConvCi + c;
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) acc[p] = fmaf(w, xr[p * kConvCi], acc[p]);
+                }
+        }
+    }
+    if (co >= cout) return;
+    const float bv = bias[co];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int t = t0 + pg * 8 + p;
+        if (t < L) {
+            float v = acc[p] + bv;
+            if (act == 1) v = v > 0.0f ? v : expm1f(v);
+            y[(b * L + t) * (size_t)ldy + coff + co] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// One (block, direction) of one recurrent layer; thread u owns hidden unit u.  gi (B, L, 2, G, H) holds W_ih x + b_ih for both
+// directions; whh_t = W_hh transposed, [k][G * H].  PyTorch cells:
+//   GRU  (r, z, n):    r = s(gi_r + W_hr h + b_hr), z = s(gi_z + W_hz h + b_hz), n = tanh(gi_n + r * (W_hn h + b_hn)), h' = (1 - z) n + z h
+//   LSTM (i, f, g, o): c' = s(f) c + s(i) tanh(g), h' = s(o) tanh(c')      (pre-activations gi_* + W_h* h + b_h*)
+//   RNN:               h' = tanh(gi + W_hh h + b_hh)
+__global__ void gen_rnn_kernel(int cell, const float* __restrict__ gi, const float* __restrict__ whh_t0, const float* __restrict__ whh_t1,
+                               const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ y, int H, int L) {
+    extern __shared__ float hs[];                      // h_{t-1}
+    const int u = threadIdx.x, dir = blockIdx.y;
+    const size_t b = blockIdx.x;
+    const int G = cell == 0 ? 3 : (cell == 1 ? 4 : 1);
+    const float* whh = dir ? whh_t1 : whh_t0;
+    const float* bhh = dir ? bhh1 : bhh0;
+    if (u < H) hs[u] = 0.0f;
+    float c = 0.0f, hprev = 0.0f;
+    __syncthreads();
+    for (int s = 0; s < L; ++s) {
+        const int t = dir ? L - 1 - s : s;
+        float hn = 0.0f;
+        if (u < H) {
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < H; ++k) {
+                const float hk = hs[k];
+                const float* w = whh + (size_t)k * G * H + u;
+                for (int g = 0; g < G; ++g) a[g] = fmaf(w[g * H], hk, a[g]);
+            }
+            const float* gp = gi + ((b * L + t) * 2 + dir) * (size_t)(G * H) + u;
+            if (cell == 0) {
+                const float r = sigm(gp[0] + (a[0] + bhh[u]));
+                const float z = sigm(gp[H] + (a[1] + bhh[H + u]));
+                const float n = tanhf(gp[2 * H] + r * (a[2] + bhh[2 * H + u]));
+                hn = (1.0f - z) * n + z * hprev;
+            } else if (cell == 1) {
+                const float ig = sigm(gp[0] + (a[0] + bhh[u]));
+                const float fg = sigm(gp[H] + (a[1] + bhh[H + u]));
+                const float gg = tanhf(gp[2 * H] + (a[2] + bhh[2 * H + u]));
+                const float og = sigm(gp[3 * H] + (a[3] + bhh[3 * H + u]));
+                c = fg * c + ig * gg;
+                hn = og * tanhf(c);
+            } else {
+                hn = tanhf(gp[0] + (a[0] + bhh[u]));
+            }
+            y[(b * L + t) * (size_t)(2 * H) + dir * H + u] = hn;
+        }
+        __syncthreads();
+        if (u < H) { hs[u] = hn; hprev = hn; }
+        __syncthreads();
+    }
+}
+
+// decoder stack inputs: XA = [r_sys, r_par1, prior = 0...], XB = [r_sys_int, r_par2, 0...] (decoders.py:87-93,221-227), W = 2 + F wide
+__global__ void gen_prep_dec_kernel(const float* __restrict__ rx, const int32_t* __restrict__ perm, float* __restrict__ XA, float* __restrict__ XB,
+                                    size_t B, int L, int W) {
+    const size_t n = B * L;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / L;
+        const int t = (int)(i - b * L);
+        const float* r = rx + i * 3;
+        float* a = XA + i * W;
+        float* c = XB + i * W;
+        a[0] = r[0]; a[1] = r[1];
+        c[0] = rx[(b * L + perm[t]) * 3]; c[1] = r[2];
+        for (int f = 2; f < W; ++f) { a[f] = 0.0f; c[f] = 0.0f; }
+    }
+}
+
+// encoder stack input (B, L, 1): CNN encoders see 2u - 1 (encoders.py:362), the RNN encoder the raw bits (encoders.py:283);
+// the third stack the interleaved sequence (encoders.py:369 / :289)
+__global__ void gen_prep_enc_kernel(const float* __restrict__ u, const int32_t* __restrict__ perm, float* __restrict__ X, size_t B, int L,
+                                    int interleaved, int bipolar) {
+    const size_t n = B * L;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / L;
+        const int t = (int)(i - b * L);
+        const float v = u[b * L + (interleaved ? perm[t] : t)];
+        X[i] = bipolar ? 2.0f * v - 1.0f : v;
+    }
+}
+
+__global__ void gen_copy_rows_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, int w, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * w; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / w;
+        const int c = (int)(i - r * w);
+        dst[r * ldd + c] = src[r * lds_ + c];
+    }
+}
+
+// o (B * L, nout) = Linear output (bias included).  Decoder: x_plr = act(o) [dec_act on the RNN decoder, decoders.py:103,115; none
+// on DEC_LargeCNN] - extrinsic input (decoders.py:105-106,117-118,235-236,246-247), scattered to the other panel at the
+// (de)interleaved row (interleave after dec1: row inv[t]; deinterleave after dec2: row p[t]); last half-iteration:
+// sigmoid(deinterleave(act(o))) (decoders.py:143-147,262-267).  Encoder (enc_stack >= 0): x_tx[., s] = enc_act(o).
+__global__ void gen_head_kernel(const float* __restrict__ o, int nout, const float* __restrict__ xcur, float* __restrict__ xnext, int W,
+                                float* __restrict__ xdec, const int32_t* __restrict__ ptab, size_t B, int L, int F, int extrinsic, int last,
+                                int act, int enc_stack, float* __restrict__ xtx) {
+    const size_t n = B * L;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / L;
+        const int t = (int)(i - b * L);
+        const float* v = o + i * nout;
+        if (enc_stack >= 0) {
+            const float x = v[0];
+            xtx[i * 3 + enc_stack] = act == 0 ? (x > 0.0f ? x : expm1f(x)) : act_apply(x, act);
+        } else if (!last) {
+            const float* xc = xcur + i * W + 2;
+            float* xn = xnext + (b * L + ptab[t]) * W + 2;
+            for (int f = 0; f < F; ++f) xn[f] = act_apply(v[f], act) - (extrinsic ? xc[f] : 0.0f);
+        } else {
+            xdec[b * L + ptab[t]] = sigm(act_apply(v[0], act));
+        }
+    }
+}
+
+// per-workgroup fp64 (sum, sum of squares) of x_tx for the power constraint (encoders.py:107-108), fixed-order tree
+__global__ __launch_bounds__(256) void gen_stats_kernel(const float* __restrict__ x, size_t n, double* __restrict__ partials) {
+    __shared__ double red[512];
+    double s = 0.0, q = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double v = (double)x[i];
+        s += v;
+        q += v * v;
+    }
+    red[threadIdx.x] = s;
+    red[256 + threadIdx.x] = q;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { red[threadIdx.x] += red[threadIdx.x + off]; red[256 + threadIdx.x] += red[256 + threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = red[0]; partials[2 * blockIdx.x + 1] = red[256]; }
+}
+
+constexpr int kStatsGrid = 256;
+
+inline int gates_of(int cell) { return cell == 0 ? 3 : (cell == 1 ? 4 : 1); }
+
+struct ConvL { size_t wt, bias; int cin, cout, k; };
+struct RnnL { size_t wih_t, bih; size_t whh_t[2], bhh[2]; int cin; };     // wih_t / bih: both directions concatenated (2 * G * H outputs)
+struct Stack {
+    bool rnn = false, dense = false;
+    int cell = 0, H = 0, cin0 = 0, nout = 0;
+    std::vector<ConvL> conv;
+    std::vector<RnnL> rl;
+    ConvL lin{};
+};
+
+}  // namespace
+
+struct GenericEngine {
+    tae_config cfg{};
+    std::vector<Stack> enc, dec;
+    float* d_w = nullptr;          // every tensor in kernel order (conv / W_ih / W_hh transposed, biases, Linear transposed)
+    int cap = 0;
+    float *d_xa = nullptr, *d_xb = nullptr, *d_p0 = nullptr, *d_p1 = nullptr, *d_gi = nullptr, *d_o = nullptr;
+    double* d_partials = nullptr;
+    size_t wide = 0, gi_w = 0;
+    bool enc_dense = false, dec_dense = false;
+};
+
+// ---- configuration envelope -------------------------------------------------------------------------------------------
+bool generic_dec_dense(const tae_config* c) {
+    // the reference builds DenseSameShapeConv1d decoders whenever the ENCODER is not the plain CNN (decoders.py:173-176)
+    return c->dec_type == 0 && (c->dense != 0 || c->enc_type == 1);
+}
+
+bool generic_needed(const tae_config* c) {
+    const bool big_k = c->enc_kernel_size > 9 || c->dec_kernel_size > 9;
+    const bool mid_k = c->enc_kernel_size > 5 || c->dec_kernel_size > 5;
+    if (big_k || c->enc_num_unit > 100 || c->dec_num_unit > 100 || c->num_iter_ft > 6) return true;
+    if ((c->enc_type == 1 && c->enc_rnn != 0) || (c->dec_type == 1 && c->dec_rnn != 0)) return true;
+    if (c->enc_type == 1 && (c->enc_num_layer != 2 || c->dec_type != 1)) return true;
+    if (c->dense && c->dec_type == 1) return true;
+    auto inst = [](int u) { return u == 32 || u == 64 || u == 100; };
+    if (c->dense && (!inst(c->enc_num_unit) || !inst(c->dec_num_unit))) return true;     // the f16x2 dense kernels do not embed narrower widths
+    if (c->precision == TAE_PREC_F32 && (c->dense || mid_k)) return true;
+    return false;
+}
+
+const char* generic_check(const tae_config* c) {
+    for (int ks : {c->enc_kernel_size, c->dec_kernel_size})
+        if (ks < 1 || ks > 63 || (ks & 1) == 0) return "kernel_size must be odd and in 1..63 (SameShapeConv1d pads with kernel_size // 2: an even size changes the length)";
+    if (c->enc_num_unit < 1 || c->enc_num_unit > 1024 || c->dec_num_unit < 1 || c->dec_num_unit > 1024) return "enc_num_unit / dec_num_unit must be in 1..1024";
+    if (c->num_iter_ft < 1 || c->num_iter_ft > 64) return "num_iter_ft must be in 1..64";
+    if (c->enc_rnn < 0 || c->enc_rnn > 2 || c->dec_rnn < 0 || c->dec_rnn > 2) return "enc_rnn / dec_rnn must be 0 (gru), 1 (lstm) or 2 (rnn)";
+    if (c->dense && c->enc_type == 1) return "dense = 1 names the dense CNN encoder (enc_type must be 0)";
+    return nullptr;
+}
+
+static size_t stack_floats(bool rnn, int cell, int H, int cin0, int n_layer, int k, bool dense, int nout) {
+    size_t n = 0;
+    if (rnn) {
+        const size_t G = gates_of(cell);
+        for (int l = 0; l < n_layer; ++l) {
+            const size_t cin = l == 0 ? cin0 : 2 * H;
+            n += 2 * (G * H * cin + G * H * (size_t)H + 2 * G * H);
+        }
+        return n + (size_t)nout * 2 * H + nout;
+    }
+    for (int l = 0; l < n_layer; ++l) {
+        const size_t cin = l == 0 ? cin0 : (dense ? cin0 + (size_t)l * H : H);
+        n += (size_t)H * cin * k + H;
+    }
+    return n + (size_t)nout * H + nout;
+}
+
+size_t generic_num_weights(const tae_config* c) {
+    const int F = c->num_iter_ft;
+    size_t n = 3 * stack_floats(c->enc_type == 1, c->enc_rnn, c->enc_num_unit, 1, c->enc_num_layer, c->enc_kernel_size, c->dense != 0, 1);
+    for (int it = 0; it < c->num_iteration; ++it)
+        for (int half = 0; half < 2; ++half) {
+            const int nout = (half == 1 && it == c->num_iteration - 1) ? 1 : F;
+            n += stack_floats(c->dec_type == 1, c->dec_rnn, c->dec_num_unit, 2 + F, c->dec_type == 1 ? 2 : c->dec_num_layer, c->dec_kernel_size,
+                              generic_dec_dense(c), nout);
+        }
+    return n;
+}
+
+// ---- weights: canonical blob (PyTorch layouts, turboae_amd/weights.py) -> kernel order ------------------------------------
+static void add_conv(std::vector<float>& out, const float*& src, int cout, int cin, int k, ConvL* L) {
+    L->cin = cin; L->cout = cout; L->k = k;
+    L->wt = out.size();
+    out.resize(out.size() + (size_t)cin * k * cout);
+    float* t = out.data() + L->wt;
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int j = 0; j < k; ++j) t[((size_t)ci * k + j) * cout + co] = src[((size_t)co * cin + ci) * k + j];
+    src += (size_t)cout * cin * k;
+    L->bias = out.size();
+    out.insert(out.end(), src, src + cout);
+    src += cout;
+}
+
+static Stack build_stack(std::vector<float>& out, const float*& src, bool rnn, int cell, int H, int cin0, int n_layer, int k, bool dense, int nout) {
+    Stack S;
+    S.rnn = rnn; S.dense = dense; S.cell = cell; S.H = H; S.cin0 = cin0; S.nout = nout;
+    if (rnn) {
+        const int G = gates_of(cell), GH = G * H;
+        for (int l = 0; l < n_layer; ++l) {
+            RnnL R;
+            R.cin = l == 0 ? cin0 : 2 * H;
+            const float* wih[2]; const float* whh[2]; const float* bih[2]; const float* bhh[2];
+            for (int d = 0; d < 2; ++d) {          // weight_ih (GH, cin) | weight_hh (GH, H) | bias_ih | bias_hh, forward then _reverse
+                wih[d] = src; src += (size_t)GH * R.cin;
+                whh[d] = src; src += (size_t)GH * H;
+                bih[d] = src; src += GH;
+                bhh[d] = src; src += GH;
+            }
+            R.wih_t = out.size();                  // [ci][dir * GH + r]: one k = 1 "convolution" yields both directions' projections
+            out.resize(out.size() + (size_t)R.cin * 2 * GH);
+            for (int d = 0; d < 2; ++d)
+                for (int r = 0; r < GH; ++r)
+                    for (int ci = 0; ci < R.cin; ++ci) out[R.wih_t + (size_t)ci * 2 * GH + d * GH + r] = wih[d][(size_t)r * R.cin + ci];
+            R.bih = out.size();
+            for (int d = 0; d < 2; ++d) out.insert(out.end(), bih[d], bih[d] + GH);
+            for (int d = 0; d < 2; ++d) {
+                R.whh_t[d] = out.size();
+                out.resize(out.size() + (size_t)H * GH);
+                for (int r = 0; r < GH; ++r)
+                    for (int kk = 0; kk < H; ++kk) out[R.whh_t[d] + (size_t)kk * GH + r] = whh[d][(size_t)r * H + kk];
+                R.bhh[d] = out.size();
+                out.insert(out.end(), bhh[d], bhh[d] + GH);
+            }
+            S.rl.push_back(R);
+        }
+        add_conv(out, src, nout, 2 * H, 1, &S.lin);
+        return S;
+    }
+    for (int l = 0; l < n_layer; ++l) {
+        ConvL C;
+        add_conv(out, src, H, l == 0 ? cin0 : (dense ? cin0 + l * H : H), k, &C);
+        S.conv.push_back(C);
+    }
+    add_conv(out, src, nout, H, 1, &S.lin);
+    return S;
+}
+
+#define GEN_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess) return fail_msg(TAE_EHIP, (std::string(#expr) + ": " + hipGetErrorString(e__)).c_str()); \
+    } while (0)
+
+void generic_destroy(GenericEngine* g) {
+    if (!g) return;
+    (void)hipFree(g->d_w); (void)hipFree(g->d_xa); (void)hipFree(g->d_xb); (void)hipFree(g->d_p0); (void)hipFree(g->d_p1);
+    (void)hipFree(g->d_gi); (void)hipFree(g->d_o); (void)hipFree(g->d_partials);
+    delete g;
+}
+
+int generic_create(const tae_config* c, const float* weights, size_t n_weights, GenericEngine** out) {
+    *out = nullptr;
+    if (const char* msg = generic_check(c)) return fail_msg(TAE_EINVAL, msg);
+    if (n_weights != generic_num_weights(c)) return fail_msg(TAE_EINVAL, "internal: generic weight count mismatch");
+    GenericEngine* g = new GenericEngine();
+    g->cfg = *c;
+    g->enc_dense = c->dense != 0;
+    g->dec_dense = generic_dec_dense(c);
+    const int F = c->num_iter_ft;
+    std::vector<float> w;
+    w.reserve(n_weights + 1024);
+    const float* src = weights;
+    for (int s = 0; s < 3; ++s)
+        g->enc.push_back(build_stack(w, src, c->enc_type == 1, c->enc_rnn, c->enc_num_unit, 1, c->enc_num_layer, c->enc_kernel_size, g->enc_dense, 1));
+    for (int it = 0; it < c->num_iteration; ++it)
+        for (int half = 0; half < 2; ++half) {
+            const int nout = (half == 1 && it == c->num_iteration - 1) ? 1 : F;
+            g->dec.push_back(build_stack(w, src, c->dec_type == 1, c->dec_rnn, c->dec_num_unit, 2 + F, c->dec_type == 1 ? 2 : c->dec_num_layer,
+                                         c->dec_kernel_size, g->dec_dense, nout));
+        }
+    if ((size_t)(src - weights) != n_weights) { delete g; return fail_msg(TAE_EINVAL, "internal: generic weight walk mismatch"); }
+    // widest activation row / projection row any stack needs
+    auto widths = [&](const Stack& S, int n_layer) {
+        if (S.rnn) {
+            g->wide = std::max(g->wide, (size_t)2 * S.H);
+            g->gi_w = std::max(g->gi_w, (size_t)2 * gates_of(S.cell) * S.H);
+        } else {
+            g->wide = std::max(g->wide, S.dense ? (size_t)S.cin0 + (size_t)n_layer * S.H : (size_t)S.H);
+        }
+    };
+    for (const Stack& S : g->enc) widths(S, c->enc_num_layer);
+    for (const Stack& S : g->dec) widths(S, c->dec_num_layer);
+    hipError_t e = hipMalloc(&g->d_w, w.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(g->d_w, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&g->d_partials, kStatsGrid * 2 * sizeof(double));
+    if (e != hipSuccess) { generic_destroy(g); return fail_msg(TAE_EHIP, hipGetErrorString(e)); }
+    *out = g;
+    return TAE_OK;
+}
+
+int generic_reserve(GenericEngine* g, int32_t B) {
+    if (B <= g->cap) return TAE_OK;
+    (void)hipFree(g->d_xa); (void)hipFree(g->d_xb); (void)hipFree(g->d_p0); (void)hipFree(g->d_p1); (void)hipFree(g->d_gi); (void)hipFree(g->d_o);
+    g->d_xa = g->d_xb = g->d_p0 = g->d_p1 = g->d_gi = g->d_o = nullptr;
+    g->cap = 0;
+    const size_t np = (size_t)B * g->cfg.block_len, W = 2 + (size_t)g->cfg.num_iter_ft;
+    GEN_HIP(hipMalloc(&g->d_xa, np * W * sizeof(float)));
+    GEN_HIP(hipMalloc(&g->d_xb, np * W * sizeof(float)));
+    GEN_HIP(hipMalloc(&g->d_p0, np * g->wide * sizeof(float)));
+    GEN_HIP(hipMalloc(&g->d_p1, np * g->wide * sizeof(float)));
+    if (g->gi_w) GEN_HIP(hipMalloc(&g->d_gi, np * g->gi_w * sizeof(float)));
+    GEN_HIP(hipMalloc(&g->d_o, np * W * sizeof(float)));
+    g->cap = B;
+    return TAE_OK;
+}
+
+static hipError_t conv(const GenericEngine* g, const ConvL& C, const float* x, int ldx, float* y, int ldy, int coff, int act, int B, hipStream_t st) {
+    const int L = g->cfg.block_len;
+    const dim3 grid((L + kConvPos - 1) / kConvPos, B, (C.cout + kConvCh - 1) / kConvCh);
+    const size_t lds = (size_t)(kConvPos + C.k - 1) * kConvCi * sizeof(float);
+    hipLaunchKernelGGL(gen_conv_kernel, grid, dim3(256), lds, st, x, ldx, C.cin, g->d_w + C.wt, g->d_w + C.bias, y, ldy, coff, C.cout, C.k, L, act);
+    return hipGetLastError();
+}
+
+// one stack: x (B, L, cin0) -> o (B, L, nout) = Linear(stack(x)); returns through g->d_o
+static int run_stack(GenericEngine* g, const Stack& S, const float* x, int B, hipStream_t st) {
+    const int L = g->cfg.block_len;
+    const size_t np = (size_t)B * L;
+    const float* feat = nullptr;
+    int ldf = 0;
+    if (S.rnn) {
+        const int G = gates_of(S.cell), GH = G * S.H;
+        if (S.H > 1024) return fail_msg(TAE_EINVAL, "recurrent units above 1024 are not supported");
+        const float* in = x;
+        int ldin = S.cin0;
+        float* bufs[2] = {g->d_p0, g->d_p1};
+        for (size_t l = 0; l < S.rl.size(); ++l) {
+            const RnnL& R = S.rl[l];
+            ConvL P{R.wih_t, R.bih, R.cin, 2 * GH, 1};
+            GEN_HIP(conv(g, P, in, ldin, g->d_gi, 2 * GH, 0, 0, B, st));
+            float* y = bufs[l & 1];
+            const int threads = (S.H + 63) / 64 * 64;
+            hipLaunchKernelGGL(gen_rnn_kernel, dim3(B, 2), dim3(threads), S.H * sizeof(float), st, S.cell, g->d_gi, g->d_w + R.whh_t[0], g->d_w + R.whh_t[1],
+                               g->d_w + R.bhh[0], g->d_w + R.bhh[1], y, S.H, L);
+            GEN_HIP(hipGetLastError());
+            in = y;
+            ldin = 2 * S.H;
+        }
+        feat = in;
+        ldf = 2 * S.H;
+    } else if (S.dense) {
+        // layer l convolves cat(inputs, out_0 .. out_{l-1}) = the first cin0 + l * H channels of one wide row (cnn_utils.py:59-62)
+        const int wtot = S.cin0 + (int)S.conv.size() * S.H;
+        const int grid = (int)std::min<size_t>((np * S.cin0 + 255) / 256, 4096);
+        hipLaunchKernelGGL(gen_copy_rows_kernel, dim3(grid), dim3(256), 0, st, x, S.cin0, g->d_p0, wtot, S.cin0, np);
+        GEN_HIP(hipGetLastError());
+        for (size_t l = 0; l < S.conv.size(); ++l) GEN_HIP(conv(g, S.conv[l], g->d_p0, wtot, g->d_p0, wtot, S.cin0 + (int)l * S.H, 1, B, st));
+        feat = g->d_p0 + S.cin0 + (S.conv.size() - 1) * (size_t)S.H;
+        ldf = wtot;
+    } else {
+        float* bufs[2] = {g->d_p0, g->d_p1};
+        const float* in = x;
+        int ldin = S.cin0;
+        for (size_t l = 0; l < S.conv.size(); ++l) {
+            float* y = bufs[l & 1];
+            GEN_HIP(conv(g, S.conv[l], in, ldin, y, S.H, 0, 1, B, st));
+            in = y;
+            ldin = S.H;
+        }
+        feat = in;
+        ldf = S.H;
+    }
+    GEN_HIP(conv(g, S.lin, feat, ldf, g->d_o, S.nout, 0, 0, B, st));
+    return TAE_OK;
+}
+
+int generic_encode(GenericEngine* g, const float* u, float* xtx, double* stats, const int32_t* perm, int32_t B, hipStream_t st) {
+    if (B > g->cap) return fail_msg(TAE_ESTATE, "batch exceeds reserved workspace");
+    const int L = g->cfg.block_len;
+    const size_t np = (size_t)B * L;
+    const int grid = (int)std::min<size_t>((np + 255) / 256, 4096);
+    for (int s = 0; s < 3; ++s) {
+        hipLaunchKernelGGL(gen_prep_enc_kernel, dim3(grid), dim3(256), 0, st, u, perm, g->d_xa, (size_t)B, L, s == 2 ? 1 : 0, g->cfg.enc_type == 1 ? 0 : 1);
+        GEN_HIP(hipGetLastError());
+        const int rc = run_stack(g, g->enc[s], g->d_xa, B, st);
+        if (rc != TAE_OK) return rc;
+        hipLaunchKernelGGL(gen_head_kernel, dim3(grid), dim3(256), 0, st, g->d_o, 1, (const float*)nullptr, (float*)nullptr, 0, (float*)nullptr,
+                           perm, (size_t)B, L, 1, 0, 0, g->cfg.enc_act, s, xtx);
+        GEN_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(gen_stats_kernel, dim3(kStatsGrid), dim3(256), 0, st, xtx, np * 3, g->d_partials);
+    GEN_HIP(hipGetLastError());
+    GEN_HIP(launch_reduce_partials(g->d_partials, kStatsGrid, (double)np * 3.0, stats, st));
+    return TAE_OK;
+}
+
+int generic_decode(GenericEngine* g, const float* rx, float* xdec, const int32_t* perm, const int32_t* inv, int32_t B, hipStream_t st) {
+    if (B > g->cap) return fail_msg(TAE_ESTATE, "batch exceeds reserved workspace");
+    const int L = g->cfg.block_len, F = g->cfg.num_iter_ft, W = 2 + F;
+    const size_t np = (size_t)B * L;
+    const int grid = (int)std::min<size_t>((np + 255) / 256, 4096);
+    hipLaunchKernelGGL(gen_prep_dec_kernel, dim3(grid), dim3(256), 0, st, rx, perm, g->d_xa, g->d_xb, (size_t)B, L, W);
+    GEN_HIP(hipGetLastError());
+    const int act = g->cfg.dec_type == 1 ? g->cfg.dec_act : TAE_ACT_LINEAR;      // DEC_LargeCNN has no dec_act
+    const int ns = 2 * g->cfg.num_iteration;
+    for (int s = 0; s < ns; ++s) {
+        const bool odd = (s & 1) != 0, last = s == ns - 1;
+        float* xin = odd ? g->d_xb : g->d_xa;
+        const int rc = run_stack(g, g->dec[s], xin, B, st);
+        if (rc != TAE_OK) return rc;
+        hipLaunchKernelGGL(gen_head_kernel, dim3(grid), dim3(256), 0, st, g->d_o, g->dec[s].nout, xin, odd ? g->d_xa : g->d_xb, W, xdec,
+                           odd ? perm : inv, (size_t)B, L, F, g->cfg.extrinsic, last ? 1 : 0, act, -1, (float*)nullptr);
+        GEN_HIP(hipGetLastError());
+    }
+    return TAE_OK;
+}
+
+}  // namespace tae

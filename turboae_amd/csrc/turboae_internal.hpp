@@ -4,6 +4,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <algorithm>
+#include "../../include/turboae_hip.h"
 
 namespace tae {
 
@@ -132,6 +133,16 @@ struct NoiseGen {
 };
 hipError_t launch_gen_noise(const NoiseGen& g, float* noise, float* fading, size_t n_blocks, size_t first_block, int L,
                             unsigned long long seed, hipStream_t st);
+// generic fp32 layer-at-a-time kernels (turboae_generic.hip): configurations outside the MFMA kernels' envelope
+struct GenericEngine;
+bool generic_needed(const tae_config* c);
+const char* generic_check(const tae_config* c);          // nullptr, or why the configuration is out of range
+size_t generic_num_weights(const tae_config* c);
+int generic_create(const tae_config* c, const float* weights, size_t n_weights, GenericEngine** out);
+void generic_destroy(GenericEngine* g);
+int generic_reserve(GenericEngine* g, int32_t B);
+int generic_encode(GenericEngine* g, const float* u, float* xtx, double* stats, const int32_t* perm, int32_t B, hipStream_t st);
+int generic_decode(GenericEngine* g, const float* rx, float* xdec, const int32_t* perm, const int32_t* inv, int32_t B, hipStream_t st);
 int fail_msg(int code, const char* msg);          // turboae_api.hip: sets the calling thread's tae_last_error string
 int fused_lds_bytes(int U, int L, int nb);
 int fused_max_positions();

@@ -26,16 +26,18 @@ def canonical_entries(cfg: TurboAEConfig) -> List[Tuple[str, Tuple[int, ...]]]:
     out: List[Tuple[str, Tuple[int, ...]]] = []
     ue, ud, f = cfg.enc_num_unit, cfg.dec_num_unit, cfg.num_iter_ft
     ke, kd = cfg.enc_kernel_size, cfg.dec_kernel_size
+    gates = {"gru": 3, "lstm": 4, "rnn": 1}       # rows of weight_ih / weight_hh per hidden unit (torch.nn.GRU / LSTM / RNN)
+    ge, gd = gates[cfg.enc_rnn], gates[cfg.dec_rnn]
     for s in (1, 2, 3):
         if cfg.encoder == "TurboAE_rate3_rnn":
             # ENC_interRNN: torch.nn.GRU(1, ue, num_layers, bidirectional=True) + Linear(2 ue, 1) (encoders.py:251-268)
             for l in range(cfg.enc_num_layer):
                 cin = 1 if l == 0 else 2 * ue
                 for sfx in ("", "_reverse"):
-                    out.append((f"enc.enc_rnn_{s}.weight_ih_l{l}{sfx}", (3 * ue, cin)))
-                    out.append((f"enc.enc_rnn_{s}.weight_hh_l{l}{sfx}", (3 * ue, ue)))
-                    out.append((f"enc.enc_rnn_{s}.bias_ih_l{l}{sfx}", (3 * ue,)))
-                    out.append((f"enc.enc_rnn_{s}.bias_hh_l{l}{sfx}", (3 * ue,)))
+                    out.append((f"enc.enc_rnn_{s}.weight_ih_l{l}{sfx}", (ge * ue, cin)))
+                    out.append((f"enc.enc_rnn_{s}.weight_hh_l{l}{sfx}", (ge * ue, ue)))
+                    out.append((f"enc.enc_rnn_{s}.bias_ih_l{l}{sfx}", (ge * ue,)))
+                    out.append((f"enc.enc_rnn_{s}.bias_hh_l{l}{sfx}", (ge * ue,)))
             out.append((f"enc.enc_linear_{s}.weight", (1, 2 * ue)))
             out.append((f"enc.enc_linear_{s}.bias", (1,)))
             continue
@@ -56,16 +58,16 @@ def canonical_entries(cfg: TurboAEConfig) -> List[Tuple[str, Tuple[int, ...]]]:
                 for l in (0, 1):
                     cin = 2 + f if l == 0 else 2 * ud
                     for sfx in ("", "_reverse"):
-                        out.append((f"dec.dec{half}_rnns.{it}.weight_ih_l{l}{sfx}", (3 * ud, cin)))
-                        out.append((f"dec.dec{half}_rnns.{it}.weight_hh_l{l}{sfx}", (3 * ud, ud)))
-                        out.append((f"dec.dec{half}_rnns.{it}.bias_ih_l{l}{sfx}", (3 * ud,)))
-                        out.append((f"dec.dec{half}_rnns.{it}.bias_hh_l{l}{sfx}", (3 * ud,)))
+                        out.append((f"dec.dec{half}_rnns.{it}.weight_ih_l{l}{sfx}", (gd * ud, cin)))
+                        out.append((f"dec.dec{half}_rnns.{it}.weight_hh_l{l}{sfx}", (gd * ud, ud)))
+                        out.append((f"dec.dec{half}_rnns.{it}.bias_ih_l{l}{sfx}", (gd * ud,)))
+                        out.append((f"dec.dec{half}_rnns.{it}.bias_hh_l{l}{sfx}", (gd * ud,)))
                 out.append((f"dec.dec{half}_outputs.{it}.weight", (nout, 2 * ud)))
                 out.append((f"dec.dec{half}_outputs.{it}.bias", (nout,)))
             else:
                 for l in range(cfg.dec_num_layer):
                     cin = 2 + f if l == 0 else ud
-                    if cfg.dense:
+                    if cfg.dec_dense:       # decoders.py:173-176: dense stacks whenever the encoder is not the plain CNN
                         cin = 2 + f + l * ud
                     out.append((f"dec.dec{half}_cnns.{it}.cnns.{l}.weight", (ud, cin, kd)))
                     out.append((f"dec.dec{half}_cnns.{it}.cnns.{l}.bias", (ud,)))
