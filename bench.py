@@ -426,7 +426,8 @@ def main():
             kname = "tae::dec_kernel_h<100,5> (fused 6-iteration decoder, fp16-split MFMA)" if is_h2 else "tae::dec_kernel<100,5> (fused 6-iteration decoder, fp32 MFMA)"
             if nb == 0:        # long blocks: the decoder is 2 * num_iteration launches of the segment kernel; `kernel_ms` covers all of them
                 kname = ("tae::seg_kernel_h<100,5>" if is_h2 else "tae::seg_kernel<100,5>") + f" x {2 * cfg.num_iteration} launches (one conv stack each, long-block decoder)"
-            pmc_dir = "r02_pmc_f16x2" if is_h2 else "r01_pmc"
+            pmc_dir = next((d for d in (("r03_pmc_f16x2", "r02_pmc_f16x2") if is_h2 else ("r01_pmc",))
+                            if os.path.isfile(os.path.join(ROOT, "profiles", d, "traffic.json"))), "r01_pmc")
             # HBM-side traffic of the decoder kernel from the committed PMC passes (rocprofv3 cannot run inside
             # this process): bytes per block measured at the same workload, scaled to this launch's blocks
             traffic = None

@@ -242,7 +242,8 @@ TAE_API int tae_probe_mfma_f16(int32_t zero_data, int32_t min_ms, double* tflops
 /* Arithmetic actually in use (*precision = 0: fp32 MFMA, 1: fp16-split MFMA) and its sticky range flag:
  * *overflow = 1 if, since the last call, an activation exceeded the fp16 range (65504) in the fp16-split
  * kernels, which clamp there - results of those launches are not trustworthy; recreate the handle with
- * TAE_PREC_F32.  Synchronises the device (reads one word back) and clears the flag. */
+ * TAE_PREC_F32.  Synchronises the WHOLE device (hipDeviceSynchronize, then reads one word back) and clears the flag: do not call it
+ * while any stream of the process is capturing a hipGraph (the synchronisation invalidates the capture) - check after the replay. */
 TAE_API int tae_range_status(tae_handle* h, int32_t* precision, int32_t* overflow);
 
 /* Test hook (no device needed): the host-side fp32 -> fp16 hi/lo split used when packing weights for the fp16-split

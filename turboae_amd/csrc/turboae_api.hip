@@ -211,6 +211,9 @@ size_t pack_stack_h(const float* src, const LayoutH& lo, int n_layer, int cin0, 
         if (S < -60) S = -60;
         const float scale = ldexpf(1.0f, S), inv = ldexpf(1.0f, -S);
         if (l == 0 && cin0 == 1) {
+            // the fold covers taps 0..11 (fold_enc_input writes channels a = 1, 2: tap q + 4a, q < 4); check_cfg keeps the f16x2 kernels
+            // at <= 9 taps - a wider kernel must never reach this packing
+            if (lo.taps > 12) { fprintf(stderr, "libturboae_hip: internal error: encoder tap fold supports <= 12 taps, got %d\n", lo.taps); abort(); }
             // encoder stacks: all taps folded into ONE slab (turboae_h2.hip::fold_enc_input): k = 8 q + a holds tap q + 4 a.  The
             // region keeps its nsl_l0 slabs (offsets unchanged); the kernel walks the first one only.
             std::vector<float> wf((size_t)lo.U * 32, 0.0f);            // as a (U, cin = 4 taps-of-8 ..) tensor: W'[co][k], k < 32

@@ -207,7 +207,17 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
             ber_p, bler_p = punctured_point(si, snr, res_pos_arg[:num_ber_puncture])
         else:
             # trainer.py:194-213 without --print_pos_ber: the second pass dies in its bare `except` on the first batch (NameError on
-            # res_pos_arg - after one forward the reference spends for nothing; skipped here), test_ber_punc stays .0
+            # res_pos_arg) - AFTER one full model(X_test, fwd_noise) forward.  The forward's results are thrown away,
+            # but with --precompute_norm_stats its encoder call has already folded that batch's mean / std into the running
+            # statistics (encoders.py:110-114), which every later SNR point then normalises with: mirror that one encoder call
+            if precomp and num_test_batch > 0:
+                first = ((snr_points + 2 + si) * num_test_batch) * batch_size + lo
+                stats = torch.zeros(3, dtype=torch.float64, device=dev)
+                if nloc > 0:
+                    u, _ = model.generate_inputs(nloc, snr, seed=seed, first_block=first)
+                    _, stats = model.encode_prenorm(u)
+                all_reduce_sum_(stats)
+                model.update_precomp(stats)
             say("no pos BER specified.")
         say("Test SNR", snr, "with ber ", float(test_ber), "with bler", float(test_bler))
         say("Punctured Test SNR", snr, "with ber ", float(ber_p), "with bler", float(bler_p))     # trainer.py:220-225 (0.0 / 0.0 without the ranking)
