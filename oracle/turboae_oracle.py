@@ -13,7 +13,9 @@ asserts equality (<= 2e-6) and commits the reference's outputs
 ``tests/golden/``; ``tests/test_oracle_golden.py`` re-checks this module against those fixtures
 everywhere (no reference needed).  ``oracle/fuzz_vs_reference.py`` adds a randomised pin: 90 random
 configurations from the GPU fuzz's own generators, reference vs this module <= 2.5e-6, with digests of
-the reference's outputs re-checked by the same test file.
+the reference's outputs re-checked by the same test file.  r03: 9 more golden cases for what the reference's parser
+accepts beyond the MFMA kernels (LSTM / RNN cells, ENC_interRNN layer counts, RNN encoder + dense CNN decoder, wide /
+many-tap / many-feature stacks), same gate.  This module holds no state: `dense` is an argument everywhere.
 
 The arithmetic lives in PyTorch ATen (oneDNN conv / elu / addmm / std), a third-party dependency of
 the reference (README.md:16 "PyTorch 1.0", no lockfile); semantics restated here are the
