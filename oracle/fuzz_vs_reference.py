@@ -140,6 +140,19 @@ def main():
         out["channel_cases"].append(rec)
         print(f"ch {i:2d}", {k: v for k, v in rec.items() if k not in ("config",)}, rec["config"]["channel"], rec["config"]["train_channel_mode"],
               "recq" if rec["config"]["rec_quantize"] else "")
+    # r03: the configuration space of the generic fp32 kernels (LSTM / RNN cells, ENC_interRNN depths, RNN encoder + dense CNN decoder,
+    # wide / many-tap / many-feature stacks) - the oracle's newest code paths against the real reference
+    out["generic_cases"] = []
+    for i, c in enumerate(fz.draw_generic_cases(28, seed + 3)):
+        rec = run(c)
+        out["generic_cases"].append(rec)
+        if not rec["degenerate"]:
+            worst["codes"] = max(worst["codes"], rec["max_abs_codes"] / rec["amplify"])
+            worst["x_dec"] = max(worst["x_dec"], rec["max_abs_x_dec"] / rec["amplify"])
+            print(f"gen {i:2d} codes {rec['max_abs_codes']:.2e} x_dec {rec['max_abs_x_dec']:.2e} flips {rec['decision_flips']} amplify {rec['amplify']:.1f} {rec['config']}")
+        else:
+            print(f"gen {i:2d} degenerate, same non-finite pattern: {rec['same_nonfinite_pattern']}")
+    out["worst_over_amplify_incl_generic"] = worst
     with open(os.path.join(GOLD, "oracle_fuzz_vs_reference.json"), "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
     print("worst (divided by the 1/std amplification):", worst)

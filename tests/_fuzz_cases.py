@@ -95,3 +95,31 @@ def channel_case_inputs(case):
         a, b = philox.random_normal(wseed + 1, 0, B * L * 3), philox.random_normal(wseed + 2, 0, B * L * 3)
         fading = (np.sqrt(a.astype(np.float64) ** 2 + b.astype(np.float64) ** 2) / np.sqrt(3.14 / 2.0)).astype(np.float32).reshape(B, L, 3)
     return cfg, sd, B, u, noise, fading
+
+
+def draw_generic_cases(n, seed):
+    """Random configurations OUTSIDE the MFMA kernels' envelope (generic fp32 kernels, csrc/turboae_generic.hip): wide stacks, many taps,
+    many features, LSTM / RNN cells, ENC_interRNN depths, RNN encoder + (dense) CNN decoder."""
+    rng = np.random.RandomState(seed)
+    cases = []
+    for i in range(n):
+        kind = ["wide", "bigk", "ft", "lstm", "rnn", "enc_rnn", "rnn_cnn"][i % 7]
+        c = dict(block_len=int(rng.choice([1, 7, 31, 32, 33, 64, 90])), num_iteration=int(rng.randint(1, 3)), num_iter_ft=int(rng.randint(1, 6)),
+                 extrinsic=int(rng.randint(0, 2)), enc_num_unit=int(rng.randint(4, 40)), dec_num_unit=int(rng.randint(4, 40)),
+                 enc_num_layer=int(rng.randint(1, 4)), dec_num_layer=int(rng.randint(1, 4)),
+                 enc_act=str(rng.choice(["elu", "linear", "tanh"])), B=int(rng.choice([1, 2, 5])), wseed=int(rng.randint(1, 1 << 30)), kind=kind)
+        if kind == "wide":
+            c.update(enc_num_unit=int(rng.randint(101, 200)), dec_num_unit=int(rng.randint(101, 260)))
+        elif kind == "bigk":
+            c.update(enc_kernel_size=int(rng.choice([11, 15, 21])), dec_kernel_size=int(rng.choice([11, 13, 63])))
+        elif kind == "ft":
+            c.update(num_iter_ft=int(rng.randint(7, 20)))
+        elif kind in ("lstm", "rnn"):
+            c.update(decoder="TurboAE_rate3_rnn", dec_rnn=kind, dec_act=str(rng.choice(["linear", "tanh", "elu"])))
+        elif kind == "enc_rnn":
+            c.update(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_rnn=str(rng.choice(["gru", "lstm", "rnn"])),
+                     dec_rnn=str(rng.choice(["gru", "lstm", "rnn"])), enc_num_layer=int(rng.choice([1, 3, 4])))
+        else:
+            c.update(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_cnn", enc_rnn=str(rng.choice(["gru", "lstm"])))
+        cases.append(c)
+    return cases

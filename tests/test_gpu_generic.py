@@ -12,6 +12,7 @@ import torch
 
 from turboae_amd import TurboAEConfig, philox, weights as W
 from oracle import turboae_oracle as O
+from _fuzz_cases import draw_generic_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -68,33 +69,7 @@ def test_precision_f32_for_dense_stacks_and_kernel_sizes_7_9(gpu_device, name):
     assert np.abs(codes - codes2).max() <= 1e-5 and np.abs(xd - xd2).max() <= 2e-5
 
 
-def _draw(n, seed):
-    rng = np.random.RandomState(seed)
-    cases = []
-    for i in range(n):
-        kind = ["wide", "bigk", "ft", "lstm", "rnn", "enc_rnn", "rnn_cnn"][i % 7]
-        c = dict(block_len=int(rng.choice([1, 7, 31, 32, 33, 64, 90])), num_iteration=int(rng.randint(1, 3)), num_iter_ft=int(rng.randint(1, 6)),
-                 extrinsic=int(rng.randint(0, 2)), enc_num_unit=int(rng.randint(4, 40)), dec_num_unit=int(rng.randint(4, 40)),
-                 enc_num_layer=int(rng.randint(1, 4)), dec_num_layer=int(rng.randint(1, 4)),
-                 enc_act=str(rng.choice(["elu", "linear", "tanh"])), B=int(rng.choice([1, 2, 5])), wseed=int(rng.randint(1, 1 << 30)), kind=kind)
-        if kind == "wide":
-            c.update(enc_num_unit=int(rng.randint(101, 200)), dec_num_unit=int(rng.randint(101, 260)))
-        elif kind == "bigk":
-            c.update(enc_kernel_size=int(rng.choice([11, 15, 21])), dec_kernel_size=int(rng.choice([11, 13, 63])))
-        elif kind == "ft":
-            c.update(num_iter_ft=int(rng.randint(7, 20)))
-        elif kind in ("lstm", "rnn"):
-            c.update(decoder="TurboAE_rate3_rnn", dec_rnn=kind, dec_act=str(rng.choice(["linear", "tanh", "elu"])))
-        elif kind == "enc_rnn":
-            c.update(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_rnn=str(rng.choice(["gru", "lstm", "rnn"])),
-                     dec_rnn=str(rng.choice(["gru", "lstm", "rnn"])), enc_num_layer=int(rng.choice([1, 3, 4])))
-        else:
-            c.update(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_cnn", enc_rnn=str(rng.choice(["gru", "lstm"])))
-        cases.append(c)
-    return cases
-
-
-@pytest.mark.parametrize("case", _draw(21, 90210), ids=lambda c: "{kind}_L{block_len}_B{B}_e{enc_num_unit}x{enc_num_layer}_d{dec_num_unit}x{dec_num_layer}_F{num_iter_ft}".format(**c))
+@pytest.mark.parametrize("case", draw_generic_cases(21, 90210), ids=lambda c: "{kind}_L{block_len}_B{B}_e{enc_num_unit}x{enc_num_layer}_d{dec_num_unit}x{dec_num_layer}_F{num_iter_ft}".format(**c))
 def test_random_generic_configurations_match_oracle(gpu_device, case):
     from turboae_amd import Channel_AE_HIP
     case = dict(case)

@@ -20,19 +20,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _load_model(dev, max_batch):
+def _load_model(dev, max_batch, channel="awgn"):
     import json
+    from dataclasses import replace
     from turboae_amd import TurboAEConfig, Channel_AE_HIP, weights as W
     manifest = json.load(open(os.path.join(GOLD, "MANIFEST.json")))
     g = np.load(os.path.join(GOLD, "trained_enc2dec5_u100.npz"))
-    cfg = TurboAEConfig(**manifest["trained"]["config"])
+    cfg = replace(TurboAEConfig(**manifest["trained"]["config"]), channel=channel)
     return Channel_AE_HIP(cfg, W.unpack_blob(cfg, g["weights_fp16"].astype(np.float32)), device=dev, max_batch=max_batch)
 
 
 SWEEP = dict(snr_test_start=0.0, snr_test_end=2.0, snr_points=2, num_block=600, batch_size=150, seed=123, verbose=False)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, channel="awgn", sweep=None):
     import torch.distributed as dist
     from turboae_amd import evaluate
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -40,8 +41,8 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    model = _load_model(dev, 150)
-    res = evaluate.test(model, **SWEEP)
+    model = _load_model(dev, 150, channel)
+    res = evaluate.test(model, **(sweep or SWEEP))
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -71,6 +72,31 @@ def test_sharded_eval_sweep_equals_single_process(gpu_device, world):
             assert abs(res["ber"][si] - single["ber"][si]) <= 1e-4
         assert abs(res["enc_power"] - single["enc_power"]) <= 1e-6
     assert single["bit_errors"][0] > single["bit_errors"][1] > 0
+
+
+@pytest.mark.parametrize("channel,lo,hi", [("ge_awgn", 4.0, 0.0), ("bsc", 0.02, 0.15), ("fading", 6.0, 2.0)])
+def test_sharded_sweep_on_other_channels_equals_single_process(gpu_device, channel, lo, hi):
+    """The noise of every channel is drawn by a device kernel keyed by the GLOBAL block index (tae_generate_noise): two ranks sharing a
+    batch draw exactly the blocks one process draws - Gilbert-Elliott chains, masks and fading coefficients included."""
+    import torch.multiprocessing as mp
+    from turboae_amd import evaluate
+    sweep = dict(SWEEP, snr_test_start=lo, snr_test_end=hi)
+    single = evaluate.test(_load_model(gpu_device, 150, channel), **sweep)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, channel, sweep)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(2):
+        for si in range(2):
+            assert abs(got[r]["bit_errors"][si] - single["bit_errors"][si]) <= 2, (channel, r, si)
+            assert abs(got[r]["block_errors"][si] - single["block_errors"][si]) <= 1, (channel, r, si)
+    assert single["bit_errors"][1] > single["bit_errors"][0]
 
 
 def test_bench_runs_with_two_ranks(gpu_device):

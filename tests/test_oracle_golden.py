@@ -198,13 +198,30 @@ def test_recorded_random_channel_option_combinations_matched_the_reference():
     assert {c["enc_quantize_level"] for c in cfgs if c["train_channel_mode"] == "block_norm_ste"} == {2.0, 4.0, 8.0}
 
 
+def test_recorded_random_generic_configurations_matched_the_reference():
+    """r03: 28 random configurations outside the MFMA kernels' envelope (what the generic fp32 kernels run)"""
+    cases = FUZZ_REF["generic_cases"]
+    assert len(cases) >= 28
+    for c in cases:
+        if c["degenerate"]:
+            assert c["same_nonfinite_pattern"], c["config"]
+            continue
+        assert c["max_abs_codes"] <= 3e-6 * c["amplify"] and c["max_abs_x_dec"] <= 2e-6 * c["amplify"], c
+        assert c["decision_flips"] == 0, c
+    cfgs = [c["config"] for c in cases]
+    assert {"lstm", "rnn"} <= {c.get("dec_rnn", "gru") for c in cfgs} and {"lstm", "rnn", "gru"} <= {c.get("enc_rnn", "gru") for c in cfgs if c.get("encoder") == "TurboAE_rate3_rnn"}
+    assert any(c.get("encoder") == "TurboAE_rate3_rnn" and c.get("decoder", "TurboAE_rate3_cnn") == "TurboAE_rate3_cnn" for c in cfgs)
+    assert max(c["dec_num_unit"] for c in cfgs) > 100 and max(c["num_iter_ft"] for c in cfgs) > 6 and max(c.get("dec_kernel_size", 5) for c in cfgs) > 9
+
+
 def _digest(a):
     a = np.asarray(a, dtype=np.float64).reshape(-1)
     sign = 1.0 - 2.0 * philox.random_bits(424242, 0, a.size).astype(np.float64)
     return float(a.sum()), float((a * sign).sum()), float(np.abs(a).max())
 
 
-_SMALL = [c for c in FUZZ_REF["cases"] if not c["degenerate"] and c["bits"] <= 3000][:40]
+_SMALL = ([c for c in FUZZ_REF["cases"] if not c["degenerate"] and c["bits"] <= 3000][:40]
+          + [c for c in FUZZ_REF.get("generic_cases", []) if not c["degenerate"] and c["bits"] <= 700][:14])
 
 
 @pytest.mark.parametrize("case", _SMALL, ids=lambda c: "L{}_B{}_w{}".format(c["config"]["block_len"], c["B"], c["weight_seed"]))
