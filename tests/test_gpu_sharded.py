@@ -119,6 +119,11 @@ def test_bench_runs_with_two_ranks(gpu_device):
     assert res["config"]["global_blocks"] == 6000 and res["config"]["blocks_per_gpu"] == 3000
     assert res["value"] > 0 and abs(res["value"] - 6000 * 100 * 2 / (res["ms_per_step"] * 2e-3)) <= 1e-3 * res["value"]
     assert "cpu_baseline" not in res and res["roofline"]["frac"] > 0
+    # diagnostics for the first real multi-GPU run: every rank reached the collectives, and every rank's own clock is in the line
+    assert res["config"]["rccl_ranks_seen"] == 2 and res["config"]["collective_backend"] == "gloo"
+    pr = res["config"]["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - res["ms_per_step"]) <= 1e-6 * res["ms_per_step"] + 1e-3
+    assert "other_configs" not in res["roofline"] and res["roofline"]["sustained_probe_tflops"] > 500      # probe on rank 0, other configs at N = 1 only
 
 
 def test_bench_runs_with_eight_ranks_strong_and_ragged(gpu_device):
@@ -140,6 +145,7 @@ def test_bench_runs_with_eight_ranks_strong_and_ragged(gpu_device):
     assert len(lines) == 1
     res = json.loads(lines[0])
     assert res["n_gpus"] == 8 and res["scaling"] == "strong" and res["config"]["global_blocks"] == 4003
+    assert res["config"]["rccl_ranks_seen"] == 8 and len(res["config"]["per_rank_ms_per_step"]["all"]) == 8
     assert abs(res["value"] - 4003 * 100 / (res["ms_per_step"] * 1e-3)) <= 1e-3 * res["value"]
     one = subprocess.run([sys.executable] + common[:1] + ["--gpus", "1"] + common[1:], capture_output=True, text=True, timeout=600, cwd=root,
                          env={k: v for k, v in os.environ.items() if k not in ("TAE_BENCH_BACKEND", "TAE_BENCH_FORCE_DIST")})
