@@ -19,7 +19,7 @@ d = json.load(open(sys.argv[1]))
 r, c, p = d["roofline"], d.get("cpu_baseline", {}), d.get("parity", {})
 print(f"bench: {d['value']/1e6:.2f} Mbit/s  ms/step {d['ms_per_step']:.2f} (median {d['ms_per_step_median']:.2f})  dec {r['kernel_ms']:.2f} ms frac {r['frac']:.4f}"
       + (f"  f32 frac {d['roofline_f32']['frac']:.4f}" if 'roofline_f32' in d else "") + f"  ber {d['ber']:.5f}")
-for o in r.get("other_configs", []):
+for o in [x for x in r.get("other_configs", []) if "error" not in x]:
     print(f"  {o['config']}: {o['ms_per_forward']:.2f} ms  {o['bits_per_s']/1e6:.2f} Mbit/s  dec {o['decoder_ms']:.2f} ms frac {o['decoder_frac']:.3f}  enc {o['encoder_plus_norm_ms']:.2f} ms frac {o['encoder_frac']:.3f}")
 print("probe:", r.get("sustained_probe_tflops"), "frac_of_sustained", r.get("frac_of_sustained"))
 print("cpu:", {k: c.get(k) for k in ("value", "cores", "run_to_run_spread", "min_max_spread", "value_B2000", "value_1_thread", "thread_sweep_bits_per_s")})
