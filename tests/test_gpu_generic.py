@@ -69,7 +69,8 @@ def test_precision_f32_for_dense_stacks_and_kernel_sizes_7_9(gpu_device, name):
     assert np.abs(codes - codes2).max() <= 1e-5 and np.abs(xd - xd2).max() <= 2e-5
 
 
-@pytest.mark.parametrize("case", draw_generic_cases(21, 90210), ids=lambda c: "{kind}_L{block_len}_B{B}_e{enc_num_unit}x{enc_num_layer}_d{dec_num_unit}x{dec_num_layer}_F{num_iter_ft}".format(**c))
+# TAE_FUZZ_CASES_GENERIC / TAE_FUZZ_SEED_GENERIC widen or move the search for a soak run (tools/gpu_soak.sh)
+@pytest.mark.parametrize("case", draw_generic_cases(int(os.environ.get("TAE_FUZZ_CASES_GENERIC", "21")), int(os.environ.get("TAE_FUZZ_SEED_GENERIC", "90210"))), ids=lambda c: "{kind}_L{block_len}_B{B}_e{enc_num_unit}x{enc_num_layer}_d{dec_num_unit}x{dec_num_layer}_F{num_iter_ft}".format(**c))
 def test_random_generic_configurations_match_oracle(gpu_device, case):
     from turboae_amd import Channel_AE_HIP
     case = dict(case)
