@@ -95,6 +95,39 @@ def test_random_generic_configurations_match_oracle(gpu_device, case):
     assert np.abs(xd - xo).max() <= tol_x, np.abs(xd - xo).max()
 
 
+@pytest.mark.parametrize("decoder", ["TurboAE_rate3_cnn", "TurboAE_rate3_rnn"])
+def test_three_independent_implementations_agree_on_the_trained_network(gpu_device, monkeypatch, decoder):
+    """TAE_FORCE_GENERIC=1 runs a standard configuration on the generic vector-ALU kernels: a third implementation next to the fp16-split
+    and the fp32 MFMA kernels.  Reference-trained weights (CNN decoder) / random weights (GRU decoder), 1 000 blocks = 100 000 bits."""
+    from dataclasses import replace
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(decoder=decoder, num_iteration=6 if decoder.endswith("cnn") else 2)
+    if decoder.endswith("cnn"):
+        sd = W.unpack_blob(TurboAEConfig(), np.load(os.path.join(GOLD, "trained_enc2dec5_u100_fp32.npz"))["weights_fp32"])
+    else:
+        sd = W.generate_state_dict(cfg, seed=77, gain=1.0)
+    B = 1000
+    auto = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    f32 = Channel_AE_HIP(replace(cfg, precision="f32"), sd, device=gpu_device, max_batch=B)
+    monkeypatch.setenv("TAE_FORCE_GENERIC", "1")
+    gen = Channel_AE_HIP(replace(cfg, precision="f32"), sd, device=gpu_device, max_batch=B)
+    monkeypatch.delenv("TAE_FORCE_GENERIC")
+    assert auto.kernel_info()[0] > 0 and gen.kernel_info() == (0, 0) and gen.range_status()[0] == "f32" and auto.range_status()[0] == "f16x2"
+    u, noise = auto.generate_inputs(B, 2.0, seed=99)
+    xg, cg = gen(u, noise)
+    tol_x = 2e-5 if decoder.endswith("cnn") else 6e-5
+    for name, m in (("f16x2", auto), ("f32 MFMA", f32)):
+        x, c = m(u, noise)
+        assert float((c - cg).abs().max()) <= 1e-5, name
+        d = float((x - xg).abs().max())
+        assert d <= tol_x, (name, d)
+        flips = (x > 0.5) != (xg > 0.5)
+        assert int(flips.sum()) <= 1 and bool(((xg[flips] - 0.5).abs() < 1e-4).all()), (name, int(flips.sum()))
+    if decoder.endswith("cnn"):
+        ber = float(((xg > 0.5) != (u > 0.5)).float().mean())
+        assert 4e-3 < ber < 1e-2, ber            # the trained network's operating point at 2 dB (reference: 6.4e-3)
+
+
 def test_generic_path_runs_the_eval_sweep_and_every_entry_point(gpu_device):
     """evaluate.test, tae_eval_snr and the hipGraph form on an LSTM decoder (all launches are plain kernels on the caller's stream)"""
     from turboae_amd import Channel_AE_HIP, evaluate

@@ -12,6 +12,7 @@
 //   Linear heads, enc_act / dec_act, extrinsic subtraction, (de)interleave, sigmoid    decoders.py:84-149,206-269, encoders.py:281-377
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -238,6 +239,9 @@ bool generic_dec_dense(const tae_config* c) {
 }
 
 bool generic_needed(const tae_config* c) {
+    // TAE_FORCE_GENERIC=1 (testing knob, read per call): run ANY configuration on the generic kernels - a third, independent
+    // implementation to hold against the two MFMA arithmetics (tests/test_gpu_generic.py)
+    if (const char* e = getenv("TAE_FORCE_GENERIC")) if (e[0] == '1') return true;
     const bool big_k = c->enc_kernel_size > 9 || c->dec_kernel_size > 9;
     const bool mid_k = c->enc_kernel_size > 5 || c->dec_kernel_size > 5;
     if (big_k || c->enc_num_unit > 100 || c->dec_num_unit > 100 || c->num_iter_ft > 6) return true;
