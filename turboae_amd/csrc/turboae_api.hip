@@ -1133,6 +1133,7 @@ int run_encoder_rnn(tae_handle* h, const float* u, float* xtx, double* stats, in
             TAE_HIP(tae::launch_gru_prep_enc(u + (size_t)c0 * L, h->d_perm, h->d_gxa, Bc, L, s == 2 ? 1 : 0, st));
             tae::GruRecParams R0, R1;
             tae::GruProjParams PP;
+            memset(&PP, 0, sizeof(PP));
             tae::GruHeadParams HP;
             memset(&R0, 0, sizeof(R0)); memset(&R1, 0, sizeof(R1)); memset(&HP, 0, sizeof(HP));
             R0.x = h->d_gxa; R0.B = Bc; R0.L = L; R0.y = h->d_gy0;
@@ -1194,6 +1195,7 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
                 TAE_HIP(tae::launch_gru_rec_h(true, R0, st));
                 const char* w1 = wb + 2 * kGHRec0B;
                 tae::GruProjParams PP;
+            memset(&PP, 0, sizeof(PP));
                 const size_t npg = (size_t)((Bc + 15) / 16) * 16 * L;       // block-group-major rows incl. the padding blocks of the last group
                 PP.yin = h->d_gy0; PP.w = reinterpret_cast<const float*>(w1); PP.gi = h->d_ggi; PP.npos = npg; PP.B = Bc; PP.L = L;
                 TAE_HIP(tae::launch_gru_proj_h(PP, st));
@@ -1225,6 +1227,7 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
             TAE_HIP(tae::launch_gru_rec(true, R0, st));
             const float* w1 = w + 2 * kGL0Dir;
             tae::GruProjParams PP;
+            memset(&PP, 0, sizeof(PP));
             PP.yin = h->d_gy0; PP.w = w1; PP.gi = h->d_ggi; PP.npos = np; PP.B = Bc; PP.L = L;
             TAE_HIP(tae::launch_gru_proj(PP, st));
             tae::GruRecParams R1;

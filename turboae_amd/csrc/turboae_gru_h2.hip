@@ -21,8 +21,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <type_traits>
 #include "turboae_internal.hpp"
 #include "turboae_device.hpp"
+
+#ifndef TAE_PROJ_X
+#define TAE_PROJ_X 0      // timing experiments (results wrong): 1 no GI stores, 2 no K loop, 4 no Y0 staging loads
+#endif
 
 namespace tae {
 
@@ -313,14 +319,14 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
 // positions): one workgroup per CU (the r02 geometry; TAE_GRU_PROJ_PG=2).  The A-fragment stream per position is the same.
 constexpr int kProjHSlabs = 7;                                // K = 200 -> 224
 constexpr uint32_t kProjHDirB = kProjHSlabs * 19 * 2048u;     // A fragments of one direction
-template <int NPG> struct ProjGeo {
-    static constexpr int kPos = 80 * NPG;
+template <int NPG, int PT = 5> struct ProjGeo {
+    static constexpr int kPos = 16 * PT * NPG;
     static constexpr int kPlaneB = kPos * 400 + 512;          // + slack for the K padding over-read of the last row
     static constexpr int kLds = 2 * kPlaneB;
     static constexpr int kThreads = 256 * NPG;
 };
 
-template <int NPG, int C0, int NC, bool NT>
+template <int NPG, int C0, int NC, bool NT, int PT = 5>
 __device__ __forceinline__ void proj_pass_h(const GruProjParams& P, const char* smem, int pg, int dir, int lane, size_t p0) {
     const int n = lane & 15, kq = lane >> 4;
     const char* wb = reinterpret_cast<const char*>(P.w);
@@ -329,26 +335,32 @@ __device__ __forceinline__ void proj_pass_h(const GruProjParams& P, const char* 
     const uint32_t soff = (uint32_t)dir * kProjHDirB;
     const float* bias = reinterpret_cast<const float*>(wb + 2 * kProjHDirB) + dir * (19 * 16);
     const float inv = reinterpret_cast<const float*>(wb + 2 * kProjHDirB)[2 * 19 * 16];
-    uint32_t bh[5], bl[5];
+    uint32_t bh[PT], bl[PT];
 #pragma unroll
-    for (int p = 0; p < 5; ++p) {
-        bh[p] = (uint32_t)(((pg * 5 + p) * 16 + n) * 400 + 16 * kq);
-        bl[p] = bh[p] + (uint32_t)ProjGeo<NPG>::kPlaneB;
+    for (int p = 0; p < PT; ++p) {
+        bh[p] = (uint32_t)(((pg * PT + p) * 16 + n) * 400 + 16 * kq);
+        bl[p] = bh[p] + (uint32_t)ProjGeo<NPG, PT>::kPlaneB;
     }
     OpsHA<NC> a0;
     load_wh<19, C0, NC>(a0, rsrc, voff, soff);
-    f32x4 acc[5][NC];
+    f32x4 acc[PT][NC];
 #pragma unroll
     for (int ct = 0; ct < NC; ++ct) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + (C0 + ct) * 16 + 4 * kq);
 #pragma unroll
-        for (int p = 0; p < 5; ++p) acc[p][ct] = bv;
+        for (int p = 0; p < PT; ++p) acc[p][ct] = bv;
     }
-    conv_accumulate_h<19, C0, NC, 5, kProjHSlabs>(acc, a0, rsrc, voff, soff, smem, bh, bl);
+#if !(TAE_PROJ_X & 2)
+    conv_accumulate_h<19, C0, NC, PT, kProjHSlabs>(acc, a0, rsrc, voff, soff, smem, bh, bl);
+#endif
 #pragma unroll
-    for (int p = 0; p < 5; ++p) {
-        const size_t pos = p0 + (pg * 5 + p) * 16 + n;
+    for (int p = 0; p < PT; ++p) {
+        const size_t pos = p0 + (pg * PT + p) * 16 + n;
+#if TAE_PROJ_X & 1
+        if (pos == (size_t)-1) {
+#else
         if (pos < P.npos) {
+#endif
             float* dst = P.gi + ((pos >> 4) * 2 + dir) * (size_t)(19 * 256) + (size_t)C0 * 256 + (n * 4 + kq) * 4;
 #pragma unroll
             for (int ct = 0; ct < NC; ++ct) {
@@ -361,9 +373,9 @@ __device__ __forceinline__ void proj_pass_h(const GruProjParams& P, const char* 
     }
 }
 
-template <int NPG, bool NT>
-__global__ __launch_bounds__(256 * NPG, 2) void gru_proj_h_kernel(GruProjParams P) {
-    using G = ProjGeo<NPG>;
+template <int NPG, bool NT, int PT = 5, int MINW = 2>
+__global__ __launch_bounds__(256 * NPG, MINW) void gru_proj_h_kernel(GruProjParams P) {
+    using G = ProjGeo<NPG, PT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -374,7 +386,7 @@ __global__ __launch_bounds__(256 * NPG, 2) void gru_proj_h_kernel(GruProjParams 
         const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(P.yin) + p0 * 800);
         for (int i = tid; i < G::kLds / 16; i += G::kThreads) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
-        for (int i = tid; i < np * 50; i += G::kThreads) {
+        for (int i = tid; i < ((TAE_PROJ_X & 4) ? 0 : np * 50); i += G::kThreads) {
             const int pos = i / 50, c = i - pos * 50, plane = c >= 25 ? 1 : 0, cc = c - plane * 25;
             *reinterpret_cast<f32x4*>(smem + plane * G::kPlaneB + pos * 400 + cc * 16) = src[i];
         }
@@ -382,11 +394,11 @@ __global__ __launch_bounds__(256 * NPG, 2) void gru_proj_h_kernel(GruProjParams 
     __syncthreads();
     const int pg = NPG == 1 ? 0 : (wave & 1), rq = NPG == 1 ? wave : (wave >> 1), dir = rq >> 1;
     if ((rq & 1) == 0) {
-        proj_pass_h<NPG, 0, 5, NT>(P, smem, pg, dir, lane, p0);
-        proj_pass_h<NPG, 5, 5, NT>(P, smem, pg, dir, lane, p0);
+        proj_pass_h<NPG, 0, 5, NT, PT>(P, smem, pg, dir, lane, p0);
+        proj_pass_h<NPG, 5, 5, NT, PT>(P, smem, pg, dir, lane, p0);
     } else {
-        proj_pass_h<NPG, 10, 5, NT>(P, smem, pg, dir, lane, p0);
-        proj_pass_h<NPG, 15, 4, NT>(P, smem, pg, dir, lane, p0);
+        proj_pass_h<NPG, 10, 5, NT, PT>(P, smem, pg, dir, lane, p0);
+        proj_pass_h<NPG, 15, 4, NT, PT>(P, smem, pg, dir, lane, p0);
     }
 }
 
@@ -464,13 +476,13 @@ hipError_t launch_gru_rec_h(bool layer0, const GruRecParams& P, hipStream_t st) 
     return hipGetLastError();
 }
 
-template <int NPG, bool NT>
+template <int NPG, bool NT, int PT = 5, int MINW = 2>
 static hipError_t launch_gru_proj_h_t(const GruProjParams& P, hipStream_t st) {
-    using G = ProjGeo<NPG>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_proj_h_kernel<NPG, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, G::kLds);
+    using G = ProjGeo<NPG, PT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_proj_h_kernel<NPG, NT, PT, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::kLds);
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)((P.npos + G::kPos - 1) / G::kPos));
-    hipLaunchKernelGGL((gru_proj_h_kernel<NPG, NT>), grid, dim3(G::kThreads), G::kLds, st, P);
+    hipLaunchKernelGGL((gru_proj_h_kernel<NPG, NT, PT, MINW>), grid, dim3(G::kThreads), G::kLds, st, P);
     return hipGetLastError();
 }
 
