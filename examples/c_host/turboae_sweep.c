@@ -1,7 +1,11 @@
 /* The reference's eval sweep (trainer.test, trainer.py:135-248) driven from plain C through the C ABI of
  * libturboae_hip.so - no Python, no torch: what a cgo / JNI / FFI binding of another host language would do.
  *
- *   turboae_sweep <weights.f32> <perm.i32> [blocks_per_snr=10000] [batch=500] [snr_points=12] [snr_lo=-1.5] [snr_hi=4.0] [seed=1] [mode=0]
+ *   turboae_sweep <weights.f32> <perm.i32> [blocks_per_snr=10000] [batch=500] [snr_points=12] [snr_lo=-1.5] [snr_hi=4.0] [seed=1] [mode=0] [channel=awgn]
+ *
+ * channel: awgn | t-dist | radar | ge_awgn | bec | bsc | ge | fading (-channel, get_args.py:43): the noise of every channel is drawn on
+ * the device (tae_generate_noise / tae_set_noise_opts) and applied by the matching branch of Channel_AE.forward (tae_set_channel_opts);
+ * for bec / bsc / ge the sweep variable is the erase / flip probability, as in the reference (channels.py:28-31).
  *
  * mode 0: one tae_eval_snr call per SNR point (the library decodes groups of batches in one launch);
  * mode 1: the same protocol spelled out call by call (tae_generate_inputs -> tae_forward -> tae_count_errors per batch).
@@ -57,6 +61,15 @@ int main(int argc, char** argv) {
     const double snr_hi = argc > 7 ? atof(argv[7]) : 4.0;
     const uint64_t seed = argc > 8 ? (uint64_t)strtoull(argv[8], NULL, 10) : 1u;
     const int mode = argc > 9 ? atoi(argv[9]) : 0;
+    const char* channel = argc > 10 ? argv[10] : "awgn";
+    static const char* const kinds[] = {"awgn", "t-dist", "radar", "ge_awgn", "bec", "bsc", "ge", "fading"};      /* TAE_NOISE_* order */
+    int kind = -1;
+    for (int i = 0; i < 8; ++i)
+        if (strcmp(channel, kinds[i]) == 0) kind = i;
+    if (kind < 0) {
+        fprintf(stderr, "unknown channel %s\n", channel);
+        return 1;
+    }
     if (tae_abi_version() != TAE_ABI_VERSION) {
         fprintf(stderr, "header / library ABI mismatch (%d vs %d)\n", TAE_ABI_VERSION, tae_abi_version());
         return 1;
@@ -103,11 +116,26 @@ int main(int argc, char** argv) {
     fclose(f);
     TAE_CHECK(tae_set_interleaver(h, perm, L));     /* enc.set_interleaver / dec.set_interleaver, channel_ae.py:32-36 */
     free(perm);
+    /* the channel: which generator draws the noise (channels.py:37-109) and how Channel_AE.forward applies it (channel_ae.py:41-56) */
+    tae_noise_opts nz;
+    memset(&nz, 0, sizeof(nz));
+    nz.struct_size = (int32_t)sizeof(nz);
+    nz.kind = kind;
+    nz.vv = 5.0f; nz.radar_prob = 0.05f; nz.radar_power = 5.0f;     /* get_args.py:53-56 defaults */
+    nz.p_gg = 0.8f; nz.p_bb = 0.8f;                                 /* channels.py:60-61,86-87 */
+    TAE_CHECK(tae_set_noise_opts(h, &nz));
+    tae_channel_opts co;
+    memset(&co, 0, sizeof(co));
+    co.struct_size = (int32_t)sizeof(co);
+    co.enc_value_limit = 1.0f; co.enc_quantize_level = 2.0f; co.rec_quantize_limit = 2.0f; co.rec_quantize_level = 2.0f;
+    co.channel = kind == TAE_NOISE_BEC ? 1 : (kind == TAE_NOISE_BSC || kind == TAE_NOISE_GE) ? 2 : kind == TAE_NOISE_FADING ? 3 : 0;
+    TAE_CHECK(tae_set_channel_opts(h, &co));
+    const size_t noise_mult = kind == TAE_NOISE_FADING ? 2 : 1;    /* fading: coefficients followed by the noise */
     const int nbatch = (int)(num_block / batch);
     float *u, *noise, *x_dec, *codes;
     uint64_t* counts;                      /* per batch: (bit errors, block errors), accumulated on the device */
     HIP_OK(hipMalloc((void**)&u, (size_t)batch * L * sizeof(float)));
-    HIP_OK(hipMalloc((void**)&noise, (size_t)batch * L * 3 * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&noise, noise_mult * (size_t)batch * L * 3 * sizeof(float)));
     HIP_OK(hipMalloc((void**)&x_dec, (size_t)batch * L * sizeof(float)));
     HIP_OK(hipMalloc((void**)&codes, (size_t)batch * L * 3 * sizeof(float)));
     HIP_OK(hipMalloc((void**)&counts, (size_t)nbatch * 2 * sizeof(uint64_t)));
@@ -125,7 +153,13 @@ int main(int argc, char** argv) {
         }
         for (int bi = 0; mode != 0 && bi < nbatch; ++bi) {
             const int64_t first = ((int64_t)si * nbatch + bi) * batch;      /* global block index: the Philox key */
-            TAE_CHECK(tae_generate_inputs(h, u, noise, batch, first, seed, seed, (float)snr, st));
+            if (kind == TAE_NOISE_AWGN) {
+                TAE_CHECK(tae_generate_inputs(h, u, noise, batch, first, seed, seed, (float)snr, st));
+            } else {
+                float* nz_out = noise + (noise_mult - 1) * (size_t)batch * L * 3;
+                TAE_CHECK(tae_generate_inputs(h, u, NULL, batch, first, seed, seed, (float)snr, st));
+                TAE_CHECK(tae_generate_noise(h, &nz, (float)snr, nz_out, kind == TAE_NOISE_FADING ? noise : NULL, batch, first, seed, st));
+            }
             TAE_CHECK(tae_forward(h, u, noise, x_dec, codes, batch, st));   /* Channel_AE.forward, channel_ae.py:32-78 */
             TAE_CHECK(tae_count_errors(h, x_dec, u, batch, counts + 2 * bi, st));
         }
