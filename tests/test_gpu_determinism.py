@@ -1,0 +1,29 @@
+"""Run-to-run determinism: the same inputs through each kernel family several times, outputs bit for bit.  (r03: the GRU recurrence once
+mixed two MFMA shapes in one dependent chain and read stale accumulators whenever two waves shared a SIMD - results changed from run to
+run at 1e-3 while every single-wave test stayed green; DESIGN.md 3.5, tools/probes/mfma_mixed_shape_hazard.hip.  tools/determinism_soak.py
+is the long version.)"""
+import pytest
+import torch
+
+from turboae_amd import TurboAEConfig, weights as W
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("cnn_f16x2", dict(), 6000), ("cnn_f32", dict(precision="f32"), 3000), ("long_blocks", dict(block_len=1000, num_iteration=2), 600),
+         ("gru_dec_f16x2_two_waves_per_simd", dict(decoder="TurboAE_rate3_rnn", num_iteration=2), 8192),
+         ("gru_dec_f32", dict(decoder="TurboAE_rate3_rnn", num_iteration=2, precision="f32"), 4096),
+         ("gru_enc_dec", dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", num_iteration=1), 4096),
+         ("generic_rnn", dict(decoder="TurboAE_rate3_rnn", dec_rnn="rnn", dec_num_unit=24, num_iteration=2), 96)]
+
+
+@pytest.mark.parametrize("name,over,B", CASES, ids=[c[0] for c in CASES])
+def test_same_inputs_same_bits(gpu_device, name, over, B):
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(**over)
+    model = Channel_AE_HIP(cfg, W.generate_state_dict(cfg, seed=5, gain=1.0), device=gpu_device, max_batch=B)
+    u, noise = model.generate_inputs(B, 1.0, seed=3)
+    x0, c0 = model(u, noise)
+    for _ in range(5):
+        x, c = model(u, noise)
+        assert torch.equal(x, x0) and torch.equal(c, c0), name
+    model.check_range()
