@@ -548,7 +548,7 @@ inline void put_split(char* dst, size_t hi_off, size_t lo_off, float w) {
     memcpy(dst + lo_off, &lo, 2);
 }
 // W_hh (3H,H) [+ layer-0 W_ih (3H,cin)] -> per gate tile: 3 slabs x (hi | lo) x [lane][8 halves], then the K = 16 remainder
-// (hi | lo) x [lane][4 halves]: k0 = unit 96 + kq, k1..3 = stack inputs 3kq .. 3kq+2 (layer 0)
+// [lane][4 hi halves | 4 lo halves]: k0 = unit 96 + kq, k1..3 = stack inputs 3kq .. 3kq+2 (layer 0)
 void pack_gru_rec_h(const float* Whh, const float* Wih0, int cin, float scale, char* dst) {
     for (int T = 0; T < kGRT; ++T)
         for (int lane = 0; lane < 64; ++lane) {
@@ -571,8 +571,8 @@ void pack_gru_rec_h(const float* Whh, const float* Wih0, int cin, float scale, c
                     else { const int qq = m >> 2, i = m & 3; rowx = i < 2 ? i * kGH + 96 + qq : (i == 3 ? 2 * kGH + 96 + qq : -1); }
                     if (rowx >= 0 && xi < cin) w = Wih0[(size_t)rowx * cin + xi] * scale;
                 }
-                const size_t o = (size_t)T * kGHTileB + 6144 + lane * 8 + j * 2;
-                put_split(dst, o, o + 512, w);
+                const size_t o = (size_t)T * kGHTileB + 6144 + lane * 16 + j * 2;      // [lane][4 hi halves | 4 lo halves]
+                put_split(dst, o, o + 8, w);
             }
         }
 }
@@ -590,8 +590,8 @@ void pack_gru_head_h(const float* Wlin, int nout, int d, float scale, char* dst)
             }
         for (int j = 0; j < 4; ++j) {
             const float w = (j == 0 && m < nout) ? Wlin[(size_t)m * 2 * kGH + d * kGH + 96 + kq] * scale : 0.0f;
-            const size_t o = 6144 + lane * 8 + j * 2;
-            put_split(dst, o, o + 512, w);
+            const size_t o = 6144 + lane * 16 + j * 2;
+            put_split(dst, o, o + 8, w);
         }
     }
 }
@@ -602,8 +602,8 @@ void pack_gru_ni_h(const float* Wih0, int cin, float scale, char* dst) {
             for (int j = 0; j < 4; ++j) {
                 const int m = lane & 15, kq = lane >> 4, xi = 3 * kq + j - 1;
                 const float w = (j >= 1 && xi < cin) ? Wih0[(size_t)(2 * kGH + 16 * ut + m) * cin + xi] * scale : 0.0f;
-                const size_t o = (size_t)ut * 1024 + lane * 8 + j * 2;
-                put_split(dst, o, o + 512, w);
+                const size_t o = (size_t)ut * 1024 + lane * 16 + j * 2;
+                put_split(dst, o, o + 8, w);
             }
 }
 // layer-1 W_ih (3H,2H) of one direction -> [slab 7][gate tile 19][hi | lo][lane][8 halves]

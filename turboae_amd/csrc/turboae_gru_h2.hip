@@ -9,7 +9,7 @@
 //   * k-slab s (32 k) of the recurrent product = unit tiles 2s and 2s+1: lane (n, kq) supplies the units
 //     16(2s) + 4kq + j (j < 4) and 16(2s+1) + 4kq + (j-4) - exactly the 8 state values that lane holds in the
 //     D layout of those two unit tiles, re-split into halves after every step;
-//   * the 4 remainder units (96..99) as one K = 16 product (a zero-extended v_mfma_f32_16x16x32_f16, see zext8): lane kq supplies unit
+//   * the 4 remainder units (96..99) as one K = 16 slab (two v_mfma_f32_16x16x32_f16 carrying hi and lo halves side by side, see mma_rem): lane kq supplies unit
 //     96 + kq in k = 4kq, and - layer 0 - its three spare k slots carry the stack inputs x_t[3kq .. 3kq+2], so
 //     the K = 7 input projection costs no extra MFMAs for the r / z rows (the n-gate input part needs its own
 //     accumulators: 6 extra K = 16 tiles);
@@ -29,6 +29,9 @@
 #ifndef TAE_PROJ_X
 #define TAE_PROJ_X 0      // timing experiments (results wrong): 1 no GI stores, 2 no K loop, 4 no Y0 staging loads
 #endif
+#ifndef TAE_REC_X
+#define TAE_REC_X 0       // timing experiments on the recurrence (results wrong): 1 no exp / rcp in the gates, 2 no LDS fragment reads in the
+#endif                    // step loop, 4 no GI loads (layer 1) / Y0 stores (layer 0), 8 no MFMAs
 
 namespace tae {
 
@@ -37,22 +40,23 @@ using h2v = __attribute__((ext_vector_type(2))) _Float16;
 
 constexpr int kGH = 100;
 constexpr int kGXW = 8;
-constexpr int kRecTileB = 3 * 2048 + 1024;                 // bytes of A fragments per gate-row tile: 3 slabs (hi | lo) + K=16 remainder (hi | lo)
+constexpr int kRecTileB = 3 * 2048 + 1024;                 // bytes of A fragments per gate-row tile: 3 slabs (hi | lo) + K=16 remainder ([lane][4 hi | 4 lo])
 constexpr int kRecFragB = 19 * kRecTileB;                   // 136 192
-constexpr int kNiFragB = 6 * 1024;                          // layer 0: n-gate input tiles (K = 16, hi | lo)
+constexpr int kNiFragB = 6 * 1024;                          // layer 0: n-gate input tiles (K = 16, [lane][hi | lo])
 constexpr int kRec0B = kRecFragB + kNiFragB + 25 * 64 + 16; // + accumulator-init rows + 2^-S
 constexpr int kRec1B = kRecFragB + kRecTileB + 7 * 64 + 16; // + Linear-head tile (this direction's half of the head weights) + b_hn rows + (2^-S, 2^-S_head)
 
-// The K = 16 remainder products run as v_mfma_f32_16x16x32_f16 with the upper four k slots of every lane zero (the same lane
-// pairing: lane (i, kq) contracts its k = 0..3), NOT as v_mfma_f32_16x16x16_f16: mixed in one stream with 16x16x32, the K = 16
-// instruction read stale accumulators on gfx950 (a dependent 16x16x32 -> 16x16x16 pair through srcC, and - once the scheduler
-// moved the K = 16 products between other chains - whole tiles; the compiler inserts no wait states for these pairs).  Found in
-// r03 when the head tile was added: results changed from run to run with two waves per SIMD.  One MFMA shape per kernel.
-__device__ __forceinline__ h8 zext8(u32x2v v) { return __builtin_bit_cast(h8, u32x4w{v.x, v.y, 0u, 0u}); }
+// The K = 16 remainder products run as v_mfma_f32_16x16x32_f16 (lane (i, kq) contracts its k = 0..3 in the instruction's k slots
+// 8kq .. 8kq+3; see mma_rem for what the slots 8kq+4 .. 8kq+7 carry), NOT as v_mfma_f32_16x16x16_f16: mixed in one stream with
+// 16x16x32, the K = 16 instruction read stale accumulators on gfx950 (a dependent 16x16x32 -> 16x16x16 pair through srcC, and - once
+// the scheduler moved the K = 16 products between other chains - whole tiles; the compiler inserts no wait states for these pairs).
+// Found in r03 when the head tile was added: results changed from run to run with two waves per SIMD.  One MFMA shape per kernel.
 __device__ __forceinline__ float sigm_h(float x) {
+    if (TAE_REC_X & 1) return fmaf(x, 0.25f, 0.5f);
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
 }
 __device__ __forceinline__ float tanh_h(float x) {
+    if (TAE_REC_X & 1) return x * 0.5f;
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)), 1.0f);
 }
 
@@ -61,22 +65,28 @@ using lds_q2 = const u32x2v __attribute__((address_space(3)));
 using lds_f4c = const f32x4 __attribute__((address_space(3)));
 
 // A fragments of one k-slab for NG gate tiles (tile stride STRIDE bytes): 32-k slabs as 8 halves per lane, the K = 16
-// remainder slab as 4 halves per lane; hi then lo, 1024 / 512 bytes apart.  Loads and MFMAs are separate calls so the
+// remainder slab as [4 hi | 4 lo] halves per lane; slabs: hi then lo, 1024 bytes apart.  Loads and MFMAs are separate calls so the
 // caller can issue the next slab's LDS reads before the current slab's MFMAs (pinned with sched_group_barrier: left to
 // the scheduler every read ends up right in front of its first use and the LDS latency is exposed 28 times per step).
 template <int NG> struct FragS { h8 ah[NG], al[NG]; };
-template <int NG> struct FragR { h8 ah[NG], al[NG]; };      // 4 halves from LDS, zero-extended
+template <int NG> struct FragR { h8 a[NG]; };                 // remainder slab: [4 hi halves | 4 lo halves] of the lane's k = 0..3, one 16-byte read
 
 template <int NG>
 __device__ __forceinline__ void load_slab(FragS<NG>& f, lds_cptr fr) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
+        if (TAE_REC_X & 2) { asm volatile("" : "+v"(f.ah[g]), "+v"(f.al[g])); continue; }
         f.ah[g] = __builtin_bit_cast(h8, *reinterpret_cast<lds_q4*>(fr + g * kRecTileB));
         f.al[g] = __builtin_bit_cast(h8, *reinterpret_cast<lds_q4*>(fr + g * kRecTileB + 1024));
     }
 }
 template <int NG>
 __device__ __forceinline__ void mma_slab(f32x4 (&acc)[NG], const FragS<NG>& f, h8 bh, h8 bl) {
+    if (TAE_REC_X & 8) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) asm volatile("" : "+v"(acc[g]) : "v"(f.ah[g]), "v"(f.al[g]), "v"(bh), "v"(bl));
+        return;
+    }
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(f.ah[g], bl, acc[g]);
 #pragma unroll
@@ -88,19 +98,25 @@ template <int NG, int STRIDE>
 __device__ __forceinline__ void load_rem(FragR<NG>& f, lds_cptr fr) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        f.ah[g] = zext8(*reinterpret_cast<lds_q2*>(fr + g * STRIDE));
-        f.al[g] = zext8(*reinterpret_cast<lds_q2*>(fr + g * STRIDE + 512));
+        if (TAE_REC_X & 2) { asm volatile("" : "+v"(f.a[g])); continue; }
+        f.a[g] = __builtin_bit_cast(h8, *reinterpret_cast<lds_q4*>(fr + g * STRIDE));
     }
 }
+// The K = 16 remainder in TWO K = 32 products: A = [a.hi | a.lo] (k slots 0..3 | 4..7 of every lane), b1 = [b.lo | b.hi] gives
+// a.hi * b.lo + a.lo * b.hi in one instruction, b2 = [b.hi | 0] adds a.hi * b.hi (its a.lo half meets zeros).  One 16-byte LDS
+// read per tile and no zero-extension of the A operand (the earlier form - three products on zero-extended 8-byte fragments -
+// cost four v_mov per MFMA, 211 per step and wave: the register tuples' zero halves were re-made for every use).
 template <int NG>
-__device__ __forceinline__ void mma_rem(f32x4 (&acc)[NG], const FragR<NG>& f, h4 bh4, h4 bl4) {
-    const h8 bh = zext8(__builtin_bit_cast(u32x2v, bh4)), bl = zext8(__builtin_bit_cast(u32x2v, bl4));
+__device__ __forceinline__ void mma_rem(f32x4 (&acc)[NG], const FragR<NG>& f, h8 b1, h8 b2) {
+    if (TAE_REC_X & 8) {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(f.ah[g], bl, acc[g]);
+        for (int g = 0; g < NG; ++g) asm volatile("" : "+v"(acc[g]) : "v"(f.a[g]), "v"(b1), "v"(b2));
+        return;
+    }
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(f.al[g], bh, acc[g]);
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(f.a[g], b1, acc[g]);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(f.ah[g], bh, acc[g]);
+    for (int g = 0; g < NG; ++g) acc[g] = mfma16x16x32h(f.a[g], b2, acc[g]);
 }
 // {ND LDS reads, then NM MFMAs}: the reads (for a LATER slab) go first, the MFMAs of the current slab cover their latency
 template <int ND, int NM>
@@ -154,6 +170,11 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) { bh[s] = h8{0, 0, 0, 0, 0, 0, 0, 0}; bl[s] = bh[s]; }
     h4 rh = {0, 0, 0, 0}, rl = {0, 0, 0, 0};   // remainder slab: k0 = h of unit 96 + q, k1..3 = this lane's share of x_t (layer 0)
+    h8 rb1, rb2;                               // ... as the two B operands of mma_rem: [lo | hi] and [hi | 0]
+    auto set_rb = [&]() {
+        rb1 = h8{rl[0], rl[1], rl[2], rl[3], rh[0], rh[1], rh[2], rh[3]};
+        rb2 = h8{rh[0], rh[1], rh[2], rh[3], 0, 0, 0, 0};
+    };
 
     // x_t (layer 0): lane group q carries x[3q .. 3q+2] (q = 2: x[6], x[7] - the panel is 8 wide; q = 3: nothing)
     auto load_x = [&](int t, f32x4& xa, f32x4& xb) {
@@ -178,6 +199,7 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
         load_x(dir ? L - 1 : 0, xa, xb);
         set_x(xa, xb);
     }
+    set_rb();
     FragS<3> fa, fb;       // A-fragment ping-pong of the unit tiles
     FragS<1> f1;           // ... of the remainder tile
     load_slab<3>(fa, lds3 + lane * 16);
@@ -191,8 +213,10 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
         } else {
             const uint32_t so = gi_wave + (uint32_t)t * (2 * 19 * 1024u);
 #pragma unroll
-            for (int T = 0; T < 19; ++T)
+            for (int T = 0; T < 19; ++T) {
+                if (TAE_REC_X & 4) { g[T] = f32x4{0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+v"(g[T])); continue; }
                 g[T] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_in, so + T * 1024u, 0));
+            }
         }
         __builtin_amdgcn_sched_barrier(0);     // keep this step's loads up here (they are consumed by the gate arithmetic / next step)
         h4 nhi[6], nlo[6];
@@ -221,21 +245,21 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
             load_slab<3>(fa, fr + 4096);
             mma_slab<3>(a3, fb, bh[1], bl[1]);
             pin_ds_mma<6, 9>();
-            load_rem<3, kRecTileB>(fq, lds3 + (3 * u) * kRecTileB + 6144 + lane * 8);
+            load_rem<3, kRecTileB>(fq, lds3 + (3 * u) * kRecTileB + 6144 + lane * 16);
             FragR<1> fn;
-            if (LAYER0) load_rem<1, 1024>(fn, lds3 + kRecFragB + u * 1024 + lane * 8);
+            if (LAYER0) load_rem<1, 1024>(fn, lds3 + kRecFragB + u * 1024 + lane * 16);
             mma_slab<3>(a3, fa, bh[2], bl[2]);
-            pin_ds_mma<LAYER0 ? 8 : 6, 9>();
+            pin_ds_mma<LAYER0 ? 4 : 3, 9>();
             if (u < 5) load_slab<3>(fa, frn);
             else load_slab<1>(f1, frn);
-            mma_rem<3>(a3, fq, rh, rl);
+            mma_rem<3>(a3, fq, rb1, rb2);
             f32x4 ani = {0.f, 0.f, 0.f, 0.f};
             if (LAYER0) {
                 f32x4 a1[1] = {acc[NG - 1]};
-                mma_rem<1>(a1, fn, rh, rl);
+                mma_rem<1>(a1, fn, rb1, rb2);
                 ani = a1[0];
             }
-            pin_ds_mma<6, LAYER0 ? 12 : 9>();
+            pin_ds_mma<6, LAYER0 ? 8 : 6>();
             f32x4 hn;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -246,7 +270,7 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
             }
             h[u] = hn;
             split4(hn, nhi[u], nlo[u]);
-            if (LAYER0) {
+            if (LAYER0 && !(TAE_REC_X & 4)) {
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nhi[u]), rs_y, v_y + u * 32, yo, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nlo[u]), rs_y, v_y + u * 32 + 400, yo, 0);
             }
@@ -262,10 +286,10 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
             mma_slab<1>(a1, f1, bh[0], bl[0]);
             load_slab<1>(f1, fr + 4096);
             mma_slab<1>(a1, f2, bh[1], bl[1]);
-            load_rem<1, kRecTileB>(fq, lds3 + 18 * kRecTileB + 6144 + lane * 8);
+            load_rem<1, kRecTileB>(fq, lds3 + 18 * kRecTileB + 6144 + lane * 16);
             mma_slab<1>(a1, f1, bh[2], bl[2]);
             load_slab<3>(fa, lds3 + lane * 16);          // slab 0 of unit tile 0 for the next step
-            mma_rem<1>(a1, fq, rh, rl);
+            mma_rem<1>(a1, fq, rb1, rb2);
             const f32x4 a = a1[0];
             const float r = sigm_h(LAYER0 ? a[0] * inv : fmaf(a[0], inv, g[18][0]));
             const float z = sigm_h(LAYER0 ? a[1] * inv : fmaf(a[1], inv, g[18][1]));
@@ -288,6 +312,7 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
                 __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, lo), rs_y, v_yr + 400, yo, 0);
                 set_x(xa, xb);
             }
+            set_rb();
         }
         if (!LAYER0) {
             // Linear head on the new state (decoders.py:103,115,143; encoders.py:284-292): tile 19 = the <= 8 output rows of this
@@ -300,11 +325,11 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
             load_slab<1>(fh0, fr);
             load_slab<1>(fh1, fr + 2048);
             load_slab<1>(fh2, fr + 4096);
-            load_rem<1, kRecTileB>(fhq, lds3 + 19 * kRecTileB + 6144 + lane * 8);
+            load_rem<1, kRecTileB>(fhq, lds3 + 19 * kRecTileB + 6144 + lane * 16);
             mma_slab<1>(ah, fh0, bh[0], bl[0]);
             mma_slab<1>(ah, fh1, bh[1], bl[1]);
             mma_slab<1>(ah, fh2, bh[2], bl[2]);
-            mma_rem<1>(ah, fhq, rh, rl);
+            mma_rem<1>(ah, fhq, rb1, rb2);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, ah[0] * inv_head), rs_y, v_y, (uint32_t)t * 1024u, 0);
         }
     }
