@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TAE_ABI_VERSION 9
+#define TAE_ABI_VERSION 10
 
 #if defined(__GNUC__)
 #define TAE_API __attribute__((visibility("default")))
@@ -77,6 +77,18 @@ typedef struct tae_config {
                                  has no dec_act; ignored for dec_type = 0).  The reference default is TAE_ACT_LINEAR (= 1, NOT 0) */
     int32_t enc_rnn;          /* -enc_rnn (get_args.py:79, encoders.py:242-247): TAE_RNN_GRU / LSTM / RNN cell of ENC_interRNN (enc_type = 1) */
     int32_t dec_rnn;          /* -dec_rnn (get_args.py:80, decoders.py:27-32): the cell of DEC_LargeRNN (dec_type = 1) */
+    int32_t range_calibration;/* fp16-split conv kernels (no reference counterpart: the reference's fp32 F.conv1d, cnn_utils.py:36-46, has 24
+                                 significant bits at any magnitude; an fp16 hi/lo pair has them only for values in about [2^-3, 2^16)):
+                                 0 (default) = tae_create / tae_set_interleaver / tae_set_channel_opts run the handle's own forward on a
+                                 synthetic batch, measure every layer's largest activation and store each panel times a per-layer power of
+                                 two that puts that maximum at [2^10, 2^11) (see tae_calibrate_range); 1 = no calibration, every exponent 0
+                                 (fp32-grade only while activations are O(1); testing / A-B) */
+    int32_t range_fallback;   /* 1: every compute entry point (tae_forward / encode / encode_prenorm / decode / eval_snr) waits for its
+                                 launches, reads the range word and, if an activation left the window (above the fp16 range, or a
+                                 workgroup's data 2^7 below the calibration maximum), runs the call again on an fp32 twin of the handle
+                                 (fp32 MFMA kernels; generic fp32 kernels for dense stacks / kernel sizes 7, 9) - and every later call goes
+                                 there directly.  Such a handle synchronises per call and refuses hipGraph capture (TAE_ESTATE).
+                                 0 (default): asynchronous; the caller checks tae_range_status */
 } tae_config;
 
 /* Configurations the MFMA kernels do not instantiate run on generic fp32 kernels (one launch per layer, vector-ALU FMA chains:
@@ -239,12 +251,34 @@ TAE_API int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_
  * against this next to the spec-peak fraction.  Allocates, launches on the null stream and SYNCHRONISES. */
 TAE_API int tae_probe_mfma_f16(int32_t zero_data, int32_t min_ms, double* tflops, double* ms_measured);
 
-/* Arithmetic actually in use (*precision = 0: fp32 MFMA, 1: fp16-split MFMA) and its sticky range flag:
- * *overflow = 1 if, since the last call, an activation exceeded the fp16 range (65504) in the fp16-split
- * kernels, which clamp there - results of those launches are not trustworthy; recreate the handle with
- * TAE_PREC_F32.  Synchronises the WHOLE device (hipDeviceSynchronize, then reads one word back) and clears the flag: do not call it
+/* Arithmetic actually in use (*precision = 0: fp32 MFMA, 1: fp16-split MFMA) and the sticky range word of the fp16-split kernels,
+ * *overflow = bit mask of what happened since the last call:
+ *   TAE_RANGE_HIGH  a scaled activation or stack input exceeded the fp16 range (65504): inf / NaN halves went through those launches,
+ *                   their results are NOT trustworthy;
+ *   TAE_RANGE_LOW   some workgroup's largest value of a panel sat below 2^3 after scaling, i.e. >= 2^7 under what the calibration
+ *                   measured: results are finite and close, but no longer fp32-grade (absolute floor 2^-25 / scale per value);
+ *   TAE_RANGE_FELL_BACK  (range_fallback handles) a flagged call was re-run on the fp32 twin, which has served every call since:
+ *                   the results handed out are the fp32 kernels'.
+ * Without range_fallback the way out of HIGH / LOW is tae_calibrate_range on representative data, or a handle with TAE_PREC_F32.
+ * Synchronises the WHOLE device (hipDeviceSynchronize, then reads one word back) and clears the HIGH / LOW bits: do not call it
  * while any stream of the process is capturing a hipGraph (the synchronisation invalidates the capture) - check after the replay. */
+#define TAE_RANGE_HIGH 1
+#define TAE_RANGE_LOW 2
+#define TAE_RANGE_FELL_BACK 4
 TAE_API int tae_range_status(tae_handle* h, int32_t* precision, int32_t* overflow);
+
+/* Measures the activation ranges of the fp16-split conv kernels on the caller's data and re-derives the per-layer exponents
+ * (tae_config.range_calibration describes the scheme): u (B,L,1) and noise as tae_forward takes them (device pointers), or both
+ * NULL for the built-in synthetic batch (Bernoulli bits; the configured channel's own kind of noise at 0 dB).  Runs the forward a
+ * few times on the NULL stream, rewrites the packed bias / scale tails (the weight fragments are untouched), SYNCHRONISES the
+ * device, clears the range word.  Every exponent is a power of two: a different calibration batch moves where the floor and the
+ * ceiling of the fp16 pairs sit, never the rounding of a value inside the window.  No-op for fp32 / GRU-only / generic handles. */
+TAE_API int tae_calibrate_range(tae_handle* h, const float* u, const float* noise, int32_t B);
+
+/* Diagnostics: the exponents in use.  *n_encoder / *n_decoder = number of int32 values per side (0: not calibrated): first one
+ * exponent per stack (its input planes), then one per (stack, layer) panel; `exponents` (capacity >= n_encoder + n_decoder, or NULL)
+ * receives encoder then decoder values; *passes = forward passes the last calibration ran. */
+TAE_API int tae_range_info(tae_handle* h, int32_t* n_encoder, int32_t* n_decoder, int32_t* exponents, int32_t capacity, int32_t* passes);
 
 /* Test hook (no device needed): the host-side fp32 -> fp16 hi/lo split used when packing weights for the fp16-split
  * kernels: hi = f16(x * scale) (round to nearest even, denormals kept), lo = f16(x * scale - hi).  Writes n values each. */

@@ -291,14 +291,15 @@ def test_precision_modes_against_fp64_oracle(gpu_device):
 
 
 def test_fp16_split_reports_out_of_range_activations(gpu_device):
-    """Weights scaled so that activations exceed 65504: the fp16-split kernels clamp and raise the sticky flag
-    (check_range() raises); precision='f32' handles the same model."""
+    """Weights scaled so that activations exceed 65504.  Without the range calibration (r03 arithmetic) the fp16-split kernels
+    produce inf halves and raise the sticky flag (check_range() raises); with it (the default) every panel is stored times its
+    own power of two and the same model runs clean, in agreement with precision='f32'."""
     from turboae_amd import Channel_AE_HIP, _lib
     cfg = TurboAEConfig(num_iteration=1)
     sd = W.generate_state_dict(cfg, seed=5, gain=40.0)
     u, noise = make_inputs(4, cfg.block_len, seed=62)
     ud, nd = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
-    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4)
+    model = Channel_AE_HIP(TurboAEConfig(num_iteration=1, range_calibration=False), sd, device=gpu_device, max_batch=4)
     model(ud, nd)
     with pytest.raises(_lib.TurboAEError):
         model.check_range()
@@ -307,6 +308,10 @@ def test_fp16_split_reports_out_of_range_activations(gpu_device):
     xd, codes = exact(ud, nd)
     exact.check_range()
     assert torch.isfinite(codes).all()
+    cal = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4)
+    xc, cc = cal(ud, nd)
+    cal.check_range()
+    assert float((cc - codes).abs().max()) <= ATOL_CODES and torch.equal(xc > 0.5, xd > 0.5)
 
 
 @pytest.mark.parametrize("prec", ["auto", "f32"])

@@ -1,0 +1,154 @@
+"""Scale-invariance of the default (fp16-split) arithmetic - VERDICT r03 item 1.
+
+The reference convolves in fp32 (cnn_utils.py:36-46: F.conv1d on fp32 tensors): 24 significant bits at ANY magnitude.  An fp16
+hi/lo pair has them only inside a window, so the library stores every panel times a calibrated per-layer power of two
+(include/turboae_hip.h: tae_config.range_calibration, tae_calibrate_range) and watches both ends of the window at run time.
+These tests walk networks whose activations are small, large, or alternate between both, against the oracle in FLOAT64, with the
+same bound as test_precision_modes_against_fp64_oracle and NO tolerance widening; the same networks fail it without the calibration.
+"""
+import numpy as np
+import pytest
+import torch
+
+from turboae_amd import TurboAEConfig, philox, weights as W, _lib
+from oracle import turboae_oracle as O
+from tests._fuzz_cases import range_cases, range_case_weights
+
+pytestmark = pytest.mark.gpu
+
+CASES = range_cases()
+
+
+def _inputs(B, L, seed=61, snr_db=2.0):
+    u = philox.random_bits(seed, 0, B * L).reshape(B, L, 1)
+    noise = (np.float32(O.snr_db2sigma(snr_db)) * philox.random_normal(seed, 0, B * L * 3)).reshape(B, L, 3).astype(np.float32)
+    return u, noise
+
+
+def _oracle64(cfg, sd, u, noise):
+    sd64 = {k: torch.from_numpy(np.asarray(v, dtype=np.float64)) for k, v in sd.items()}
+    x64, c64 = O.channel_ae_forward(torch.from_numpy(u).double(), torch.from_numpy(noise).double(), sd64, cfg.to_dict())
+    return x64, c64
+
+
+def _errors(cfg_kw, sd, u, noise, x64, c64, dev, **extra):
+    from turboae_amd import Channel_AE_HIP
+    err, words = {}, {}
+    ud, nd = torch.from_numpy(u).to(dev), torch.from_numpy(noise).to(dev)
+    for prec in ("auto", "f32"):
+        cfg = TurboAEConfig(precision=prec, **cfg_kw, **extra)
+        if prec == "f32" and (cfg.dense or max(cfg.enc_kernel_size, cfg.dec_kernel_size) > 5):
+            pass                                   # the generic fp32 kernels take these
+        model = Channel_AE_HIP(cfg, sd, device=dev, max_batch=u.shape[0])
+        xd, codes = model(ud, nd)
+        words[prec] = model._eng.range_word()
+        err[prec] = (float((codes.cpu().double() - c64).abs().max()), float((xd.cpu().double() - x64).abs().max()))
+    return err, words
+
+
+@pytest.mark.parametrize("name,cfg_kw,wseed,spec", CASES, ids=[c[0] for c in CASES])
+def test_fp16_split_is_fp32_grade_at_any_activation_scale(gpu_device, name, cfg_kw, wseed, spec):
+    base = TurboAEConfig(**cfg_kw)
+    sd = range_case_weights(base, wseed, spec)
+    B = 4 if base.block_len >= 1000 else 12
+    u, noise = _inputs(B, base.block_len)
+    x64, c64 = _oracle64(base, sd, u, noise)
+    err, words = _errors(cfg_kw, sd, u, noise, x64, c64, gpu_device)
+    print(name, "max |err| vs fp64 oracle (codes, x_dec):", err, words)
+    assert words["auto"] == ("f16x2", 0), words            # inside the window on both sides
+    for k in (0, 1):
+        assert err["auto"][k] <= 2.0 * err["f32"][k] + 5e-7, (name, err)
+
+
+@pytest.mark.parametrize("name", ["balanced_0.01", "balanced_16", "alt_2^-8_2^+8"])
+def test_uncalibrated_arithmetic_fails_these_networks(gpu_device, name):
+    """The r03 arithmetic (all exponents 0 = range_calibration off) on the same networks: either the range word says so or the error
+    bound is missed by a wide margin - i.e. the cases above do test the low and the high side."""
+    _, cfg_kw, wseed, spec = [c for c in CASES if c[0] == name][0]
+    base = TurboAEConfig(**cfg_kw)
+    sd = range_case_weights(base, wseed, spec)
+    u, noise = _inputs(12, base.block_len)
+    x64, c64 = _oracle64(base, sd, u, noise)
+    err, words = _errors(cfg_kw, sd, u, noise, x64, c64, gpu_device, range_calibration=False)
+    print(name, err, words)
+    bad_bound = any(not (err["auto"][k] <= 2.0 * err["f32"][k] + 5e-7) for k in (0, 1))
+    assert bad_bound or (words["auto"][1] & _lib.RANGE_HIGH)
+
+
+def test_exponents_follow_the_network_scale(gpu_device):
+    """Scaling layer l's weights and biases by 2^k moves that layer's measured maximum by 2^k and its exponent by -k (ELU is close to
+    linear at the small end), and nothing is measured twice: two passes."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(num_iteration=1)
+    sd = W.generate_state_dict(cfg, seed=7, gain=1.0)
+    from tests._fuzz_cases import scale_layers
+    a = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=8)
+    b = Channel_AE_HIP(cfg, scale_layers(sd, cfg, None, [2.0 ** -6, 1.0, 1.0, 1.0, 2.0 ** 6]), device=gpu_device, max_batch=8)
+    ea, da, pa = a._eng.range_info()
+    eb, db, pb = b._eng.range_info()
+    n_stack, nl = 2, cfg.dec_num_layer
+    assert len(da) == n_stack + n_stack * nl and ea == eb and pa <= 3 and pb <= 3
+    A, Bx = np.array(da[n_stack:]).reshape(n_stack, nl), np.array(db[n_stack:]).reshape(n_stack, nl)
+    # the first stack sees identical inputs: its panels 0..3 sit 2^-6 lower (within one binade: ELU saturates the negative side)
+    assert np.all(np.abs((Bx[0, :4] - A[0, :4]) - 6) <= 1), (A, Bx)
+    assert np.all(A[:, 4] == 0) and np.all(Bx[:, 4] == 0)            # the last layer feeds the Linear head in fp32
+
+
+def test_range_word_reports_both_ends_and_c_abi_fallback(gpu_device):
+    """Data far outside what the handle was calibrated on: received values 2^12 larger raise TAE_RANGE_HIGH, 2^-12 smaller
+    TAE_RANGE_LOW (tae_decode, the entry point a caller with its own channel uses); calibrating on that data clears both; a
+    range_fallback handle re-runs the flagged call in fp32 inside the library and says so."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(num_iteration=2)
+    sd = W.generate_state_dict(cfg, seed=7, gain=1.0)
+    B = 6
+    u, noise = _inputs(B, cfg.block_len)
+    ud, nd = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    xd, codes = model(ud, nd)
+    assert model._eng.range_word() == ("f16x2", 0)
+    rx = codes + nd
+    for factor, bit in ((2.0 ** 14, _lib.RANGE_HIGH), (2.0 ** -14, _lib.RANGE_LOW)):
+        model.dec(rx * factor)
+        mode, bits = model._eng.range_word()
+        assert mode == "f16x2" and bits & bit, (factor, bits)
+        with pytest.raises(_lib.TurboAEError):
+            model.dec(rx * factor)
+            model.check_range()
+    # calibrating on the caller's own data moves the window there
+    sd_o = O.to_torch(sd)
+    small = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    small.calibrate_range(ud, nd * 2.0 ** -14)              # codes + tiny noise is still O(1): stays clean
+    small(ud, nd * 2.0 ** -14)
+    assert small._eng.range_word() == ("f16x2", 0)
+    # C-ABI fall-back: same flagged decode, re-run on the fp32 twin
+    fb = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B, range_fallback=True)
+    x1 = fb.dec(rx * 2.0 ** 14)
+    assert fb.fell_back
+    mode, bits = fb._eng.range_word()
+    assert bits & _lib.RANGE_FELL_BACK
+    exact = Channel_AE_HIP(TurboAEConfig(num_iteration=2, precision="f32"), sd, device=gpu_device, max_batch=B)
+    x2 = exact.dec(rx * 2.0 ** 14)
+    assert torch.equal(x1, x2)                                 # the fp32 kernels' own result
+    x3 = fb.dec(rx)                                            # ... which serve every later call
+    assert torch.equal(x3, exact.dec(rx))
+
+
+def test_calibration_does_not_change_in_window_results(gpu_device):
+    """Every exponent is a power of two: on an O(1) network the calibrated and the uncalibrated arithmetic agree to the last few
+    ulps of fp32 (they differ only where a lo half meets the absolute floor), and two handles calibrate identically."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig()
+    sd = W.generate_state_dict(cfg, seed=7, gain=1.0)
+    u, noise = _inputs(9, cfg.block_len)
+    ud, nd = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
+    a = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=9)
+    b = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=500)
+    raw = Channel_AE_HIP(TurboAEConfig(range_calibration=False), sd, device=gpu_device, max_batch=9)
+    xa, ca = a(ud, nd)
+    xb, cb = b(ud, nd)
+    xr, cr = raw(ud, nd)
+    assert a._eng.range_info() == b._eng.range_info()
+    assert torch.equal(xa, xb) and torch.equal(ca, cb)
+    assert float((ca - cr).abs().max()) <= 2e-6 and float((xa - xr).abs().max()) <= 2e-6
+    assert raw._eng.range_info()[:2] == ([], [])

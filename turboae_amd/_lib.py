@@ -12,14 +12,15 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TAE_LIB", os.path.join(_HERE, "lib", "libturboae_hip.so"))   # TAE_LIB: kernel-variant experiments
 
-TAE_ABI_VERSION = 9
+TAE_ABI_VERSION = 10
 
 
 class TaeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "struct_size", "block_len", "enc_num_layer", "enc_num_unit", "enc_kernel_size",
         "dec_num_layer", "dec_num_unit", "dec_kernel_size", "num_iteration", "num_iter_ft",
-        "extrinsic", "enc_act", "max_batch", "dec_type", "enc_type", "dense", "precision", "dec_act", "enc_rnn", "dec_rnn")]
+        "extrinsic", "enc_act", "max_batch", "dec_type", "enc_type", "dense", "precision", "dec_act", "enc_rnn", "dec_rnn",
+        "range_calibration", "range_fallback")]
 
 
 class TaeChannelOpts(C.Structure):
@@ -33,6 +34,8 @@ class TaeNoiseOpts(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("kind", C.c_int32), ("vv", C.c_float), ("radar_prob", C.c_float),
                 ("radar_power", C.c_float), ("p_gg", C.c_float), ("p_bb", C.c_float)]
 
+
+RANGE_HIGH, RANGE_LOW, RANGE_FELL_BACK = 1, 2, 4        # TAE_RANGE_* bits of tae_range_status
 
 NOISE_KIND = {"awgn": 0, "t-dist": 1, "radar": 2, "ge_awgn": 3, "bec": 4, "bsc": 5, "ge": 6, "fading": 7}      # TAE_NOISE_*
 
@@ -62,6 +65,8 @@ SIGNATURES = {
     "tae_eval_snr": (C.c_int, [_P, C.c_float, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64, _P, _P]),
     "tae_kernel_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tae_range_status": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "tae_calibrate_range": (C.c_int, [_P, _P, _P, C.c_int32]),
+    "tae_range_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, C.c_int32, C.POINTER(C.c_int32)]),
     "tae_debug_split_f16": (C.c_int, [_P, C.c_size_t, C.c_float, _P, _P]),
 }
 

@@ -63,7 +63,7 @@ class _Engine:
                            cfg.num_iteration, cfg.num_iter_ft, cfg.extrinsic, _ACT[cfg.enc_act], max_batch,
                            1 if cfg.decoder == "TurboAE_rate3_rnn" else 0, 1 if cfg.encoder == "TurboAE_rate3_rnn" else 0,
                            1 if cfg.dense else 0, 1 if cfg.precision == "f32" else 0, _ACT[cfg.dec_act],
-                           _RNN[cfg.enc_rnn], _RNN[cfg.dec_rnn])
+                           _RNN[cfg.enc_rnn], _RNN[cfg.dec_rnn], 0 if cfg.range_calibration else 1, 1 if cfg.range_fallback else 0)
         n = self.lib.tae_num_weights(C.byref(c))
         if n != blob.size:
             raise _lib.TurboAEError(f"weight count mismatch: library wants {n}, blob has {blob.size}")
@@ -72,6 +72,7 @@ class _Engine:
             _lib.check(self.lib.tae_create(C.byref(c), blob.ctypes.data_as(C.c_void_p), blob.size, C.byref(h)))
         self.h = h
         self.cap = max_batch
+        self.fell_back = False
         self.p_array: Optional[np.ndarray] = None
         self.set_interleaver(rand_interleaver(cfg.block_len, cfg.interleaver_seed))
         self.reset_precomp()
@@ -149,19 +150,52 @@ class _Engine:
         _lib.check(self.lib.tae_kernel_info(self.h, C.byref(nb), C.byref(lds)))
         return nb.value, lds.value
 
-    def range_status(self) -> Tuple[str, bool]:
-        """('f16x2' | 'f32', overflow): the arithmetic in use and whether an activation left the fp16 range since
-        the last call (the f16x2 kernels clamp at 65504 and report).  Synchronises the device."""
+    def range_word(self) -> Tuple[str, int]:
+        """('f16x2' | 'f32', bits): the arithmetic in use and the TAE_RANGE_* bits raised since the last call (_lib.RANGE_HIGH:
+        a scaled activation left the fp16 range - results invalid; RANGE_LOW: data far below the calibrated window - results no
+        longer fp32-grade; RANGE_FELL_BACK: a flagged call was re-run in fp32 and fp32 serves every call since).  Synchronises the device."""
         prec, ovf = C.c_int32(), C.c_int32()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.tae_range_status(self.h, C.byref(prec), C.byref(ovf)))
-        return ("f16x2" if prec.value == 1 else "f32"), bool(ovf.value)
+        return ("f16x2" if prec.value == 1 else "f32"), int(ovf.value)
+
+    def range_status(self) -> Tuple[str, bool]:
+        """('f16x2' | 'f32', out_of_window): True when a launch since the last call left the window of the fp16-split
+        representation on either side and was NOT re-run in fp32."""
+        mode, bits = self.range_word()
+        self.fell_back = self.fell_back or bool(bits & _lib.RANGE_FELL_BACK)
+        return mode, bool(bits & (_lib.RANGE_HIGH | _lib.RANGE_LOW)) and not (bits & _lib.RANGE_FELL_BACK)
 
     def check_range(self) -> None:
-        prec, ovf = self.range_status()
-        if ovf:
-            raise _lib.TurboAEError("an activation exceeded the fp16 range in the fp16-split kernels (clamped at 65504); "
-                                    "results are not trustworthy - use TurboAEConfig(precision='f32')")
+        mode, bits = self.range_word()
+        self.fell_back = self.fell_back or bool(bits & _lib.RANGE_FELL_BACK)
+        if bits & _lib.RANGE_FELL_BACK:
+            return
+        if bits & _lib.RANGE_HIGH:
+            raise _lib.TurboAEError("an activation exceeded the fp16 range in the fp16-split kernels; results are not trustworthy - "
+                                    "calibrate on representative data (calibrate_range), use range_fallback=True or TurboAEConfig(precision='f32')")
+        if bits & _lib.RANGE_LOW:
+            raise _lib.TurboAEError("activations fell far below the calibrated window of the fp16-split kernels; results are finite but not "
+                                    "fp32-grade - calibrate on representative data (calibrate_range), use range_fallback=True or precision='f32'")
+
+    def calibrate_range(self, u: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None) -> None:
+        """tae_calibrate_range: re-measure the per-layer exponents on the caller's batch (or the synthetic one)."""
+        with torch.cuda.device(self.device):
+            if u is None:
+                _lib.check(self.lib.tae_calibrate_range(self.h, None, None, 0))
+            else:
+                uu, nn = self._in(u, 1, "u"), noise.to(self.device).contiguous().float()
+                torch.cuda.synchronize(self.device)
+                _lib.check(self.lib.tae_calibrate_range(self.h, _ptr(uu), _ptr(nn), int(uu.shape[0])))
+
+    def range_info(self):
+        """(encoder exponents, decoder exponents, passes): per side one exponent per stack input, then one per (stack, layer)."""
+        ne, nd, ps = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self.lib.tae_range_info(self.h, C.byref(ne), C.byref(nd), None, 0, C.byref(ps)))
+        buf = (C.c_int32 * max(1, ne.value + nd.value))()
+        _lib.check(self.lib.tae_range_info(self.h, C.byref(ne), C.byref(nd), buf, ne.value + nd.value, C.byref(ps)))
+        v = list(buf)
+        return v[:ne.value], v[ne.value:ne.value + nd.value], ps.value
 
     # ---- tensor helpers
     def _in(self, t: torch.Tensor, last: int, name: str) -> torch.Tensor:
@@ -273,11 +307,15 @@ class Channel_AE_HIP:
             is_variable_block_len = bool(getattr(args_or_cfg, "is_variable_block_len", False))
         self.is_variable_block_len = is_variable_block_len
         self._by_len: Dict[int, _Engine] = {}
-        # range_fallback: after every forward the fp16-split kernels' range flag is read (one device synchronisation per call); if an
-        # activation left the fp16 range the engine is rebuilt with precision='f32' and the call runs again - `fell_back` says so.
-        # Off by default: the entry points stay asynchronous and capturable, the caller checks with check_range().
-        self.range_fallback = bool(range_fallback)
-        self.fell_back = False
+        # range_fallback (= tae_config.range_fallback): the library waits for every call, reads the fp16-split kernels' range word and,
+        # if a launch left the window, runs that call again on an fp32 twin of the engine - which serves every later call; `fell_back`
+        # says so.  The retry happens inside the library call, so the mirror's own side effects (running statistics of
+        # --precompute_norm_stats, the per-call interleaver draw) happen once.  Off by default: the entry points stay asynchronous and
+        # capturable, the caller checks with check_range().
+        if range_fallback and not cfg.range_fallback:
+            from dataclasses import replace
+            cfg = replace(cfg, range_fallback=True)
+        self.range_fallback = bool(cfg.range_fallback)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         self.cfg = cfg
@@ -363,18 +401,21 @@ class Channel_AE_HIP:
             raise ValueError("fading and fwd_noise shapes differ")
         return torch.cat([fh.reshape(-1), noise.reshape(-1)])
 
+    @property
+    def fell_back(self) -> bool:
+        """True once a call of a range_fallback model was re-run on the fp32 kernels (they serve every call since)."""
+        engines = [self._eng] + list(self._by_len.values())
+        if self.range_fallback and not any(e.fell_back for e in engines):
+            for e in engines:
+                e.range_status()
+        return any(e.fell_back for e in engines)
+
+    def calibrate_range(self, input: Optional[torch.Tensor] = None, fwd_noise: Optional[torch.Tensor] = None) -> None:
+        """Re-measure the fp16-split kernels' per-layer exponents on this batch (default: the library's synthetic batch)."""
+        self._eng.calibrate_range(input, fwd_noise)
+
     def forward(self, input: torch.Tensor, fwd_noise: torch.Tensor, fading: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-        out = self._forward_once(input, fwd_noise, fading)
-        if self.range_fallback and not self.fell_back and self.cfg.precision != "f32":
-            e = self._engine_for(input.shape[1]) if input.dim() == 3 else self._eng
-            mode, overflow = e.range_status()
-            if overflow:
-                from dataclasses import replace
-                self.cfg = replace(self.cfg, precision="f32")
-                self.fell_back = True
-                self.load_state_dict(self._eng._state)          # rebuilds the engine(s) with the fp32 kernels, keeps interleaver / statistics
-                out = self._forward_once(input, fwd_noise, fading)
-        return out
+        return self._forward_once(input, fwd_noise, fading)
 
     def _forward_once(self, input: torch.Tensor, fwd_noise: torch.Tensor, fading: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         e = self._engine_for(input.shape[1]) if input.dim() == 3 else self._eng

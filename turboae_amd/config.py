@@ -36,6 +36,9 @@ class TurboAEConfig:
     interleaver_seed: int = 0     # channel_ae.py:33 (RandInterlv(block_len, 0))
     precision: str = "auto"       # no reference counterpart: 'auto' = fp16-split MFMA contraction (fp32-grade)
                                   # where the whole-block kernels apply; 'f32' = fp32 MFMA everywhere
+    range_calibration: bool = True   # no reference counterpart (the reference's fp32 conv, cnn_utils.py:36-46, has no range): per-layer
+                                     # power-of-two exponents for the fp16-split panels, measured at engine creation (tae_config.range_calibration)
+    range_fallback: bool = False     # tae_config.range_fallback: re-run a call that left the fp16 window on the fp32 kernels (synchronises per call)
     # ---- encoder-output / channel variants on the same kernels
     channel: str = "awgn"                 # get_args.py:43; channel_ae.py:41-56 ('fading': the caller supplies fading_h, which the
                                           # reference draws inside forward)

@@ -195,8 +195,29 @@ void pack_conv_h(const float* W, int U, int cin, int cin_pad, int nslab, int CT,
                 }
 }
 
-// canonical stack -> f16x2 packed stack (bytes at dst); returns floats consumed from src
-size_t pack_stack_h(const float* src, const LayoutH& lo, int n_layer, int cin0, int nout, char* dst) {
+// The tail of one packed layer as the host keeps it for the range calibration (calibrate_range below): the layer's accumulators carry
+// 2^(S + A_in) (S: the weights' own power-of-two scale, A_in: exponent of the panel / stack inputs it reads), its ELU output is
+// stored * 2^A_out.  Device tail = bias * 2^(S + A_in) [CP] | 2^-(S + A_in) | 2^A_out | low-side threshold | 0.
+struct TailRef {
+    uint32_t off = 0;              // byte offset of the tail inside the side's packed buffer
+    int S = 0;
+    std::vector<float> bias_s;     // bias * 2^S, padded to CP
+};
+
+void tail_values(const TailRef& t, int A_in, int A_out, float low, std::vector<float>& out) {
+    const size_t CP = t.bias_s.size();
+    out.resize(CP + 4);
+    for (size_t c = 0; c < CP; ++c) out[c] = ldexpf(t.bias_s[c], A_in);
+    out[CP] = ldexpf(1.0f, -(t.S + A_in));
+    out[CP + 1] = ldexpf(1.0f, A_out);
+    out[CP + 2] = low;
+    out[CP + 3] = 0.0f;
+}
+
+// canonical stack -> f16x2 packed stack (bytes at dst); returns floats consumed from src.  `tails` (optional) receives one
+// TailRef per layer, offsets relative to `base_off` = byte offset of dst inside the side's buffer.
+size_t pack_stack_h(const float* src, const LayoutH& lo, int n_layer, int cin0, int nout, char* dst, std::vector<TailRef>* tails = nullptr,
+                    uint32_t base_off = 0) {
     const float* s = src;
     char* d = dst;
     for (int l = 0; l < n_layer; ++l) {
@@ -230,7 +251,14 @@ size_t pack_stack_h(const float* src, const LayoutH& lo, int n_layer, int cin0, 
         const float* b = s + nw;
         float* t = reinterpret_cast<float*>(d);
         for (int c = 0; c < lo.CP; ++c) t[c] = c < lo.U ? b[c] * scale : 0.0f;
-        for (int c = 0; c < 4; ++c) t[lo.CP + c] = inv;
+        t[lo.CP] = inv; t[lo.CP + 1] = 1.0f; t[lo.CP + 2] = 0.0f; t[lo.CP + 3] = 0.0f;      // exponents 0 until calibrate_range
+        if (tails) {
+            TailRef r;
+            r.off = base_off + (uint32_t)(d - dst);
+            r.S = S;
+            r.bias_s.assign(t, t + lo.CP);
+            tails->push_back(std::move(r));
+        }
         d += lo.tailb;
         s = b + lo.U;
     }
@@ -302,6 +330,20 @@ struct tae_handle {
     tae::NormOpts nopts;       // encoder-output / channel variant (tae_set_channel_opts)
     tae_noise_opts noise_opts; // generator tae_eval_snr draws from (tae_set_noise_opts; default AWGN)
     tae::GenericEngine* gen = nullptr;   // generic fp32 kernels (configurations outside the MFMA kernels' envelope)
+    // ---- range calibration of the fp16-split conv kernels (calibrate_range): per-layer activation exponents
+    std::vector<TailRef> enc_tails, dec_tails;      // [stack * n_layer + l]; empty: the side has no fp16-split conv stacks
+    std::vector<int> enc_A, dec_A;                  // exponent of every layer's OUTPUT panel ([stack * n_layer + l]; unused for the last layer)
+    std::vector<int> enc_Ax, dec_Ax;                // exponent of every stack's input planes (whole-block decoder: all equal)
+    std::vector<float> enc_low, dec_low;            // low-side threshold per layer (0: not checked)
+    float dec_r_low = 0.0f;                         // 2^-7 of the largest received value of the calibration batch (0: not checked); x_low = this * 2^A_x
+    int enc_min_values = 0, dec_min_values = 0;     // values of one panel a workgroup holds at least (positions x real channels)
+    uint32_t* d_cal = nullptr;                      // calibration launches: per-layer / per-stack maxima (float bits), encoder then decoder
+    bool calibrating = false;
+    bool calibrated = false;
+    int cal_passes = 0;
+    // ---- tae_config.range_fallback: fp32 twin of this handle and what the last flagged call did
+    tae_handle* fb = nullptr;
+    uint32_t last_flags = 0;                         // range bits accumulated since the last tae_range_status (bit 2: a call was re-run in fp32)
 };
 
 namespace {
@@ -312,6 +354,7 @@ inline int kernel_width(int u) { return u <= 32 ? 32 : (u <= 64 ? 64 : (u <= 100
 int check_cfg(const tae_config* c) {
     if (!c) return fail(TAE_EINVAL, "config is NULL");
     if (c->struct_size != (int32_t)sizeof(tae_config)) return fail(TAE_EINVAL, "tae_config.struct_size mismatch (ABI)");
+    if ((c->range_calibration | c->range_fallback) & ~1) return fail(TAE_EINVAL, "range_calibration / range_fallback must be 0 or 1");
     if (c->enc_rnn < 0 || c->enc_rnn > 2 || c->dec_rnn < 0 || c->dec_rnn > 2) return fail(TAE_EINVAL, "enc_rnn / dec_rnn must be TAE_RNN_GRU, TAE_RNN_LSTM or TAE_RNN_RNN");
     if (tae::generic_needed(c)) {          // outside the MFMA kernels' envelope: the generic fp32 kernels' (wider) limits apply
         if (const char* msg = tae::generic_check(c)) return fail(TAE_EINVAL, msg);
@@ -384,13 +427,17 @@ size_t dense_stack_bytes(const LayoutH& lo, int n_layer) {
 }
 
 // canonical dense stack -> per layer: input-part fragments | l x panel-part fragments | bias * 2^S | 2^-S; then the Linear head
-size_t pack_stack_h_dense(const float* src, const LayoutH& lo, int n_layer, int cin0, int nout, char* dst) {
+size_t pack_stack_h_dense(const float* src, const LayoutH& lo, int n_layer, int cin0, int nout, char* dst, std::vector<TailRef>* tails = nullptr,
+                          uint32_t base_off = 0) {
     const float* s = src;
     char* d = dst;
     for (int l = 0; l < n_layer; ++l) {
         const int cin = cin0 + l * lo.U;
         const size_t nw = (size_t)lo.U * cin * 5;
         const float scale = pow2_scale(max_abs(s, nw)), inv = 1.0f / scale;
+        int S = 0;
+        (void)frexpf(scale, &S);
+        S -= 1;                                    // scale = 2^S
         pack_conv_part_h(s, lo.U, cin, 0, cin0, 8, 2, lo.CT, scale, reinterpret_cast<uint16_t*>(d));
         d += lo.l0b;
         for (int k = 0; k < l; ++k) {
@@ -400,7 +447,14 @@ size_t pack_stack_h_dense(const float* src, const LayoutH& lo, int n_layer, int 
         const float* b = s + nw;
         float* t = reinterpret_cast<float*>(d);
         for (int c = 0; c < lo.CP; ++c) t[c] = c < lo.U ? b[c] * scale : 0.0f;
-        for (int c = 0; c < 4; ++c) t[lo.CP + c] = inv;
+        t[lo.CP] = inv; t[lo.CP + 1] = 1.0f; t[lo.CP + 2] = 0.0f; t[lo.CP + 3] = 0.0f;
+        if (tails) {
+            TailRef r;
+            r.off = base_off + (uint32_t)(d - dst);
+            r.S = S;
+            r.bias_s.assign(t, t + lo.CP);
+            tails->push_back(std::move(r));
+        }
         d += lo.tailb;
         s = b + lo.U;
     }
@@ -978,6 +1032,16 @@ tae::NormOpts default_norm_opts() {
     return o;
 }
 
+// Calibration array (tae_handle::d_cal, uint32 float bits): encoder part [0] unused | [1 + s * nl + l] layer maxima | then one slot per
+// stack (unused: encoder inputs are +-1); decoder part at cal_dec_offset: [0] max |stack input| of the whole-block kernel |
+// [1 + s * nl + l] | [1 + n_stack * nl + s] max |extrinsic value| stack s staged on the long-block path | [cal_dec_r] max |received value|.
+constexpr float kRangeLow = 8.0f;        // low end of the window in scaled units (packed into the tails / launch parameters)
+constexpr int kRangeTarget = 11;         // calibrated maxima land in [2^10, 2^11)
+constexpr int kRangeMinValues = 2048;    // panels with fewer values per workgroup are not low-checked
+size_t cal_dec_offset(const tae_handle* h) { return 1 + 3 * (size_t)h->cfg.enc_num_layer + 3; }
+size_t cal_dec_r(const tae_handle* h) { return 1 + 2 * (size_t)h->cfg.num_iteration * ((size_t)h->cfg.dec_num_layer + 1); }     // relative to the decoder part
+size_t cal_words(const tae_handle* h) { return cal_dec_offset(h) + cal_dec_r(h) + 1; }
+
 tae::FusedParams base_params(const tae_handle* h, int32_t B, bool decoder) {
     tae::FusedParams P;
     memset(&P, 0, sizeof(P));
@@ -993,6 +1057,13 @@ tae::FusedParams base_params(const tae_handle* h, int32_t B, bool decoder) {
     P.act = h->cfg.enc_act;
     P.lds_bytes = decoder ? h->lds_bytes_d : h->lds_bytes;
     P.super = decoder ? h->super_d : h->super;
+    // stack-input planes of the fp16-split kernels: the encoder's are +-1 (exponent 0), the whole-block decoder has one exponent
+    const int ax = decoder && !h->dec_Ax.empty() ? h->dec_Ax[0] : 0;
+    P.x_scale = ldexpf(1.0f, ax);
+    P.x_inv = ldexpf(1.0f, -ax);
+    P.x_low = decoder && h->calibrated && !h->calibrating ? ldexpf(h->dec_r_low, ax) : 0.0f;
+    P.cal = h->calibrating ? h->d_cal + (decoder ? cal_dec_offset(h) : 0) : nullptr;
+    P.cal_r = (int32_t)cal_dec_r(h);
     return P;
 }
 
@@ -1009,6 +1080,10 @@ tae::SegParams seg_params(const tae_handle* h, int32_t B, bool decoder) {
     P.super = decoder ? h->super_d : h->super;
     P.taps = decoder ? h->cfg.dec_kernel_size : h->cfg.enc_kernel_size;
     P.dense = h->cfg.dense;
+    for (int s = 0; s < 3; ++s) P.x_scale[s] = (!decoder && (size_t)s < h->enc_Ax.size()) ? ldexpf(1.0f, h->enc_Ax[s]) : 1.0f;
+    P.x_low = 0.0f;                      // decoder: per launch (run_decoder_long), the exponent is the stack's
+    P.cal = h->calibrating ? h->d_cal + (decoder ? cal_dec_offset(h) : 0) : nullptr;
+    P.cal_r = (int32_t)cal_dec_r(h);
     return P;
 }
 
@@ -1065,6 +1140,9 @@ int run_decoder_long(tae_handle* h, const float* rx, float* xdec, int32_t B, hip
     for (int s = 0; s < n_stack; ++s) {
         P.stack = s;
         P.last = (s == n_stack - 1);
+        P.x_scale[0] = (size_t)s < h->dec_Ax.size() ? ldexpf(1.0f, h->dec_Ax[s]) : 1.0f;
+        P.x_low = (size_t)s < h->dec_Ax.size() && h->calibrated && !h->calibrating ? ldexpf(h->dec_r_low, h->dec_Ax[s]) : 0.0f;
+        P.cal_x = 1 + n_stack * h->cfg.dec_num_layer + s;
         P.eprev = (s & 1) ? h->d_e0 : h->d_e1;
         P.ecur = (s & 1) ? h->d_e1 : h->d_e0;
         if (h->prec == 1) TAE_HIP(tae::launch_seg_h(h->Ud, P, grid, st));
@@ -1284,6 +1362,204 @@ int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStrea
     return TAE_OK;
 }
 
+// ---- range calibration of the fp16-split conv kernels ---------------------------------------------------------------------
+// The reference convolves in fp32 (cnn_utils.py:36-46: F.conv1d on fp32 tensors), 24 significant bits at any magnitude; an fp16
+// hi/lo pair has them only inside a window (turboae_h2.hip, "range bookkeeping").  calibrate_range puts every panel into that
+// window: it runs the handle's own forward on a calibration batch with the kernels collecting each layer's max |activation|
+// (FusedParams::cal), picks per layer the power of two that brings the maximum to [2^10, 2^11), rewrites the packed tails (bias,
+// scales, thresholds - the weight fragments are untouched) and repeats until no exponent moves (a layer whose input was out of
+// the window in one pass is measured correctly in the next; 2 passes for anything sane, at most kCalMaxPass).  Everything is a
+// power of two, so the calibration batch only decides where the floor and the ceiling sit, never a rounding of an in-window value.
+constexpr int kCalMaxPass = 5;
+
+// tae_config.range_calibration (0 = on), overridden by env TAE_RANGE_CAL=0|1 (testing knob: 0 reproduces the uncalibrated r03 arithmetic)
+bool range_calibration_on(const tae_config* c) {
+    if (const char* e = getenv("TAE_RANGE_CAL")) {
+        if (e[0] == '0') return false;
+        if (e[0] == '1') return true;
+    }
+    return c->range_calibration == 0;
+}
+
+int upload_tails(tae_handle* h, bool decoder) {
+    const std::vector<TailRef>& tails = decoder ? h->dec_tails : h->enc_tails;
+    if (tails.empty()) return TAE_OK;
+    const std::vector<int>& A = decoder ? h->dec_A : h->enc_A;
+    const std::vector<int>& Ax = decoder ? h->dec_Ax : h->enc_Ax;
+    const std::vector<float>& low = decoder ? h->dec_low : h->enc_low;
+    const int nl = decoder ? h->cfg.dec_num_layer : h->cfg.enc_num_layer;
+    char* base = decoder ? h->d_wdec_h : h->d_wenc_h;
+    std::vector<float> t;
+    for (size_t i = 0; i < tails.size(); ++i) {
+        const int s = (int)i / nl, l = (int)i % nl;
+        const int a_in = l == 0 ? Ax[s] : A[i - 1];
+        const int a_out = l + 1 < nl ? A[i] : 0;               // the last layer feeds the Linear head in fp32: no panel, no scale
+        tail_values(tails[i], a_in, a_out, l + 1 < nl ? low[i] : 0.0f, t);
+        TAE_HIP(hipMemcpy(base + tails[i].off, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return TAE_OK;
+}
+
+// exponent that brings a measured maximum into the target window; `overflowed`: the pass that measured it saturated
+inline int range_exponent(float m, int a_old, bool* again) {
+    if (!std::isfinite(m)) { *again = true; return a_old - 8 < -80 ? -80 : a_old - 8; }     // overflowed under the old exponent: back off, measure again
+    if (!(m > 0.0f)) return 0;                                     // an all-zero panel is exact under any exponent
+    int e = 0;
+    (void)frexpf(m, &e);                                           // m in [2^(e-1), 2^e)
+    int a = kRangeTarget - e;
+    return a > 80 ? 80 : (a < -80 ? -80 : a);
+}
+
+// u (B,L,1), noise as tae_forward takes it (device pointers), or nullptr: a synthetic batch - Bernoulli bits and the configured
+// channel's own kind of noise at 0 dB (masks with p = 0.1 for bec / bsc).  Synchronises the device.
+int calibrate_range(tae_handle* h, const float* u_user, const float* noise_user, int32_t B_user) {
+    if (h->gen || h->prec != 1 || (h->enc_tails.empty() && h->dec_tails.empty())) return TAE_OK;
+    const int L = h->cfg.block_len, nle = h->cfg.enc_num_layer, nld = h->cfg.dec_num_layer, n_stack = 2 * h->cfg.num_iteration;
+    const bool do_dec = !h->dec_tails.empty(), do_enc = !h->enc_tails.empty();
+    int32_t B = B_user;
+    if (!u_user) {
+        B = 76800 / L;
+        if (B > 768) B = 768;
+        if (B < 8) B = 8;
+        if (h->cfg.dec_type == 1 && B > 64) B = 64;            // GRU decoder: only the CNN encoder is calibrated; keep its chunk workspace small
+    }
+    TAE_HIP(hipDeviceSynchronize());
+    if (B > h->cap) { const int rc = tae_reserve(h, B); if (rc != TAE_OK) return rc; }
+    if (!h->d_cal) TAE_HIP(hipMalloc(&h->d_cal, cal_words(h) * sizeof(uint32_t)));
+    float *d_u = nullptr, *d_noise = nullptr, *d_x = nullptr;
+    const size_t nbits = (size_t)B * L;
+    const int nmult = h->nopts.channel == 3 ? 2 : 1;
+    auto cleanup = [&]() { (void)hipFree(d_u); (void)hipFree(d_noise); (void)hipFree(d_x); h->calibrating = false; };
+#define TAE_CAL(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { cleanup(); return fail(TAE_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
+    TAE_CAL(hipMalloc(&d_x, nbits * sizeof(float)));
+    const float* u = u_user;
+    const float* noise = noise_user;
+    if (!u_user) {
+        TAE_CAL(hipMalloc(&d_u, nbits * sizeof(float)));
+        TAE_CAL(hipMalloc(&d_noise, (size_t)nmult * nbits * 3 * sizeof(float)));
+        TAE_CAL(tae::launch_gen_inputs(d_u, nullptr, nbits, 0, 0xCA11B8A7E0ull, 0, 1.0f, nullptr));
+        tae_noise_opts no = default_noise_opts();
+        float ts = 0.0f;
+        if (h->nopts.channel == 1) { no.kind = TAE_NOISE_BEC; ts = 0.1f; }
+        else if (h->nopts.channel == 2) { no.kind = TAE_NOISE_BSC; ts = 0.1f; }
+        else if (h->nopts.channel == 3) no.kind = TAE_NOISE_FADING;
+        tae::NoiseGen g;
+        if (make_noise_gen(&no, ts, &g) != TAE_OK) { cleanup(); return TAE_EINVAL; }
+        TAE_CAL(tae::launch_gen_noise(g, d_noise + (size_t)(nmult - 1) * nbits * 3, nmult == 2 ? d_noise : nullptr, (size_t)B, 0, L, 0xCA11B8A7E1ull, nullptr));
+        u = d_u;
+        noise = d_noise;
+    }
+    // start from the current exponents (first call: all 0) with the low-side checks off
+    if (h->enc_A.empty()) { h->enc_A.assign(h->enc_tails.size(), 0); h->enc_Ax.assign(3, 0); }
+    if (h->dec_A.empty()) { h->dec_A.assign(h->dec_tails.size(), 0); h->dec_Ax.assign(do_dec ? n_stack : 0, 0); }
+    h->enc_low.assign(h->enc_tails.size(), 0.0f);
+    h->dec_low.assign(h->dec_tails.size(), 0.0f);
+    std::vector<uint32_t> cal(cal_words(h));
+    const size_t doff = cal_dec_offset(h);
+    auto word = [&](size_t i) { float f; memcpy(&f, &cal[i], 4); return f; };
+    h->calibrating = true;
+    h->cal_passes = 0;
+    int rc = TAE_OK;
+    for (int pass = 0; pass < kCalMaxPass; ++pass) {
+        if ((rc = upload_tails(h, false)) != TAE_OK || (rc = upload_tails(h, true)) != TAE_OK) break;
+        TAE_CAL(hipMemset(h->d_cal, 0, cal.size() * sizeof(uint32_t)));
+        if (do_enc || do_dec) {
+            if ((rc = run_encoder(h, u, h->d_xtx, h->d_stats, B, nullptr)) != TAE_OK) break;
+            if (do_dec) {
+                if ((rc = tae_normalize(h, h->d_xtx, h->d_stats, noise, nullptr, h->d_rx, B, nullptr)) != TAE_OK) break;
+                if ((rc = run_decoder(h, h->d_rx, d_x, B, nullptr)) != TAE_OK) break;
+            }
+        }
+        TAE_CAL(hipDeviceSynchronize());
+        TAE_CAL(hipMemcpy(cal.data(), h->d_cal, cal.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        ++h->cal_passes;
+        bool again = false, moved = false;
+        auto side = [&](bool decoder) {
+            std::vector<int>& A = decoder ? h->dec_A : h->enc_A;
+            std::vector<int>& Ax = decoder ? h->dec_Ax : h->enc_Ax;
+            const int nl = decoder ? nld : nle, ns = decoder ? n_stack : 3;
+            const size_t o = decoder ? doff : 0;
+            if (A.empty()) return;
+            for (int s = 0; s < ns; ++s) {
+                // stack inputs: the encoder's are +-1; decoder: one exponent from the global maximum (dense stacks: one per stack)
+                float mx = 1.0f;
+                const float rmax = decoder ? word(o + cal_dec_r(h)) : 0.0f;
+                auto both = [](float a, float b) { return !(a <= b) ? a : b; };      // max where inf wins
+                if (decoder && h->nbd >= 1) mx = both(word(o), rmax);
+                else if (decoder && h->cfg.dense) mx = both(word(o + 1 + (size_t)ns * nl + s), rmax);
+                else if (decoder) {
+                    // plain long-block decoder: the same ONE exponent the whole-block kernel would use (the union of what the stacks
+                    // stage is what that kernel's planes see), so both paths stay bit-identical on blocks either can run
+                    mx = rmax;
+                    for (int k = 0; k < ns; ++k) mx = both(word(o + 1 + (size_t)ns * nl + k), mx);
+                }
+                int ax = decoder ? range_exponent(mx, Ax[s], &again) : 0;
+                if (h->cfg.dense) {
+                    // dense stacks contract the inputs and every earlier panel into one accumulator: one exponent per stack
+                    float m = mx;
+                    bool inf = !std::isfinite(mx);
+                    for (int l = 0; l + 1 < nl; ++l) { const float v = word(o + 1 + (size_t)s * nl + l); if (!std::isfinite(v)) inf = true; else if (v > m) m = v; }
+                    ax = range_exponent(inf ? INFINITY : m, Ax[s], &again);
+                    for (int l = 0; l < nl; ++l) { if (A[(size_t)s * nl + l] != ax) moved = true; A[(size_t)s * nl + l] = ax; }
+                } else {
+                    for (int l = 0; l + 1 < nl; ++l) {
+                        const size_t i = (size_t)s * nl + l;
+                        const int a = range_exponent(word(o + 1 + i), A[i], &again);
+                        if (a != A[i]) moved = true;
+                        A[i] = a;
+                    }
+                }
+                if (ax != Ax[s]) moved = true;
+                Ax[s] = ax;
+            }
+        };
+        side(false);
+        side(true);
+        if (!moved && !again) break;
+    }
+    if (rc == TAE_OK) {
+        // low-side checks on for every panel that holds something (an all-zero panel - embedded channels, dead layers - stays unchecked)
+        // ... and that is large enough for its maximum to say something about the data's scale: the check is per workgroup, and the
+        // largest of a few dozen values (block_len 1, width 3) can sit 2^7 under the calibration batch's by chance
+        const bool ce = h->enc_min_values >= kRangeMinValues, cd = h->dec_min_values >= kRangeMinValues;
+        for (size_t i = 0; i < h->enc_tails.size(); ++i) h->enc_low[i] = ce && (int)(i % nle) + 1 < nle && word(1 + i) > 0.0f ? kRangeLow : 0.0f;
+        for (size_t i = 0; i < h->dec_tails.size(); ++i) h->dec_low[i] = cd && (int)(i % nld) + 1 < nld && word(doff + 1 + i) > 0.0f ? kRangeLow : 0.0f;
+        // received values: flagged when a workgroup's largest one is 2^7 under the calibration batch's largest (they share the
+        // extrinsic values' exponent, which may put them well under the layer window to begin with)
+        h->dec_r_low = 0.0f;
+        if (do_dec && L * 3 >= 48) {
+            const float rmax = word(doff + cal_dec_r(h));
+            if (std::isfinite(rmax) && rmax > 0.0f) h->dec_r_low = ldexpf(rmax, -7);
+        }
+        if ((rc = upload_tails(h, false)) == TAE_OK) rc = upload_tails(h, true);
+    }
+    h->calibrated = rc == TAE_OK;
+    if (hipMemset(h->d_flags, 0, sizeof(uint32_t)) != hipSuccess) rc = rc == TAE_OK ? TAE_EHIP : rc;     // whatever the calibration passes raised
+    cleanup();
+#undef TAE_CAL
+    return rc;
+}
+
+// tae_config.range_fallback: run `call` on the fp16-split handle, wait for it, read the range word, and if a launch left the window
+// run the same call on the fp32 twin - from then on every call goes there (a network that left the window once will again).
+template <class F>
+int with_fallback(tae_handle* h, hipStream_t st, F&& call) {
+    if (!h || !h->fb) return call(h);
+    if (h->last_flags & 4u) return call(h->fb);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return fail(TAE_ESTATE, "a handle created with range_fallback synchronises after every call and cannot be captured into a hipGraph");
+    int rc = call(h);
+    if (rc != TAE_OK) return rc;
+    uint32_t f = 0;
+    TAE_HIP(hipStreamSynchronize(st));
+    TAE_HIP(hipMemcpy(&f, h->d_flags, sizeof(f), hipMemcpyDeviceToHost));
+    if ((f & 3u) == 0u) return TAE_OK;
+    TAE_HIP(hipMemset(h->d_flags, 0, sizeof(f)));
+    h->last_flags |= (f & 3u) | 4u;
+    return call(h->fb);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1348,6 +1624,9 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         *out = h;
         return TAE_OK;
     }
+    const tae_config user_cfg = *cfg;
+    const float* const user_weights = weights;
+    const size_t user_n_weights = n_weights;
     std::vector<float> w5;
     tae_config cfg5 = *cfg;
     if (needs_embedding(cfg)) {          // narrower stacks / kernel sizes 1, 3: run, exactly, in the next instantiated geometry
@@ -1388,6 +1667,12 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
             delete h;
             return fail(TAE_EINVAL, "too many conv layers for the segmented long-block kernels (halo exceeds the panel)");
         }
+    }
+    {   // positions x real channels a workgroup holds at least (one block, or the last segment of one): see kRangeMinValues
+        const int le = h->nb >= 1 ? cfg->block_len : cfg->block_len - (h->enc_nseg - 1) * h->enc_T;
+        const int ld = h->nbd >= 1 ? cfg->block_len : cfg->block_len - (h->dec_nseg - 1) * h->dec_T;
+        h->enc_min_values = (le > 0 ? le : 1) * user_cfg.enc_num_unit;
+        h->dec_min_values = (ld > 0 ? ld : 1) * user_cfg.dec_num_unit;
     }
     const Layout lo(h->U), lod(h->Ud);
     const int F = cfg->num_iter_ft;
@@ -1447,11 +1732,13 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         h->enc_bytes_h = (uint32_t)penc_h.size();
         h->dec_bytes_h = (uint32_t)pdec_h.size();
         const float* s2 = weights;
-        for (int s = 0; s < 3; ++s) s2 += pack_stack_h_dense(s2, lh, cfg->enc_num_layer, 1, 1, penc_h.data() + (size_t)s * h->enc_stride_h);
+        for (int s = 0; s < 3; ++s)
+            s2 += pack_stack_h_dense(s2, lh, cfg->enc_num_layer, 1, 1, penc_h.data() + (size_t)s * h->enc_stride_h, &h->enc_tails, (uint32_t)s * h->enc_stride_h);
         for (int it = 0; it < cfg->num_iteration; ++it)
             for (int half = 0; half < 2; ++half) {
                 const int nout = (half == 1 && it == cfg->num_iteration - 1) ? 1 : F;
-                s2 += pack_stack_h_dense(s2, lhd, cfg->dec_num_layer, 2 + F, nout, pdec_h.data() + (size_t)(2 * it + half) * h->dec_stride_h);
+                s2 += pack_stack_h_dense(s2, lhd, cfg->dec_num_layer, 2 + F, nout, pdec_h.data() + (size_t)(2 * it + half) * h->dec_stride_h, &h->dec_tails,
+                                         (uint32_t)(2 * it + half) * h->dec_stride_h);
             }
         if ((size_t)(s2 - weights) != n_weights) { delete h; return fail(TAE_EINVAL, "internal: dense weight walk mismatch"); }
     } else if (big_taps && !h2_ok) {
@@ -1466,14 +1753,16 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         h->enc_bytes_h = (uint32_t)penc_h.size();
         const float* s2 = weights;
         if (cfg->enc_type == 0)
-            for (int s = 0; s < 3; ++s) s2 += pack_stack_h(s2, lh, cfg->enc_num_layer, 1, 1, penc_h.data() + (size_t)s * h->enc_stride_h);
+            for (int s = 0; s < 3; ++s)
+                s2 += pack_stack_h(s2, lh, cfg->enc_num_layer, 1, 1, penc_h.data() + (size_t)s * h->enc_stride_h, &h->enc_tails, (uint32_t)s * h->enc_stride_h);
         if (cfg->dec_type == 0) {
             pdec_h.assign((size_t)2 * cfg->num_iteration * h->dec_stride_h, 0);
             h->dec_bytes_h = (uint32_t)pdec_h.size();
             for (int it = 0; it < cfg->num_iteration; ++it)
                 for (int half = 0; half < 2; ++half) {
                     const int nout = (half == 1 && it == cfg->num_iteration - 1) ? 1 : F;
-                    s2 += pack_stack_h(s2, lhd, cfg->dec_num_layer, 2 + F, nout, pdec_h.data() + (size_t)(2 * it + half) * h->dec_stride_h);
+                    s2 += pack_stack_h(s2, lhd, cfg->dec_num_layer, 2 + F, nout, pdec_h.data() + (size_t)(2 * it + half) * h->dec_stride_h, &h->dec_tails,
+                                       (uint32_t)(2 * it + half) * h->dec_stride_h);
                 }
         }
     }
@@ -1535,6 +1824,19 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
 #undef TAE_HIP_H
     rc = tae_reserve(h, cfg->max_batch > 0 ? cfg->max_batch : 1);
     if (rc != TAE_OK) { tae_destroy(h); return rc; }
+    if (h->prec == 1 && range_calibration_on(cfg)) {
+        rc = calibrate_range(h, nullptr, nullptr, 0);
+        if (rc != TAE_OK) { tae_destroy(h); return rc; }
+    }
+    if (h->prec == 1 && user_cfg.range_fallback) {
+        // fp32 twin (fp32 MFMA kernels, or the generic fp32 kernels where those do not exist): a call that raises a range flag is
+        // re-run there, and so is every later call
+        tae_config fc = user_cfg;
+        fc.precision = TAE_PREC_F32;
+        fc.range_fallback = 0;
+        rc = tae_create(&fc, user_weights, user_n_weights, &h->fb);
+        if (rc != TAE_OK) { tae_destroy(h); return rc; }
+    }
     *out = h;
     return TAE_OK;
 }
@@ -1543,6 +1845,8 @@ int tae_destroy(tae_handle* h) {
     if (!h) return TAE_OK;
     tae::generic_destroy(h->gen);
     h->gen = nullptr;
+    if (h->fb) { tae_destroy(h->fb); h->fb = nullptr; }
+    (void)hipFree(h->d_cal);
     (void)hipFree(h->d_wenc); (void)hipFree(h->d_wdec); (void)hipFree(h->d_perm); (void)hipFree(h->d_inv);
     (void)hipFree(h->d_xtx); (void)hipFree(h->d_rx); (void)hipFree(h->d_partials); (void)hipFree(h->d_stats);
     (void)hipFree(h->d_e0); (void)hipFree(h->d_e1);
@@ -1558,6 +1862,7 @@ int tae_destroy(tae_handle* h) {
 int tae_reserve(tae_handle* h, int32_t max_batch) {
     { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
     if (max_batch < 1) return fail(TAE_EINVAL, "max_batch must be >= 1");
+    if (h->fb) { const int rc_f = tae_reserve(h->fb, max_batch); if (rc_f != TAE_OK) return rc_f; }
     if (max_batch <= h->cap) return TAE_OK;
     TAE_HIP(hipDeviceSynchronize());
     (void)hipFree(h->d_xtx); (void)hipFree(h->d_rx); (void)hipFree(h->d_partials); (void)hipFree(h->d_e0); (void)hipFree(h->d_e1);
@@ -1622,11 +1927,15 @@ int tae_set_interleaver(tae_handle* h, const int32_t* p, int32_t L) {
     TAE_HIP(hipDeviceSynchronize());
     TAE_HIP(hipMemcpy(h->d_perm, p, L * sizeof(int32_t), hipMemcpyHostToDevice));
     TAE_HIP(hipMemcpy(h->d_inv, inv.data(), L * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (h->fb) { const int rc_f = tae_set_interleaver(h->fb, p, L); if (rc_f != TAE_OK) return rc_f; }
+    // the extrinsic values a trained decoder exchanges depend on the permutation: measure the ranges again
+    if (h->calibrated) return calibrate_range(h, nullptr, nullptr, 0);
     return TAE_OK;
 }
 
 int tae_set_noise_opts(tae_handle* h, const tae_noise_opts* o) {
     if (!h) return fail(TAE_EINVAL, "handle is NULL");
+    if (h->fb) { const int rc_f = tae_set_noise_opts(h->fb, o); if (rc_f != TAE_OK) return rc_f; }
     if (!o) { h->noise_opts = default_noise_opts(); return TAE_OK; }
     const int rc = check_noise_opts(o);
     if (rc != TAE_OK) return rc;
@@ -1651,7 +1960,20 @@ int tae_generate_noise(tae_handle* h, const tae_noise_opts* opts, float test_sig
 
 int tae_set_channel_opts(tae_handle* h, const tae_channel_opts* o) {
     if (!h) return fail(TAE_EINVAL, "handle is NULL");
-    if (!o) { h->nopts = default_norm_opts(); return TAE_OK; }
+    if (h->fb) { const int rc_f = tae_set_channel_opts(h->fb, o); if (rc_f != TAE_OK) return rc_f; }
+    const tae::NormOpts before = h->nopts;
+    // what the decoder receives changes class with these fields (not with the running mean / std of norm_mode 2): measure again
+    auto recalibrate = [&]() {
+        const tae::NormOpts& a = before; const tae::NormOpts& b = h->nopts;
+        const bool same = a.norm_mode == b.norm_mode && a.ste == b.ste && a.channel == b.channel && a.rec_quantize == b.rec_quantize &&
+                          a.enc_truncate_limit == b.enc_truncate_limit && a.enc_value_limit == b.enc_value_limit &&
+                          a.enc_quantize_level == b.enc_quantize_level && a.rec_quantize_limit == b.rec_quantize_limit &&
+                          a.rec_quantize_level == b.rec_quantize_level;
+        if (same || !h->calibrated || h->dec_tails.empty()) return (int)TAE_OK;
+        if (check_handle(h) != TAE_OK) return (int)TAE_OK;      // no device context here: the next tae_set_interleaver / tae_calibrate_range measures
+        return calibrate_range(h, nullptr, nullptr, 0);
+    };
+    if (!o) { h->nopts = default_norm_opts(); return recalibrate(); }
     if (o->struct_size != (int32_t)sizeof(tae_channel_opts)) return fail(TAE_EINVAL, "tae_channel_opts.struct_size mismatch (ABI)");
     if (o->norm_mode < 0 || o->norm_mode > 2) return fail(TAE_EINVAL, "norm_mode must be 0, 1 or 2");
     if (o->norm_mode == 2 && !(o->std > 0.0f)) return fail(TAE_EINVAL, "fixed std must be > 0");
@@ -1665,14 +1987,14 @@ int tae_set_channel_opts(tae_handle* h, const tae_channel_opts* o) {
     n.channel = o->channel; n.rec_quantize = o->rec_quantize;
     n.rec_quantize_limit = o->rec_quantize_limit; n.rec_quantize_level = o->rec_quantize_level;
     h->nopts = n;
-    return TAE_OK;
+    return recalibrate();
 }
 
 int tae_encode_prenorm(tae_handle* h, const float* u, float* x_tx, double* stats3, int32_t B, void* stream) {
     int rc = check_batch(h, B);
     if (rc != TAE_OK) return rc;
     if (!u || !x_tx || !stats3) return fail(TAE_EINVAL, "NULL tensor");
-    return run_encoder(h, u, x_tx, stats3, B, (hipStream_t)stream);
+    return with_fallback(h, (hipStream_t)stream, [&](tae_handle* e) { return run_encoder(e, u, x_tx, stats3, B, (hipStream_t)stream); });
 }
 
 int tae_normalize(tae_handle* h, const float* x_tx, const double* stats3, const float* noise, float* codes, float* received,
@@ -1690,16 +2012,18 @@ int tae_encode(tae_handle* h, const float* u, float* codes, int32_t B, void* str
     int rc = check_batch(h, B);
     if (rc != TAE_OK) return rc;
     if (!u || !codes) return fail(TAE_EINVAL, "NULL tensor");
-    rc = run_encoder(h, u, h->d_xtx, h->d_stats, B, (hipStream_t)stream);
-    if (rc != TAE_OK) return rc;
-    return tae_normalize(h, h->d_xtx, h->d_stats, nullptr, codes, nullptr, B, stream);
+    return with_fallback(h, (hipStream_t)stream, [&](tae_handle* e) {
+        const int r = run_encoder(e, u, e->d_xtx, e->d_stats, B, (hipStream_t)stream);
+        if (r != TAE_OK) return r;
+        return tae_normalize(e, e->d_xtx, e->d_stats, nullptr, codes, nullptr, B, stream);
+    });
 }
 
 int tae_decode(tae_handle* h, const float* received, float* x_dec, int32_t B, void* stream) {
     int rc = check_batch(h, B);
     if (rc != TAE_OK) return rc;
     if (!received || !x_dec) return fail(TAE_EINVAL, "NULL tensor");
-    return run_decoder(h, received, x_dec, B, (hipStream_t)stream);
+    return with_fallback(h, (hipStream_t)stream, [&](tae_handle* e) { return run_decoder(e, received, x_dec, B, (hipStream_t)stream); });
 }
 
 int tae_decode_taps(tae_handle* h, const float* received, float* x_dec, float* taps, int32_t B, void* stream) {
@@ -1715,18 +2039,28 @@ int tae_forward(tae_handle* h, const float* u, const float* noise, float* x_dec,
     if (rc != TAE_OK) return rc;
     if (!u || !noise || !x_dec) return fail(TAE_EINVAL, "NULL tensor");
     hipStream_t st = (hipStream_t)stream;
-    rc = run_encoder(h, u, h->d_xtx, h->d_stats, B, st);
-    if (rc != TAE_OK) return rc;
-    rc = tae_normalize(h, h->d_xtx, h->d_stats, noise, codes, h->d_rx, B, stream);
-    if (rc != TAE_OK) return rc;
-    return run_decoder(h, h->d_rx, x_dec, B, st);
+    return with_fallback(h, st, [&](tae_handle* e) {
+        int r = run_encoder(e, u, e->d_xtx, e->d_stats, B, st);
+        if (r != TAE_OK) return r;
+        r = tae_normalize(e, e->d_xtx, e->d_stats, noise, codes, e->d_rx, B, stream);
+        if (r != TAE_OK) return r;
+        return run_decoder(e, e->d_rx, x_dec, B, st);
+    });
 }
 
 // One SNR point of trainer.test (trainer.py:160-217) on the device: per batch generate inputs -> encoder -> power constraint with
 // that batch's statistics -> AWGN; the received blocks of a group of batches are decoded in one call (the decoder never mixes
 // blocks) and the errors are counted per batch.
+static int eval_snr_impl(tae_handle* h, float snr_db, int32_t batch, int32_t n_batches, int64_t first_block, uint64_t seed_bits,
+                         uint64_t seed_noise, uint64_t* counts, void* stream);
 int tae_eval_snr(tae_handle* h, float snr_db, int32_t batch, int32_t n_batches, int64_t first_block, uint64_t seed_bits,
                  uint64_t seed_noise, uint64_t* counts, void* stream) {
+    return with_fallback(h, (hipStream_t)stream, [&](tae_handle* e) {
+        return eval_snr_impl(e, snr_db, batch, n_batches, first_block, seed_bits, seed_noise, counts, stream);
+    });
+}
+static int eval_snr_impl(tae_handle* h, float snr_db, int32_t batch, int32_t n_batches, int64_t first_block, uint64_t seed_bits,
+                         uint64_t seed_noise, uint64_t* counts, void* stream) {
     if (!h || !counts) return fail(TAE_EINVAL, "NULL argument");
     { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
     if (batch < 1 || n_batches < 1 || first_block < 0) return fail(TAE_EINVAL, "bad batch geometry");
@@ -1834,7 +2168,32 @@ int tae_range_status(tae_handle* h, int32_t* precision, int32_t* overflow) {
         TAE_HIP(hipDeviceSynchronize());
         TAE_HIP(hipMemcpy(&f, h->d_flags, sizeof(f), hipMemcpyDeviceToHost));
         if (f) TAE_HIP(hipMemset(h->d_flags, 0, sizeof(f)));
-        *overflow = (int32_t)(f & 1u);
+        *overflow = (int32_t)((f & 3u) | h->last_flags);
+        h->last_flags &= 4u;           // the fall-back is permanent, the range bits it reacted to are reported once
+    }
+    return TAE_OK;
+}
+
+int tae_calibrate_range(tae_handle* h, const float* u, const float* noise, int32_t B) {
+    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
+    if ((u == nullptr) != (noise == nullptr)) return fail(TAE_EINVAL, "u and noise must be given together (both NULL: the synthetic batch)");
+    if (u && B < 1) return fail(TAE_EINVAL, "batch must be >= 1");
+    return calibrate_range(h, u, noise, B);
+}
+
+int tae_range_info(tae_handle* h, int32_t* n_encoder, int32_t* n_decoder, int32_t* exponents, int32_t capacity, int32_t* passes) {
+    if (!h) return fail(TAE_EINVAL, "handle is NULL");
+    const int32_t ne = (int32_t)(h->enc_A.size() + h->enc_Ax.size()), nd = (int32_t)(h->dec_A.size() + h->dec_Ax.size());
+    if (n_encoder) *n_encoder = h->calibrated ? ne : 0;
+    if (n_decoder) *n_decoder = h->calibrated ? nd : 0;
+    if (passes) *passes = h->cal_passes;
+    if (exponents && h->calibrated) {
+        if (capacity < ne + nd) return fail(TAE_EINVAL, "tae_range_info: capacity too small");
+        int32_t* o = exponents;
+        for (int v : h->enc_Ax) *o++ = v;
+        for (int v : h->enc_A) *o++ = v;
+        for (int v : h->dec_Ax) *o++ = v;
+        for (int v : h->dec_A) *o++ = v;
     }
     return TAE_OK;
 }

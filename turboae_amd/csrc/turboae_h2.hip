@@ -57,6 +57,7 @@ __device__ __forceinline__ TapGeo tap_geo(int taps) {
 }
 
 constexpr int kXRowB = 16;        // bytes per row of an X plane (8 halves)
+constexpr int kRangeBytes = 32;   // PanelsH::RNG
 constexpr int kXSlack = 3;        // extra rows of the X planes: the first layer's last slab over-reads up to 4 * nsl_l0 - 2 * pad - 2 <= 2 rows past the panel
 
 // one stack-input panel = two fp16 planes
@@ -96,6 +97,9 @@ struct PanelsH {
     int* INV;
     int* ROWT;       // [kHeadSlots] panel row of every position slot of the workgroup
     float* HS;
+    uint32_t* RNG;   // range bookkeeping (kRangeBytes): [0], [1] per-layer workgroup maxima by layer parity, [2] the staged stack inputs'
+                     // maximum (float bits); [4..5] the launch's flag word, [6..7] its calibration array (device pointers, parked here
+                     // so that they cost no scalar registers across the K loops)
 };
 
 template <int U>
@@ -113,6 +117,7 @@ __device__ __forceinline__ PanelsH carve_h(char* smem, int rows, int L) {
     pn.INV = pn.PERM + L;
     pn.ROWT = pn.INV + L;
     pn.HS = reinterpret_cast<float*>(smem + (((reinterpret_cast<char*>(pn.ROWT + kHeadSlots) - smem) + 15) & ~15));
+    pn.RNG = reinterpret_cast<uint32_t*>(pn.HS + kHeadSlots * 8);
     return pn;
 }
 
@@ -198,25 +203,81 @@ struct WeightStreamH {
     __device__ __forceinline__ void prefetch(uint32_t soff) { load_wh<GeoH<U>::CT, C0, NC>(a, rsrc, voff, soff); }
 };
 
-// Layer epilogue for 4 accumulator values: x = acc * 2^-S, ELU, running max (range report), split into fp16
+// ---- range bookkeeping of the fp16-split representation ------------------------------------------------------------
+// hi + lo carries a value to 2^-22 relative only while its lo half is a NORMAL fp16 number, i.e. for |x| >= 2^-3; below that
+// the pair has an absolute floor of 2^-25, and above 65504 it overflows.  fp32 has neither limit, so every panel is stored
+// SCALED: layer l writes ELU(v) * 2^A_l with a per-layer exponent the host calibrates (turboae_api.hip::calibrate_range) so
+// that the layer's largest activation lands in [2^10, 2^11): 2^5 of headroom above, and every value down to 2^-13 of the
+// maximum keeps the full 2^-22 (the floor is then 2^-35 of the maximum - far below the fp32 accumulation noise of the dot
+// products that consume it).  The next layer's accumulators carry 2^(S + A_l) (its bias is pre-scaled, its 2^-(S + A_l) comes
+// from the packed tail), so the scale costs no instruction: ELU(a k) c = med3(a (k c), exp2(a (k log2 e)) c - c, 0).
+// Every scale is a power of two: results do not depend on A_l except where a value meets the floor or the ceiling.
+// At run time each layer's workgroup-wide maximum is checked against both ends (flags bit 0: above 65504, results invalid;
+// bit 1: below the threshold the host packs beside the scales - 2^3, i.e. the data sits >= 2^7 under the calibration maximum
+// and the pair is no longer fp32-grade).
+
+struct EluScale {
+    float k1;      // 2^-(S + A_in) * 2^A_out : accumulator -> scaled value
+    float k2;      // 2^-(S + A_in) * log2(e) : accumulator -> exp2 argument
+    float c;       // 2^A_out
+};
+
+struct RangeH {
+    uint32_t* slot;    // PanelsH::RNG
+    int cal_base;      // calibration launches: index of this stack's layer 0 in the calibration array
+};
+
+__device__ __forceinline__ void range_park(uint32_t* rng, uint32_t* flags, uint32_t* cal) {     // thread 0, before the first barrier
+    reinterpret_cast<uint32_t**>(rng + 4)[0] = flags;
+    reinterpret_cast<uint32_t**>(rng + 4)[1] = cal;
+}
+__device__ __forceinline__ uint32_t* range_flags(const uint32_t* rng) { return reinterpret_cast<uint32_t* const*>(rng + 4)[0]; }
+__device__ __forceinline__ uint32_t* range_cal(const uint32_t* rng) { return reinterpret_cast<uint32_t* const*>(rng + 4)[1]; }
+
+__device__ __forceinline__ void lds_max_bits(uint32_t* slot, float v) {
+    using lds_u32 = uint32_t __attribute__((address_space(3)));
+    __hip_atomic_fetch_max(reinterpret_cast<lds_u32*>((uint32_t)(uintptr_t)slot), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// thread 0, after the barrier that follows a layer's panel writes: the workgroup's maximum of the SCALED values of that layer.
+// `tail` = the layer's packed tail (2^-(S + A_in) | 2^A_out | low-side threshold | -)
+__device__ __forceinline__ void range_check_layer(const RangeH& rg, int l, const float* tail) {
+    uint32_t* s = rg.slot + (l & 1);
+    const float m = __uint_as_float(*s);
+    *s = 0u;
+    const uint32_t f = (!(m <= kH2Limit) ? 1u : 0u) | ((m < tail[2]) ? 2u : 0u);
+    uint32_t* flags = range_flags(rg.slot);
+    if (f != 0u && flags != nullptr) atomicOr(flags, f);
+    uint32_t* cal = range_cal(rg.slot);
+    if (cal != nullptr) atomicMax(cal + rg.cal_base + l, __float_as_uint(m / tail[1]));
+}
+
+// Layer epilogue for 4 accumulator values: ELU(acc * 2^-S') * 2^A, running max of |.| (range report), split into fp16
 // halves.  Scalar fp32 ops on purpose: the packed forms (v_pk_mul_f32 / v_pk_add_f32) measured 6 % slower
 // here.  No clamp: an out-of-range activation turns into inf / NaN halves and `vmax` reports it
 // (tae_range_status).
-__device__ __forceinline__ void elu_split4(f32x4 a, float inv_scale, float& vmax, h4& hi, h4& lo) {
-    f32x4 v = a * inv_scale;
-    if (!(TAE_X & 4)) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
-    vmax = fmaxf(fmaxf(vmax, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));   // ELU output >= -1: only the upper side can overflow
+__device__ __forceinline__ float elu_scaled(float a, const EluScale& s) {
+    const float e = __builtin_fmaf(__builtin_amdgcn_exp2f(a * s.k2), s.c, -s.c);
+    return __builtin_amdgcn_fmed3f(a * s.k1, e, 0.0f);
+}
+__device__ __forceinline__ void elu_split4(f32x4 a, const EluScale& s, float& vmax, h4& hi, h4& lo) {
+    f32x4 v;
+    if (!(TAE_X & 4)) { v.x = elu_scaled(a.x, s); v.y = elu_scaled(a.y, s); v.z = elu_scaled(a.z, s); v.w = elu_scaled(a.w, s); }
+    else v = a * s.k1;
+    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     split4(v, hi, lo);
 }
 
 // One SameShapeConv1d stack (cnn_utils.py:36-46) + Linear head; same contract as run_stack in
-// turboae_kernels.hip, except that `g` is the first position TILE of the wave's group (not the group index).  `vmax` collects max |activation| before the fp16-range clamp (overflow report).
+// turboae_kernels.hip, except that `g` is the first position TILE of the wave's group (not the group index).  `rg`: range
+// bookkeeping of the layer panels (above); the stack inputs are `xin` as the caller scaled them (the first layer's packed
+// 2^-(S + A_x) undoes it).
 // `l0_slabs` > 0: the first layer walks that many K slabs instead of the tap_geo count (encoder stacks: C_in = 1 folds all taps
 // into ONE slab, see fold_enc_input).
 template <int U, int PT, int C0, int NC, class Epi>
 __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint32_t soff, uint32_t snext, int n_layer, char* smem,
                                             const PanelsH& pn, const XPlane& xin, const TileH<PT>& tc, int g, int lane,
-                                            WeightStreamH<U, C0, NC>& ws, float& vmax, Epi epi, int l0_slabs = 0) {
+                                            WeightStreamH<U, C0, NC>& ws, const RangeH& rg, Epi epi, int l0_slabs = 0) {
     using G = GeoH<U>;
     constexpr int CTT = G::CT;
     const int q = lane >> 4;
@@ -229,7 +290,6 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
         const bool first = (l == 0);
         const uint32_t fragb = first ? tg.l0b : tg.midb;
         const float* bias = reinterpret_cast<const float*>(wpack + lo + fragb);
-        inv_scale = bias[G::CP];
         {
             f32x4 b4[NC];
 #pragma unroll
@@ -250,6 +310,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
         }
         conv_accumulate_h<CTT, C0, NC, PT, 0>(acc, ws.a, ws.rsrc, ws.voff, lo, smem, bh, bl,
                                               first ? (l0_slabs > 0 ? l0_slabs : tg.nsl_l0) : tg.nsl_mid);
+        inv_scale = bias[G::CP];                   // tail: 2^-(S + A_in) | 2^A_out | low-side threshold | -
         lo += fragb + G::TAILB;
         {
             const uint32_t nxt = (l + 1 < n_layer) ? lo : snext;
@@ -260,12 +321,15 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
             int wrow[PT];
 #pragma unroll
             for (int p = 0; p < PT; ++p) wrow[p] = tc.row(p);
+            const float out_scale = bias[G::CP + 1];
+            const EluScale es{inv_scale * out_scale, inv_scale * 1.44269504088896341f, out_scale};
+            float vmax = 0.0f;
 #pragma unroll
             for (int p = 0; p < PT; ++p) {
 #pragma unroll
                 for (int i = 0; i < NC; ++i) {
                     h4 hi, lw;
-                    elu_split4(acc[p][i], inv_scale, vmax, hi, lw);
+                    elu_split4(acc[p][i], es, vmax, hi, lw);
                     // channels >= U exist only in the last channel tile (zero weights, zero bias -> ELU(0) = 0): they are
                     // steered to the dump row instead of branching
                     const int ch = (C0 + i) * 16 + 4 * q;
@@ -278,7 +342,9 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
                     }
                 }
             }
+            lds_max_bits(rg.slot + (l & 1), vmax);
             if (!(TAE_X & 1)) __syncthreads();
+            if (threadIdx.x == 0) range_check_layer(rg, l, bias + G::CP);
         }
     }
     // ---- Linear head on the accumulators of the last conv layer, fp32 vector ALU (as in run_stack)
@@ -343,7 +409,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
 template <int U, int PT, int C0, int NC, class Epi>
 __device__ __forceinline__ void run_stack_h_dense(const char* __restrict__ wpack, uint32_t soff, int n_layer, char* smem,
                                                   const PanelsH& pn, const XPlane& xin, const TileH<PT>& tc, int g, int lane,
-                                                  WeightStreamH<U, C0, NC>& ws, float& vmax, bool active, Epi epi) {
+                                                  WeightStreamH<U, C0, NC>& ws, const RangeH& rg, bool active, Epi epi) {
     using G = GeoH<U>;
     constexpr int CTT = G::CT;
     const int q = lane >> 4;
@@ -353,6 +419,7 @@ __device__ __forceinline__ void run_stack_h_dense(const char* __restrict__ wpack
     float inv_scale = 1.0f;
     for (int l = 0; l < n_layer; ++l) {
         const uint32_t tail = lo + G::L0B + (uint32_t)l * G::MIDB;
+        const float* tailf = reinterpret_cast<const float*>(wpack + tail) + G::CP;     // 2^-(S + A) | 2^A | low-side threshold (one exponent per dense stack)
         if (active) {
             const float* bias = reinterpret_cast<const float*>(wpack + tail);
             inv_scale = bias[G::CP];
@@ -393,13 +460,16 @@ __device__ __forceinline__ void run_stack_h_dense(const char* __restrict__ wpack
             if (active) {
                 char* PH = pn.AH + (size_t)l * pn.panel_bytes;
                 char* PL = PH + (pn.AL - pn.AH);
+                const float out_scale = tailf[1];
+                const EluScale es{inv_scale * out_scale, inv_scale * 1.44269504088896341f, out_scale};
+                float vmax = 0.0f;
 #pragma unroll
                 for (int p = 0; p < PT; ++p) {
                     const int wrow = tc.row(p);
 #pragma unroll
                     for (int i = 0; i < NC; ++i) {
                         h4 hi, lw;
-                        elu_split4(acc[p][i], inv_scale, vmax, hi, lw);
+                        elu_split4(acc[p][i], es, vmax, hi, lw);
                         const int ch = (C0 + i) * 16 + 4 * q;
                         const bool inb = (((C0 + i) * 16 + 16 <= U) || (ch < U)) && tc.ok(p);
                         const int off = inb ? (wrow * U + ch) * 2 : (dump_row * U + 4 * q) * 2;
@@ -407,8 +477,10 @@ __device__ __forceinline__ void run_stack_h_dense(const char* __restrict__ wpack
                         *reinterpret_cast<h4*>(PL + off) = lw;
                     }
                 }
+                lds_max_bits(rg.slot + (l & 1), vmax);
             }
             __syncthreads();
+            if (threadIdx.x == 0) range_check_layer(rg, l, tailf);
         }
     }
     // ---- Linear head (as run_stack_h)
@@ -479,6 +551,22 @@ __device__ __forceinline__ float track_abs(float vmax, float x) {
 __device__ __forceinline__ void report_range(float vmax, uint32_t* flags) {
     if (flags != nullptr && !(vmax <= kH2Limit)) atomicOr(flags, 1u);
 }
+// stack inputs (received values, extrinsic values): `xmax` = this lane's max of the SCALED values it wrote; calibration launches
+// also collect the unscaled maximum in cal[0]
+__device__ __forceinline__ void report_range_x(float xmax, float x_inv, uint32_t* flags, uint32_t* cal) {
+    report_range(xmax, flags);
+    if (cal != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, off));
+        if ((threadIdx.x & 63) == 0) atomicMax(cal, __float_as_uint(xmax * x_inv));
+    }
+}
+// after the staging loop of a decoder workgroup: its largest staged input against the low end of the window (thread 0, after a barrier)
+__device__ __forceinline__ void range_check_inputs(uint32_t* slot, float low, uint32_t* flags) {
+    const float m = __uint_as_float(*slot);
+    *slot = 0u;
+    if (m < low && flags != nullptr) atomicOr(flags, 2u);
+}
 
 // =============================================================================================
 // Decoder: DEC_LargeCNN.forward (decoders.py:206-269)
@@ -494,29 +582,32 @@ __device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, con
     ws.init(wpack, P.wpack_bytes, lane);
     ws.prefetch(0);
     const uint32_t sstride = P.stack_stride;       // bytes in this representation
-    float vmax = 0.0f;
+    const float xs = P.x_scale, xinv = P.x_inv;    // the X planes hold value * 2^A_x (one exponent for the whole decoder)
+    float xmax = 0.0f;
     for (int s = 0; s < n_stack; ++s) {
         const XPlane Xin = (s & 1) ? pn.XB : pn.XA;
         const XPlane Xout = (s & 1) ? pn.XA : pn.XB;
         const int* ptab = (s & 1) ? pn.PERM : pn.INV;
+        const RangeH rg{pn.RNG, 1 + s * P.n_layer};
         if (s + 1 < n_stack) {
-            run_stack_h<U, PT, C0, NC>(wpack, s * sstride, (s + 1) * sstride, P.n_layer, smem, pn, Xin, tc, g, lane, ws, vmax,
+            run_stack_h<U, PT, C0, NC>(wpack, s * sstride, (s + 1) * sstride, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
                                        [&](int p, int f, float v) {
                 if (f < F) {
-                    if (extrinsic) v -= Xin.read(tc.row(p), 2 + f);            // decoders.py:235-236,246-247
-                    vmax = track_abs(vmax, v);
+                    if (extrinsic) v -= Xin.read(tc.row(p), 2 + f) * xinv;     // decoders.py:235-236,246-247
                     if constexpr (TAPS) P.tap_out[(((size_t)s * P.B + blk0 + tc.blk(p)) * L + tc.t(p)) * F + f] = v;
-                    Xout.write(tc.rowbase(p) + ptab[tc.t(p)], 2 + f, v);       // interleave / deinterleave (decoders.py:238,249)
+                    const float vs = v * xs;
+                    xmax = track_abs(xmax, vs);
+                    Xout.write(tc.rowbase(p) + ptab[tc.t(p)], 2 + f, vs);      // interleave / deinterleave (decoders.py:238,249)
                 }
             });
         } else {
-            run_stack_h<U, PT, C0, NC>(wpack, s * sstride, 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, vmax,
+            run_stack_h<U, PT, C0, NC>(wpack, s * sstride, 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
                                        [&](int p, int f, float v) {
                 if (f == 0) xdec[tc.blk(p) * L + ptab[tc.t(p)]] = 1.0f / (1.0f + expf(-v));   // decoders.py:262-267
             });
         }
     }
-    report_range(vmax, P.flags);
+    report_range_x(xmax, xinv, range_flags(pn.RNG), range_cal(pn.RNG));
 }
 
 template <int U, int PT, bool TAPS = false>
@@ -539,24 +630,28 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
 
     zero_lds(smem, P.lds_bytes, tid);
     __syncthreads();
+    if (tid == 0) range_park(pn.RNG, P.flags, P.cal);
     for (int i = tid; i < L; i += kThreads) { pn.PERM[i] = P.perm[i]; pn.INV[i] = P.inv[i]; }
     __syncthreads();
     // r_sys, r_par1 -> XA ch 0,1 (natural order); r_sys_int, r_par2 -> XB ch 0,1 (decoders.py:221-224)
     const float* rx = P.in + (size_t)blk0 * L * 3;
     float vmax = 0.0f;
+    const float xs = P.x_scale;
     for (int m = tid; m < npos; m += kThreads) {
         const int b = m / L, t = m - b * L;
         const int row = b * (L + pad) + pad + t;
         const float* r = rx + (size_t)m * 3;
-        const float r0 = r[0], r1 = r[1], r2 = r[2], ri = rx[((size_t)b * L + pn.PERM[t]) * 3 + 0];
+        const float r0 = r[0] * xs, r1 = r[1] * xs, r2 = r[2] * xs, ri = rx[((size_t)b * L + pn.PERM[t]) * 3 + 0] * xs;
         vmax = track_abs(track_abs(track_abs(vmax, r0), r1), r2);       // ri is some position's r0: covered
         pn.XA.write(row, 0, r0);
         pn.XA.write(row, 1, r1);
         pn.XB.write(row, 0, ri);
         pn.XB.write(row, 1, r2);
     }
-    report_range(vmax, P.flags);
+    report_range_x(vmax, P.x_inv, P.flags, P.cal ? P.cal + P.cal_r : nullptr);     // the received values have their own slot: x_low is relative to them
+    lds_max_bits(pn.RNG + 2, vmax);
     __syncthreads();
+    if (tid == 0) range_check_inputs(pn.RNG + 2, P.x_low, P.flags);
 
     // The workgroup's position tiles are dealt out evenly over the 4 position groups and a group walks only its own
     // tiles (3 blocks of 100 = 19 tiles -> 5, 5, 5, 4; 2 blocks -> 4, 3, 3, 3; 1 block -> 2, 2, 2, 1): tiles that hold no
@@ -588,10 +683,10 @@ __device__ __forceinline__ void enc_body_h(const FusedParams& P, char* smem, con
     ws.init(wpack, P.wpack_bytes, lane);
     ws.prefetch(0);
     const uint32_t sstride = P.stack_stride;
-    float vmax = 0.0f;
     for (int s = 0; s < 3; ++s) {
         const XPlane Xin = (s == 2) ? pn.XB : pn.XA;
-        run_stack_h<U, PT, C0, NC>(wpack, s * sstride, s < 2 ? (s + 1) * sstride : 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, vmax,
+        const RangeH rg{pn.RNG, 1 + s * P.n_layer};
+        run_stack_h<U, PT, C0, NC>(wpack, s * sstride, s < 2 ? (s + 1) * sstride : 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
                                    [&](int p, int f, float v) {
             if (f == 0) {
                 v = act_apply(v, act);                                     // enc_act (encoders.py:364)
@@ -601,7 +696,6 @@ __device__ __forceinline__ void enc_body_h(const FusedParams& P, char* smem, con
             }
         }, 1);
     }
-    report_range(vmax, P.flags);
 }
 
 template <int U, int PT>
@@ -624,6 +718,7 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
 
     zero_lds(smem, P.lds_bytes, tid);
     __syncthreads();
+    if (tid == 0) range_park(pn.RNG, P.flags, P.cal);
     for (int i = tid; i < L; i += kThreads) { pn.PERM[i] = P.perm[i]; pn.INV[i] = P.inv[i]; }
     __syncthreads();
     // inputs = 2u - 1 (encoders.py:362); XB holds the interleaved copy (encoders.py:369)
@@ -669,10 +764,10 @@ __device__ __forceinline__ void seg_body_h(const SegParams& P, char* smem, const
     const uint32_t soff = (uint32_t)stack * P.stack_stride;
     if (!DENSE) ws.prefetch(soff);
     const XPlane X = pn.XA;
-    float vmax = 0.0f;
+    const RangeH rg{pn.RNG, 1 + stack * P.n_layer};
     auto run = [&](auto epi) {
-        if constexpr (DENSE) run_stack_h_dense<U, PT, C0, NC>(wpack, soff, P.n_layer, smem, pn, X, tc, g, lane, ws, vmax, active, epi);
-        else run_stack_h<U, PT, C0, NC>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, vmax, epi, P.mode == 0 ? 1 : 0);
+        if constexpr (DENSE) run_stack_h_dense<U, PT, C0, NC>(wpack, soff, P.n_layer, smem, pn, X, tc, g, lane, ws, rg, active, epi);
+        else run_stack_h<U, PT, C0, NC>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, rg, epi, P.mode == 0 ? 1 : 0);
     };
     if (P.mode == 0) {
         const int act = P.act;
@@ -688,12 +783,12 @@ __device__ __forceinline__ void seg_body_h(const SegParams& P, char* smem, const
     } else if (!P.last) {
         const int F = P.F;
         const bool extrinsic = P.extrinsic != 0;
+        const float xinv = 1.0f / P.x_scale[0];
         float* ecur = P.ecur + (size_t)b * L * 8;
         run([&](int p, int f, float v) {
             if (f < F) {
-                if (extrinsic) v -= X.read(tc.row(p), 2 + f);
-                vmax = track_abs(vmax, v);
-                ecur[(size_t)(tstart + tc.m0 + 16 * p) * 8 + f] = v;
+                if (extrinsic) v -= X.read(tc.row(p), 2 + f) * xinv;
+                ecur[(size_t)(tstart + tc.m0 + 16 * p) * 8 + f] = v;      // fp32 in HBM: scaled (and range-checked) when the next launch stages it
             }
         });
     } else {
@@ -702,7 +797,6 @@ __device__ __forceinline__ void seg_body_h(const SegParams& P, char* smem, const
             if (f == 0) xdec[P.perm[tstart + tc.m0 + 16 * p]] = 1.0f / (1.0f + expf(-v));    // sigmoid(deinterleave), decoders.py:267
         });
     }
-    report_range(vmax, P.flags);
 }
 
 template <int U>
@@ -720,6 +814,7 @@ __device__ __forceinline__ PanelsH carve_seg_h(char* smem, int rows, int npanel 
     pn.INV = nullptr;
     pn.ROWT = reinterpret_cast<int*>(pn.XA.l + xb);
     pn.HS = reinterpret_cast<float*>(smem + (((reinterpret_cast<char*>(pn.ROWT + kHeadSlots) - smem) + 15) & ~15));
+    pn.RNG = reinterpret_cast<uint32_t*>(pn.HS + kHeadSlots * 8);
     return pn;
 }
 
@@ -749,20 +844,22 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
 
     zero_lds(smem, P.lds_bytes, tid);
     __syncthreads();
-    float vmax = 0.0f;
+    if (tid == 0) range_park(pn.RNG, P.flags, P.cal);
+    float vmax = 0.0f, emax = 0.0f;
+    const float xs = P.x_scale[P.mode == 0 ? stack : 0];          // the X planes hold value * 2^A_x (per stack on this path)
     for (int m = tid; m < NP; m += kThreads) {
         const int t = tstart + m;
         if (t < 0 || t >= L) continue;
         const int row = pad + m;
         if (P.mode == 0) {
             const int src = (stack == 2) ? P.perm[t] : t;                           // encoders.py:369
-            const float v = 2.0f * P.in[(size_t)b * L + src] - 1.0f;                // encoders.py:362
+            const float v = (2.0f * P.in[(size_t)b * L + src] - 1.0f) * xs;         // encoders.py:362
             pn.XA.write(row, 0, v);
             if (!P.dense) fold_enc_input(pn.XA, row, t, pad, 0, v);
         } else {
             const float* rx = P.in + (size_t)b * L * 3;
-            const float r0 = odd ? rx[(size_t)P.perm[t] * 3] : rx[(size_t)t * 3];   // r_sys_int / r_sys
-            const float r1 = rx[(size_t)t * 3 + (odd ? 2 : 1)];                     // r_par2 / r_par1
+            const float r0 = (odd ? rx[(size_t)P.perm[t] * 3] : rx[(size_t)t * 3]) * xs;   // r_sys_int / r_sys
+            const float r1 = rx[(size_t)t * 3 + (odd ? 2 : 1)] * xs;                       // r_par2 / r_par1
             vmax = track_abs(track_abs(vmax, r0), r1);
             pn.XA.write(row, 0, r0);
             pn.XA.write(row, 1, r1);
@@ -770,11 +867,21 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
                 // dec2 reads q[p[i]] (interleave, decoders.py:238); dec1 reads q2[inv[j]] (deinterleave, :249)
                 const int gi = odd ? P.perm[t] : P.inv[t];
                 const float* e = P.eprev + ((size_t)b * L + gi) * 8;
-                for (int f = 0; f < P.F; ++f) pn.XA.write(row, 2 + f, e[f]);
+                for (int f = 0; f < P.F; ++f) {
+                    const float ev = e[f] * xs;
+                    emax = track_abs(emax, ev);
+                    pn.XA.write(row, 2 + f, ev);
+                }
             }
         }
     }
-    report_range(vmax, P.flags);
+    if (P.mode != 0) {
+        report_range_x(vmax, 1.0f / xs, P.flags, P.cal ? P.cal + P.cal_r : nullptr);      // received values
+        report_range_x(emax, 1.0f / xs, P.flags, P.cal ? P.cal + P.cal_x : nullptr);      // the previous stack's extrinsic values
+        lds_max_bits(pn.RNG + 2, vmax);
+        __syncthreads();
+        if (tid == 0) range_check_inputs(pn.RNG + 2, P.x_low, P.flags);
+    }
 
     // tiles of the wave's position group: panel rows [2 + m] of the segment; `center` marks the positions this workgroup owns
     auto make_tiles = [&](auto& tc, int gt0) {
@@ -871,7 +978,7 @@ int seg_lds_bytes_h(int U, int T, int n_layer, int taps) {
     const int pad = taps / 2, rows = T + 2 * pad * n_layer + 3 + 2 * pad;
     size_t b = 2 * (size_t)(rows + 2) * U * 2 + 2 * (size_t)(rows + 1 + kXSlack) * kXRowB + (size_t)kHeadSlots * 4;
     b = (b + 15) & ~(size_t)15;
-    b += (size_t)kHeadSlots * 8 * 4;
+    b += (size_t)kHeadSlots * 8 * 4 + kRangeBytes;     // head-combine scratch + range slots
     if (b < 2 * kThreads * sizeof(double)) b = 2 * kThreads * sizeof(double);
     return (int)b;
 }
@@ -881,7 +988,7 @@ int seg_lds_bytes_h_dense(int U, int T, int n_layer) {
     const int npanel = n_layer > 1 ? n_layer - 1 : 1;
     size_t b = (size_t)npanel * 2 * (size_t)(rows + 2) * U * 2 + 2 * (size_t)(rows + 1 + kXSlack) * kXRowB + (size_t)kHeadSlots * 4;
     b = (b + 15) & ~(size_t)15;
-    b += (size_t)kHeadSlots * 8 * 4;
+    b += (size_t)kHeadSlots * 8 * 4 + kRangeBytes;     // head-combine scratch + range slots
     if (b < 2 * kThreads * sizeof(double)) b = 2 * kThreads * sizeof(double);
     return (int)b;
 }
@@ -890,7 +997,7 @@ int fused_lds_bytes_h(int U, int L, int nb, int taps) {
     const int pad = taps / 2, rows = nb * (L + pad) + pad;
     size_t b = 2 * (size_t)(rows + 2) * U * 2 + 4 * (size_t)(rows + 1 + kXSlack) * kXRowB + 2 * (size_t)L * 4 + (size_t)kHeadSlots * 4;
     b = (b + 15) & ~(size_t)15;
-    b += (size_t)kHeadSlots * 8 * 4;
+    b += (size_t)kHeadSlots * 8 * 4 + kRangeBytes;     // head-combine scratch + range slots
     if (b < 2 * kThreads * sizeof(double)) b = 2 * kThreads * sizeof(double);
     return (int)b;
 }

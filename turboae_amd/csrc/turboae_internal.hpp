@@ -32,6 +32,12 @@ struct FusedParams {
                             // partial round of workgroups runs thinner, see tail_geometry in turboae_api.hip); n_full < 0: all own nb
     float* tap_out;         // decoder, debug instantiation only (tae_decode_taps): [2*n_iter-1][B][L][F] extrinsic outputs of every
                             // non-final stack in the producing stack's own position order (before the (de)interleave scatter)
+    // f16x2 kernels: the stack-input planes hold value * x_scale (a power of two; x_inv = 1 / x_scale); a workgroup whose largest
+    // staged input * x_scale is below x_low raises flags bit 1 (0 disables: encoder inputs are +-1)
+    float x_scale, x_inv, x_low;
+    uint32_t* cal;          // calibration launches only (else nullptr): float bits, atomicMax'ed - [0] max |extrinsic value| a stack handed on
+                            // (unscaled), [1 + stack * n_layer + l] max |ELU output| of layer l, [cal_r] max |received value|
+    int32_t cal_r;
 };
 
 // Arguments of the per-stack segmented kernel used when a block does not fit one workgroup.
@@ -57,6 +63,10 @@ struct SegParams {
     int32_t super;
     uint32_t* flags;        // f16x2 kernels: range flag (stack_stride is in BYTES there)
     int32_t dense;          // 1: DenseSameShapeConv1d stacks (cnn_utils.py:49-82), f16x2 long-block kernels only
+    float x_scale[3];       // f16x2 kernels: scale of the stack-input planes; decoder: [0] = this launch's stack, encoder: per stack
+    float x_low;            // decoder: low end of the window for the staged inputs (see FusedParams)
+    uint32_t* cal;          // calibration launches only: as FusedParams::cal, with [cal_x] = max |extrinsic value| this decoder stack staged
+    int32_t cal_x, cal_r;
 };
 
 // ---- GRU decoder (turboae_gru.hip)
