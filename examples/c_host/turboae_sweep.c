@@ -1,7 +1,11 @@
 /* The reference's eval sweep (trainer.test, trainer.py:135-248) driven from plain C through the C ABI of
  * libturboae_hip.so - no Python, no torch: what a cgo / JNI / FFI binding of another host language would do.
  *
- *   turboae_sweep <weights.f32> <perm.i32> [blocks_per_snr=10000] [batch=500] [snr_points=12] [snr_lo=-1.5] [snr_hi=4.0] [seed=1] [mode=0] [channel=awgn]
+ *   turboae_sweep <weights.f32> <perm.i32> [blocks_per_snr=10000] [batch=500] [snr_points=12] [snr_lo=-1.5] [snr_hi=4.0] [seed=1] [mode=0] [channel=awgn] [range_fallback=0]
+ *
+ * range_fallback 1: tae_config.range_fallback - a call whose activations leave the window of the fp16-split kernels is run again on the
+ * library's fp32 twin of the handle (and so is every later call); the last line then reports it.  This is how a host without the
+ * Python mirror gets fp32-grade numbers from ANY checkpoint.
  *
  * channel: awgn | t-dist | radar | ge_awgn | bec | bsc | ge | fading (-channel, get_args.py:43): the noise of every channel is drawn on
  * the device (tae_generate_noise / tae_set_noise_opts) and applied by the matching branch of Channel_AE.forward (tae_set_channel_opts);
@@ -62,6 +66,7 @@ int main(int argc, char** argv) {
     const uint64_t seed = argc > 8 ? (uint64_t)strtoull(argv[8], NULL, 10) : 1u;
     const int mode = argc > 9 ? atoi(argv[9]) : 0;
     const char* channel = argc > 10 ? argv[10] : "awgn";
+    const int range_fallback = argc > 11 ? atoi(argv[11]) : 0;
     static const char* const kinds[] = {"awgn", "t-dist", "radar", "ge_awgn", "bec", "bsc", "ge", "fading"};      /* TAE_NOISE_* order */
     int kind = -1;
     for (int i = 0; i < 8; ++i)
@@ -92,6 +97,8 @@ int main(int argc, char** argv) {
     cfg.max_batch = batch;
     cfg.precision = TAE_PREC_AUTO;
     cfg.dec_act = TAE_ACT_LINEAR;       /* the reference default (only the GRU decoder reads it) */
+    cfg.range_calibration = 0;          /* 0 = on: per-layer exponents of the fp16-split panels, measured at create / set_interleaver */
+    cfg.range_fallback = range_fallback ? 1 : 0;
 
     const size_t nw = tae_num_weights(&cfg);
     float* w = (float*)malloc(nw * sizeof(float));
@@ -179,7 +186,8 @@ int main(int argc, char** argv) {
     const double dt = now_s() - t0;
     int32_t prec = 0, overflow = 0;
     TAE_CHECK(tae_range_status(h, &prec, &overflow));
-    printf("arithmetic %s overflow %d\n", prec == 1 ? "f16x2" : "f32", overflow);
+    printf("arithmetic %s overflow %d\n", prec == 1 ? "f16x2" : "f32", overflow & (TAE_RANGE_HIGH | TAE_RANGE_LOW));
+    if (overflow & TAE_RANGE_FELL_BACK) printf("range fall-back: the fp32 kernels served the flagged call and every call after it\n");
     printf("blocks %ld seconds %.3f info_bits_per_s %.3e\n", (long)snr_points * nbatch * batch, dt,
            (double)snr_points * nbatch * batch * L / dt);
 
@@ -187,5 +195,5 @@ int main(int argc, char** argv) {
     HIP_OK(hipFree(u)); HIP_OK(hipFree(noise)); HIP_OK(hipFree(x_dec)); HIP_OK(hipFree(codes)); HIP_OK(hipFree(counts));
     free(hc);
     TAE_CHECK(tae_destroy(h));
-    return overflow ? 4 : 0;
+    return (overflow & (TAE_RANGE_HIGH | TAE_RANGE_LOW)) && !(overflow & TAE_RANGE_FELL_BACK) ? 4 : 0;
 }

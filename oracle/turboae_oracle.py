@@ -221,6 +221,7 @@ def _rnn_model(cell: str):          # decoders.py:27-32, encoders.py:242-247
 
 def _gru_stack(x: torch.Tensor, w: Dict[str, torch.Tensor], prefix: str, hidden: int, cell: str = "gru", num_layers: int = 2) -> torch.Tensor:
     gru = _rnn_model(cell)(x.shape[2], hidden, num_layers=num_layers, bias=True, batch_first=True, dropout=0.0, bidirectional=True)
+    gru = gru.to(x.dtype)           # float64 runs of the oracle (precision tests): the module follows its input
     with torch.no_grad():
         for name, _ in gru.named_parameters():
             getattr(gru, name).copy_(w[f"{prefix}.{name}"])

@@ -60,6 +60,23 @@ def test_fp16_split_is_fp32_grade_at_any_activation_scale(gpu_device, name, cfg_
         assert err["auto"][k] <= 2.0 * err["f32"][k] + 5e-7, (name, err)
 
 
+@pytest.mark.parametrize("gain", [1.0, 0.3, 0.1, 0.03])
+def test_gru_decoder_at_small_gains(gpu_device, gain):
+    """The GRU decoder's fp16-split operands are its hidden states, bounded by tanh: |h| < 1 whatever the weights, so they are
+    stored unscaled (2^-25 absolute = 2^-25 of their natural maximum).  Small weight gains (the biases keep PyTorch's scale) must
+    stay inside the same bound against the float64 oracle as the CNN path."""
+    cfg_kw = dict(decoder="TurboAE_rate3_rnn", num_iteration=2, block_len=40)
+    base = TurboAEConfig(**cfg_kw)
+    sd = W.generate_state_dict(base, seed=11, gain=gain)
+    u, noise = _inputs(16, base.block_len)
+    x64, c64 = _oracle64(base, sd, u, noise)
+    err, words = _errors(cfg_kw, sd, u, noise, x64, c64, gpu_device)
+    print("gru gain", gain, err, words)
+    assert words["auto"] == ("f16x2", 0)
+    for k in (0, 1):
+        assert err["auto"][k] <= 2.0 * err["f32"][k] + 5e-7, (gain, err)
+
+
 @pytest.mark.parametrize("name", ["balanced_0.01", "balanced_16", "alt_2^-8_2^+8"])
 def test_uncalibrated_arithmetic_fails_these_networks(gpu_device, name):
     """The r03 arithmetic (all exponents 0 = range_calibration off) on the same networks: either the range word says so or the error

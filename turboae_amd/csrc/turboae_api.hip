@@ -129,7 +129,7 @@ struct LayoutH {   // must mirror tae::GeoH<U> / tae::tap_geo<U>(taps)
         slb = (uint32_t)CT * 2048u;
         midb = (uint32_t)nsl_mid * slb;
         l0b = (uint32_t)nsl_l0 * slb;
-        tailb = (uint32_t)CP * 4u + 16u;
+        tailb = (uint32_t)CP * 4u + 32u;
     }
     size_t stack_bytes(int n_layer) const {
         return (size_t)l0b + (size_t)(n_layer - 1) * midb + (size_t)n_layer * tailb + (size_t)8 * CP * 4 + 32;
@@ -197,21 +197,22 @@ void pack_conv_h(const float* W, int U, int cin, int cin_pad, int nslab, int CT,
 
 // The tail of one packed layer as the host keeps it for the range calibration (calibrate_range below): the layer's accumulators carry
 // 2^(S + A_in) (S: the weights' own power-of-two scale, A_in: exponent of the panel / stack inputs it reads), its ELU output is
-// stored * 2^A_out.  Device tail = bias * 2^(S + A_in) [CP] | 2^-(S + A_in) | 2^A_out | low-side threshold | 0.
+// stored * 2^A_out.  Device tail = bias * 2^(S + A_in) [CP] | 2^-(S + A_in) | 2^A_out | low-side threshold | high-side threshold | ELU kind | 3 spare.
 struct TailRef {
     uint32_t off = 0;              // byte offset of the tail inside the side's packed buffer
     int S = 0;
     std::vector<float> bias_s;     // bias * 2^S, padded to CP
 };
 
-void tail_values(const TailRef& t, int A_in, int A_out, float low, std::vector<float>& out) {
+void tail_values(const TailRef& t, int A_in, int A_out, float low, float high, int elu_kind, std::vector<float>& out) {
     const size_t CP = t.bias_s.size();
-    out.resize(CP + 4);
+    out.assign(CP + 8, 0.0f);
     for (size_t c = 0; c < CP; ++c) out[c] = ldexpf(t.bias_s[c], A_in);
     out[CP] = ldexpf(1.0f, -(t.S + A_in));
     out[CP + 1] = ldexpf(1.0f, A_out);
     out[CP + 2] = low;
-    out[CP + 3] = 0.0f;
+    out[CP + 3] = high;
+    out[CP + 4] = (float)elu_kind;
 }
 
 // canonical stack -> f16x2 packed stack (bytes at dst); returns floats consumed from src.  `tails` (optional) receives one
@@ -251,7 +252,7 @@ size_t pack_stack_h(const float* src, const LayoutH& lo, int n_layer, int cin0, 
         const float* b = s + nw;
         float* t = reinterpret_cast<float*>(d);
         for (int c = 0; c < lo.CP; ++c) t[c] = c < lo.U ? b[c] * scale : 0.0f;
-        t[lo.CP] = inv; t[lo.CP + 1] = 1.0f; t[lo.CP + 2] = 0.0f; t[lo.CP + 3] = 0.0f;      // exponents 0 until calibrate_range
+        t[lo.CP] = inv; t[lo.CP + 1] = 1.0f; t[lo.CP + 2] = 0.0f; t[lo.CP + 3] = 65504.0f;      // exponents 0, ELU kind 0 (t[CP + 4]) until calibrate_range
         if (tails) {
             TailRef r;
             r.off = base_off + (uint32_t)(d - dst);
@@ -335,6 +336,8 @@ struct tae_handle {
     std::vector<int> enc_A, dec_A;                  // exponent of every layer's OUTPUT panel ([stack * n_layer + l]; unused for the last layer)
     std::vector<int> enc_Ax, dec_Ax;                // exponent of every stack's input planes (whole-block decoder: all equal)
     std::vector<float> enc_low, dec_low;            // low-side threshold per layer (0: not checked)
+    std::vector<float> enc_high, dec_high;          // high-side threshold per layer: 65504, or 2^-3 * 2^A for a layer whose ELU runs as a polynomial
+    std::vector<int> enc_kind, dec_kind;            // ELU branch per layer (turboae_h2.hip, TAE_ELU_MODE 2): 0 exp2, 1 polynomial, 2 both
     float dec_r_low = 0.0f;                         // 2^-7 of the largest received value of the calibration batch (0: not checked); x_low = this * 2^A_x
     int enc_min_values = 0, dec_min_values = 0;     // values of one panel a workgroup holds at least (positions x real channels)
     uint32_t* d_cal = nullptr;                      // calibration launches: per-layer / per-stack maxima (float bits), encoder then decoder
@@ -447,7 +450,7 @@ size_t pack_stack_h_dense(const float* src, const LayoutH& lo, int n_layer, int 
         const float* b = s + nw;
         float* t = reinterpret_cast<float*>(d);
         for (int c = 0; c < lo.CP; ++c) t[c] = c < lo.U ? b[c] * scale : 0.0f;
-        t[lo.CP] = inv; t[lo.CP + 1] = 1.0f; t[lo.CP + 2] = 0.0f; t[lo.CP + 3] = 0.0f;
+        t[lo.CP] = inv; t[lo.CP + 1] = 1.0f; t[lo.CP + 2] = 0.0f; t[lo.CP + 3] = 65504.0f;
         if (tails) {
             TailRef r;
             r.off = base_off + (uint32_t)(d - dst);
@@ -867,10 +870,10 @@ bool needs_embedding(const tae_config* c) {
 }
 
 // `h2`: size for the f16x2 kernels' panels (the arithmetic that will run); `taps` > 5 exists there only
-int choose_nb(int U, int L, int* lds_out, bool h2 = false, int taps = 5) {
+int choose_nb(int U, int L, int* lds_out, bool h2 = false, int taps = 5, int range_layers = 0) {
     const int max_pos = tae::fused_max_positions();
     int nb = max_pos / L;
-    auto bytes = [&](int n) { return h2 ? tae::fused_lds_bytes_h(U, L, n, taps) : tae::fused_lds_bytes(U, L, n); };
+    auto bytes = [&](int n) { return h2 ? tae::fused_lds_bytes_h(U, L, n, taps, range_layers) : tae::fused_lds_bytes(U, L, n); };
     while (nb >= 1 && bytes(nb) > 160 * 1024) --nb;
     if (nb < 1) return 0;
     *lds_out = bytes(nb);
@@ -1178,7 +1181,7 @@ int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_
         P.wpack = reinterpret_cast<const float*>(h->d_wenc_h);
         P.stack_stride = h->enc_stride_h;
         P.wpack_bytes = h->enc_bytes_h;
-        P.lds_bytes = P.nb == h->nb ? h->lds_bytes_h : tae::fused_lds_bytes_h(h->U, h->cfg.block_len, P.nb, P.taps);
+        P.lds_bytes = P.nb == h->nb ? h->lds_bytes_h : tae::fused_lds_bytes_h(h->U, h->cfg.block_len, P.nb, P.taps, 3 * h->cfg.enc_num_layer);
         P.flags = h->d_flags;
         TAE_HIP(tae::launch_fused_h(h->U, false, P, grid, st));
     } else
@@ -1353,7 +1356,7 @@ int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStrea
         P.wpack = reinterpret_cast<const float*>(h->d_wdec_h);
         P.stack_stride = h->dec_stride_h;
         P.wpack_bytes = h->dec_bytes_h;
-        P.lds_bytes = P.nb == h->nbd ? h->lds_bytes_hd : tae::fused_lds_bytes_h(h->Ud, h->cfg.block_len, P.nb, P.taps);
+        P.lds_bytes = P.nb == h->nbd ? h->lds_bytes_hd : tae::fused_lds_bytes_h(h->Ud, h->cfg.block_len, P.nb, P.taps, 2 * h->cfg.num_iteration * h->cfg.dec_num_layer);
         P.flags = h->d_flags;
         TAE_HIP(tae::launch_fused_h(h->Ud, true, P, grid, st));
         return TAE_OK;
@@ -1387,6 +1390,8 @@ int upload_tails(tae_handle* h, bool decoder) {
     const std::vector<int>& A = decoder ? h->dec_A : h->enc_A;
     const std::vector<int>& Ax = decoder ? h->dec_Ax : h->enc_Ax;
     const std::vector<float>& low = decoder ? h->dec_low : h->enc_low;
+    const std::vector<float>& high = decoder ? h->dec_high : h->enc_high;
+    const std::vector<int>& kind = decoder ? h->dec_kind : h->enc_kind;
     const int nl = decoder ? h->cfg.dec_num_layer : h->cfg.enc_num_layer;
     char* base = decoder ? h->d_wdec_h : h->d_wenc_h;
     std::vector<float> t;
@@ -1394,7 +1399,7 @@ int upload_tails(tae_handle* h, bool decoder) {
         const int s = (int)i / nl, l = (int)i % nl;
         const int a_in = l == 0 ? Ax[s] : A[i - 1];
         const int a_out = l + 1 < nl ? A[i] : 0;               // the last layer feeds the Linear head in fp32: no panel, no scale
-        tail_values(tails[i], a_in, a_out, l + 1 < nl ? low[i] : 0.0f, t);
+        tail_values(tails[i], a_in, a_out, l + 1 < nl ? low[i] : 0.0f, l + 1 < nl ? high[i] : 65504.0f, kind[i], t);
         TAE_HIP(hipMemcpy(base + tails[i].off, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     return TAE_OK;
@@ -1454,6 +1459,8 @@ int calibrate_range(tae_handle* h, const float* u_user, const float* noise_user,
     if (h->dec_A.empty()) { h->dec_A.assign(h->dec_tails.size(), 0); h->dec_Ax.assign(do_dec ? n_stack : 0, 0); }
     h->enc_low.assign(h->enc_tails.size(), 0.0f);
     h->dec_low.assign(h->dec_tails.size(), 0.0f);
+    if (h->enc_high.empty()) { h->enc_high.assign(h->enc_tails.size(), 65504.0f); h->enc_kind.assign(h->enc_tails.size(), 0); }
+    if (h->dec_high.empty()) { h->dec_high.assign(h->dec_tails.size(), 65504.0f); h->dec_kind.assign(h->dec_tails.size(), 0); }
     std::vector<uint32_t> cal(cal_words(h));
     const size_t doff = cal_dec_offset(h);
     auto word = [&](size_t i) { float f; memcpy(&f, &cal[i], 4); return f; };
@@ -1504,9 +1511,20 @@ int calibrate_range(tae_handle* h, const float* u_user, const float* noise_user,
                 } else {
                     for (int l = 0; l + 1 < nl; ++l) {
                         const size_t i = (size_t)s * nl + l;
-                        const int a = range_exponent(word(o + 1 + i), A[i], &again);
+                        const float m = word(o + 1 + i);
+                        const int a = range_exponent(m, A[i], &again);
                         if (a != A[i]) moved = true;
                         A[i] = a;
+                        // ELU branch of the layer (turboae_h2.hip, TAE_ELU_MODE 2): all |x| <= 2^-5 -> polynomial, valid to |x| = 2^-3;
+                        // maximum below 1 -> both expm1 branches per value; else exp2 - 1 (3e-8 absolute = 2^-25 of a maximum >= 1)
+                        const bool ok = std::isfinite(m) && m > 0.0f;
+                        const int k = ok && m <= 0.03125f ? 1 : (ok && m < 1.0f ? 2 : 0);
+                        const float hi = k == 1 ? ldexpf(0.125f, a) : 65504.0f;
+                        std::vector<float>& H = decoder ? h->dec_high : h->enc_high;
+                        std::vector<int>& K = decoder ? h->dec_kind : h->enc_kind;
+                        if (H[i] != hi || K[i] != k) moved = true;
+                        H[i] = hi;
+                        K[i] = k;
                     }
                 }
                 if (ax != Ax[s]) moved = true;
@@ -1653,8 +1671,8 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         if (!strcmp(pe, "f32")) want_h2 = 0;
         else if (!strcmp(pe, "f16x2")) want_h2 = 1;
     }
-    h->nb = choose_nb(h->U, cfg->block_len, &h->lds_bytes, want_h2 != 0, taps_e);
-    h->nbd = choose_nb(h->Ud, cfg->block_len, &h->lds_bytes_d, want_h2 != 0, taps_d);
+    h->nb = choose_nb(h->U, cfg->block_len, &h->lds_bytes, want_h2 != 0, taps_e, 3 * cfg->enc_num_layer);
+    h->nbd = choose_nb(h->Ud, cfg->block_len, &h->lds_bytes_d, want_h2 != 0, taps_d, 2 * cfg->num_iteration * cfg->dec_num_layer);
     // Testing knobs (documented in DESIGN.md): TAE_FORCE_SEGMENTED=1 selects the long-block path even
     // when whole blocks fit; TAE_SEG_T=<n> caps the centre length of a segment.
     const char* force_seg = getenv("TAE_FORCE_SEGMENTED");
@@ -1710,8 +1728,8 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     std::vector<char> penc_h, pdec_h;
     bool h2_ok = false;
     if (want_h2 && h->nb >= 1) {
-        h->lds_bytes_h = tae::fused_lds_bytes_h(h->U, cfg->block_len, h->nb, taps_e);
-        h->lds_bytes_hd = tae::fused_lds_bytes_h(h->Ud, cfg->block_len, h->nbd, taps_d);
+        h->lds_bytes_h = tae::fused_lds_bytes_h(h->U, cfg->block_len, h->nb, taps_e, 3 * cfg->enc_num_layer);
+        h->lds_bytes_hd = tae::fused_lds_bytes_h(h->Ud, cfg->block_len, h->nbd, taps_d, 2 * cfg->num_iteration * cfg->dec_num_layer);
         h2_ok = h->lds_bytes_h <= 160 * 1024 && h->lds_bytes_hd <= 160 * 1024;
     } else if (want_h2) {               // long-block path: same segment geometry, f16x2 panels
         h->enc_lds_h = tae::seg_lds_bytes_h(h->U, h->enc_T, cfg->enc_num_layer, taps_e);

@@ -36,7 +36,7 @@ struct GeoH {
     static constexpr uint32_t SLB = CT * 2048u;         // bytes of A fragments per slab
     static constexpr uint32_t MIDB = NSL_MID * SLB;
     static constexpr uint32_t L0B = NSL_L0 * SLB;
-    static constexpr uint32_t TAILB = CP * 4u + 16u;    // bias + scale block after the fragments
+    static constexpr uint32_t TAILB = CP * 4u + 32u;    // bias + scale block (8 floats) after the fragments
 };
 
 // The same for a kernel size known at run time (5, 7, 9): the plain conv stacks take it from the launch parameters; the
@@ -57,7 +57,7 @@ __device__ __forceinline__ TapGeo tap_geo(int taps) {
 }
 
 constexpr int kXRowB = 16;        // bytes per row of an X plane (8 halves)
-constexpr int kRangeBytes = 32;   // PanelsH::RNG
+constexpr int kRangeHeaderB = 32, kRangeLayerB = 32;   // PanelsH::RNG: header + one row of per-wave maxima per (stack, layer) the workgroup runs
 constexpr int kXSlack = 3;        // extra rows of the X planes: the first layer's last slab over-reads up to 4 * nsl_l0 - 2 * pad - 2 <= 2 rows past the panel
 
 // one stack-input panel = two fp16 planes
@@ -97,9 +97,9 @@ struct PanelsH {
     int* INV;
     int* ROWT;       // [kHeadSlots] panel row of every position slot of the workgroup
     float* HS;
-    uint32_t* RNG;   // range bookkeeping (kRangeBytes): [0], [1] per-layer workgroup maxima by layer parity, [2] the staged stack inputs'
-                     // maximum (float bits); [4..5] the launch's flag word, [6..7] its calibration array (device pointers, parked here
-                     // so that they cost no scalar registers across the K loops)
+    uint32_t* RNG;   // range bookkeeping: [0..1] the launch's flag word, [2..3] its calibration array (device pointers, parked here so that
+                     // they cost no scalar registers across the K loops), [4] the staged stack inputs' maximum (float bits), then
+                     // [8 + 8 * layer + wave]: every wave's max |scaled ELU output| of (stack, layer) `layer`, checked once at the end
 };
 
 template <int U>
@@ -210,62 +210,142 @@ struct WeightStreamH {
 // that the layer's largest activation lands in [2^10, 2^11): 2^5 of headroom above, and every value down to 2^-13 of the
 // maximum keeps the full 2^-22 (the floor is then 2^-35 of the maximum - far below the fp32 accumulation noise of the dot
 // products that consume it).  The next layer's accumulators carry 2^(S + A_l) (its bias is pre-scaled, its 2^-(S + A_l) comes
-// from the packed tail), so the scale costs no instruction: ELU(a k) c = med3(a (k c), exp2(a (k log2 e)) c - c, 0).
+// from the packed tail), so the scale costs no instruction of its own: ELU(a k) c = med3(a (k c), expm1(a k) c, 0) with c folded
+// into the last operation of either expm1 branch.
 // Every scale is a power of two: results do not depend on A_l except where a value meets the floor or the ceiling.
 // At run time each layer's workgroup-wide maximum is checked against both ends (flags bit 0: above 65504, results invalid;
 // bit 1: below the threshold the host packs beside the scales - 2^3, i.e. the data sits >= 2^7 under the calibration maximum
 // and the pair is no longer fp32-grade).
 
 struct EluScale {
+    float inv;     // 2^-(S + A_in)           : accumulator -> value
     float k1;      // 2^-(S + A_in) * 2^A_out : accumulator -> scaled value
     float k2;      // 2^-(S + A_in) * log2(e) : accumulator -> exp2 argument
     float c;       // 2^A_out
 };
 
 struct RangeH {
-    uint32_t* slot;    // PanelsH::RNG
-    int cal_base;      // calibration launches: index of this stack's layer 0 in the calibration array
+    uint32_t* row;     // PanelsH::RNG row of this stack's layer 0 (8 words per layer: one per wave)
 };
 
 __device__ __forceinline__ void range_park(uint32_t* rng, uint32_t* flags, uint32_t* cal) {     // thread 0, before the first barrier
-    reinterpret_cast<uint32_t**>(rng + 4)[0] = flags;
-    reinterpret_cast<uint32_t**>(rng + 4)[1] = cal;
+    reinterpret_cast<uint32_t**>(rng)[0] = flags;
+    reinterpret_cast<uint32_t**>(rng)[1] = cal;
 }
-__device__ __forceinline__ uint32_t* range_flags(const uint32_t* rng) { return reinterpret_cast<uint32_t* const*>(rng + 4)[0]; }
-__device__ __forceinline__ uint32_t* range_cal(const uint32_t* rng) { return reinterpret_cast<uint32_t* const*>(rng + 4)[1]; }
+__device__ __forceinline__ uint32_t* range_flags(const uint32_t* rng) { return reinterpret_cast<uint32_t* const*>(rng)[0]; }
+__device__ __forceinline__ uint32_t* range_cal(const uint32_t* rng) { return reinterpret_cast<uint32_t* const*>(rng)[1]; }
+__device__ __forceinline__ uint32_t* range_rows(uint32_t* rng) { return rng + 8; }
 
 __device__ __forceinline__ void lds_max_bits(uint32_t* slot, float v) {
     using lds_u32 = uint32_t __attribute__((address_space(3)));
     __hip_atomic_fetch_max(reinterpret_cast<lds_u32*>((uint32_t)(uintptr_t)slot), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// thread 0, after the barrier that follows a layer's panel writes: the workgroup's maximum of the SCALED values of that layer.
-// `tail` = the layer's packed tail (2^-(S + A_in) | 2^A_out | low-side threshold | -)
-__device__ __forceinline__ void range_check_layer(const RangeH& rg, int l, const float* tail) {
-    uint32_t* s = rg.slot + (l & 1);
-    const float m = __uint_as_float(*s);
-    *s = 0u;
-    const uint32_t f = (!(m <= kH2Limit) ? 1u : 0u) | ((m < tail[2]) ? 2u : 0u);
-    uint32_t* flags = range_flags(rg.slot);
+// Maximum of a non-negative float over the 64 lanes as a wave-uniform bit pattern: four DPP steps inside the rows of 16, then the
+// four row results through scalar registers.  (Non-negative floats order like their bit patterns.)  A dozen instructions per
+// layer and wave - against the r04 first cut, an LDS atomic per lane plus a check by thread 0 behind the layer barrier: +8.6 %
+// decoder time (tools/ab_libs.sh, TAE_RANGE_BOOK builds): every layer's barrier waited for wave 0's dependent LDS / global reads.
+__device__ __forceinline__ uint32_t wave_max_bits(float x) {
+    int v = (int)__float_as_uint(x);
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false));     // quad_perm [1, 0, 3, 2]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false));     // quad_perm [2, 3, 0, 1]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false));    // row_half_mirror
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false));    // row_mirror
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return (uint32_t)max(max(a, b), max(c, d));
+}
+// after a layer's panel writes: park this wave's maximum of the SCALED values; nothing reads it before range_finish
+__device__ __forceinline__ void range_note_layer(const RangeH& rg, int l, float vmax) {
+    const uint32_t m = wave_max_bits(vmax);
+    if ((threadIdx.x & 63) == 0) rg.row[l * 8 + (threadIdx.x >> 6)] = m;
+}
+// End of the kernel, after a barrier: thread i checks (stack, layer) row i against the layer's packed tail (2^-(S + A_in) |
+// 2^A_out | low-side threshold | high-side threshold) - `tail_of(i)` returns it, or nullptr for a row that holds no panel.
+template <class TailOf>
+__device__ __forceinline__ void range_finish(uint32_t* rng, int n_rows, int cal_base, TailOf tail_of) {
+    const int i = threadIdx.x;
+    if (i >= n_rows) return;
+    const float* tail = tail_of(i);
+    if (tail == nullptr) return;
+    const uint32_t* r = range_rows(rng) + i * 8;
+    uint32_t mb = 0u;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) mb = max(mb, r[w]);
+    const float m = __uint_as_float(mb);
+    const uint32_t f = (!(m <= tail[3]) ? 1u : 0u) | ((m < tail[2]) ? 2u : 0u);
+    uint32_t* flags = range_flags(rng);
     if (f != 0u && flags != nullptr) atomicOr(flags, f);
-    uint32_t* cal = range_cal(rg.slot);
-    if (cal != nullptr) atomicMax(cal + rg.cal_base + l, __float_as_uint(m / tail[1]));
+    uint32_t* cal = range_cal(rng);
+    if (cal != nullptr) atomicMax(cal + cal_base + i, __float_as_uint(m / tail[1]));
 }
 
 // Layer epilogue for 4 accumulator values: ELU(acc * 2^-S') * 2^A, running max of |.| (range report), split into fp16
 // halves.  Scalar fp32 ops on purpose: the packed forms (v_pk_mul_f32 / v_pk_add_f32) measured 6 % slower
 // here.  No clamp: an out-of-range activation turns into inf / NaN halves and `vmax` reports it
 // (tae_range_status).
-__device__ __forceinline__ float elu_scaled(float a, const EluScale& s) {
+// TAE_ELU_MODE (A/B builds): 0 = exp2 only (r03: absolute error 3e-8 * c), 1 = both expm1 branches per value (elu1's own
+// arithmetic: +9 vector-ALU instructions per value, measured +7 % decoder time - the epilogues of the two waves of a SIMD
+// coincide behind the layer barrier, so their vector-ALU time is exposed), 2 (default) = the host picks per LAYER from the
+// layer's calibrated maximum M (tail[4]; calibrate_range in turboae_api.hip):
+//   kind 1, M <= 2^-5: x (1 + x/2 + x^2/6 + x^3/24) for both signs of x, no exp2 - truncation x^4/120 <= 1.3e-7 relative up to
+//     |x| = 1/16; the layer's high-side threshold is lowered to |x| = 1/8 (2e-6) so that data which outgrows the polynomial
+//     raises TAE_RANGE_HIGH instead of losing accuracy silently;
+//   kind 2, 2^-5 < M < 1: both branches per value (exact to fp32 rounding at any magnitude);
+//   kind 0, M >= 1: exp2 - 1, absolute error 3e-8 <= 2^-25 of the layer's largest value - what every O(1) network (the
+//     trained ones: layer maxima 0.5 .. 16) has always run, at the r03 cost.
+#ifndef TAE_ELU_MODE
+#define TAE_ELU_MODE 2
+#endif
+#ifndef TAE_RANGE_BOOK
+#define TAE_RANGE_BOOK 1     // A/B builds: 0 = no maxima, no range checks of the panels; 2 = the per-value maximum only (what r03 carried)
+#endif
+__device__ __forceinline__ float elu_scaled_exp(float a, const EluScale& s) {
     const float e = __builtin_fmaf(__builtin_amdgcn_exp2f(a * s.k2), s.c, -s.c);
     return __builtin_amdgcn_fmed3f(a * s.k1, e, 0.0f);
 }
+__device__ __forceinline__ float elu_scaled_poly(float a, const EluScale& s) {
+    const float x = a * s.inv, xs = a * s.k1;
+    float p = __builtin_fmaf(x, 1.0f / 24.0f, 1.0f / 6.0f);
+    p = __builtin_fmaf(x, p, 0.5f);
+    p = __builtin_fmaf(x, p, 1.0f);
+    return __builtin_amdgcn_fmed3f(xs, xs * p, 0.0f);          // x > 0: xs p > xs > 0 -> xs; x < 0: xs < xs p < 0 -> xs p
+}
+__device__ __forceinline__ float elu_scaled_both(float a, const EluScale& s) {      // elu1(a * inv) * c (turboae_device.hpp), the scale folded in
+    const float x = a * s.inv, xs = a * s.k1;
+    const float small = xs * expm1_poly(x);
+    const float big = __builtin_fmaf(__builtin_amdgcn_exp2f(a * s.k2), s.c, -s.c);
+    return __builtin_amdgcn_fmed3f(xs, x > kExpm1Switch ? small : big, 0.0f);
+}
+template <int KIND>      // 0: exp2 branch, 1: polynomial branch, 2: both per value
 __device__ __forceinline__ void elu_split4(f32x4 a, const EluScale& s, float& vmax, h4& hi, h4& lo) {
     f32x4 v;
-    if (!(TAE_X & 4)) { v.x = elu_scaled(a.x, s); v.y = elu_scaled(a.y, s); v.z = elu_scaled(a.z, s); v.w = elu_scaled(a.w, s); }
-    else v = a * s.k1;
+    if (TAE_X & 4) v = a * s.k1;
+    else if constexpr (KIND == 0) { v.x = elu_scaled_exp(a.x, s); v.y = elu_scaled_exp(a.y, s); v.z = elu_scaled_exp(a.z, s); v.w = elu_scaled_exp(a.w, s); }
+    else if constexpr (KIND == 1) { v.x = elu_scaled_poly(a.x, s); v.y = elu_scaled_poly(a.y, s); v.z = elu_scaled_poly(a.z, s); v.w = elu_scaled_poly(a.w, s); }
+    else { v.x = elu_scaled_both(a.x, s); v.y = elu_scaled_both(a.y, s); v.z = elu_scaled_both(a.z, s); v.w = elu_scaled_both(a.w, s); }
     vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     split4(v, hi, lo);
+}
+// Packed tail (CP bias values, then 2^-(S + A_in) | 2^A_out | low | high) of (stack, layer) row i of a plain conv network, or
+// nullptr for a stack's last layer (it feeds the Linear head: no panel).  Layout as pack_stack_h writes it.
+template <int U>
+__device__ __forceinline__ const float* plain_tail(const float* wpack, uint32_t stack_stride, int n_layer, int taps, int i) {
+    using G = GeoH<U>;
+    const int s = i / n_layer, l = i - s * n_layer;
+    if (l + 1 >= n_layer) return nullptr;
+    const TapGeo tg = tap_geo<U>(taps);
+    const uint32_t off = (uint32_t)s * stack_stride + tg.l0b + (uint32_t)l * (tg.midb + G::TAILB);
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(wpack) + off) + G::CP;
+}
+template <int U>
+__device__ __forceinline__ const float* dense_tail(const float* wpack, uint32_t soff, int n_layer, int l) {
+    using G = GeoH<U>;
+    if (l + 1 >= n_layer) return nullptr;
+    uint32_t off = soff;
+    for (int k = 0; k < l; ++k) off += G::L0B + (uint32_t)k * G::MIDB + G::TAILB;
+    off += G::L0B + (uint32_t)l * G::MIDB;
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(wpack) + off) + G::CP;
 }
 
 // One SameShapeConv1d stack (cnn_utils.py:36-46) + Linear head; same contract as run_stack in
@@ -310,7 +390,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
         }
         conv_accumulate_h<CTT, C0, NC, PT, 0>(acc, ws.a, ws.rsrc, ws.voff, lo, smem, bh, bl,
                                               first ? (l0_slabs > 0 ? l0_slabs : tg.nsl_l0) : tg.nsl_mid);
-        inv_scale = bias[G::CP];                   // tail: 2^-(S + A_in) | 2^A_out | low-side threshold | -
+        inv_scale = bias[G::CP];                   // tail: 2^-(S + A_in) | 2^A_out | low-side threshold | high-side threshold | ELU kind
         lo += fragb + G::TAILB;
         {
             const uint32_t nxt = (l + 1 < n_layer) ? lo : snext;
@@ -322,29 +402,42 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
 #pragma unroll
             for (int p = 0; p < PT; ++p) wrow[p] = tc.row(p);
             const float out_scale = bias[G::CP + 1];
-            const EluScale es{inv_scale * out_scale, inv_scale * 1.44269504088896341f, out_scale};
+            const EluScale es{inv_scale, inv_scale * out_scale, inv_scale * 1.44269504088896341f, out_scale};
             float vmax = 0.0f;
+            auto write_panel = [&](auto kind) {
+                constexpr int KIND = decltype(kind)::value;
 #pragma unroll
-            for (int p = 0; p < PT; ++p) {
+                for (int p = 0; p < PT; ++p) {
 #pragma unroll
-                for (int i = 0; i < NC; ++i) {
-                    h4 hi, lw;
-                    elu_split4(acc[p][i], es, vmax, hi, lw);
-                    // channels >= U exist only in the last channel tile (zero weights, zero bias -> ELU(0) = 0): they are
-                    // steered to the dump row instead of branching
-                    const int ch = (C0 + i) * 16 + 4 * q;
-                    const bool inb = (((C0 + i) * 16 + 16 <= U) || (ch < U)) && tc.ok(p);
-                    const int off = inb ? (wrow[p] * U + ch) * 2 : (dump_row * U + 4 * q) * 2;
-                    if (TAE_X & 2) asm volatile("" :: "v"(hi), "v"(lw));
-                    else {
-                        *reinterpret_cast<h4*>(pn.AH + off) = hi;
-                        *reinterpret_cast<h4*>(pn.AL + off) = lw;
+                    for (int i = 0; i < NC; ++i) {
+                        h4 hi, lw;
+                        elu_split4<KIND>(acc[p][i], es, vmax, hi, lw);
+                        // channels >= U exist only in the last channel tile (zero weights, zero bias -> ELU(0) = 0): they are
+                        // steered to the dump row instead of branching
+                        const int ch = (C0 + i) * 16 + 4 * q;
+                        const bool inb = (((C0 + i) * 16 + 16 <= U) || (ch < U)) && tc.ok(p);
+                        const int off = inb ? (wrow[p] * U + ch) * 2 : (dump_row * U + 4 * q) * 2;
+                        if (TAE_X & 2) asm volatile("" :: "v"(hi), "v"(lw));
+                        else {
+                            *reinterpret_cast<h4*>(pn.AH + off) = hi;
+                            *reinterpret_cast<h4*>(pn.AL + off) = lw;
+                        }
                     }
                 }
-            }
-            lds_max_bits(rg.slot + (l & 1), vmax);
+            };
+#if TAE_ELU_MODE == 2
+            const int kind = __builtin_amdgcn_readfirstlane((int)bias[G::CP + 4]);
+            if (kind == 0) write_panel(std::integral_constant<int, 0>{});
+            else if (kind == 1) write_panel(std::integral_constant<int, 1>{});
+            else write_panel(std::integral_constant<int, 2>{});
+#elif TAE_ELU_MODE == 1
+            write_panel(std::integral_constant<int, 2>{});
+#else
+            write_panel(std::integral_constant<int, 0>{});
+#endif
+            if (TAE_RANGE_BOOK == 1) range_note_layer(rg, l, vmax);
+            else if (TAE_RANGE_BOOK == 2) asm volatile("" :: "v"(vmax));      // A/B: the per-value maximum alone (as r03 carried it), no per-layer reduction
             if (!(TAE_X & 1)) __syncthreads();
-            if (threadIdx.x == 0) range_check_layer(rg, l, bias + G::CP);
         }
     }
     // ---- Linear head on the accumulators of the last conv layer, fp32 vector ALU (as in run_stack)
@@ -461,7 +554,7 @@ __device__ __forceinline__ void run_stack_h_dense(const char* __restrict__ wpack
                 char* PH = pn.AH + (size_t)l * pn.panel_bytes;
                 char* PL = PH + (pn.AL - pn.AH);
                 const float out_scale = tailf[1];
-                const EluScale es{inv_scale * out_scale, inv_scale * 1.44269504088896341f, out_scale};
+                const EluScale es{inv_scale, inv_scale * out_scale, inv_scale * 1.44269504088896341f, out_scale};
                 float vmax = 0.0f;
 #pragma unroll
                 for (int p = 0; p < PT; ++p) {
@@ -469,7 +562,7 @@ __device__ __forceinline__ void run_stack_h_dense(const char* __restrict__ wpack
 #pragma unroll
                     for (int i = 0; i < NC; ++i) {
                         h4 hi, lw;
-                        elu_split4(acc[p][i], es, vmax, hi, lw);
+                        elu_split4<2>(acc[p][i], es, vmax, hi, lw);       // both expm1 branches per value: dense stacks are a parity path, not a bench line
                         const int ch = (C0 + i) * 16 + 4 * q;
                         const bool inb = (((C0 + i) * 16 + 16 <= U) || (ch < U)) && tc.ok(p);
                         const int off = inb ? (wrow * U + ch) * 2 : (dump_row * U + 4 * q) * 2;
@@ -477,10 +570,9 @@ __device__ __forceinline__ void run_stack_h_dense(const char* __restrict__ wpack
                         *reinterpret_cast<h4*>(PL + off) = lw;
                     }
                 }
-                lds_max_bits(rg.slot + (l & 1), vmax);
+                range_note_layer(rg, l, vmax);
             }
             __syncthreads();
-            if (threadIdx.x == 0) range_check_layer(rg, l, tailf);
         }
     }
     // ---- Linear head (as run_stack_h)
@@ -588,7 +680,7 @@ __device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, con
         const XPlane Xin = (s & 1) ? pn.XB : pn.XA;
         const XPlane Xout = (s & 1) ? pn.XA : pn.XB;
         const int* ptab = (s & 1) ? pn.PERM : pn.INV;
-        const RangeH rg{pn.RNG, 1 + s * P.n_layer};
+        const RangeH rg{range_rows(pn.RNG) + s * P.n_layer * 8};
         if (s + 1 < n_stack) {
             run_stack_h<U, PT, C0, NC>(wpack, s * sstride, (s + 1) * sstride, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
                                        [&](int p, int f, float v) {
@@ -649,9 +741,9 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
         pn.XB.write(row, 1, r2);
     }
     report_range_x(vmax, P.x_inv, P.flags, P.cal ? P.cal + P.cal_r : nullptr);     // the received values have their own slot: x_low is relative to them
-    lds_max_bits(pn.RNG + 2, vmax);
+    lds_max_bits(pn.RNG + 4, vmax);
     __syncthreads();
-    if (tid == 0) range_check_inputs(pn.RNG + 2, P.x_low, P.flags);
+    if (tid == 0) range_check_inputs(pn.RNG + 4, P.x_low, P.flags);
 
     // The workgroup's position tiles are dealt out evenly over the 4 position groups and a group walks only its own
     // tiles (3 blocks of 100 = 19 tiles -> 5, 5, 5, 4; 2 blocks -> 4, 3, 3, 3; 1 block -> 2, 2, 2, 1): tiles that hold no
@@ -668,6 +760,8 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
         else dec_body_h<U, T, Split<U>::CTA, Split<U>::CTB, TAPS>(P, smem, pn, tc, gs.gt0, lane, blk0);
     };
     dispatch_tiles<PT>(gs.live, run);
+    // every stack ends with a barrier: all rows are in place.  Row i = (stack i / n_layer, layer i % n_layer); the last layer of a stack has no panel
+    if (TAE_RANGE_BOOK == 1) range_finish(pn.RNG, 2 * P.n_iter * P.n_layer, 1, [&](int i) { return plain_tail<U>(P.wpack, P.stack_stride, P.n_layer, P.taps, i); });
 }
 
 // =============================================================================================
@@ -685,7 +779,7 @@ __device__ __forceinline__ void enc_body_h(const FusedParams& P, char* smem, con
     const uint32_t sstride = P.stack_stride;
     for (int s = 0; s < 3; ++s) {
         const XPlane Xin = (s == 2) ? pn.XB : pn.XA;
-        const RangeH rg{pn.RNG, 1 + s * P.n_layer};
+        const RangeH rg{range_rows(pn.RNG) + s * P.n_layer * 8};
         run_stack_h<U, PT, C0, NC>(wpack, s * sstride, s < 2 ? (s + 1) * sstride : 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
                                    [&](int p, int f, float v) {
             if (f == 0) {
@@ -746,6 +840,8 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
         else enc_body_h<U, T, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, gs.gt0, lane, blk0, sum, sumsq);
     };
     dispatch_tiles<PT>(gs.live, run);
+    if (TAE_RANGE_BOOK == 1) range_finish(pn.RNG, 3 * P.n_layer, 1, [&](int i) { return plain_tail<U>(P.wpack, P.stack_stride, P.n_layer, P.taps, i); });
+    __syncthreads();         // the statistics scratch below aliases the panels, not the range rows - but keep the phases apart
     block_reduce_stats(smem, tid, sum, sumsq, P.partials);
 }
 
@@ -764,7 +860,7 @@ __device__ __forceinline__ void seg_body_h(const SegParams& P, char* smem, const
     const uint32_t soff = (uint32_t)stack * P.stack_stride;
     if (!DENSE) ws.prefetch(soff);
     const XPlane X = pn.XA;
-    const RangeH rg{pn.RNG, 1 + stack * P.n_layer};
+    const RangeH rg{range_rows(pn.RNG)};
     auto run = [&](auto epi) {
         if constexpr (DENSE) run_stack_h_dense<U, PT, C0, NC>(wpack, soff, P.n_layer, smem, pn, X, tc, g, lane, ws, rg, active, epi);
         else run_stack_h<U, PT, C0, NC>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, rg, epi, P.mode == 0 ? 1 : 0);
@@ -878,9 +974,9 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
     if (P.mode != 0) {
         report_range_x(vmax, 1.0f / xs, P.flags, P.cal ? P.cal + P.cal_r : nullptr);      // received values
         report_range_x(emax, 1.0f / xs, P.flags, P.cal ? P.cal + P.cal_x : nullptr);      // the previous stack's extrinsic values
-        lds_max_bits(pn.RNG + 2, vmax);
+        lds_max_bits(pn.RNG + 4, vmax);
         __syncthreads();
-        if (tid == 0) range_check_inputs(pn.RNG + 2, P.x_low, P.flags);
+        if (tid == 0) range_check_inputs(pn.RNG + 4, P.x_low, P.flags);
     }
 
     // tiles of the wave's position group: panel rows [2 + m] of the segment; `center` marks the positions this workgroup owns
@@ -926,7 +1022,13 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
         };
         dispatch_tiles<PT>(gs.live, run);
     }
-    if (P.mode == 0) block_reduce_stats(smem, tid, sum, sumsq, P.partials);
+    if (TAE_RANGE_BOOK == 1) {
+        // one stack per workgroup: rows 0 .. n_layer - 1; calibration slots of stack `stack`
+        const int nl = P.n_layer;
+        if (P.dense) range_finish(pn.RNG, nl, 1 + stack * nl, [&](int i) { return dense_tail<U>(P.wpack, (uint32_t)stack * P.stack_stride, nl, i); });
+        else range_finish(pn.RNG, nl, 1 + stack * nl, [&](int i) { return plain_tail<U>(P.wpack, P.stack_stride, nl, P.taps, stack * nl + i); });
+    }
+    if (P.mode == 0) { __syncthreads(); block_reduce_stats(smem, tid, sum, sumsq, P.partials); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -975,29 +1077,31 @@ hipError_t launch_seg_h(int U, const SegParams& P, int grid, hipStream_t st) {
 }
 
 int seg_lds_bytes_h(int U, int T, int n_layer, int taps) {
+    const int range_layers = n_layer;
     const int pad = taps / 2, rows = T + 2 * pad * n_layer + 3 + 2 * pad;
     size_t b = 2 * (size_t)(rows + 2) * U * 2 + 2 * (size_t)(rows + 1 + kXSlack) * kXRowB + (size_t)kHeadSlots * 4;
     b = (b + 15) & ~(size_t)15;
-    b += (size_t)kHeadSlots * 8 * 4 + kRangeBytes;     // head-combine scratch + range slots
+    b += (size_t)kHeadSlots * 8 * 4 + kRangeHeaderB + (size_t)range_layers * kRangeLayerB;     // head-combine scratch + range bookkeeping
     if (b < 2 * kThreads * sizeof(double)) b = 2 * kThreads * sizeof(double);
     return (int)b;
 }
 
 int seg_lds_bytes_h_dense(int U, int T, int n_layer) {
+    const int range_layers = n_layer;
     const int rows = T + 4 * n_layer + 3 + 4;
     const int npanel = n_layer > 1 ? n_layer - 1 : 1;
     size_t b = (size_t)npanel * 2 * (size_t)(rows + 2) * U * 2 + 2 * (size_t)(rows + 1 + kXSlack) * kXRowB + (size_t)kHeadSlots * 4;
     b = (b + 15) & ~(size_t)15;
-    b += (size_t)kHeadSlots * 8 * 4 + kRangeBytes;     // head-combine scratch + range slots
+    b += (size_t)kHeadSlots * 8 * 4 + kRangeHeaderB + (size_t)range_layers * kRangeLayerB;     // head-combine scratch + range bookkeeping
     if (b < 2 * kThreads * sizeof(double)) b = 2 * kThreads * sizeof(double);
     return (int)b;
 }
 
-int fused_lds_bytes_h(int U, int L, int nb, int taps) {
+int fused_lds_bytes_h(int U, int L, int nb, int taps, int range_layers) {
     const int pad = taps / 2, rows = nb * (L + pad) + pad;
     size_t b = 2 * (size_t)(rows + 2) * U * 2 + 4 * (size_t)(rows + 1 + kXSlack) * kXRowB + 2 * (size_t)L * 4 + (size_t)kHeadSlots * 4;
     b = (b + 15) & ~(size_t)15;
-    b += (size_t)kHeadSlots * 8 * 4 + kRangeBytes;     // head-combine scratch + range slots
+    b += (size_t)kHeadSlots * 8 * 4 + kRangeHeaderB + (size_t)range_layers * kRangeLayerB;     // head-combine scratch + range bookkeeping
     if (b < 2 * kThreads * sizeof(double)) b = 2 * kThreads * sizeof(double);
     return (int)b;
 }

@@ -117,7 +117,7 @@ hipError_t launch_seg(int U, const SegParams& P, int grid, hipStream_t st);
 int seg_lds_bytes(int U, int T, int n_layer);
 hipError_t launch_fused(int U, bool decoder, const FusedParams& P, int grid, hipStream_t st);       // P.tap_out != nullptr: tap-exporting decoder
 hipError_t launch_fused_h(int U, bool decoder, const FusedParams& P, int grid, hipStream_t st);
-int fused_lds_bytes_h(int U, int L, int nb, int taps = 5);
+int fused_lds_bytes_h(int U, int L, int nb, int taps, int range_layers);     // range_layers: (stack, layer) rows of range bookkeeping = stacks * layers of the side
 hipError_t launch_seg_h(int U, const SegParams& P, int grid, hipStream_t st);
 int seg_lds_bytes_h(int U, int T, int n_layer, int taps = 5);
 int seg_lds_bytes_h_dense(int U, int T, int n_layer);
