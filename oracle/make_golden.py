@@ -251,13 +251,31 @@ TRAINED_FP32_BATCHES = {2.0: 4, 4.0: 4, 6.0: 4, 8.0: 20}      # batches of 500 b
 TRAINED_FP32_SEED = 515151
 
 
-def trained_fp32(manifest, pt_path):
-    """Full-precision twin of trained(): the checkpoint's fp32 weights as they are (no fp16 rounding, so the hi/lo split of the
+TRAINED_KINDS = {
+    # manifest key / file stem -> (TurboAEConfig overrides, how the checkpoint was produced)
+    "trained_fp32": ({}, "enc2dec5_u100",
+                     "reference main.py trained in the build container (oracle/train_fixture.py)"),
+    "trained_enc5dec5_fp32": (dict(enc_num_layer=5), "enc5dec5_u100",
+                              "BASELINE configs[2]. reference main.py (oracle/train_chain.sh: 7 stages x 4 epochs, -batch_size 200 -num_block 4000 "
+                              "-num_train_enc 1 -num_train_dec 3 -enc_lr 2e-4 -dec_lr 2e-4, encoder at 2 dB, decoder at 0..2 dB), warm-started with "
+                              "-init_nw_weight from oracle/make_init_checkpoint.py enc5: the reference-trained enc2/dec5 network with three "
+                              "near-identity encoder layers inserted; every tensor was trained further by the reference's own optimisers"),
+    "trained_cnn_gru_fp32": (dict(decoder="TurboAE_rate3_rnn"), "cnn_gru_u100",
+                             "BASELINE configs[4]. reference main.py (oracle/train_chain.sh: 3 stages x 4 epochs, -decoder TurboAE_rate3_rnn "
+                             "-batch_size 100 -num_block 2000 -num_train_enc 0 -num_train_dec 5 -dec_lr 1e-3, decoder at 1..2 dB): the "
+                             "GRU decoder trained from torch's default init against the FIXED reference-trained enc2 encoder "
+                             "(oracle/make_init_checkpoint.py encoder_only)"),
+}
+
+
+def trained_fp32(manifest, pt_path, kind="trained_fp32"):
+    """A reference-trained checkpoint as a fixture: the fp32 weights as they are (no fp16 rounding, so the hi/lo split of the
     fp16-split kernels has non-zero lo halves for every weight and the per-layer 2^S scales see a trained network's dynamic
     range), 4 batches of 500 blocks per SNR point at 2 / 4 / 6 dB (200 000 bits per point: a BER difference of 1e-4 is 20 bit
-    errors) and 20 batches at 8 dB (10^6 bits at the low-BER end), hard decisions of the REAL reference for all of them, its x_dec for batch 0 of each point, and the per-stage
-    decoder taps of 4 blocks (reference_taps)."""
-    cfg = TurboAEConfig()
+    errors) and 20 batches at 8 dB (10^6 bits at the low-BER end), hard decisions of the REAL reference for all of them, its x_dec for batch 0 of each point, and - CNN decoders - the per-stage
+    decoder taps of 4 blocks (reference_taps).  kind: a key of TRAINED_KINDS (enc2/dec5, enc5/dec5 = BASELINE configs[2], CNN encoder + GRU decoder = configs[4])."""
+    over, stem, how = TRAINED_KINDS[kind]
+    cfg = TurboAEConfig(**over)
     obj = torch.load(pt_path, map_location="cpu", weights_only=False)
     sd = obj.state_dict() if hasattr(obj, "state_dict") else obj
     sd = W.check_state_dict(cfg, sd)
@@ -266,10 +284,12 @@ def trained_fp32(manifest, pt_path):
     model, _ = R.build_reference_model(cfg.to_dict(), B)
     R.load_weights(model, sd)
     out = {"weights_fp32": blob}
+    rnn = cfg.decoder == "TurboAE_rate3_rnn"
+    tol_x = 5e-5 if rnn else 5e-6          # the oracle builds torch.nn.GRU itself: same arithmetic, summed in PyTorch's order
     info = {"config": cfg.to_dict(), "batch": B, "n_batches": {f"{k:g}dB": v for k, v in TRAINED_FP32_BATCHES.items()},
             "input_seed": TRAINED_FP32_SEED, "snrs": list(TRAINED_FP32_SNRS),
             "bit_errors": {}, "block_errors": {}, "ber": {}, "oracle_vs_reference_max_abs": {},
-            "note": "reference main.py trained in the build container (oracle/train_fixture.py, " + os.path.basename(pt_path) + "); "
+            "note": how + " (" + os.path.basename(pt_path) + "); "
                     "inputs: Philox seed, blocks [i*500, (i+1)*500) of batch i, noise = sigma(snr) * N(0,1) of the same stream for every SNR"}
     w = O.to_torch(sd)
     for snr in TRAINED_FP32_SNRS:
@@ -278,16 +298,18 @@ def trained_fp32(manifest, pt_path):
         hard, be, ble, dmax = [], [], [], [0.0, 0.0]
         for i in range(NB):
             u, noise = make_inputs(B, L, snr, seed=TRAINED_FP32_SEED, offset=i * B)
-            if i == 0 and snr == TRAINED_FP32_SNRS[0]:
+            if i == 0 and snr == TRAINED_FP32_SNRS[0] and not rnn:
                 x_ref, c_ref, taps = reference_taps(model, cfg, u, noise)
                 out["dec_taps_first4"] = taps[:, :4]
                 out["codes_batch0"] = c_ref
             else:
                 x_ref, c_ref = R.reference_forward(model, u, noise)
+                if i == 0 and snr == TRAINED_FP32_SNRS[0]:
+                    out["codes_batch0"] = c_ref
             if i == 0:
                 x_or, c_or = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), w, cfg.to_dict())
                 dmax = [float(np.abs(x_ref - x_or.numpy()).max()), float(np.abs(c_ref - c_or.numpy()).max())]
-                assert dmax[1] <= 2e-6 and dmax[0] <= 5e-6, (snr, dmax)
+                assert dmax[1] <= 2e-6 and dmax[0] <= tol_x, (snr, dmax)
                 out[f"x_dec_batch0_{key}"] = x_ref
             a, b = O.error_counts(torch.from_numpy(u), torch.from_numpy(x_ref))
             be.append(a)
@@ -297,9 +319,9 @@ def trained_fp32(manifest, pt_path):
         info["bit_errors"][key], info["block_errors"][key] = be, ble
         info["ber"][key] = float(np.mean([a / (B * L) for a in be]))          # mean of batch means (trainer.py:176-177,215-216)
         info["oracle_vs_reference_max_abs"][key] = {"x_dec": dmax[0], "codes": dmax[1]}
-        print(f"trained_fp32 {key}: bit errors per batch {be}, blocks in error {ble}, BER {info['ber'][key]:.3e}, oracle dx={dmax[0]:.2e} dc={dmax[1]:.2e}")
-    np.savez_compressed(os.path.join(GOLD, "trained_enc2dec5_u100_fp32.npz"), **out)
-    manifest["trained_fp32"] = info
+        print(f"{kind} {key}: bit errors per batch {be}, blocks in error {ble}, BER {info['ber'][key]:.3e}, oracle dx={dmax[0]:.2e} dc={dmax[1]:.2e}", flush=True)
+    np.savez_compressed(os.path.join(GOLD, f"trained_{stem}_fp32.npz"), **out)
+    manifest[kind] = info
 
 
 def main():
@@ -311,8 +333,8 @@ def main():
             manifest = json.load(fh)
         manifest.setdefault("cases", {})
     only_trained = len(sys.argv) > 2 and sys.argv[1] == "--trained"
-    if len(sys.argv) > 2 and sys.argv[1] == "--trained-fp32":      # python oracle/make_golden.py --trained-fp32 <checkpoint.pt>
-        trained_fp32(manifest, sys.argv[2])
+    if len(sys.argv) > 2 and sys.argv[1] == "--trained-fp32":      # python oracle/make_golden.py --trained-fp32 <checkpoint.pt> [kind = key of TRAINED_KINDS]
+        trained_fp32(manifest, sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "trained_fp32")
         with open(mpath, "w") as fh:
             json.dump(manifest, fh, indent=1, sort_keys=True)
         return

@@ -124,14 +124,19 @@ def test_oracle_matches_reference_on_trained_weights():
     assert meta["ber"] == pytest.approx(1.44e-2, rel=0.05)
 
 
-def test_oracle_matches_reference_on_full_precision_trained_weights():
-    """trained_enc2dec5_u100_fp32.npz (weights NOT rounded to fp16; oracle/make_golden.py::trained_fp32): batch 0 at each SNR."""
+@pytest.mark.parametrize("kind,fname", [("trained_fp32", "trained_enc2dec5_u100_fp32.npz"),
+                                        ("trained_enc5dec5_fp32", "trained_enc5dec5_u100_fp32.npz"),
+                                        ("trained_cnn_gru_fp32", "trained_cnn_gru_u100_fp32.npz")])
+def test_oracle_matches_reference_on_full_precision_trained_weights(kind, fname):
+    """Reference-trained fp32 checkpoints (weights NOT rounded to fp16; oracle/make_golden.py::trained_fp32) of BASELINE's three
+    trained shapes - enc2/dec5, enc5/dec5 (configs[2]), CNN encoder + GRU decoder (configs[4]): batch 0 at each SNR."""
     from turboae_amd import philox
-    g = np.load(os.path.join(GOLD, "trained_enc2dec5_u100_fp32.npz"))
-    meta = MANIFEST["trained_fp32"]
+    g = np.load(os.path.join(GOLD, fname))
+    meta = MANIFEST[kind]
     cfg = TurboAEConfig(**meta["config"])
+    rnn = cfg.decoder == "TurboAE_rate3_rnn"
     sd = W.unpack_blob(cfg, g["weights_fp32"])
-    B, L, n = meta["batch"], cfg.block_len, 24        # encode the whole batch (power_constraint couples it), decode the first n blocks
+    B, L, n = meta["batch"], cfg.block_len, 8 if rnn else 24        # encode the whole batch (power_constraint couples it), decode the first n blocks
     w = O.to_torch(sd)
     p = torch.from_numpy(O.rand_interleaver(L, 0))
     u = philox.random_bits(meta["input_seed"], 0, B * L).reshape(B, L, 1)
@@ -143,16 +148,22 @@ def test_oracle_matches_reference_on_full_precision_trained_weights():
         key = f"{snr:g}dB"
         noise = (np.float32(O.snr_db2sigma(snr)) * z).astype(np.float32)
         taps = {}
+        rx = codes[:n] + torch.from_numpy(noise[:n])
         with torch.no_grad():
-            x = O.decode(codes[:n] + torch.from_numpy(noise[:n]), w, p, cfg.dec_num_layer, cfg.num_iteration, cfg.num_iter_ft, 1, taps)
-        assert np.abs(x.numpy() - g[f"x_dec_batch0_{key}"][:n]).max() <= 5e-6
+            if rnn:
+                x = O.decode_rnn(rx, w, p, cfg.dec_num_unit, cfg.num_iteration, cfg.num_iter_ft, 1)
+            else:
+                x = O.decode(rx, w, p, cfg.dec_num_layer, cfg.num_iteration, cfg.num_iter_ft, 1, taps)
+        xr = g[f"x_dec_batch0_{key}"][:n]
+        assert np.abs(x.numpy() - xr).max() <= (5e-5 if rnn else 5e-6)
         hard_ref = np.unpackbits(g[f"hard_bits_{key}"])[: n * L].reshape(n, L)
-        assert np.array_equal((x.numpy()[:, :, 0] > 0.5).astype(np.uint8), hard_ref)
-        if snr == meta["snrs"][0]:
+        flips = (x.numpy()[:, :, 0] > 0.5).astype(np.uint8) != hard_ref
+        assert np.all(np.abs(xr[:, :, 0][flips] - 0.5) < 1e-4) and flips.sum() <= (1 if rnn else 0)
+        if snr == meta["snrs"][0] and not rnn:
             for it in range(cfg.num_iteration - 1):
                 ref_prior = O.deinterleave(torch.from_numpy(g["dec_taps_first4"][2 * it + 1]), p)
                 assert float((ref_prior - taps[f"prior_{it}"][:4]).abs().max()) <= 5e-6
-    assert meta["ber"]["6dB"] < 0.1 * meta["ber"]["2dB"]
+    assert meta["ber"]["6dB"] < 0.1 * meta["ber"]["2dB"] and meta["ber"]["2dB"] < 2e-2
 
 
 # ---- randomised pin: oracle == REAL reference on the configuration space the GPU fuzz walks (oracle/fuzz_vs_reference.py)

@@ -255,10 +255,28 @@ __device__ __forceinline__ uint32_t wave_max_bits(float x) {
     const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
     return (uint32_t)max(max(a, b), max(c, d));
 }
-// after a layer's panel writes: park this wave's maximum of the SCALED values; nothing reads it before range_finish
+// after a layer's panel writes: park this wave's maximum of the SCALED values; nothing reads it before range_finish.
+// TAE_WAVE_REDUCE 1: reduce inside the rows of 16 with DPP, then the four row leaders meet in the wave's slot with an LDS max
+// (4 lanes, no scalar round trip); 0: the full reduction to a scalar and one plain store.
+#ifndef TAE_WAVE_REDUCE
+#define TAE_WAVE_REDUCE 1
+#endif
 __device__ __forceinline__ void range_note_layer(const RangeH& rg, int l, float vmax) {
+#if TAE_WAVE_REDUCE
+    int v = (int)__float_as_uint(vmax);
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false));
+    if ((threadIdx.x & 15) == 0) {
+        using lds_u32 = uint32_t __attribute__((address_space(3)));
+        __hip_atomic_fetch_max(reinterpret_cast<lds_u32*>((uint32_t)(uintptr_t)(rg.row + l * 8 + (threadIdx.x >> 6))), (uint32_t)v,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#else
     const uint32_t m = wave_max_bits(vmax);
     if ((threadIdx.x & 63) == 0) rg.row[l * 8 + (threadIdx.x >> 6)] = m;
+#endif
 }
 // End of the kernel, after a barrier: thread i checks (stack, layer) row i against the layer's packed tail (2^-(S + A_in) |
 // 2^A_out | low-side threshold | high-side threshold) - `tail_of(i)` returns it, or nullptr for a row that holds no panel.
