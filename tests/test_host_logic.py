@@ -137,3 +137,53 @@ def test_variant_configs_and_param_counts():
     with pytest.raises(ValueError):
         TurboAEConfig(channel="nope").validate()
     TurboAEConfig(channel="fading").validate()
+
+
+# ---- static ISA hazard audit (tools/isa_audit.py) -----------------------------------------------------------
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+def _isa_audit():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(ROOT, "tools", "isa_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_isa_audit_is_clean_on_the_built_library():
+    """One MFMA shape per kernel, no scratch on the kernels the bench times, no memory instruction in inline assembly - on the
+    library as built (the code objects inside libturboae_hip.so and their metadata), in a few seconds."""
+    A = _isa_audit()
+    if not A.tools_available() or not os.path.isfile(A.DEFAULT_LIB):
+        pytest.skip("needs the ROCm llvm tools and the built library")
+    res = A.audit_binary(A.DEFAULT_LIB)
+    assert res["violations"] == [], res["violations"]
+    assert A.audit_sources() == []
+    names = list(res["kernels"])
+    for prefix in A.BENCH_KERNELS:                       # every bench kernel was actually found (a renamed kernel must not drop out of rule ii)
+        assert any(n.startswith(prefix) for n in names), prefix
+    k = res["kernels"][[n for n in names if n.startswith("tae::dec_kernel_h<100, 5, false>")][0]]
+    assert list(k["mfma"]) == ["v_mfma_f32_16x16x32_f16"] and k["scratch"] == 0 and k["vgpr"] <= 256
+
+
+def test_isa_audit_flags_a_mixed_shape_kernel_and_inline_asm_loads(tmp_path):
+    """Red cases: the isolated gfx950 hazard (tools/probes/mfma_mixed_shape_hazard.hip mixes 16x16x32 and 16x16x16 f16 MFMAs on
+    purpose) must be reported by rule (i); a source with a hand-issued global_load by rule (iii)."""
+    import shutil
+    import subprocess
+    A = _isa_audit()
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not A.tools_available() or not os.path.isfile(hipcc):
+        pytest.skip("needs hipcc and the ROCm llvm tools")
+    obj = str(tmp_path / "mixed.o")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-c", os.path.join(ROOT, "tools", "probes", "mfma_mixed_shape_hazard.hip"), "-o", obj])
+    res = A.audit_binary(obj)
+    assert any(v.startswith("(i) mixed MFMA shapes") for v in res["violations"]), res
+    src = tmp_path / "csrc"
+    src.mkdir()
+    (src / "bad.hip").write_text('__device__ void f(float* p, float& v) {\n    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p));\n'
+                                 '    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(v));\n}\n')
+    bad = A.audit_sources(str(src))
+    assert len(bad) == 1 and "global_load" in bad[0] and "bad.hip:2" in bad[0], bad

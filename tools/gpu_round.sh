@@ -27,7 +27,8 @@ print("parity:", p)
 PY
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity --no-other-configs --no-probe > $OUT/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity --no-other-configs --no-probe --no-graph --no-sweep > $OUT/prof_$TAG.log 2>&1
+python $R/tools/trace_summary.py $OUT/prof_$TAG $OUT/prof_${TAG}_by_grid.txt
 f=$(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -14 "$f"
 if [ "${PROF_CFG:-0}" = "1" ]; then     # kernel traces of the long-block (cfg 4 shape) and GRU (cfg 5) configurations
@@ -35,6 +36,6 @@ if [ "${PROF_CFG:-0}" = "1" ]; then     # kernel traces of the long-block (cfg 4
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_cfg5 -o cfg5 -- python $R/tools/quick_bench_cfg.py 100 16384 2 TurboAE_rate3_rnn > $OUT/prof_${TAG}_cfg5.log 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_cfg2 -o cfg2 -- python $R/tools/quick_bench_cfg.py 100 100000 5 > $OUT/prof_${TAG}_cfg2.log 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_cfg0 -o cfg0 -- python $R/tools/quick_bench_cfg.py 100 500 2 > $OUT/prof_${TAG}_cfg0.log 2>&1
-  for c in cfg4 cfg5 cfg2 cfg0; do f=$(find $OUT/prof_${TAG}_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { echo "== $c"; head -6 "$f"; }; done
+  for c in cfg4 cfg5 cfg2 cfg0; do f=$(find $OUT/prof_${TAG}_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { echo "== $c"; head -6 "$f"; }; python $R/tools/trace_summary.py $OUT/prof_${TAG}_$c $OUT/prof_${TAG}_${c}_by_grid.txt > /dev/null; done
 fi
 if [ "${PMC:-0}" = "1" ]; then cd $R; bash tools/gpu_pmc.sh $TAG; fi

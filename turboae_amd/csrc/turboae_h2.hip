@@ -140,8 +140,11 @@ struct TileH {
     }
     __device__ __forceinline__ bool ok(int p) const { return (valid >> p) & 1u; }
     __device__ __forceinline__ bool own(int p) const { return (center >> p) & 1u; }
-    __device__ __forceinline__ int blk(int p) const { return (m0 + 16 * p) / L; }
-    __device__ __forceinline__ int t(int p) const { const int m = m0 + 16 * p; return m - (m / L) * L; }
+    // block / index-in-block of tile p's position: recomputed where they are used (the head epilogues, once per stack) - computed
+    // once and kept, the ten values are loop-invariant across the stack loop and were what the register allocator spilled
+    __device__ __forceinline__ int mpos(int p) const { int m = m0 + 16 * p; asm volatile("" : "+v"(m)); return m; }
+    __device__ __forceinline__ int blk(int p) const { return mpos(p) / L; }
+    __device__ __forceinline__ int t(int p) const { const int m = mpos(p); return m - (m / L) * L; }
     __device__ __forceinline__ int rowbase(int p) const { return blk(p) * (L + pad) + pad; }
 };
 
@@ -341,7 +344,14 @@ __device__ __forceinline__ void elu_split4(f32x4 a, const EluScale& s, float& vm
     if (TAE_X & 4) v = a * s.k1;
     else if constexpr (KIND == 0) { v.x = elu_scaled_exp(a.x, s); v.y = elu_scaled_exp(a.y, s); v.z = elu_scaled_exp(a.z, s); v.w = elu_scaled_exp(a.w, s); }
     else if constexpr (KIND == 1) { v.x = elu_scaled_poly(a.x, s); v.y = elu_scaled_poly(a.y, s); v.z = elu_scaled_poly(a.z, s); v.w = elu_scaled_poly(a.w, s); }
-    else { v.x = elu_scaled_both(a.x, s); v.y = elu_scaled_both(a.y, s); v.z = elu_scaled_both(a.z, s); v.w = elu_scaled_both(a.w, s); }
+    else {
+        // the rare branch (layer maxima in (2^-5, 1)): one value at a time - interleaved four deep, its temporaries were what
+        // pushed three registers of the decoder into scratch
+        v.x = elu_scaled_both(a.x, s); __builtin_amdgcn_sched_barrier(0);
+        v.y = elu_scaled_both(a.y, s); __builtin_amdgcn_sched_barrier(0);
+        v.z = elu_scaled_both(a.z, s); __builtin_amdgcn_sched_barrier(0);
+        v.w = elu_scaled_both(a.w, s); __builtin_amdgcn_sched_barrier(0);
+    }
     vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     split4(v, hi, lo);
 }
