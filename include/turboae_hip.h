@@ -201,7 +201,7 @@ TAE_API int tae_generate_inputs(tae_handle* h, float* u, float* noise, int32_t B
  * (channels.py:7-109, the test_sigma != 'default' branches trainer.test uses, trainer.py:167-169) and, for -channel fading, the
  * Rayleigh coefficients Channel_AE.forward draws itself (channel_ae.py:51-56).  Counter-based: every value is a function of
  * (seed, global element index ((first_block + b) * L + t) * 3 + c) on named Philox streams (turboae_amd/philox.py; the numpy mirror
- * turboae_amd/channels.py::generate_noise_host reproduces the draws), so any shard of any batch can be drawn on any rank. */
+ * turboae_amd/channels.py::generate_noise reproduces the draws), so any shard of any batch can be drawn on any rank. */
 #define TAE_NOISE_AWGN 0      /* sigma * N(0,1)                                                     channels.py:37-38 (== tae_generate_inputs' noise) */
 #define TAE_NOISE_TDIST 1     /* sigma * sqrt((vv-2)/vv) * standard_t(vv)                           channels.py:40-41 */
 #define TAE_NOISE_RADAR 2     /* sigma * N(0,1) + radar_power * N(0,1) * Bernoulli(radar_prob)      channels.py:43-49 */

@@ -168,3 +168,27 @@ def test_range_fallback_reruns_on_fp32_kernels(gpu_device):
     assert np.abs(codes.cpu().numpy() - co.numpy()).max() <= 1e-5
     xd2, _ = model(ut, nt)                                          # stays on the fp32 kernels
     assert torch.equal(xd2, xd)
+
+
+def test_generic_path_takes_batches_beyond_the_grid_y_limit(gpu_device):
+    """gen_conv_kernel rides the block index in grid.y (HIP: <= 65535).  70 000 tiny blocks on a configuration only the
+    generic kernels run (width 101): the call succeeds, the blocks past the limit equal a small call on the same blocks bit for bit
+    (blocks never interact), and a subsample matches the oracle."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(block_len=6, enc_num_unit=101, dec_num_unit=101, enc_num_layer=1, dec_num_layer=1, num_iteration=1)
+    assert cfg.generic
+    sd = W.generate_state_dict(cfg, seed=31, gain=1.0)
+    B = 70000
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    u, noise = model.generate_inputs(B, 2.0, seed=3)
+    x_dec, codes = model(u, noise)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(x_dec).all())
+    rx = codes + noise
+    for lo, hi in ((0, 9), (65530, 65545), (B - 5, B)):
+        assert torch.equal(model.dec(rx[lo:hi].contiguous()), x_dec[lo:hi]), (lo, hi)
+    idx = torch.tensor([0, 65534, 65535, 65536, B - 1], device=gpu_device)
+    p = torch.from_numpy(O.rand_interleaver(cfg.block_len, 0))
+    with torch.no_grad():
+        xo = O.decode(rx[idx].cpu(), O.to_torch(sd), p, cfg.dec_num_layer, cfg.num_iteration, cfg.num_iter_ft)
+    assert float((x_dec[idx].cpu() - xo).abs().max()) <= 2e-5

@@ -395,7 +395,7 @@ class Channel_AE_HIP:
             return noise
         if fading is None:
             raise ValueError("channel='fading' needs the fading coefficients (the reference draws them inside forward, "
-                             "channel_ae.py:51-56; turboae_amd.channels.rayleigh_fading generates them)")
+                             "channel_ae.py:51-56; Channel_AE_HIP.generate_noise(B, test_sigma, seed) returns (noise, fading) on the device)")
         fh = e._in(fading, 3, "fading")
         if fh.shape != noise.shape:
             raise ValueError("fading and fwd_noise shapes differ")

@@ -1019,7 +1019,6 @@ int make_noise_gen(const tae_noise_opts* o, float test_sigma, tae::NoiseGen* g) 
     g->p = mask ? test_sigma : 0.0f;
     g->s_good = (float)pow(10.0, -(snr_back + 1.0) / 20.0);
     g->s_bad = (float)pow(10.0, -(snr_back - 1.0) / 20.0);
-    g->t_scale = 0.0f;
     g->vv = o->vv; g->radar_prob = o->radar_prob; g->radar_power = o->radar_power; g->p_gg = o->p_gg; g->p_bb = o->p_bb;
     return TAE_OK;
 }

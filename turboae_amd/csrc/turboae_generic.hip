@@ -239,8 +239,9 @@ bool generic_dec_dense(const tae_config* c) {
 }
 
 bool generic_needed(const tae_config* c) {
-    // TAE_FORCE_GENERIC=1 (testing knob, read per call): run ANY configuration on the generic kernels - a third, independent
-    // implementation to hold against the two MFMA arithmetics (tests/test_gpu_generic.py)
+    // TAE_FORCE_GENERIC=1 (testing knob): run ANY configuration on the generic kernels - a third, independent implementation to hold
+    // against the two MFMA arithmetics (tests/test_gpu_generic.py).  Read per call on purpose (the tests flip it between handles); a
+    // handle's own choice is made once, in tae_create, and tae_create re-checks the blob size under the value it sees
     if (const char* e = getenv("TAE_FORCE_GENERIC")) if (e[0] == '1') return true;
     const bool big_k = c->enc_kernel_size > 9 || c->dec_kernel_size > 9;
     const bool mid_k = c->enc_kernel_size > 5 || c->dec_kernel_size > 5;
@@ -423,10 +424,17 @@ int generic_reserve(GenericEngine* g, int32_t B) {
 
 static hipError_t conv(const GenericEngine* g, const ConvL& C, const float* x, int ldx, float* y, int ldy, int coff, int act, int B, hipStream_t st) {
     const int L = g->cfg.block_len;
-    const dim3 grid((L + kConvPos - 1) / kConvPos, B, (C.cout + kConvCh - 1) / kConvCh);
     const size_t lds = (size_t)(kConvPos + C.k - 1) * kConvCi * sizeof(float);
-    hipLaunchKernelGGL(gen_conv_kernel, grid, dim3(256), lds, st, x, ldx, C.cin, g->d_w + C.wt, g->d_w + C.bias, y, ldy, coff, C.cout, C.k, L, act);
-    return hipGetLastError();
+    // the block index rides in grid.y, which HIP caps at 65535: larger batches go out in slices
+    for (int b0 = 0; b0 < B; b0 += 65535) {
+        const int nb = B - b0 < 65535 ? B - b0 : 65535;
+        const dim3 grid((L + kConvPos - 1) / kConvPos, nb, (C.cout + kConvCh - 1) / kConvCh);
+        hipLaunchKernelGGL(gen_conv_kernel, grid, dim3(256), lds, st, x + (size_t)b0 * L * ldx, ldx, C.cin, g->d_w + C.wt, g->d_w + C.bias,
+                           y + (size_t)b0 * L * ldy, ldy, coff, C.cout, C.k, L, act);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // one stack: x (B, L, cin0) -> o (B, L, nout) = Linear(stack(x)); returns through g->d_o

@@ -491,7 +491,8 @@ hipError_t launch_gru_rec_h(bool layer0, const GruRecParams& P, hipStream_t st) 
     const int lds = gru_rec_h_lds_bytes(layer0);
     int nw = 8;
     while (nw > 1 && 2 * ((P.B + 16 * nw - 1) / (16 * nw)) < 256) nw >>= 1;
-    if (const char* e = getenv("TAE_GRU_NW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) nw = v; }   // experiments
+    static const int nw_env = [] { const char* e = getenv("TAE_GRU_NW"); return e ? atoi(e) : 0; }();     // experiments: read once
+    if (nw_env == 1 || nw_env == 2 || nw_env == 4 || nw_env == 8) nw = nw_env;
     const dim3 grid((P.B + 16 * nw - 1) / (16 * nw), 2);
     const void* fn = layer0 ? reinterpret_cast<const void*>(gru_rec_h_kernel<true>) : reinterpret_cast<const void*>(gru_rec_h_kernel<false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -138,7 +138,6 @@ struct NoiseGen {
     float sigma;               // additive kinds: 10^(-test_sigma / 20)
     float p;                   // bec / bsc: erase / flip probability; ge: P(1) in the bad state
     float s_good, s_bad;       // ge_awgn: sigma one dB up / one dB down
-    float t_scale;             // t-dist: sigma * sqrt((vv - 2) / vv)
     float vv, radar_prob, radar_power, p_gg, p_bb;
 };
 hipError_t launch_gen_noise(const NoiseGen& g, float* noise, float* fading, size_t n_blocks, size_t first_block, int L,

@@ -702,7 +702,7 @@ __global__ void gen_inputs_kernel(float* __restrict__ u, float* __restrict__ noi
 
 // Test-time noise of the reference's other channels on the device (replaces generate_noise, channels.py:37-109, and the fading
 // coefficients of channel_ae.py:51-56).  Every value is a function of (seed, global element index e = ((block * L) + t) * 3 + c) on
-// named Philox streams; turboae_amd/channels.py::generate_noise_host is the numpy mirror.  fp64 inside, one rounding to fp32.
+// named Philox streams; turboae_amd/channels.py::generate_noise is the numpy mirror.  fp64 inside, one rounding to fp32.
 // chi-square with vv degrees of freedom = 2 * Gamma(vv / 2), Marsaglia-Tsang (shape >= 1 because vv > 2), attempt k of element e
 // draws Philox counter (e, STREAM_GAMMA, k): normal from words 0, 1, uniform from word 2.
 __device__ __forceinline__ double chi_square_at(unsigned long long seed, uint64_t e, double vv) {
