@@ -313,6 +313,61 @@ def sweep_cfg1(sd, dev):
     return out
 
 
+def pmc_child(batch: int, block_len: int, snr: float, precision: str) -> None:
+    """`bench.py --pmc-child`: what the two rocprofv3 --pmc passes of measure_traffic_pmc profile - the benchmark's own decoder launch
+    (trained weights, `batch` resident blocks), one warm-up + two more dispatches, nothing else at full size."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    cfg = TurboAEConfig(block_len=block_len, precision=precision)
+    sd = W.unpack_blob(TurboAEConfig(), np.load(TRAINED)["weights_fp32"]) if os.path.isfile(TRAINED) else W.generate_state_dict(cfg, seed=SEED, gain=1.0)
+    model = Channel_AE_HIP(cfg, sd, device=dev, max_batch=batch)
+    u, noise = model.generate_inputs(batch, snr, seed=SEED)
+    x_tx, stats = model.encode_prenorm(u)
+    _, rx = model.normalize(x_tx, stats, noise, want_codes=False)
+    for _ in range(3):
+        model.dec(rx)
+    torch.cuda.synchronize()
+
+
+def measure_traffic_pmc(batch: int, block_len: int, snr: float, precision: str, kernel_substr: str, timeout_s: float = 180.0):
+    """HBM-side bytes per full-size decoder launch, measured NOW on this box: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE:
+    they do not fit one pass, MI355X_MICROARCH.md) over `bench.py --pmc-child`, counters averaged over the full-size dispatches of the
+    decoder kernel (largest grid), FETCH_SIZE doubled as the guide's gfx950 note prescribes.  Returns a dict or raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.isfile(rocprof):
+        raise RuntimeError("rocprofv3 not found")
+    vals = {}
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", td, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--batch", str(batch), "--block-len", str(block_len), "--snr", str(snr), "--precision", precision]
+            subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                raise RuntimeError(f"rocprofv3 wrote no counter file for {counter}")
+            rows = [r for r in csv.DictReader(open(files[0])) if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if not rows:
+                raise RuntimeError(f"no {kernel_substr} dispatch in the {counter} pass")
+            gmax = max(int(r.get("Grid_Size", 0) or 0) for r in rows)
+            full = [float(r["Counter_Value"]) for r in rows if int(r.get("Grid_Size", 0) or 0) == gmax]
+            vals[counter] = (sum(full) / len(full), len(full))
+    fetch_kb, write_kb = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+    return {"bytes_per_launch": fetch_kb * 1024.0 * 2.0 + write_kb * 1024.0, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+            "fetch_correction": 2.0, "dispatches_averaged": vals["FETCH_SIZE"][1],
+            "how": "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE as two separate passes over `bench.py --pmc-child` (the same "
+                   "decoder launch: trained weights, same batch), mean over the full-size dispatches; FETCH_SIZE x 2 (gfx950 tallies 128-B "
+                   "requests at 64 B, MI355X_MICROARCH.md HBM section); Infinity-Cache hits are counted by these counters"}
+
+
 def relaunch_distributed(n: int) -> int:
     """`python bench.py --gpus N` without a torch.distributed environment: start N ranks of this script, one per GPU, exactly as
     the driver's documented launch line does; the exit code of the launcher is returned."""
@@ -347,11 +402,16 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph-replay variant of the timed pass (graph_replay)")
     ap.add_argument("--no-sweep", action="store_true", help="skip BASELINE configs[1] as quoted, the 12-point sweep (sweep_cfg1)")
     ap.add_argument("--graph-replays", type=int, default=20)
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child passes (falls back to the committed figure, labelled)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=75.0, help="wall-time bound of the CPU leg in seconds")
     ap.add_argument("--precision", choices=("auto", "f32"), default="auto",
                     help="auto: fp16-split MFMA contraction (fp32-grade, DESIGN.md 3.7); f32: v_mfma_f32_16x16x4_f32")
     args = ap.parse_args()
 
+    if args.pmc_child:
+        pmc_child(args.batch, args.block_len, args.snr, args.precision)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -517,6 +577,16 @@ def main():
     if args.precision == "auto" and not args.no_f32_pass and main_res["mode"] == "f16x2":
         f32_res, f32_par = timed_pass("f32")
 
+    pmc_live = {}
+    if rank == 0 and world == 1 and not args.no_pmc and trained and args.enc_layers == 2:
+        for is_h2, res, prec, kn in ((True, main_res if main_res["mode"] == "f16x2" else None, "auto", "dec_kernel_h" if L <= 320 else "seg_kernel_h"),):
+            if res is None:
+                continue
+            try:
+                torch.cuda.synchronize()
+                pmc_live[is_h2] = measure_traffic_pmc(B, L, args.snr, prec, kn)
+            except Exception as e:            # a side measurement: never takes the headline line down
+                pmc_live[is_h2] = f"{type(e).__name__}: {e}"
     if rank == 0:
         steps = args.steps
         elapsed = main_res["elapsed"]
@@ -536,18 +606,26 @@ def main():
             kname = "tae::dec_kernel_h<100,5> (fused 6-iteration decoder, fp16-split MFMA)" if is_h2 else "tae::dec_kernel<100,5> (fused 6-iteration decoder, fp32 MFMA)"
             if nb == 0:        # long blocks: the decoder is 2 * num_iteration launches of the segment kernel; `kernel_ms` covers all of them
                 kname = ("tae::seg_kernel_h<100,5>" if is_h2 else "tae::seg_kernel<100,5>") + f" x {2 * cfg.num_iteration} launches (one conv stack each, long-block decoder)"
-            pmc_dir = next((d for d in (("r03_pmc_f16x2", "r02_pmc_f16x2") if is_h2 else ("r01_pmc",))
-                            if os.path.isfile(os.path.join(ROOT, "profiles", d, "traffic.json"))), "r01_pmc")
-            # HBM-side traffic of the decoder kernel from the committed PMC passes (rocprofv3 cannot run inside
-            # this process): bytes per block measured at the same workload, scaled to this launch's blocks
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", pmc_dir, "traffic.json")
-            if os.path.isfile(tpath) and cfg.enc_num_layer == 2 and L == 100:
-                with open(tpath) as fh:
-                    traffic = json.load(fh)["bytes_per_block"] * B / 1e9
+            # HBM-side traffic of the decoder launch: measured in THIS run by two rocprofv3 --pmc child passes (measure_traffic_pmc);
+            # if that is not possible here (no rocprofv3, N > 1, --no-pmc) the figure of the committed PMC passes, labelled as such
+            traffic, traffic_how = None, None
+            live = pmc_live.get(is_h2)
+            if isinstance(live, dict):
+                traffic, traffic_how = live["bytes_per_launch"] / 1e9, live
+            else:
+                pmc_dir = next((d for d in (("r04_pmc_f16x2", "r03_pmc_f16x2", "r02_pmc_f16x2") if is_h2 else ("r01_pmc",))
+                                if os.path.isfile(os.path.join(ROOT, "profiles", d, "traffic.json"))), "r01_pmc")
+                tpath = os.path.join(ROOT, "profiles", pmc_dir, "traffic.json")
+                if os.path.isfile(tpath) and cfg.enc_num_layer == 2 and L == 100:
+                    with open(tpath) as fh:
+                        traffic = json.load(fh)["bytes_per_block"] * B / 1e9
+                    traffic_how = {"how": f"NOT measured in this run ({live or 'not attempted'}): bytes per block of the committed PMC passes "
+                                          f"profiles/{pmc_dir}/traffic.json scaled to this launch"}
+            algorithmic_gb = (B * L * 16 + 4.0 * W.num_params(cfg)) / 1e9          # received 12 B + x_dec 4 B per bit, the weights once
             return {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                     "frac": achieved / peak, "traffic": traffic,
-                    "traffic_unit": f"GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{pmc_dir}/traffic.json)",
+                    "traffic_unit": "GB per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE)", "traffic_source": traffic_how,
+                    "traffic_algorithmic": algorithmic_gb,
                     "peak_basis": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 products per fp32-equivalent MAC" if is_h2
                                    else "dense fp32 MFMA peak"),
                     "mfma_tflops_executed": achieved * (F16X2_PRODUCTS if is_h2 else 1),
