@@ -127,7 +127,9 @@ def test_decoder_stage_taps_match_reference(gpu_device, name, precision):
     rx = torch.from_numpy(g["codes"] + g["noise"]).to(gpu_device)          # channel_ae.py:42 on the reference's own codes
     xd, taps = model.decode_taps(rx)
     torch.cuda.synchronize()
-    assert torch.equal(xd, model.dec(rx))                                  # the tap instantiation computes the same decoder
+    # the tap instantiation computes the same decoder; its Linear heads evaluate both expm1 branches where the production
+    # instantiation keeps exp2 - 1 (3e-8 absolute on ELU outputs of O(1))
+    assert float((xd - model.dec(rx)).abs().max()) <= 1e-6
     ref = g["dec_taps"]
     taps = taps.cpu().numpy()
     assert taps.shape == ref.shape

@@ -1066,6 +1066,13 @@ tae::FusedParams base_params(const tae_handle* h, int32_t B, bool decoder) {
     P.x_low = decoder && h->calibrated && !h->calibrating ? ldexpf(h->dec_r_low, ax) : 0.0f;
     P.cal = h->calibrating ? h->d_cal + (decoder ? cal_dec_offset(h) : 0) : nullptr;
     P.cal_r = (int32_t)cal_dec_r(h);
+    {   // see FusedParams::track; a side needs the full instantiation when one of its last layers asked for both expm1 branches
+        const std::vector<int>& K = decoder ? h->dec_kind : h->enc_kind;
+        const int nl = decoder ? h->cfg.dec_num_layer : h->cfg.enc_num_layer;
+        bool full = h->calibrating;
+        for (size_t i = 0; i < K.size(); ++i) full = full || ((int)(i % nl) == nl - 1 && K[i] == 2);
+        P.track = full ? 2 : (decoder ? 1 : (h->calibrated ? 0 : 2));
+    }
     return P;
 }
 
@@ -1398,7 +1405,7 @@ int upload_tails(tae_handle* h, bool decoder) {
         const int s = (int)i / nl, l = (int)i % nl;
         const int a_in = l == 0 ? Ax[s] : A[i - 1];
         const int a_out = l + 1 < nl ? A[i] : 0;               // the last layer feeds the Linear head in fp32: no panel, no scale
-        tail_values(tails[i], a_in, a_out, l + 1 < nl ? low[i] : 0.0f, l + 1 < nl ? high[i] : 65504.0f, kind[i], t);
+        tail_values(tails[i], a_in, a_out, l + 1 < nl ? low[i] : 0.0f, high[i], kind[i], t);
         TAE_HIP(hipMemcpy(base + tails[i].off, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     return TAE_OK;
@@ -1508,16 +1515,17 @@ int calibrate_range(tae_handle* h, const float* u_user, const float* noise_user,
                     ax = range_exponent(inf ? INFINITY : m, Ax[s], &again);
                     for (int l = 0; l < nl; ++l) { if (A[(size_t)s * nl + l] != ax) moved = true; A[(size_t)s * nl + l] = ax; }
                 } else {
-                    for (int l = 0; l + 1 < nl; ++l) {
+                    for (int l = 0; l < nl; ++l) {
                         const size_t i = (size_t)s * nl + l;
                         const float m = word(o + 1 + i);
-                        const int a = range_exponent(m, A[i], &again);
+                        const bool panel = l + 1 < nl;       // the last layer's ELU output feeds the Linear head in fp32: no panel, exponent 0
+                        const int a = panel ? range_exponent(m, A[i], &again) : 0;
                         if (a != A[i]) moved = true;
                         A[i] = a;
                         // ELU branch of the layer (turboae_h2.hip, TAE_ELU_MODE 2): all |x| <= 2^-5 -> polynomial, valid to |x| = 2^-3;
-                        // maximum below 1 -> both expm1 branches per value; else exp2 - 1 (3e-8 absolute = 2^-25 of a maximum >= 1)
+                        // maximum below 1/4 -> both expm1 branches per value; else exp2 - 1 (3e-8 absolute <= 2^-23 of the maximum)
                         const bool ok = std::isfinite(m) && m > 0.0f;
-                        const int k = ok && m <= 0.03125f ? 1 : (ok && m < 1.0f ? 2 : 0);
+                        const int k = ok && m <= 0.03125f && panel ? 1 : (ok && m < 0.25f ? 2 : 0);     // a last layer: 0 or 2 (nothing checks a polynomial's bound there)
                         const float hi = k == 1 ? ldexpf(0.125f, a) : 65504.0f;
                         std::vector<float>& H = decoder ? h->dec_high : h->enc_high;
                         std::vector<int>& K = decoder ? h->dec_kind : h->enc_kind;

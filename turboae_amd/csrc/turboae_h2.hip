@@ -312,9 +312,9 @@ __device__ __forceinline__ void range_finish(uint32_t* rng, int n_rows, int cal_
 //   kind 1, M <= 2^-5: x (1 + x/2 + x^2/6 + x^3/24) for both signs of x, no exp2 - truncation x^4/120 <= 1.3e-7 relative up to
 //     |x| = 1/16; the layer's high-side threshold is lowered to |x| = 1/8 (2e-6) so that data which outgrows the polynomial
 //     raises TAE_RANGE_HIGH instead of losing accuracy silently;
-//   kind 2, 2^-5 < M < 1: both branches per value (exact to fp32 rounding at any magnitude);
-//   kind 0, M >= 1: exp2 - 1, absolute error 3e-8 <= 2^-25 of the layer's largest value - what every O(1) network (the
-//     trained ones: layer maxima 0.5 .. 16) has always run, at the r03 cost.
+//   kind 2, 2^-5 < M < 1/4: both branches per value (exact to fp32 rounding at any magnitude);
+//   kind 0, M >= 1/4: exp2 - 1, absolute error 3e-8 <= 2^-23 of the layer's largest value (one fp32 ulp of it) - what every O(1)
+//     network (the trained ones: layer maxima 0.5 .. 16) has always run, at the r03 cost.
 #ifndef TAE_ELU_MODE
 #define TAE_ELU_MODE 2
 #endif
@@ -338,6 +338,16 @@ __device__ __forceinline__ float elu_scaled_both(float a, const EluScale& s) {  
     const float big = __builtin_fmaf(__builtin_amdgcn_exp2f(a * s.k2), s.c, -s.c);
     return __builtin_amdgcn_fmed3f(xs, x > kExpm1Switch ? small : big, 0.0f);
 }
+template <int KIND>      // the same three branches on an unscaled value (the last layer of a stack: its ELU feeds the Linear head in fp32)
+__device__ __forceinline__ float elu_kind(float x) {
+    if constexpr (KIND == 0) return __builtin_amdgcn_fmed3f(x, __builtin_amdgcn_exp2f(x * 1.44269504088896341f) - 1.0f, 0.0f);
+    else if constexpr (KIND == 1) {
+        float p = __builtin_fmaf(x, 1.0f / 24.0f, 1.0f / 6.0f);
+        p = __builtin_fmaf(x, p, 0.5f);
+        p = __builtin_fmaf(x, p, 1.0f);
+        return __builtin_amdgcn_fmed3f(x, x * p, 0.0f);
+    } else return elu1(x);
+}
 template <int KIND>      // 0: exp2 branch, 1: polynomial branch, 2: both per value
 __device__ __forceinline__ void elu_split4(f32x4 a, const EluScale& s, float& vmax, h4& hi, h4& lo) {
     f32x4 v;
@@ -352,16 +362,17 @@ __device__ __forceinline__ void elu_split4(f32x4 a, const EluScale& s, float& vm
         v.z = elu_scaled_both(a.z, s); __builtin_amdgcn_sched_barrier(0);
         v.w = elu_scaled_both(a.w, s); __builtin_amdgcn_sched_barrier(0);
     }
-    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    // two v_max3_f32 with |.| modifiers per four values (written as a tree the compiler spent 3.2 instructions on them)
+    vmax = fmaxf(fmaxf(vmax, fabsf(v.x)), fabsf(v.y));
+    vmax = fmaxf(fmaxf(vmax, fabsf(v.z)), fabsf(v.w));
     split4(v, hi, lo);
 }
-// Packed tail (CP bias values, then 2^-(S + A_in) | 2^A_out | low | high) of (stack, layer) row i of a plain conv network, or
-// nullptr for a stack's last layer (it feeds the Linear head: no panel).  Layout as pack_stack_h writes it.
+// Packed tail (CP bias values, then 2^-(S + A_in) | 2^A_out | low | high | ELU kind) of (stack, layer) row i of a plain conv network
+// (a stack's last layer feeds the Linear head unscaled: 2^A_out = 1, no low-side check).  Layout as pack_stack_h writes it.
 template <int U>
 __device__ __forceinline__ const float* plain_tail(const float* wpack, uint32_t stack_stride, int n_layer, int taps, int i) {
     using G = GeoH<U>;
     const int s = i / n_layer, l = i - s * n_layer;
-    if (l + 1 >= n_layer) return nullptr;
     const TapGeo tg = tap_geo<U>(taps);
     const uint32_t off = (uint32_t)s * stack_stride + tg.l0b + (uint32_t)l * (tg.midb + G::TAILB);
     return reinterpret_cast<const float*>(reinterpret_cast<const char*>(wpack) + off) + G::CP;
@@ -378,11 +389,12 @@ __device__ __forceinline__ const float* dense_tail(const float* wpack, uint32_t 
 
 // One SameShapeConv1d stack (cnn_utils.py:36-46) + Linear head; same contract as run_stack in
 // turboae_kernels.hip, except that `g` is the first position TILE of the wave's group (not the group index).  `rg`: range
-// bookkeeping of the layer panels (above); the stack inputs are `xin` as the caller scaled them (the first layer's packed
-// 2^-(S + A_x) undoes it).
+// bookkeeping of the layer panels (above; TRACK = 0 compiles it out, 1 = the panels, 2 = also the maximum of the last layer's ELU
+// output, which only calibration launches need - in the production decoder it cost nine spilled registers); the stack inputs are `xin` as the caller scaled them
+// (the first layer's packed 2^-(S + A_x) undoes it).
 // `l0_slabs` > 0: the first layer walks that many K slabs instead of the tap_geo count (encoder stacks: C_in = 1 folds all taps
 // into ONE slab, see fold_enc_input).
-template <int U, int PT, int C0, int NC, class Epi>
+template <int U, int PT, int C0, int NC, int TRACK = 1, class Epi>
 __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint32_t soff, uint32_t snext, int n_layer, char* smem,
                                             const PanelsH& pn, const XPlane& xin, const TileH<PT>& tc, int g, int lane,
                                             WeightStreamH<U, C0, NC>& ws, const RangeH& rg, Epi epi, int l0_slabs = 0) {
@@ -398,6 +410,12 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
         const bool first = (l == 0);
         const uint32_t fragb = first ? tg.l0b : tg.midb;
         const float* bias = reinterpret_cast<const float*>(wpack + lo + fragb);
+        // the layer's scales (tail: 2^-(S + A_in) | 2^A_out | low | high | ELU kind) are fetched HERE, a K loop ahead of the epilogue
+        // that needs them: fetched after the loop (r04 first cut, to spare three scalar registers) every layer's epilogue began with
+        // an exposed scalar-load latency - 60 of them per decoder workgroup, +2 % (tools/ab_abi.sh against the r03 library)
+        inv_scale = bias[G::CP];
+        const float out_scale_l = bias[G::CP + 1];
+        const int kind_l = (int)bias[G::CP + 4];
         {
             f32x4 b4[NC];
 #pragma unroll
@@ -418,7 +436,6 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
         }
         conv_accumulate_h<CTT, C0, NC, PT, 0>(acc, ws.a, ws.rsrc, ws.voff, lo, smem, bh, bl,
                                               first ? (l0_slabs > 0 ? l0_slabs : tg.nsl_l0) : tg.nsl_mid);
-        inv_scale = bias[G::CP];                   // tail: 2^-(S + A_in) | 2^A_out | low-side threshold | high-side threshold | ELU kind
         lo += fragb + G::TAILB;
         {
             const uint32_t nxt = (l + 1 < n_layer) ? lo : snext;
@@ -429,7 +446,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
             int wrow[PT];
 #pragma unroll
             for (int p = 0; p < PT; ++p) wrow[p] = tc.row(p);
-            const float out_scale = bias[G::CP + 1];
+            const float out_scale = out_scale_l;
             const EluScale es{inv_scale, inv_scale * out_scale, inv_scale * 1.44269504088896341f, out_scale};
             float vmax = 0.0f;
             auto write_panel = [&](auto kind) {
@@ -454,7 +471,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
                 }
             };
 #if TAE_ELU_MODE == 2
-            const int kind = __builtin_amdgcn_readfirstlane((int)bias[G::CP + 4]);
+            const int kind = __builtin_amdgcn_readfirstlane(kind_l);
             if (kind == 0) write_panel(std::integral_constant<int, 0>{});
             else if (kind == 1) write_panel(std::integral_constant<int, 1>{});
             else write_panel(std::integral_constant<int, 2>{});
@@ -463,18 +480,41 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
 #else
             write_panel(std::integral_constant<int, 0>{});
 #endif
-            if (TAE_RANGE_BOOK == 1) range_note_layer(rg, l, vmax);
+            if (TAE_RANGE_BOOK == 1 && TRACK) range_note_layer(rg, l, vmax);      // !TRACK: vmax is dead, its arithmetic goes with it
             else if (TAE_RANGE_BOOK == 2) asm volatile("" :: "v"(vmax));      // A/B: the per-value maximum alone (as r03 carried it), no per-layer reduction
             if (!(TAE_X & 1)) __syncthreads();
         }
     }
     // ---- Linear head on the accumulators of the last conv layer, fp32 vector ALU (as in run_stack)
     const float* wl = reinterpret_cast<const float*>(wpack + lo);
+    // ELU of the last layer with the branch the host picked for it (its outputs are a fifth of all ELU evaluations: both expm1
+    // branches on every one of them cost the decoder 1.4 %), fused with the Linear FMAs so that every accumulator dies as it is
+    // used (ELU in place first, FMAs after: 12 spilled registers).  TRACK == 2 (calibration launches): their maximum goes to the
+    // stack's last range row.
     float part[PT][8];
 #pragma unroll
     for (int p = 0; p < PT; ++p)
 #pragma unroll
         for (int f = 0; f < 8; ++f) part[p][f] = 0.0f;
+    // calibration: max |ELU output| of the last layer from its pre-activations, in a loop of its own (threaded through the head's
+    // FMAs a running maximum spilled 60 registers): ELU(x) = x above 0, 1 - exp(-|x|) below
+    float hmax = 0.0f;
+    if constexpr (TRACK == 2) {
+        float hneg = 0.0f;
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                hmax = fmaxf(fmaxf(hmax, fmaxf(acc[p][i].x, acc[p][i].y)), fmaxf(acc[p][i].z, acc[p][i].w));
+                hneg = fmaxf(fmaxf(hneg, fmaxf(-acc[p][i].x, -acc[p][i].y)), fmaxf(-acc[p][i].z, -acc[p][i].w));
+            }
+        hmax = fmaxf(hmax * inv_scale, 1.0f - __expf(-hneg * inv_scale));
+    }
+    // Which expm1 the last layer gets is a COMPILE-TIME property of the instantiation (a run-time choice - two copies of the head, or
+    // a wave-uniform branch per tile - spilled 10 / 48 registers): TRACK == 2, the "full" instantiation (calibration launches, tap
+    // export, and every launch of a network one of whose last layers stays below 1: the host decides, FusedParams::track), evaluates
+    // both branches per value; the production instantiations keep r03's exp2 - 1 (3e-8 absolute against a layer maximum >= 1).
+    constexpr int HEAD_KIND = (TAE_ELU_MODE == 0) ? 0 : ((TAE_ELU_MODE == 1 || TRACK == 2) ? 2 : 0);
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         f32x4 w4[8];
@@ -483,7 +523,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
             f32x4 v = acc[p][i] * inv_scale;
-            v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
+            v.x = elu_kind<HEAD_KIND>(v.x); v.y = elu_kind<HEAD_KIND>(v.y); v.z = elu_kind<HEAD_KIND>(v.z); v.w = elu_kind<HEAD_KIND>(v.w);
 #pragma unroll
             for (int f = 0; f < 8; ++f) {
                 float s = part[p][f];
@@ -493,6 +533,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
             }
         }
     }
+    if constexpr (TAE_RANGE_BOOK == 1 && TRACK == 2) range_note_layer(rg, n_layer - 1, hmax);
     const bool hi32 = (q & 2) != 0, hi16 = (q & 1) != 0;
     float k2[PT][2];
 #pragma unroll
@@ -710,18 +751,18 @@ __device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, con
         const int* ptab = (s & 1) ? pn.PERM : pn.INV;
         const RangeH rg{range_rows(pn.RNG) + s * P.n_layer * 8};
         if (s + 1 < n_stack) {
-            run_stack_h<U, PT, C0, NC>(wpack, s * sstride, (s + 1) * sstride, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
+            run_stack_h<U, PT, C0, NC, TAPS ? 2 : 1>(wpack, s * sstride, (s + 1) * sstride, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
                                        [&](int p, int f, float v) {
                 if (f < F) {
                     if (extrinsic) v -= Xin.read(tc.row(p), 2 + f) * xinv;     // decoders.py:235-236,246-247
-                    if constexpr (TAPS) P.tap_out[(((size_t)s * P.B + blk0 + tc.blk(p)) * L + tc.t(p)) * F + f] = v;
+                    if constexpr (TAPS) { if (P.tap_out != nullptr) P.tap_out[(((size_t)s * P.B + blk0 + tc.blk(p)) * L + tc.t(p)) * F + f] = v; }
                     const float vs = v * xs;
                     xmax = track_abs(xmax, vs);
                     Xout.write(tc.rowbase(p) + ptab[tc.t(p)], 2 + f, vs);      // interleave / deinterleave (decoders.py:238,249)
                 }
             });
         } else {
-            run_stack_h<U, PT, C0, NC>(wpack, s * sstride, 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
+            run_stack_h<U, PT, C0, NC, TAPS ? 2 : 1>(wpack, s * sstride, 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
                                        [&](int p, int f, float v) {
                 if (f == 0) xdec[tc.blk(p) * L + ptab[tc.t(p)]] = 1.0f / (1.0f + expf(-v));   // decoders.py:262-267
             });
@@ -794,7 +835,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
 
 // =============================================================================================
 // Encoder before power normalisation: ENC_interCNN.forward (encoders.py:362-373)
-template <int U, int PT, int C0, int NC>
+template <int U, int PT, int C0, int NC, int TRACK>
 __device__ __forceinline__ void enc_body_h(const FusedParams& P, char* smem, const PanelsH& pn, const TileH<PT>& tc, int g, int lane,
                                            int blk0, double& sum, double& sumsq) {
     const int L = P.L;
@@ -808,7 +849,7 @@ __device__ __forceinline__ void enc_body_h(const FusedParams& P, char* smem, con
     for (int s = 0; s < 3; ++s) {
         const XPlane Xin = (s == 2) ? pn.XB : pn.XA;
         const RangeH rg{range_rows(pn.RNG) + s * P.n_layer * 8};
-        run_stack_h<U, PT, C0, NC>(wpack, s * sstride, s < 2 ? (s + 1) * sstride : 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
+        run_stack_h<U, PT, C0, NC, TRACK>(wpack, s * sstride, s < 2 ? (s + 1) * sstride : 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
                                    [&](int p, int f, float v) {
             if (f == 0) {
                 v = act_apply(v, act);                                     // enc_act (encoders.py:364)
@@ -820,7 +861,10 @@ __device__ __forceinline__ void enc_body_h(const FusedParams& P, char* smem, con
     }
 }
 
-template <int U, int PT>
+// TRACK = 0: no range bookkeeping (2: all of it, the last layers' maxima included).  The encoder's inputs are bit patterns - the calibration batch samples exactly the
+// distribution every later call draws from - so once a handle is calibrated its encoder panels cannot leave their window unless the
+// weights change; the host launches the tracking instantiation only for calibration passes and for uncalibrated handles.
+template <int U, int PT, int TRACK>
 __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -864,12 +908,11 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
         TileH<T> tc;
         make_tiles_h<T>(tc, pn.ROWT, gs.gt0, lane, L, npos, pad);
         __syncthreads();
-        if (!upper) enc_body_h<U, T, 0, Split<U>::CTA>(P, smem, pn, tc, gs.gt0, lane, blk0, sum, sumsq);
-        else enc_body_h<U, T, Split<U>::CTA, Split<U>::CTB>(P, smem, pn, tc, gs.gt0, lane, blk0, sum, sumsq);
+        if (!upper) enc_body_h<U, T, 0, Split<U>::CTA, TRACK>(P, smem, pn, tc, gs.gt0, lane, blk0, sum, sumsq);
+        else enc_body_h<U, T, Split<U>::CTA, Split<U>::CTB, TRACK>(P, smem, pn, tc, gs.gt0, lane, blk0, sum, sumsq);
     };
     dispatch_tiles<PT>(gs.live, run);
-    if (TAE_RANGE_BOOK == 1) range_finish(pn.RNG, 3 * P.n_layer, 1, [&](int i) { return plain_tail<U>(P.wpack, P.stack_stride, P.n_layer, P.taps, i); });
-    __syncthreads();         // the statistics scratch below aliases the panels, not the range rows - but keep the phases apart
+    if (TAE_RANGE_BOOK == 1 && TRACK) range_finish(pn.RNG, 3 * P.n_layer, 1, [&](int i) { return plain_tail<U>(P.wpack, P.stack_stride, P.n_layer, P.taps, i); });
     block_reduce_stats(smem, tid, sum, sumsq, P.partials);
 }
 
@@ -891,7 +934,7 @@ __device__ __forceinline__ void seg_body_h(const SegParams& P, char* smem, const
     const RangeH rg{range_rows(pn.RNG)};
     auto run = [&](auto epi) {
         if constexpr (DENSE) run_stack_h_dense<U, PT, C0, NC>(wpack, soff, P.n_layer, smem, pn, X, tc, g, lane, ws, rg, active, epi);
-        else run_stack_h<U, PT, C0, NC>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, rg, epi, P.mode == 0 ? 1 : 0);
+        else run_stack_h<U, PT, C0, NC, 1>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, rg, epi, P.mode == 0 ? 1 : 0);     // (long blocks: the last layers keep exp2 - 1)
     };
     if (P.mode == 0) {
         const int act = P.act;
@@ -1064,14 +1107,19 @@ template <int U>
 static hipError_t launch_fused_h_u(bool decoder, const FusedParams& P, int grid, hipStream_t st) {
     constexpr int PT = 5;
     auto kd = dec_kernel_h<U, PT>;
-    auto kt = dec_kernel_h<U, PT, true>;       // debug instantiation exporting every stack's extrinsic outputs (tae_decode_taps)
-    auto ke = enc_kernel_h<U, PT>;
-    const bool taps = decoder && P.tap_out != nullptr;
-    const void* fn = decoder ? (taps ? reinterpret_cast<const void*>(kt) : reinterpret_cast<const void*>(kd)) : reinterpret_cast<const void*>(ke);
+    auto kt = dec_kernel_h<U, PT, true>;       // the instantiation for tae_decode_taps (exports every stack's extrinsic outputs) and for
+                                               // calibration launches (also tracks the last layers' ELU maxima)
+    auto ke = enc_kernel_h<U, PT, 0>;
+    auto ket = enc_kernel_h<U, PT, 2>;
+    const bool taps = decoder && (P.tap_out != nullptr || P.cal != nullptr || P.track == 2);
+    const bool etrack = !decoder && (P.track != 0 || P.cal != nullptr);
+    const void* fn = decoder ? (taps ? reinterpret_cast<const void*>(kt) : reinterpret_cast<const void*>(kd))
+                             : (etrack ? reinterpret_cast<const void*>(ket) : reinterpret_cast<const void*>(ke));
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes);
     if (e != hipSuccess) return e;
     if (taps) hipLaunchKernelGGL(kt, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
     else if (decoder) hipLaunchKernelGGL(kd, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
+    else if (etrack) hipLaunchKernelGGL(ket, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
     else hipLaunchKernelGGL(ke, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
     return hipGetLastError();
 }

@@ -38,6 +38,9 @@ struct FusedParams {
     uint32_t* cal;          // calibration launches only (else nullptr): float bits, atomicMax'ed - [0] max |extrinsic value| a stack handed on
                             // (unscaled), [1 + stack * n_layer + l] max |ELU output| of layer l, [cal_r] max |received value|
     int32_t cal_r;
+    int32_t track;          // which instantiation of the f16x2 whole-block kernels: 0 = no range bookkeeping (calibrated encoders), 1 = the
+                            // panels (production decoder), 2 = full: + the last layers' maxima, both expm1 branches in the heads (calibration
+                            // launches, uncalibrated encoders, networks whose last layers stay below 1)
 };
 
 // Arguments of the per-stack segmented kernel used when a block does not fit one workgroup.
