@@ -35,7 +35,7 @@ DEFAULT_LIB = os.path.join(ROOT, "turboae_amd", "lib", "libturboae_hip.so")
 CSRC = os.path.join(ROOT, "turboae_amd", "csrc")
 
 # demangled-name prefixes of the kernels bench.py times (headline line + roofline.other_configs), production instantiations only
-BENCH_KERNELS = [r"tae::dec_kernel_h<100, 5, false>", r"tae::enc_kernel_h<100, 5, false>", r"tae::seg_kernel_h<100, 5>",
+BENCH_KERNELS = [r"tae::dec_kernel_h<100, 5, false>", r"tae::enc_kernel_h<100, 5, 0>", r"tae::seg_kernel_h<100, 5>",
                  r"tae::dec_kernel<100, 5, false>", r"tae::enc_kernel<100, 5>",
                  r"tae::gru_rec_h_kernel<", r"tae::gru_proj_h_kernel<", r"tae::gru_head_part_kernel"]
 MEM_ASM = re.compile(r"\b(global_load|global_store|global_atomic|buffer_load|buffer_store|buffer_atomic|flat_load|flat_store|flat_atomic|"
