@@ -99,6 +99,10 @@ CASES = [
     ("gen_enc_gru_dec_cnn_dense", dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_cnn", enc_num_layer=1, enc_num_unit=24, dec_num_unit=20,
                                        dec_num_layer=3, num_iteration=2, block_len=45), 3, 54, 1.0, 2.0),
     ("gen_wide_e120_d136", dict(enc_num_unit=120, dec_num_unit=136, dec_num_layer=3, num_iteration=2, block_len=64), 3, 55, 1.0, 2.0),
+    # widths 101 .. 124 (r04): the fp16-split MFMA kernels' 124-wide instantiation, exact and embedded, whole-block and long-block paths
+    ("var_width_e124_d124", dict(enc_num_unit=124, dec_num_unit=124, num_iteration=2), 4, 60, 1.0, 2.0),
+    ("var_width_e104_d120_L400", dict(enc_num_unit=104, dec_num_unit=120, num_iteration=2, dec_num_layer=3, block_len=400), 2, 61, 1.0, 2.0),
+    ("var_width_e120_d101_k7", dict(enc_num_unit=120, dec_num_unit=101, num_iteration=2, dec_num_layer=2, dec_kernel_size=7, block_len=64), 3, 62, 1.0, 2.0),
     ("gen_ft9", dict(enc_num_unit=32, dec_num_unit=32, num_iter_ft=9, num_iteration=2, dec_num_layer=2, block_len=70), 3, 56, 1.0, 2.0),
     ("gen_kernel_e11_d13", dict(enc_num_unit=32, dec_num_unit=40, enc_kernel_size=11, dec_kernel_size=13, num_iteration=2, dec_num_layer=2,
                                 block_len=60), 3, 57, 1.0, 2.0),

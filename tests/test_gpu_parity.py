@@ -670,3 +670,44 @@ def test_handle_is_bound_to_its_device(gpu_device):
         e = model._engine_for(cfg.block_len)
         rc = e.lib.tae_decode(e.h, C.c_void_p(u.data_ptr()), C.c_void_p(u.data_ptr()), 4, None)
         assert rc == -4 and b"current device" in e.lib.tae_last_error()      # TAE_ESTATE
+
+
+@pytest.mark.parametrize("ue,ud,L,B", [(124, 124, 100, 5), (101, 124, 37, 9), (110, 104, 330, 2), (124, 64, 64, 4), (32, 117, 100, 7)])
+def test_widths_101_to_124_run_on_the_mfma_kernels(gpu_device, ue, ud, L, B):
+    """-enc_num_unit / -dec_num_unit 101 .. 124 (get_args.py:97-98) used to fall to the generic vector-ALU kernels
+    (a >100x cliff at width 104).  The fp16-split kernels are instantiated for 124 (8 full channel tiles; like 100 it is = 4 mod 8,
+    the widths whose unpadded LDS rows are bank-conflict-free), narrower stacks run embedded: same tolerances as every other width,
+    the fp16-split arithmetic reported, and - against the generic kernels on the same network - the speed of an MFMA path."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(enc_num_unit=ue, dec_num_unit=ud, block_len=L, num_iteration=2, dec_num_layer=3)
+    assert not cfg.generic
+    sd = W.generate_state_dict(cfg, seed=100 + ue + ud, gain=1.0)
+    u, noise = make_inputs(B, L, seed=71)
+    xd, codes, xo, co, taps = run_both(cfg, sd, u, noise, gpu_device)
+    assert np.abs(codes - co).max() <= ATOL_CODES and np.abs(xd - xo).max() <= ATOL_XDEC
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    assert model.range_status() == ("f16x2", False)
+
+
+def test_width_104_is_no_longer_a_performance_cliff(gpu_device, monkeypatch):
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(enc_num_unit=104, dec_num_unit=104)
+    sd = W.generate_state_dict(cfg, seed=5, gain=1.0)
+    B = 1536
+
+    def ms(model):
+        u, noise = model.generate_inputs(B, 2.0, seed=3)
+        model(u, noise)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        x, _ = model(u, noise)
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b), x
+    t_mfma, x1 = ms(Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B))
+    monkeypatch.setenv("TAE_FORCE_GENERIC", "1")
+    t_gen, x2 = ms(Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B))
+    print(f"width 104, {B} blocks: MFMA {t_mfma:.2f} ms, generic {t_gen:.2f} ms")
+    assert float((x1 - x2).abs().max()) <= 5e-5
+    assert t_gen >= 20.0 * t_mfma

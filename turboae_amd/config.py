@@ -71,7 +71,10 @@ class TurboAEConfig:
         (csrc/turboae_generic.hip; mirrors tae::generic_needed): one launch per layer, same results, far slower."""
         ks = (self.enc_kernel_size, self.dec_kernel_size)
         enc_rnn, dec_rnn = self.encoder == "TurboAE_rate3_rnn", self.decoder == "TurboAE_rate3_rnn"
-        if max(ks) > 9 or self.enc_num_unit > 100 or self.dec_num_unit > 100 or self.num_iter_ft > 6:
+        # CNN stacks up to 124 wide on the fp16-split MFMA kernels (32 / 64 / 100 / 124 instantiated), fp32 MFMA and GRU kernels up to 100
+        cnn_max = 100 if self.precision == "f32" else 124
+        enc_max, dec_max = (100 if enc_rnn else cnn_max), (100 if dec_rnn else cnn_max)
+        if max(ks) > 9 or self.enc_num_unit > enc_max or self.dec_num_unit > dec_max or self.num_iter_ft > 6:
             return True
         if (enc_rnn and self.enc_rnn != "gru") or (dec_rnn and self.dec_rnn != "gru"):
             return True
@@ -99,8 +102,8 @@ class TurboAEConfig:
         acts = ("tanh", "selu", "relu", "elu", "sigmoid", "linear")
         if self.enc_act not in acts or self.dec_act not in acts:
             raise ValueError("enc_act / dec_act must be one of tanh, selu, relu, elu, sigmoid, linear (get_args.py:100-101)")
-        if not (1 <= self.enc_num_unit <= 100 and 1 <= self.dec_num_unit <= 100):
-            raise ValueError("channel widths (enc_num_unit, dec_num_unit) must be in 1..100 (kernels exist for 32 / 64 / 100; a "
+        if not (1 <= self.enc_num_unit <= 124 and 1 <= self.dec_num_unit <= 124):
+            raise ValueError("channel widths (enc_num_unit, dec_num_unit) must be in 1..124 (kernels exist for 32 / 64 / 100 / 124; a "
                              "narrower stack is embedded exactly into the next wider one)")
         if self.dense and (self.enc_num_unit not in (32, 64, 100) or self.dec_num_unit not in (32, 64, 100)):
             raise ValueError("dense stacks need channel widths of 32, 64 or 100")

@@ -352,7 +352,7 @@ struct tae_handle {
 namespace {
 
 // Instantiated kernel widths / the width a configured one runs at (0: too wide)
-inline int kernel_width(int u) { return u <= 32 ? 32 : (u <= 64 ? 64 : (u <= 100 ? 100 : 0)); }
+inline int kernel_width(int u) { return u <= 32 ? 32 : (u <= 64 ? 64 : (u <= 100 ? 100 : (u <= 124 ? 124 : 0))); }
 
 int check_cfg(const tae_config* c) {
     if (!c) return fail(TAE_EINVAL, "config is NULL");
@@ -373,8 +373,8 @@ int check_cfg(const tae_config* c) {
         if (ks > 5 && (c->precision != TAE_PREC_AUTO || c->dense))
             return fail(TAE_EINVAL, "kernel sizes 7 and 9 are built in the fp16-split kernels only (precision = TAE_PREC_AUTO, no dense stacks)");
     }
-    if (c->enc_num_unit < 1 || c->enc_num_unit > 100 || c->dec_num_unit < 1 || c->dec_num_unit > 100)
-        return fail(TAE_EINVAL, "channel width (enc_num_unit, dec_num_unit) must be in 1..100 (kernels exist for 32 / 64 / 100; narrower stacks are embedded)");
+    if (c->enc_num_unit < 1 || c->enc_num_unit > 124 || c->dec_num_unit < 1 || c->dec_num_unit > 124)
+        return fail(TAE_EINVAL, "channel width (enc_num_unit, dec_num_unit) must be in 1..124 (kernels exist for 32 / 64 / 100 / 124; narrower stacks are embedded)");
     if (c->dense && (kernel_width(c->enc_num_unit) != c->enc_num_unit || kernel_width(c->dec_num_unit) != c->dec_num_unit))
         return fail(TAE_EINVAL, "dense stacks need a channel width of 32, 64 or 100");
     if (c->enc_num_layer < 1 || c->dec_num_layer < 1 || c->num_iteration < 1) return fail(TAE_EINVAL, "layer/iteration counts must be >= 1");
@@ -1678,6 +1678,10 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         if (!strcmp(pe, "f32")) want_h2 = 0;
         else if (!strcmp(pe, "f16x2")) want_h2 = 1;
     }
+    if (!want_h2 && (h->U > 100 || h->Ud > 100)) {
+        delete h;
+        return fail(TAE_EINVAL, "channel widths 101..124 run on the fp16-split kernels only (TAE_PRECISION=f32 given): use tae_config.precision = TAE_PREC_F32 for the generic fp32 kernels");
+    }
     h->nb = choose_nb(h->U, cfg->block_len, &h->lds_bytes, want_h2 != 0, taps_e, 3 * cfg->enc_num_layer);
     h->nbd = choose_nb(h->Ud, cfg->block_len, &h->lds_bytes_d, want_h2 != 0, taps_d, 2 * cfg->num_iteration * cfg->dec_num_layer);
     // Testing knobs (documented in DESIGN.md): TAE_FORCE_SEGMENTED=1 selects the long-block path even
@@ -1766,9 +1770,9 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
                                          (uint32_t)(2 * it + half) * h->dec_stride_h);
             }
         if ((size_t)(s2 - weights) != n_weights) { delete h; return fail(TAE_EINVAL, "internal: dense weight walk mismatch"); }
-    } else if (big_taps && !h2_ok) {
+    } else if ((big_taps || h->U > 100 || h->Ud > 100) && !h2_ok) {
         delete h;
-        return fail(TAE_EINVAL, "kernel sizes 7 and 9 need the fp16-split kernels (precision auto; TAE_PRECISION=f32 given, or the panels do not fit the LDS)");
+        return fail(TAE_EINVAL, "kernel sizes 7 / 9 and channel widths above 100 need the fp16-split kernels (precision auto; TAE_PRECISION=f32 given, or the panels do not fit the LDS)");
     } else if (h2_ok) {
         h->prec = 1;
         const LayoutH lh(h->U, taps_e), lhd(h->Ud, taps_d);

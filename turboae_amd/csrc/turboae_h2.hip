@@ -1126,6 +1126,7 @@ static hipError_t launch_fused_h_u(bool decoder, const FusedParams& P, int grid,
 
 hipError_t launch_fused_h(int U, bool decoder, const FusedParams& P, int grid, hipStream_t st) {
     switch (U) {
+        case 124: return launch_fused_h_u<124>(decoder, P, grid, st);
         case 100: return launch_fused_h_u<100>(decoder, P, grid, st);
         case 64: return launch_fused_h_u<64>(decoder, P, grid, st);
         case 32: return launch_fused_h_u<32>(decoder, P, grid, st);
@@ -1145,6 +1146,7 @@ static hipError_t launch_seg_h_u(const SegParams& P, int grid, hipStream_t st) {
 
 hipError_t launch_seg_h(int U, const SegParams& P, int grid, hipStream_t st) {
     switch (U) {
+        case 124: return launch_seg_h_u<124>(P, grid, st);
         case 100: return launch_seg_h_u<100>(P, grid, st);
         case 64: return launch_seg_h_u<64>(P, grid, st);
         case 32: return launch_seg_h_u<32>(P, grid, st);
