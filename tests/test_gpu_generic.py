@@ -172,10 +172,10 @@ def test_range_fallback_reruns_on_fp32_kernels(gpu_device):
 
 def test_generic_path_takes_batches_beyond_the_grid_y_limit(gpu_device):
     """gen_conv_kernel rides the block index in grid.y (HIP: <= 65535).  70 000 tiny blocks on a configuration only the
-    generic kernels run (width 101): the call succeeds, the blocks past the limit equal a small call on the same blocks bit for bit
+    generic kernels run (width 125): the call succeeds, the blocks past the limit equal a small call on the same blocks bit for bit
     (blocks never interact), and a subsample matches the oracle."""
     from turboae_amd import Channel_AE_HIP
-    cfg = TurboAEConfig(block_len=6, enc_num_unit=101, dec_num_unit=101, enc_num_layer=1, dec_num_layer=1, num_iteration=1)
+    cfg = TurboAEConfig(block_len=6, enc_num_unit=125, dec_num_unit=125, enc_num_layer=1, dec_num_layer=1, num_iteration=1)
     assert cfg.generic
     sd = W.generate_state_dict(cfg, seed=31, gain=1.0)
     B = 70000
