@@ -126,6 +126,24 @@ def test_bench_runs_with_two_ranks(gpu_device):
     assert "other_configs" not in res["roofline"] and res["roofline"]["sustained_probe_tflops"] > 500      # probe on rank 0, other configs at N = 1 only
 
 
+def test_plain_bench_command_relaunches_itself_for_n_gpus(gpu_device):
+    """`python bench.py --gpus 2` WITHOUT a torch.distributed environment (how the driver starts N = 1; nobody knows
+    how it will start N = 8) re-executes itself under torch.distributed.run with one rank per GPU and prints the same single line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TAE_BENCH_BACKEND"] = "gloo"                    # both ranks share this box's one GPU
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2000"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_blocks"] == 4000 and res["config"]["rccl_ranks_seen"] == 2
+
+
 def test_bench_runs_with_eight_ranks_strong_and_ragged(gpu_device):
     """The driver's widest launch shape - 8 ranks - on this box's one GPU (gloo hook): a global batch that does not divide by 8
     (--strong 4003 -> shards of 500 / 501 blocks) decodes to the same BER as ONE process decoding the same 4003 blocks, and the
