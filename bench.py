@@ -329,7 +329,7 @@ def pmc_child(batch: int, block_len: int, snr: float, precision: str) -> None:
     torch.cuda.synchronize()
 
 
-def measure_traffic_pmc(batch: int, block_len: int, snr: float, precision: str, kernel_substr: str, timeout_s: float = 180.0):
+def measure_traffic_pmc(batch: int, block_len: int, snr: float, precision: str, kernel_substr: str, timeout_s: float = 90.0):
     """HBM-side bytes per full-size decoder launch, measured NOW on this box: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE:
     they do not fit one pass, MI355X_MICROARCH.md) over `bench.py --pmc-child`, counters averaged over the full-size dispatches of the
     decoder kernel (largest grid), FETCH_SIZE doubled as the guide's gfx950 note prescribes.  Returns a dict or raises."""
@@ -341,6 +341,9 @@ def measure_traffic_pmc(batch: int, block_len: int, snr: float, precision: str, 
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.isfile(rocprof):
         raise RuntimeError("rocprofv3 not found")
+    # never nest profilers: if THIS process already runs under rocprofv3 / a rocprofiler tool library, leave the counters to it
+    if any(k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        raise RuntimeError("this process is itself being profiled (rocprofiler environment present)")
     vals = {}
     env = dict(os.environ)
     env["TMPDIR"] = "/tmp"
