@@ -32,6 +32,24 @@ def draw_cases(n, seed):
     return cases
 
 
+def draw_wide_cases(n, seed):
+    """Channel widths 101 .. 124 on at least one side (r04: the 124-wide instantiation of the fp16-split kernels; precision='f32' takes the
+    same networks to the generic kernels).  Its own generator: draw_cases' random stream is pinned by oracle/fuzz_vs_reference.py."""
+    rng = np.random.RandomState(seed)
+    cases = []
+    for i in range(n):
+        wide = lambda: int(rng.randint(101, 125))                                # noqa: E731
+        U, Ud = (wide(), wide()) if i % 3 == 0 else ((wide(), int(rng.choice([32, 64, 100, int(rng.randint(1, 101))]))) if i % 3 == 1
+                                                     else (int(rng.choice([32, 64, 100])), wide()))
+        L = int(rng.choice([1, 7, 16, 33, 100, 106, 160, 161, 213, 214, 320, 321, 400]))
+        B = int(rng.choice([1, 2, 3, 5, 9, int(rng.randint(1, 24))]))
+        cases.append(dict(block_len=L, enc_num_unit=U, dec_num_unit=Ud, enc_num_layer=int(rng.randint(1, 4)), dec_num_layer=int(rng.randint(1, 4)),
+                          num_iter_ft=int(rng.randint(1, 7)), num_iteration=int(rng.randint(1, 3)), extrinsic=int(rng.randint(0, 2)),
+                          enc_kernel_size=int(rng.choice([5, 5, 3, 7])), dec_kernel_size=int(rng.choice([5, 5, 1, 9])),
+                          enc_act=str(rng.choice(["elu", "linear", "tanh"])), B=B, fixed_nb=str(int(rng.randint(0, 2))), wseed=int(rng.randint(1, 1 << 30))))
+    return cases
+
+
 def draw_variant_cases(n, seed):
     """GRU decoder (CNN or GRU encoder) and DenseSameShapeConv1d stacks: fixed widths, random lengths / batches."""
     rng = np.random.RandomState(seed)

@@ -9,7 +9,7 @@ import torch
 
 from turboae_amd import TurboAEConfig, philox, weights as W
 from oracle import turboae_oracle as O
-from _fuzz_cases import draw_cases, draw_variant_cases, draw_channel_cases, channel_case_inputs
+from _fuzz_cases import draw_cases, draw_variant_cases, draw_channel_cases, channel_case_inputs, draw_wide_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -19,6 +19,19 @@ CASES = draw_cases(int(os.environ.get("TAE_FUZZ_CASES", "48")), int(os.environ.g
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "U{enc_num_unit}x{dec_num_unit}_k{enc_kernel_size}{dec_kernel_size}_L{block_len}_B{B}_e{enc_num_layer}d{dec_num_layer}_F{num_iter_ft}_it{num_iteration}_nb{fixed_nb}".format(**c))
 def test_random_shape_matches_oracle_in_both_precisions(gpu_device, monkeypatch, case):
+    _check_shape_case(gpu_device, monkeypatch, case)
+
+
+WIDE_CASES = draw_wide_cases(int(os.environ.get("TAE_FUZZ_CASES", "18")), int(os.environ.get("TAE_FUZZ_SEED", "12404")))
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: "U{enc_num_unit}x{dec_num_unit}_k{enc_kernel_size}{dec_kernel_size}_L{block_len}_B{B}_e{enc_num_layer}d{dec_num_layer}_F{num_iter_ft}_it{num_iteration}".format(**c))
+def test_random_wide_shape_matches_oracle(gpu_device, monkeypatch, case):
+    """Widths 101 .. 124: the 124-wide fp16-split kernels (whole-block and long-block paths) and, as precision='f32', the generic kernels."""
+    _check_shape_case(gpu_device, monkeypatch, case)
+
+
+def _check_shape_case(gpu_device, monkeypatch, case):
     from turboae_amd import Channel_AE_HIP
     case = dict(case)
     B, fixed_nb, wseed = case.pop("B"), case.pop("fixed_nb"), case.pop("wseed")
