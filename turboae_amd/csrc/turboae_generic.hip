@@ -79,47 +79,73 @@ __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x))
 //   GRU  (r, z, n):    r = s(gi_r + W_hr h + b_hr), z = s(gi_z + W_hz h + b_hz), n = tanh(gi_n + r * (W_hn h + b_hn)), h' = (1 - z) n + z h
 //   LSTM (i, f, g, o): c' = s(f) c + s(i) tanh(g), h' = s(o) tanh(c')      (pre-activations gi_* + W_h* h + b_h*)
 //   RNN:               h' = tanh(gi + W_hh h + b_hh)
+// One workgroup = NB blocks x one direction, thread = hidden unit: every recurrent weight a thread fetches is used for its NB
+// blocks (r03: NB = 1, i.e. the whole W_hh - 160 KB for an LSTM - re-read from L2 per block and step; r04: up to 8 blocks share it).
+// The per-(block, unit) FMA chain is the same for every NB (k ascending), so results do not depend on the batch or on NB.
+template <int NB>
 __global__ void gen_rnn_kernel(int cell, const float* __restrict__ gi, const float* __restrict__ whh_t0, const float* __restrict__ whh_t1,
-                               const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ y, int H, int L) {
-    extern __shared__ float hs[];                      // h_{t-1}
+                               const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ y, int H, int L, int B) {
+    extern __shared__ float hs[];                      // h_{t-1}: [NB][H]
     const int u = threadIdx.x, dir = blockIdx.y;
-    const size_t b = blockIdx.x;
+    const size_t b0 = (size_t)blockIdx.x * NB;
     const int G = cell == 0 ? 3 : (cell == 1 ? 4 : 1);
     const float* whh = dir ? whh_t1 : whh_t0;
     const float* bhh = dir ? bhh1 : bhh0;
-    if (u < H) hs[u] = 0.0f;
-    float c = 0.0f, hprev = 0.0f;
+    float c[NB], hprev[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { c[j] = 0.0f; hprev[j] = 0.0f; if (u < H) hs[j * H + u] = 0.0f; }
     __syncthreads();
     for (int s = 0; s < L; ++s) {
         const int t = dir ? L - 1 - s : s;
-        float hn = 0.0f;
+        float hn[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) hn[j] = 0.0f;
         if (u < H) {
-            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            float a[4][NB];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) a[g][j] = 0.0f;
             for (int k = 0; k < H; ++k) {
-                const float hk = hs[k];
                 const float* w = whh + (size_t)k * G * H + u;
-                for (int g = 0; g < G; ++g) a[g] = fmaf(w[g * H], hk, a[g]);
+                float wg[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) wg[g] = g < G ? w[g * H] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const float hk = hs[j * H + k];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) a[g][j] = fmaf(wg[g], hk, a[g][j]);
+                }
             }
-            const float* gp = gi + ((b * L + t) * 2 + dir) * (size_t)(G * H) + u;
-            if (cell == 0) {
-                const float r = sigm(gp[0] + (a[0] + bhh[u]));
-                const float z = sigm(gp[H] + (a[1] + bhh[H + u]));
-                const float n = tanhf(gp[2 * H] + r * (a[2] + bhh[2 * H + u]));
-                hn = (1.0f - z) * n + z * hprev;
-            } else if (cell == 1) {
-                const float ig = sigm(gp[0] + (a[0] + bhh[u]));
-                const float fg = sigm(gp[H] + (a[1] + bhh[H + u]));
-                const float gg = tanhf(gp[2 * H] + (a[2] + bhh[2 * H + u]));
-                const float og = sigm(gp[3 * H] + (a[3] + bhh[3 * H + u]));
-                c = fg * c + ig * gg;
-                hn = og * tanhf(c);
-            } else {
-                hn = tanhf(gp[0] + (a[0] + bhh[u]));
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const size_t b = b0 + j;
+                if (b >= (size_t)B) continue;
+                const float* gp = gi + ((b * L + t) * 2 + dir) * (size_t)(G * H) + u;
+                if (cell == 0) {
+                    const float r = sigm(gp[0] + (a[0][j] + bhh[u]));
+                    const float z = sigm(gp[H] + (a[1][j] + bhh[H + u]));
+                    const float n = tanhf(gp[2 * H] + r * (a[2][j] + bhh[2 * H + u]));
+                    hn[j] = (1.0f - z) * n + z * hprev[j];
+                } else if (cell == 1) {
+                    const float ig = sigm(gp[0] + (a[0][j] + bhh[u]));
+                    const float fg = sigm(gp[H] + (a[1][j] + bhh[H + u]));
+                    const float gg = tanhf(gp[2 * H] + (a[2][j] + bhh[2 * H + u]));
+                    const float og = sigm(gp[3 * H] + (a[3][j] + bhh[3 * H + u]));
+                    c[j] = fg * c[j] + ig * gg;
+                    hn[j] = og * tanhf(c[j]);
+                } else {
+                    hn[j] = tanhf(gp[0] + (a[0][j] + bhh[u]));
+                }
+                y[(b * L + t) * (size_t)(2 * H) + dir * H + u] = hn[j];
             }
-            y[(b * L + t) * (size_t)(2 * H) + dir * H + u] = hn;
         }
         __syncthreads();
-        if (u < H) { hs[u] = hn; hprev = hn; }
+        if (u < H) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { hs[j * H + u] = hn[j]; hprev[j] = hn[j]; }
+        }
         __syncthreads();
     }
 }
@@ -459,8 +485,16 @@ static int run_stack(GenericEngine* g, const Stack& S, const float* x, int B, hi
             GEN_HIP(conv(g, P, in, ldin, g->d_gi, 2 * GH, 0, 0, B, st));
             float* y = bufs[l & 1];
             const int threads = (S.H + 63) / 64 * 64;
-            hipLaunchKernelGGL(gen_rnn_kernel, dim3(B, 2), dim3(threads), S.H * sizeof(float), st, S.cell, g->d_gi, g->d_w + R.whh_t[0], g->d_w + R.whh_t[1],
-                               g->d_w + R.bhh[0], g->d_w + R.bhh[1], y, S.H, L);
+            // blocks per workgroup: share the recurrent weights where the batch still fills the chip with workgroups
+            if (B >= 4096)
+                hipLaunchKernelGGL(gen_rnn_kernel<8>, dim3((B + 7) / 8, 2), dim3(threads), 8 * S.H * sizeof(float), st, S.cell, g->d_gi, g->d_w + R.whh_t[0],
+                                   g->d_w + R.whh_t[1], g->d_w + R.bhh[0], g->d_w + R.bhh[1], y, S.H, L, B);
+            else if (B >= 1024)
+                hipLaunchKernelGGL(gen_rnn_kernel<4>, dim3((B + 3) / 4, 2), dim3(threads), 4 * S.H * sizeof(float), st, S.cell, g->d_gi, g->d_w + R.whh_t[0],
+                                   g->d_w + R.whh_t[1], g->d_w + R.bhh[0], g->d_w + R.bhh[1], y, S.H, L, B);
+            else
+                hipLaunchKernelGGL(gen_rnn_kernel<1>, dim3(B, 2), dim3(threads), S.H * sizeof(float), st, S.cell, g->d_gi, g->d_w + R.whh_t[0],
+                                   g->d_w + R.whh_t[1], g->d_w + R.bhh[0], g->d_w + R.bhh[1], y, S.H, L, B);
             GEN_HIP(hipGetLastError());
             in = y;
             ldin = 2 * S.H;
