@@ -8,7 +8,7 @@ if os.path.isdir(src):
 rows = collections.defaultdict(list)
 for r in csv.DictReader(open(src)):
     name = r["Kernel_Name"]
-    name = name.split("(")[0].replace("void ", "")
+    name = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
     grid = r.get("Grid_Size") or r.get("Grid_Size_X") or "?"
     rows[(name, grid)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 lines = [f"# {src}", f"# {'kernel':70s} {'grid':>10s} {'calls':>6s} {'avg ms':>10s} {'min ms':>10s} {'max ms':>10s} {'total ms':>10s}"]

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -69,6 +71,88 @@ __global__ __launch_bounds__(256) void gen_conv_kernel(const float* __restrict__
             if (act == 1) v = v > 0.0f ? v : expm1f(v);
             y[(b * L + t) * (size_t)ldy + coff + co] = v;
         }
+    }
+}
+
+// The same convolution on the fp32 matrix cores (r04; the vector-ALU kernel above reached 13 TFLOP/s on the LSTM decoder's input
+// projection, 585 of its 857 ms per forward): v_mfma_f32_16x16x4_f32 with A = weights (M = output channel), B = activations
+// (N = position), fp32 operands and accumulation - no operand split, so no range limits (this is also the fall-back arithmetic).
+// Workgroup = 4 waves = 128 positions (FLATTENED over the batch, so short blocks fill tiles; a tap that would reach across a block
+// boundary is masked when the operand is read) x 64 output channels; wave = 32 positions x 64 channels = 8 accumulator tiles, 6 LDS
+// reads per 8 MFMAs.  Input channels are staged 32 at a time (rows padded to 36 floats: the 16 positions x 4 k of one operand read
+// fall into 64 different banks), weights 32 channels x up to 4 taps x 64 outputs (rows padded to 80).
+constexpr int kMP = 128, kMC = 64, kMK = 32, kMKP = 36, kMWP = 80, kMJ = 4;
+
+__global__ __launch_bounds__(256) void gen_conv_mfma_kernel(const float* __restrict__ x, int ldx, int cin, const float* __restrict__ wt,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int ldy, int coff, int cout,
+                                                            int k, int L, size_t np, int act) {
+    extern __shared__ float sm[];
+    const int rows = kMP + k - 1, pad = k / 2;
+    float* xs = sm;                                    // [rows][kMKP]: flattened positions p0 - pad ...
+    float* ws = sm + rows * kMKP;                      // [taps staged][kMK][kMWP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
+    const size_t p0 = (size_t)blockIdx.x * kMP;
+    const int ch0 = blockIdx.y * kMC;
+    int tn[2];                                         // time index of this lane's two positions inside their blocks
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const size_t p = p0 + wave * 32 + nt * 16 + n;
+        tn[nt] = p < np ? (int)(p % (size_t)L) : -(1 << 24);
+    }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < cin; c0 += kMK) {
+        const int nc = min(kMK, cin - c0), kend = (nc + 3) & ~3;
+        __syncthreads();
+        for (int i = tid; i < rows * kMK; i += 256) {
+            const int r = i / kMK, c = i % kMK;
+            const long long p = (long long)p0 - pad + r;
+            xs[r * kMKP + c] = (p >= 0 && (size_t)p < np && c < nc) ? x[(size_t)p * ldx + c0 + c] : 0.0f;
+        }
+        for (int j0 = 0; j0 < k; j0 += kMJ) {
+            const int nj = min(kMJ, k - j0);
+            if (j0) __syncthreads();
+            for (int i = tid; i < nj * kMK * kMC; i += 256) {
+                const int m = i % kMC, c = (i / kMC) % kMK, jj = i / (kMC * kMK);
+                ws[(jj * kMK + c) * kMWP + m] = (c < nc && ch0 + m < cout) ? wt[((size_t)(c0 + c) * k + j0 + jj) * cout + ch0 + m] : 0.0f;
+            }
+            __syncthreads();
+            for (int jj = 0; jj < nj; ++jj) {
+                const int j = j0 + jj;
+                const bool ok0 = (unsigned)(tn[0] + j - pad) < (unsigned)L, ok1 = (unsigned)(tn[1] + j - pad) < (unsigned)L;
+                const float* xr = xs + (wave * 32 + n + j) * kMKP + q;
+                const float* wr = ws + (jj * kMK + q) * kMWP + n;
+                for (int kk = 0; kk < kend; kk += 4) {
+                    const float b0 = ok0 ? xr[kk] : 0.0f, b1 = ok1 ? xr[16 * kMKP + kk] : 0.0f;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const float a = wr[kk * kMWP + mt * 16];
+                        acc[mt][0] = mfma16x16x4(a, b0, acc[mt][0]);
+                        acc[mt][1] = mfma16x16x4(a, b1, acc[mt][1]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const size_t p = p0 + wave * 32 + nt * 16 + n;
+        if (p >= np) continue;
+        float* yr = y + p * (size_t)ldy + coff;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = ch0 + mt * 16 + 4 * q + i;
+                if (ch < cout) {
+                    float v = acc[mt][nt][i] + bias[ch];
+                    if (act == 1) v = v > 0.0f ? v : expm1f(v);
+                    yr[ch] = v;
+                }
+            }
     }
 }
 
@@ -148,6 +232,119 @@ __global__ void gen_rnn_kernel(int cell, const float* __restrict__ gi, const flo
         }
         __syncthreads();
     }
+}
+
+// The same recurrence on the fp32 matrix cores for H <= 128 (r04; the vector-ALU kernel above took 287 of the LSTM decoder's 857 ms):
+// workgroup = 16 blocks x one direction, wave w owns hidden units [16w, 16w + 16) of every gate and keeps ITS rows of W_hh in
+// registers for the whole sequence (G * ceil(H / 4) operand registers: 100 for the LSTM at H = 100 - the matrix that does not fit in
+// LDS fits in the register files of 7 waves).  Per step: a = W_hh h_{t-1} as G accumulator tiles (M = 16 units, N = 16 blocks,
+// K = H in steps of 4; v_mfma_f32_16x16x4_f32, fp32 operands - no range limits), h_{t-1} read as B operands from LDS (rows of
+// 4 KS + {0, 4} floats: 16 blocks x 4 k fall into 64 banks), gates on the lane's 4 units x 1 block, h_t to the other LDS buffer
+// (one barrier per step) and to y.  sigmoid / tanh through v_exp_f32 + v_rcp_f32 as in turboae_gru.hip.
+__device__ __forceinline__ float sigm_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)), 1.0f); }
+
+template <int G, int KS>
+__global__ __launch_bounds__(512) void gen_rnn_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ whh_t0, const float* __restrict__ whh_t1,
+                                                           const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ y, int H, int L, int B) {
+    constexpr int HP = 4 * KS + ((4 * KS) % 8 == 4 ? 0 : 4);
+    extern __shared__ float hs[];                      // h_{t-1} / h_t: [2][16][HP]
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y, b0 = blockIdx.x * 16, nb = min(16, B - b0), GH = G * H;
+    const bool valid = n < nb;
+    const size_t bn = (size_t)b0 + (valid ? n : nb - 1);
+    const int u0 = wave * 16, ul = u0 + 4 * q;         // first of this lane's 4 units in the accumulator tiles
+    const float* whh = dir ? whh_t1 : whh_t0;
+    const float* bhh = dir ? bhh1 : bhh0;
+    const bool h4 = (H & 3) == 0;
+    float w[G][KS];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int u = u0 + n, k = 4 * ks + q;
+            w[g][ks] = (u < H && k < H) ? whh[(size_t)k * GH + g * H + u] : 0.0f;
+        }
+    f32x4 bias[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias[g][i] = ul + i < H ? bhh[g * H + ul + i] : 0.0f;
+    for (int i = tid; i < 2 * 16 * HP; i += (int)blockDim.x) hs[i] = 0.0f;
+    float hprev[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int s = 0; s < L; ++s) {
+        const int t = dir ? L - 1 - s : s;
+        const float* gp = gi + ((bn * L + t) * 2 + dir) * (size_t)GH + ul;
+        f32x4 gv[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (h4) gv[g] = ul < H ? *reinterpret_cast<const f32x4*>(gp + g * H) : f32x4{0.f, 0.f, 0.f, 0.f};
+            else
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gv[g][i] = ul + i < H ? gp[g * H + i] : 0.0f;
+        }
+        const float* hc = hs + (s & 1) * 16 * HP + n * HP + q;
+        f32x4 acc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] = bias[g];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float hb = hc[4 * ks];
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = mfma16x16x4(w[g][ks], hb, acc[g]);
+        }
+        f32x4 hn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (G == 3) {
+                const float r = sigm_fast(gv[0][i] + acc[0][i]);
+                const float z = sigm_fast(gv[1][i] + acc[1][i]);
+                const float nn = tanh_fast(fmaf(r, acc[2][i], gv[2][i]));
+                hn[i] = fmaf(z, hprev[i] - nn, nn);
+            } else if constexpr (G == 4) {
+                const float ig = sigm_fast(gv[0][i] + acc[0][i]);
+                const float fg = sigm_fast(gv[1][i] + acc[1][i]);
+                const float gg = tanh_fast(gv[2][i] + acc[2][i]);
+                const float og = sigm_fast(gv[3][i] + acc[3][i]);
+                c[i] = fmaf(fg, c[i], ig * gg);
+                hn[i] = og * tanh_fast(c[i]);
+            } else {
+                hn[i] = tanh_fast(gv[0][i] + acc[0][i]);
+            }
+            hprev[i] = hn[i];
+        }
+        float* hnext = hs + ((s + 1) & 1) * 16 * HP + n * HP + ul;
+        float* yp = y + (bn * L + t) * (size_t)(2 * H) + dir * H + ul;
+        if (h4) {
+            if (ul < H) {
+                *reinterpret_cast<f32x4*>(hnext) = hn;
+                if (valid) *reinterpret_cast<f32x4*>(yp) = hn;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (ul + i < H) {
+                    hnext[i] = hn[i];
+                    if (valid) yp[i] = hn[i];
+                }
+        }
+        __syncthreads();
+    }
+}
+
+template <int G>
+static hipError_t launch_rnn_mfma(const float* gi, const float* w0, const float* w1, const float* b0, const float* b1, float* y, int H, int L, int B, hipStream_t st) {
+    const dim3 grid((B + 15) / 16, 2), block(64 * ((H + 15) / 16));
+    const int ks = (H + 3) / 4;
+#define TAE_RNN_LAUNCH(KS) hipLaunchKernelGGL((gen_rnn_mfma_kernel<G, KS>), grid, block, 2 * 16 * (4 * KS + ((4 * KS) % 8 == 4 ? 0 : 4)) * sizeof(float), st, gi, w0, w1, b0, b1, y, H, L, B)
+    if (ks <= 8) TAE_RNN_LAUNCH(8);
+    else if (ks <= 16) TAE_RNN_LAUNCH(16);
+    else if (ks <= 25) TAE_RNN_LAUNCH(25);
+    else TAE_RNN_LAUNCH(32);
+#undef TAE_RNN_LAUNCH
+    return hipGetLastError();
 }
 
 // decoder stack inputs: XA = [r_sys, r_par1, prior = 0...], XB = [r_sys_int, r_par2, 0...] (decoders.py:87-93,221-227), W = 2 + F wide
@@ -454,6 +651,20 @@ int generic_reserve(GenericEngine* g, int32_t B) {
 
 static hipError_t conv(const GenericEngine* g, const ConvL& C, const float* x, int ldx, float* y, int ldy, int coff, int act, int B, hipStream_t st) {
     const int L = g->cfg.block_len;
+    static const bool valu = [] { const char* e = getenv("TAE_GEN_CONV"); return e && !strcmp(e, "valu"); }();     // experiments: the r03 vector-ALU kernel
+    if (!valu) {
+        const size_t np = (size_t)B * L;
+        const size_t lds = ((size_t)(kMP + C.k - 1) * kMKP + (size_t)std::min(C.k, kMJ) * kMK * kMWP) * sizeof(float);
+        static size_t lds_set = 0;
+        if (lds > lds_set) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gen_conv_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            lds_set = lds;
+        }
+        const dim3 grid((unsigned)((np + kMP - 1) / kMP), (C.cout + kMC - 1) / kMC);
+        hipLaunchKernelGGL(gen_conv_mfma_kernel, grid, dim3(256), lds, st, x, ldx, C.cin, g->d_w + C.wt, g->d_w + C.bias, y, ldy, coff, C.cout, C.k, L, np, act);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)(kConvPos + C.k - 1) * kConvCi * sizeof(float);
     // the block index rides in grid.y, which HIP caps at 65535: larger batches go out in slices
     for (int b0 = 0; b0 < B; b0 += 65535) {
@@ -486,10 +697,22 @@ static int run_stack(GenericEngine* g, const Stack& S, const float* x, int B, hi
             float* y = bufs[l & 1];
             const int threads = (S.H + 63) / 64 * 64;
             // blocks per workgroup: share the recurrent weights where the batch still fills the chip with workgroups
-            if (B >= 4096)
+            static const bool rnn_valu = [] { const char* e = getenv("TAE_GEN_RNN"); return e && !strcmp(e, "valu"); }();     // experiments: the vector-ALU kernel
+            if (S.H <= 128 && !rnn_valu) {
+                const float *w0 = g->d_w + R.whh_t[0], *w1 = g->d_w + R.whh_t[1], *b0 = g->d_w + R.bhh[0], *b1 = g->d_w + R.bhh[1];
+                GEN_HIP(S.cell == 0 ? launch_rnn_mfma<3>(g->d_gi, w0, w1, b0, b1, y, S.H, L, B, st)
+                      : S.cell == 1 ? launch_rnn_mfma<4>(g->d_gi, w0, w1, b0, b1, y, S.H, L, B, st)
+                                    : launch_rnn_mfma<1>(g->d_gi, w0, w1, b0, b1, y, S.H, L, B, st));
+                in = y;
+                ldin = 2 * S.H;
+                continue;
+            }
+            static const int nb_env = [] { const char* e = getenv("TAE_GEN_RNN_NB"); return e ? atoi(e) : 0; }();     // experiments: read once
+            const int nb = nb_env ? nb_env : (B >= 4096 ? 8 : (B >= 1024 ? 4 : 1));
+            if (nb == 8)
                 hipLaunchKernelGGL(gen_rnn_kernel<8>, dim3((B + 7) / 8, 2), dim3(threads), 8 * S.H * sizeof(float), st, S.cell, g->d_gi, g->d_w + R.whh_t[0],
                                    g->d_w + R.whh_t[1], g->d_w + R.bhh[0], g->d_w + R.bhh[1], y, S.H, L, B);
-            else if (B >= 1024)
+            else if (nb == 4)
                 hipLaunchKernelGGL(gen_rnn_kernel<4>, dim3((B + 3) / 4, 2), dim3(threads), 4 * S.H * sizeof(float), st, S.cell, g->d_gi, g->d_w + R.whh_t[0],
                                    g->d_w + R.whh_t[1], g->d_w + R.bhh[0], g->d_w + R.bhh[1], y, S.H, L, B);
             else
