@@ -77,61 +77,88 @@ __global__ __launch_bounds__(256) void gen_conv_kernel(const float* __restrict__
 // The same convolution on the fp32 matrix cores (r04; the vector-ALU kernel above reached 13 TFLOP/s on the LSTM decoder's input
 // projection, 585 of its 857 ms per forward): v_mfma_f32_16x16x4_f32 with A = weights (M = output channel), B = activations
 // (N = position), fp32 operands and accumulation - no operand split, so no range limits (this is also the fall-back arithmetic).
-// Workgroup = 4 waves = 128 positions (FLATTENED over the batch, so short blocks fill tiles; a tap that would reach across a block
-// boundary is masked when the operand is read) x 64 output channels; wave = 32 positions x 64 channels = 8 accumulator tiles, 6 LDS
-// reads per 8 MFMAs.  Input channels are staged 32 at a time (rows padded to 36 floats: the 16 positions x 4 k of one operand read
-// fall into 64 different banks), weights 32 channels x up to 4 taps x 64 outputs (rows padded to 80).
-constexpr int kMP = 128, kMC = 64, kMK = 32, kMKP = 36, kMWP = 80, kMJ = 4;
+// Workgroup = 8 waves = 256 positions (FLATTENED over the batch, so short blocks fill tiles; a tap that would reach across a block
+// boundary is masked when the operand is read) x 128 output channels, 171 flops per staged float; wave = 32 positions x 128
+// channels = 16 accumulator tiles, 2 + 2 LDS reads per 16 MFMAs.  Input channels are staged 32 at a time (rows padded to 36 floats:
+// the 16 positions x 4 k of one operand read fall into 64 different banks), weights 32 channels x up to 4 taps x 128 outputs with
+// the outputs of a row permuted (channel 16 mt + n at n * 8 + mt) so that a lane's 8 A operands are two 16-byte reads.
+constexpr int kMP = 256, kMC = 128, kMK = 32, kMKP = 36, kMWP = 136, kMJ = 4;
 
-__global__ __launch_bounds__(256) void gen_conv_mfma_kernel(const float* __restrict__ x, int ldx, int cin, const float* __restrict__ wt,
+__global__ __launch_bounds__(512) void gen_conv_mfma_kernel(const float* __restrict__ x, int ldx, int cin, const float* __restrict__ wt,
                                                             const float* __restrict__ bias, float* __restrict__ y, int ldy, int coff, int cout,
                                                             int k, int L, size_t np, int act) {
-    extern __shared__ float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     const int rows = kMP + k - 1, pad = k / 2;
     float* xs = sm;                                    // [rows][kMKP]: flattened positions p0 - pad ...
     float* ws = sm + rows * kMKP;                      // [taps staged][kMK][kMWP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
     const size_t p0 = (size_t)blockIdx.x * kMP;
     const int ch0 = blockIdx.y * kMC;
+    const bool xv = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    const bool wv = (cout & 3) == 0 && (reinterpret_cast<uintptr_t>(wt) & 15) == 0;
+    const bool yv = (ldy & 3) == 0 && (coff & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
     int tn[2];                                         // time index of this lane's two positions inside their blocks
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const size_t p = p0 + wave * 32 + nt * 16 + n;
         tn[nt] = p < np ? (int)(p % (size_t)L) : -(1 << 24);
     }
-    f32x4 acc[4][2];
+    f32x4 acc[8][2];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int c0 = 0; c0 < cin; c0 += kMK) {
         const int nc = min(kMK, cin - c0), kend = (nc + 3) & ~3;
         __syncthreads();
-        for (int i = tid; i < rows * kMK; i += 256) {
-            const int r = i / kMK, c = i % kMK;
+        for (int i = tid; i < rows * (kMK / 4); i += 512) {
+            const int r = i / (kMK / 4), c = (i % (kMK / 4)) * 4;
             const long long p = (long long)p0 - pad + r;
-            xs[r * kMKP + c] = (p >= 0 && (size_t)p < np && c < nc) ? x[(size_t)p * ldx + c0 + c] : 0.0f;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p >= 0 && (size_t)p < np && c < nc) {
+                const float* src = x + (size_t)p * ldx + c0 + c;
+                if (xv && c + 4 <= nc) v = *reinterpret_cast<const f32x4*>(src);
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = c + e < nc ? src[e] : 0.0f;
+            }
+            *reinterpret_cast<f32x4*>(xs + r * kMKP + c) = v;
         }
         for (int j0 = 0; j0 < k; j0 += kMJ) {
             const int nj = min(kMJ, k - j0);
             if (j0) __syncthreads();
-            for (int i = tid; i < nj * kMK * kMC; i += 256) {
-                const int m = i % kMC, c = (i / kMC) % kMK, jj = i / (kMC * kMK);
-                ws[(jj * kMK + c) * kMWP + m] = (c < nc && ch0 + m < cout) ? wt[((size_t)(c0 + c) * k + j0 + jj) * cout + ch0 + m] : 0.0f;
+            for (int i = tid; i < nj * kMK * (kMC / 4); i += 512) {
+                const int m = (i % (kMC / 4)) * 4, c = (i / (kMC / 4)) % kMK, jj = i / ((kMC / 4) * kMK);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (c < nc && ch0 + m < cout) {
+                    const float* src = wt + ((size_t)(c0 + c) * k + j0 + jj) * cout + ch0 + m;
+                    if (wv && ch0 + m + 4 <= cout) v = *reinterpret_cast<const f32x4*>(src);
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ch0 + m + e < cout ? src[e] : 0.0f;
+                }
+                float* dst = ws + (jj * kMK + c) * kMWP + (m >> 4);      // m .. m + 3 share a channel tile (m is a multiple of 4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[((m & 15) + e) * 8] = v[e];
             }
             __syncthreads();
             for (int jj = 0; jj < nj; ++jj) {
                 const int j = j0 + jj;
                 const bool ok0 = (unsigned)(tn[0] + j - pad) < (unsigned)L, ok1 = (unsigned)(tn[1] + j - pad) < (unsigned)L;
                 const float* xr = xs + (wave * 32 + n + j) * kMKP + q;
-                const float* wr = ws + (jj * kMK + q) * kMWP + n;
+                const float* wr = ws + (jj * kMK + q) * kMWP + n * 8;
                 for (int kk = 0; kk < kend; kk += 4) {
                     const float b0 = ok0 ? xr[kk] : 0.0f, b1 = ok1 ? xr[16 * kMKP + kk] : 0.0f;
+                    const f32x4 alo = *reinterpret_cast<const f32x4*>(wr + kk * kMWP), ahi = *reinterpret_cast<const f32x4*>(wr + kk * kMWP + 4);
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) {
-                        const float a = wr[kk * kMWP + mt * 16];
-                        acc[mt][0] = mfma16x16x4(a, b0, acc[mt][0]);
-                        acc[mt][1] = mfma16x16x4(a, b1, acc[mt][1]);
+                        acc[mt][0] = mfma16x16x4(alo[mt], b0, acc[mt][0]);
+                        acc[mt][1] = mfma16x16x4(alo[mt], b1, acc[mt][1]);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        acc[4 + mt][0] = mfma16x16x4(ahi[mt], b0, acc[4 + mt][0]);
+                        acc[4 + mt][1] = mfma16x16x4(ahi[mt], b1, acc[4 + mt][1]);
                     }
                 }
             }
@@ -143,16 +170,22 @@ __global__ __launch_bounds__(256) void gen_conv_mfma_kernel(const float* __restr
         if (p >= np) continue;
         float* yr = y + p * (size_t)ldy + coff;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 8; ++mt) {
+            const int ch = ch0 + mt * 16 + 4 * q;
+            if (ch >= cout) continue;
+            f32x4 v;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int ch = ch0 + mt * 16 + 4 * q + i;
-                if (ch < cout) {
-                    float v = acc[mt][nt][i] + bias[ch];
-                    if (act == 1) v = v > 0.0f ? v : expm1f(v);
-                    yr[ch] = v;
-                }
+                float t = acc[mt][nt][i] + (ch + i < cout ? bias[ch + i] : 0.0f);
+                if (act == 1) t = t > 0.0f ? t : expm1f(t);
+                v[i] = t;
             }
+            if (yv && ch + 4 <= cout) *reinterpret_cast<f32x4*>(yr + ch) = v;
+            else
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ch + i < cout) yr[ch + i] = v[i];
+        }
     }
 }
 
@@ -662,7 +695,7 @@ static hipError_t conv(const GenericEngine* g, const ConvL& C, const float* x, i
             lds_set = lds;
         }
         const dim3 grid((unsigned)((np + kMP - 1) / kMP), (C.cout + kMC - 1) / kMC);
-        hipLaunchKernelGGL(gen_conv_mfma_kernel, grid, dim3(256), lds, st, x, ldx, C.cin, g->d_w + C.wt, g->d_w + C.bias, y, ldy, coff, C.cout, C.k, L, np, act);
+        hipLaunchKernelGGL(gen_conv_mfma_kernel, grid, dim3(512), lds, st, x, ldx, C.cin, g->d_w + C.wt, g->d_w + C.bias, y, ldy, coff, C.cout, C.k, L, np, act);
         return hipGetLastError();
     }
     const size_t lds = (size_t)(kConvPos + C.k - 1) * kConvCi * sizeof(float);
