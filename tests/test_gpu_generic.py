@@ -98,6 +98,43 @@ def test_random_generic_configurations_match_oracle(gpu_device, case):
     assert np.abs(xd - xo).max() <= tol_x, np.abs(xd - xo).max()
 
 
+# r04: the generic recurrence runs on the fp32 matrix cores for H <= 128 (gen_rnn_mfma_kernel<G, KS>, KS = 8 / 16 / 25 / 32 k-steps),
+# 16 blocks per workgroup; above that on the vector-ALU kernel (1 / 4 / 8 blocks per workgroup by batch).  One case per
+# instantiation and edge: widths that are not multiples of 4 (scalar loads / stores), batches that leave a ragged last workgroup,
+# the last width of the MFMA kernel and the first of the vector-ALU one.
+@pytest.mark.parametrize("cell,H,B,L", [("lstm", 27, 5, 12), ("gru", 64, 37, 10), ("rnn", 100, 16, 9), ("lstm", 100, 33, 16), ("gru", 101, 3, 7),
+                                         ("lstm", 128, 17, 6), ("rnn", 126, 50, 5), ("lstm", 130, 9, 6), ("gru", 200, 4, 5), ("rnn", 7, 1, 1)])
+def test_generic_recurrence_kernels_every_instantiation(gpu_device, monkeypatch, cell, H, B, L):
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn=cell, dec_num_unit=H, enc_num_unit=20, block_len=L, num_iteration=2)
+    if not cfg.generic:            # 2-layer GRUs up to 100 units have their own MFMA kernels: the testing knob puts them on these
+        monkeypatch.setenv("TAE_FORCE_GENERIC", "1")
+    wseed = 1000 + H
+    sd = W.generate_state_dict(cfg, seed=wseed, gain=1.0)
+    u = philox.random_bits(wseed, 0, B * L).reshape(B, L, 1)
+    noise = (np.float32(O.snr_db2sigma(1.0)) * philox.random_normal(wseed, 0, B * L * 3)).reshape(B, L, 3).astype(np.float32)
+    xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict(), {})
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    assert model.kernel_info() == (0, 0)
+    xd, codes = model(torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device))
+    assert np.abs(codes.cpu().numpy() - co.numpy()).max() <= 2e-5
+    d = np.abs(xd.cpu().numpy() - xo.numpy()).max()
+    assert d <= 6e-5, d
+
+
+def test_generic_recurrence_does_not_depend_on_the_batch(gpu_device):
+    """The vector-ALU recurrence (H > 128) shares W_hh between 1 / 4 / 8 blocks of a workgroup depending on the batch, the MFMA one
+    (H <= 128) between 16: a block's result must not depend on which batch it arrived in (same FMA chain / same MFMA operands)."""
+    from turboae_amd import Channel_AE_HIP
+    for H, L in ((130, 3), (100, 4)):
+        cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="lstm", dec_num_unit=H, enc_num_unit=8, enc_num_layer=1, block_len=L, num_iteration=1)
+        model = Channel_AE_HIP(cfg, W.generate_state_dict(cfg, seed=5, gain=1.0), device=gpu_device, max_batch=4100)
+        rx = torch.from_numpy(philox.random_normal(6, 0, 4100 * L * 3).reshape(4100, L, 3).astype(np.float32)).to(gpu_device)
+        big = model.dec(rx)                        # 8 blocks per workgroup (H = 130)
+        for nb in (1029, 5):                       # 4 blocks per workgroup, 1 block per workgroup
+            assert torch.equal(model.dec(rx[:nb].contiguous()), big[:nb]), (H, nb)
+
+
 @pytest.mark.parametrize("decoder", ["TurboAE_rate3_cnn", "TurboAE_rate3_rnn"])
 def test_three_independent_implementations_agree_on_the_trained_network(gpu_device, monkeypatch, decoder):
     """TAE_FORCE_GENERIC=1 runs a standard configuration on the generic vector-ALU kernels: a third implementation next to the fp16-split

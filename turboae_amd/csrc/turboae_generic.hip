@@ -277,16 +277,21 @@ __global__ void gen_rnn_kernel(int cell, const float* __restrict__ gi, const flo
 __device__ __forceinline__ float sigm_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
 __device__ __forceinline__ float tanh_fast(float x) { return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)), 1.0f); }
 
-template <int G, int KS>
+template <int G, int KS, int NT>
 __global__ __launch_bounds__(512) void gen_rnn_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ whh_t0, const float* __restrict__ whh_t1,
                                                            const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ y, int H, int L, int B) {
-    constexpr int HP = 4 * KS + ((4 * KS) % 8 == 4 ? 0 : 4);
-    extern __shared__ float hs[];                      // h_{t-1} / h_t: [2][16][HP]
+    constexpr int HP = 4 * KS + ((4 * KS) % 8 == 4 ? 0 : 4), NBLK = 16 * NT;
+    extern __shared__ float hs[];                      // h_{t-1} / h_t: [2][NBLK][HP]
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dir = blockIdx.y, b0 = blockIdx.x * 16, nb = min(16, B - b0), GH = G * H;
-    const bool valid = n < nb;
-    const size_t bn = (size_t)b0 + (valid ? n : nb - 1);
+    const int dir = blockIdx.y, b0 = blockIdx.x * NBLK, nb = min(NBLK, B - b0), GH = G * H;
+    bool valid[NT];
+    size_t bn[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        valid[nt] = n + 16 * nt < nb;
+        bn[nt] = (size_t)b0 + (valid[nt] ? n + 16 * nt : nb - 1);
+    }
     const int u0 = wave * 16, ul = u0 + 4 * q;         // first of this lane's 4 units in the accumulator tiles
     const float* whh = dir ? whh_t1 : whh_t0;
     const float* bhh = dir ? bhh1 : bhh0;
@@ -304,80 +309,103 @@ __global__ __launch_bounds__(512) void gen_rnn_mfma_kernel(const float* __restri
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias[g][i] = ul + i < H ? bhh[g * H + ul + i] : 0.0f;
-    for (int i = tid; i < 2 * 16 * HP; i += (int)blockDim.x) hs[i] = 0.0f;
-    float hprev[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < 2 * NBLK * HP; i += (int)blockDim.x) hs[i] = 0.0f;
+    f32x4 hprev[NT], c[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) hprev[nt] = c[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     for (int s = 0; s < L; ++s) {
         const int t = dir ? L - 1 - s : s;
-        const float* gp = gi + ((bn * L + t) * 2 + dir) * (size_t)GH + ul;
-        f32x4 gv[G];
+        f32x4 gv[NT][G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            if (h4) gv[g] = ul < H ? *reinterpret_cast<const f32x4*>(gp + g * H) : f32x4{0.f, 0.f, 0.f, 0.f};
-            else
+        for (int nt = 0; nt < NT; ++nt) {
+            const float* gp = gi + ((bn[nt] * L + t) * 2 + dir) * (size_t)GH + ul;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) gv[g][i] = ul + i < H ? gp[g * H + i] : 0.0f;
+            for (int g = 0; g < G; ++g) {
+                if (h4) gv[nt][g] = ul < H ? *reinterpret_cast<const f32x4*>(gp + g * H) : f32x4{0.f, 0.f, 0.f, 0.f};
+                else
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gv[nt][g][i] = ul + i < H ? gp[g * H + i] : 0.0f;
+            }
         }
-        const float* hc = hs + (s & 1) * 16 * HP + n * HP + q;
-        f32x4 acc[G];
+        const float* hc = hs + (s & 1) * NBLK * HP + n * HP + q;
+        f32x4 acc[NT][G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) acc[g] = bias[g];
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[nt][g] = bias[g];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const float hb = hc[4 * ks];
 #pragma unroll
-            for (int g = 0; g < G; ++g) acc[g] = mfma16x16x4(w[g][ks], hb, acc[g]);
-        }
-        f32x4 hn;
+            for (int nt = 0; nt < NT; ++nt) {
+                const float hb = hc[nt * 16 * HP + 4 * ks];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if constexpr (G == 3) {
-                const float r = sigm_fast(gv[0][i] + acc[0][i]);
-                const float z = sigm_fast(gv[1][i] + acc[1][i]);
-                const float nn = tanh_fast(fmaf(r, acc[2][i], gv[2][i]));
-                hn[i] = fmaf(z, hprev[i] - nn, nn);
-            } else if constexpr (G == 4) {
-                const float ig = sigm_fast(gv[0][i] + acc[0][i]);
-                const float fg = sigm_fast(gv[1][i] + acc[1][i]);
-                const float gg = tanh_fast(gv[2][i] + acc[2][i]);
-                const float og = sigm_fast(gv[3][i] + acc[3][i]);
-                c[i] = fmaf(fg, c[i], ig * gg);
-                hn[i] = og * tanh_fast(c[i]);
-            } else {
-                hn[i] = tanh_fast(gv[0][i] + acc[0][i]);
+                for (int g = 0; g < G; ++g) acc[nt][g] = mfma16x16x4(w[g][ks], hb, acc[nt][g]);
             }
-            hprev[i] = hn[i];
         }
-        float* hnext = hs + ((s + 1) & 1) * 16 * HP + n * HP + ul;
-        float* yp = y + (bn * L + t) * (size_t)(2 * H) + dir * H + ul;
-        if (h4) {
-            if (ul < H) {
-                *reinterpret_cast<f32x4*>(hnext) = hn;
-                if (valid) *reinterpret_cast<f32x4*>(yp) = hn;
-            }
-        } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (ul + i < H) {
-                    hnext[i] = hn[i];
-                    if (valid) yp[i] = hn[i];
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 hn;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (G == 3) {
+                    const float r = sigm_fast(gv[nt][0][i] + acc[nt][0][i]);
+                    const float z = sigm_fast(gv[nt][1][i] + acc[nt][1][i]);
+                    const float nn = tanh_fast(fmaf(r, acc[nt][2][i], gv[nt][2][i]));
+                    hn[i] = fmaf(z, hprev[nt][i] - nn, nn);
+                } else if constexpr (G == 4) {
+                    const float ig = sigm_fast(gv[nt][0][i] + acc[nt][0][i]);
+                    const float fg = sigm_fast(gv[nt][1][i] + acc[nt][1][i]);
+                    const float gg = tanh_fast(gv[nt][2][i] + acc[nt][2][i]);
+                    const float og = sigm_fast(gv[nt][3][i] + acc[nt][3][i]);
+                    c[nt][i] = fmaf(fg, c[nt][i], ig * gg);
+                    hn[i] = og * tanh_fast(c[nt][i]);
+                } else {
+                    hn[i] = tanh_fast(gv[nt][0][i] + acc[nt][0][i]);
                 }
+            }
+            hprev[nt] = hn;
+            float* hnext = hs + ((s + 1) & 1) * NBLK * HP + (n + 16 * nt) * HP + ul;
+            float* yp = y + (bn[nt] * L + t) * (size_t)(2 * H) + dir * H + ul;
+            if (h4) {
+                if (ul < H) {
+                    *reinterpret_cast<f32x4*>(hnext) = hn;
+                    if (valid[nt]) *reinterpret_cast<f32x4*>(yp) = hn;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ul + i < H) {
+                        hnext[i] = hn[i];
+                        if (valid[nt]) yp[i] = hn[i];
+                    }
+            }
         }
         __syncthreads();
     }
 }
 
-template <int G>
-static hipError_t launch_rnn_mfma(const float* gi, const float* w0, const float* w1, const float* b0, const float* b1, float* y, int H, int L, int B, hipStream_t st) {
-    const dim3 grid((B + 15) / 16, 2), block(64 * ((H + 15) / 16));
+template <int G, int NT>
+static hipError_t launch_rnn_mfma_nt(const float* gi, const float* w0, const float* w1, const float* b0, const float* b1, float* y, int H, int L, int B, hipStream_t st) {
+    const dim3 grid((B + 16 * NT - 1) / (16 * NT), 2), block(64 * ((H + 15) / 16));
     const int ks = (H + 3) / 4;
-#define TAE_RNN_LAUNCH(KS) hipLaunchKernelGGL((gen_rnn_mfma_kernel<G, KS>), grid, block, 2 * 16 * (4 * KS + ((4 * KS) % 8 == 4 ? 0 : 4)) * sizeof(float), st, gi, w0, w1, b0, b1, y, H, L, B)
+#define TAE_RNN_LAUNCH(KS) hipLaunchKernelGGL((gen_rnn_mfma_kernel<G, KS, NT>), grid, block, 2 * 16 * NT * (4 * KS + ((4 * KS) % 8 == 4 ? 0 : 4)) * sizeof(float), st, gi, w0, w1, b0, b1, y, H, L, B)
     if (ks <= 8) TAE_RNN_LAUNCH(8);
     else if (ks <= 16) TAE_RNN_LAUNCH(16);
     else if (ks <= 25) TAE_RNN_LAUNCH(25);
     else TAE_RNN_LAUNCH(32);
 #undef TAE_RNN_LAUNCH
     return hipGetLastError();
+}
+
+// 16 blocks per workgroup.  32 (NT = 2: two position tiles share the register-resident W_hh and the per-step barrier) measured the
+// same - 4.65 vs 4.73 ms per launch of the LSTM decoder at 16 384 blocks, profiles/r04_gen_rnn_nt_ab.txt: the step is bound by the
+// fp32 MFMA issue, not by the barrier - and stays behind TAE_GEN_RNN_NT=2 for experiments.
+template <int G>
+static hipError_t launch_rnn_mfma(const float* gi, const float* w0, const float* w1, const float* b0, const float* b1, float* y, int H, int L, int B, hipStream_t st) {
+    static const int nt_env = [] { const char* e = getenv("TAE_GEN_RNN_NT"); return e ? atoi(e) : 0; }();     // experiments: read once
+    const int nt = nt_env == 2 ? 2 : 1;
+    return nt == 2 ? launch_rnn_mfma_nt<G, 2>(gi, w0, w1, b0, b1, y, H, L, B, st) : launch_rnn_mfma_nt<G, 1>(gi, w0, w1, b0, b1, y, H, L, B, st);
 }
 
 // decoder stack inputs: XA = [r_sys, r_par1, prior = 0...], XB = [r_sys_int, r_par2, 0...] (decoders.py:87-93,221-227), W = 2 + F wide
