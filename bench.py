@@ -246,7 +246,9 @@ def time_other_config(name: str, cfg: TurboAEConfig, sd, B: int, dev, snr: float
     dec_tf = 2.0 * macs["dec"] * B * L / (dec_ms * 1e-3) / 1e12
     enc_tf = 2.0 * macs["enc"] * B * L / (enc_ms * 1e-3) / 1e12
     nb, lds = model.kernel_info()
-    if cfg.decoder == "TurboAE_rate3_rnn":
+    if cfg.generic:
+        kern = "generic fp32 MFMA kernels: tae::gen_conv_mfma_kernel" + (" / tae::gen_rnn_mfma_kernel" if cfg.decoder == "TurboAE_rate3_rnn" else "")
+    elif cfg.decoder == "TurboAE_rate3_rnn":
         kern = ("gru_rec_h / gru_proj_h / gru_head" if is_h2 else "gru_rec / gru_proj / gru_head") + f" x {2 * cfg.num_iteration} stacks (GRU decoder)"
     elif nb == 0:
         kern = ("tae::seg_kernel_h<100,5>" if is_h2 else "tae::seg_kernel<100,5>") + f" x {2 * cfg.num_iteration} launches (long-block decoder)"
@@ -284,6 +286,19 @@ def other_configs(dev, snr: float, sd_trained):
     c4 = TurboAEConfig(decoder="TurboAE_rate3_rnn")
     sd4, w4 = fixture(TRAINED_GRU, c4)
     res.append(time_other_config("configs[4]: TurboAE_rate3_rnn (GRU decoder), block_len=100, batch=16384", c4, sd4, 16384, dev, snr, w4))
+    return res
+
+
+def generic_configs(dev, snr: float):
+    """Two configurations outside the f16x2 kernels' envelope, on the library's generic fp32 MFMA kernels: an LSTM
+    decoder (`-dec_rnn lstm`) and a 256-wide CNN pair.  Random-init weights (no reference-trained fixture): timing only."""
+    res = []
+    cl = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="lstm")
+    res.append(time_other_config("-dec_rnn lstm (DEC_LargeRNN, LSTM cell), block_len=100, batch=16384", cl,
+                                 W.generate_state_dict(cl, seed=SEED, gain=1.0), 16384, dev, snr, "random-init", runs=3))
+    cw = TurboAEConfig(enc_num_unit=256, dec_num_unit=256)
+    res.append(time_other_config("-enc_num_unit 256 -dec_num_unit 256, block_len=100, batch=2048", cw,
+                                 W.generate_state_dict(cw, seed=SEED, gain=1.0), 2048, dev, snr, "random-init", runs=3))
     return res
 
 
@@ -680,6 +695,10 @@ def main():
                 out["roofline"]["other_configs"] = other_configs(dev, args.snr, sd if trained else None)
             except Exception as e:       # the headline line must not depend on a side measurement: report, do not die
                 out["roofline"]["other_configs"] = [{"error": f"{type(e).__name__}: {e}"}]
+            try:
+                out["roofline"]["generic_configs"] = generic_configs(dev, args.snr)
+            except Exception as e:
+                out["roofline"]["generic_configs"] = [{"error": f"{type(e).__name__}: {e}"}]
         if main_res.get("graph") is not None:
             gr = dict(main_res["graph"])
             gr["eager_ms_per_step"] = elapsed / steps * 1e3
