@@ -277,10 +277,15 @@ __global__ void gen_rnn_kernel(int cell, const float* __restrict__ gi, const flo
 __device__ __forceinline__ float sigm_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
 __device__ __forceinline__ float tanh_fast(float x) { return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)), 1.0f); }
 
-template <int G, int KS, int NT>
-__global__ __launch_bounds__(512) void gen_rnn_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ whh_t0, const float* __restrict__ whh_t1,
+// XK > 0 (layer inputs of <= 4 XK channels, i.e. every first layer: 2 + num_iter_ft <= 8 decoder inputs, 1 encoder input): the input
+// projection W_ih x_t + b_ih is XK more MFMAs per gate and step on operands fetched from x itself, so GI (2 G H floats per position
+// written by a projection launch and read back here: 2 x 5.2 GB per LSTM layer at 16 384 blocks) never exists.
+template <int G, int KS, int NT, int XK>
+__global__ __launch_bounds__(512) void gen_rnn_mfma_kernel(const float* __restrict__ gi, const float* __restrict__ xin, int ldin, int cin,
+                                                           const float* __restrict__ wih_t, const float* __restrict__ bih,
+                                                           const float* __restrict__ whh_t0, const float* __restrict__ whh_t1,
                                                            const float* __restrict__ bhh0, const float* __restrict__ bhh1, float* __restrict__ y, int H, int L, int B) {
-    constexpr int HP = 4 * KS + ((4 * KS) % 8 == 4 ? 0 : 4), NBLK = 16 * NT;
+    constexpr int HP = 4 * KS + ((4 * KS) % 8 == 4 ? 0 : 4), NBLK = 16 * NT, XKR = XK > 0 ? XK : 1;
     extern __shared__ float hs[];                      // h_{t-1} / h_t: [2][NBLK][HP]
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -296,19 +301,28 @@ __global__ __launch_bounds__(512) void gen_rnn_mfma_kernel(const float* __restri
     const float* whh = dir ? whh_t1 : whh_t0;
     const float* bhh = dir ? bhh1 : bhh0;
     const bool h4 = (H & 3) == 0;
-    float w[G][KS];
+    float w[G][KS], wx[G][XKR];
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+    for (int g = 0; g < G; ++g) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int u = u0 + n, k = 4 * ks + q;
             w[g][ks] = (u < H && k < H) ? whh[(size_t)k * GH + g * H + u] : 0.0f;
         }
-    f32x4 bias[G];
+#pragma unroll
+        for (int j = 0; j < XKR; ++j) {
+            const int u = u0 + n, k = 4 * j + q;
+            wx[g][j] = (XK > 0 && u < H && k < cin) ? wih_t[(size_t)k * (2 * GH) + dir * GH + g * H + u] : 0.0f;
+        }
+    }
+    f32x4 bias[G], biasx[G];
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bias[g][i] = ul + i < H ? bhh[g * H + ul + i] : 0.0f;
+        for (int i = 0; i < 4; ++i) {
+            bias[g][i] = ul + i < H ? bhh[g * H + ul + i] : 0.0f;
+            biasx[g][i] = (XK > 0 && ul + i < H) ? bih[dir * GH + g * H + ul + i] : 0.0f;
+        }
     for (int i = tid; i < 2 * NBLK * HP; i += (int)blockDim.x) hs[i] = 0.0f;
     f32x4 hprev[NT], c[NT];
 #pragma unroll
@@ -319,13 +333,26 @@ __global__ __launch_bounds__(512) void gen_rnn_mfma_kernel(const float* __restri
         f32x4 gv[NT][G];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const float* gp = gi + ((bn[nt] * L + t) * 2 + dir) * (size_t)GH + ul;
+            if constexpr (XK > 0) {
+                const float* xp = xin + (bn[nt] * L + t) * (size_t)ldin + q;
+                float xb[XKR];
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if (h4) gv[nt][g] = ul < H ? *reinterpret_cast<const f32x4*>(gp + g * H) : f32x4{0.f, 0.f, 0.f, 0.f};
-                else
+                for (int j = 0; j < XKR; ++j) xb[j] = 4 * j + q < cin ? xp[4 * j] : 0.0f;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) gv[nt][g][i] = ul + i < H ? gp[g * H + i] : 0.0f;
+                for (int g = 0; g < G; ++g) {
+                    gv[nt][g] = biasx[g];
+#pragma unroll
+                    for (int j = 0; j < XKR; ++j) gv[nt][g] = mfma16x16x4(wx[g][j], xb[j], gv[nt][g]);
+                }
+            } else {
+                const float* gp = gi + ((bn[nt] * L + t) * 2 + dir) * (size_t)GH + ul;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (h4) gv[nt][g] = ul < H ? *reinterpret_cast<const f32x4*>(gp + g * H) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    else
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) gv[nt][g][i] = ul + i < H ? gp[g * H + i] : 0.0f;
+                }
             }
         }
         const float* hc = hs + (s & 1) * NBLK * HP + n * HP + q;
@@ -385,11 +412,17 @@ __global__ __launch_bounds__(512) void gen_rnn_mfma_kernel(const float* __restri
     }
 }
 
-template <int G, int NT>
-static hipError_t launch_rnn_mfma_nt(const float* gi, const float* w0, const float* w1, const float* b0, const float* b1, float* y, int H, int L, int B, hipStream_t st) {
-    const dim3 grid((B + 16 * NT - 1) / (16 * NT), 2), block(64 * ((H + 15) / 16));
-    const int ks = (H + 3) / 4;
-#define TAE_RNN_LAUNCH(KS) hipLaunchKernelGGL((gen_rnn_mfma_kernel<G, KS, NT>), grid, block, 2 * 16 * NT * (4 * KS + ((4 * KS) % 8 == 4 ? 0 : 4)) * sizeof(float), st, gi, w0, w1, b0, b1, y, H, L, B)
+struct RnnArgs { const float *gi, *xin; int ldin, cin; const float *wih_t, *bih, *w0, *w1, *b0, *b1; float* y; int H, L, B; };
+
+// 16 blocks per workgroup.  32 (NT = 2: two position tiles share the register-resident W_hh and the per-step barrier) measured the
+// same - 4.65 vs 4.73 ms per launch of the LSTM decoder at 16 384 blocks, profiles/r04_gen_rnn_nt_ab.txt: the step is bound by the
+// fp32 MFMA issue, not by the barrier - and is not instantiated.
+template <int G, int XK>
+static hipError_t launch_rnn_mfma_x(const RnnArgs& a, hipStream_t st) {
+    const dim3 grid((a.B + 15) / 16, 2), block(64 * ((a.H + 15) / 16));
+    const int ks = (a.H + 3) / 4;
+#define TAE_RNN_LAUNCH(KS) hipLaunchKernelGGL((gen_rnn_mfma_kernel<G, KS, 1, XK>), grid, block, 2 * 16 * (4 * KS + ((4 * KS) % 8 == 4 ? 0 : 4)) * sizeof(float), st, \
+                                              a.gi, a.xin, a.ldin, a.cin, a.wih_t, a.bih, a.w0, a.w1, a.b0, a.b1, a.y, a.H, a.L, a.B)
     if (ks <= 8) TAE_RNN_LAUNCH(8);
     else if (ks <= 16) TAE_RNN_LAUNCH(16);
     else if (ks <= 25) TAE_RNN_LAUNCH(25);
@@ -398,14 +431,9 @@ static hipError_t launch_rnn_mfma_nt(const float* gi, const float* w0, const flo
     return hipGetLastError();
 }
 
-// 16 blocks per workgroup.  32 (NT = 2: two position tiles share the register-resident W_hh and the per-step barrier) measured the
-// same - 4.65 vs 4.73 ms per launch of the LSTM decoder at 16 384 blocks, profiles/r04_gen_rnn_nt_ab.txt: the step is bound by the
-// fp32 MFMA issue, not by the barrier - and stays behind TAE_GEN_RNN_NT=2 for experiments.
 template <int G>
-static hipError_t launch_rnn_mfma(const float* gi, const float* w0, const float* w1, const float* b0, const float* b1, float* y, int H, int L, int B, hipStream_t st) {
-    static const int nt_env = [] { const char* e = getenv("TAE_GEN_RNN_NT"); return e ? atoi(e) : 0; }();     // experiments: read once
-    const int nt = nt_env == 2 ? 2 : 1;
-    return nt == 2 ? launch_rnn_mfma_nt<G, 2>(gi, w0, w1, b0, b1, y, H, L, B, st) : launch_rnn_mfma_nt<G, 1>(gi, w0, w1, b0, b1, y, H, L, B, st);
+static hipError_t launch_rnn_mfma(const RnnArgs& a, bool fused, hipStream_t st) {
+    return fused ? launch_rnn_mfma_x<G, 2>(a, st) : launch_rnn_mfma_x<G, 0>(a, st);
 }
 
 // decoder stack inputs: XA = [r_sys, r_par1, prior = 0...], XB = [r_sys_int, r_par2, 0...] (decoders.py:87-93,221-227), W = 2 + F wide
@@ -753,21 +781,24 @@ static int run_stack(GenericEngine* g, const Stack& S, const float* x, int B, hi
         float* bufs[2] = {g->d_p0, g->d_p1};
         for (size_t l = 0; l < S.rl.size(); ++l) {
             const RnnL& R = S.rl[l];
-            ConvL P{R.wih_t, R.bih, R.cin, 2 * GH, 1};
-            GEN_HIP(conv(g, P, in, ldin, g->d_gi, 2 * GH, 0, 0, B, st));
-            float* y = bufs[l & 1];
-            const int threads = (S.H + 63) / 64 * 64;
-            // blocks per workgroup: share the recurrent weights where the batch still fills the chip with workgroups
             static const bool rnn_valu = [] { const char* e = getenv("TAE_GEN_RNN"); return e && !strcmp(e, "valu"); }();     // experiments: the vector-ALU kernel
-            if (S.H <= 128 && !rnn_valu) {
-                const float *w0 = g->d_w + R.whh_t[0], *w1 = g->d_w + R.whh_t[1], *b0 = g->d_w + R.bhh[0], *b1 = g->d_w + R.bhh[1];
-                GEN_HIP(S.cell == 0 ? launch_rnn_mfma<3>(g->d_gi, w0, w1, b0, b1, y, S.H, L, B, st)
-                      : S.cell == 1 ? launch_rnn_mfma<4>(g->d_gi, w0, w1, b0, b1, y, S.H, L, B, st)
-                                    : launch_rnn_mfma<1>(g->d_gi, w0, w1, b0, b1, y, S.H, L, B, st));
+            static const bool no_fuse = [] { const char* e = getenv("TAE_GEN_RNN_FUSE"); return e && e[0] == '0'; }();         // experiments: GI through HBM for every layer
+            const bool mfma = S.H <= 128 && !rnn_valu, fused = mfma && R.cin <= 8 && !no_fuse;
+            float* y = bufs[l & 1];
+            if (!fused) {
+                ConvL P{R.wih_t, R.bih, R.cin, 2 * GH, 1};
+                GEN_HIP(conv(g, P, in, ldin, g->d_gi, 2 * GH, 0, 0, B, st));
+            }
+            if (mfma) {
+                const RnnArgs a{g->d_gi, in, ldin, R.cin, g->d_w + R.wih_t, g->d_w + R.bih, g->d_w + R.whh_t[0], g->d_w + R.whh_t[1],
+                                g->d_w + R.bhh[0], g->d_w + R.bhh[1], y, S.H, L, B};
+                GEN_HIP(S.cell == 0 ? launch_rnn_mfma<3>(a, fused, st) : S.cell == 1 ? launch_rnn_mfma<4>(a, fused, st) : launch_rnn_mfma<1>(a, fused, st));
                 in = y;
                 ldin = 2 * S.H;
                 continue;
             }
+            const int threads = (S.H + 63) / 64 * 64;
+            // blocks per workgroup: share the recurrent weights where the batch still fills the chip with workgroups
             static const int nb_env = [] { const char* e = getenv("TAE_GEN_RNN_NB"); return e ? atoi(e) : 0; }();     // experiments: read once
             const int nb = nb_env ? nb_env : (B >= 4096 ? 8 : (B >= 1024 ? 4 : 1));
             if (nb == 8)
