@@ -267,7 +267,7 @@ __global__ void gen_rnn_kernel(int cell, const float* __restrict__ gi, const flo
     }
 }
 
-// The same recurrence on the fp32 matrix cores for H <= 128 (r04; the vector-ALU kernel above took 287 of the LSTM decoder's 857 ms):
+// The same recurrence on the fp32 matrix cores for H <= 128, H a multiple of 4 (r04; the vector-ALU kernel above took 287 of the LSTM decoder's 857 ms):
 // workgroup = 16 blocks x one direction, wave w owns hidden units [16w, 16w + 16) of every gate and keeps ITS rows of W_hh in
 // registers for the whole sequence (G * ceil(H / 4) operand registers: 100 for the LSTM at H = 100 - the matrix that does not fit in
 // LDS fits in the register files of 7 waves).  Per step: a = W_hh h_{t-1} as G accumulator tiles (M = 16 units, N = 16 blocks,
@@ -300,7 +300,6 @@ __global__ __launch_bounds__(512) void gen_rnn_mfma_kernel(const float* __restri
     const int u0 = wave * 16, ul = u0 + 4 * q;         // first of this lane's 4 units in the accumulator tiles
     const float* whh = dir ? whh_t1 : whh_t0;
     const float* bhh = dir ? bhh1 : bhh0;
-    const bool h4 = (H & 3) == 0;
     float w[G][KS], wx[G][XKR];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -328,32 +327,49 @@ __global__ __launch_bounds__(512) void gen_rnn_mfma_kernel(const float* __restri
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) hprev[nt] = c[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    for (int s = 0; s < L; ++s) {
+    // GI (or x) of step s + 1 is fetched while step s computes: unconditional loads from clamped addresses (a predicated load
+    // compiles to a branch with s_waitcnt vmcnt(0) behind it - four serialised HBM latencies per step in the first cut of this
+    // kernel, 4.7 instead of 3.4 ms per launch); lanes of units >= H compute on whatever they got and never store.
+    const int ulc = min(ul, H - 4);                    // H is a multiple of 4 here (the launcher sends other widths to gen_rnn_kernel)
+    f32x4 gnext[NT][G];
+    float xnext[NT][XKR];
+    auto fetch = [&](int s) {
         const int t = dir ? L - 1 - s : s;
-        f32x4 gv[NT][G];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if constexpr (XK > 0) {
-                const float* xp = xin + (bn[nt] * L + t) * (size_t)ldin + q;
-                float xb[XKR];
+                const float* xp = xin + (bn[nt] * L + t) * (size_t)ldin;
 #pragma unroll
-                for (int j = 0; j < XKR; ++j) xb[j] = 4 * j + q < cin ? xp[4 * j] : 0.0f;
+                for (int j = 0; j < XKR; ++j) xnext[nt][j] = xp[min(4 * j + q, cin - 1)];
+            } else {
+                const float* gp = gi + ((bn[nt] * L + t) * 2 + dir) * (size_t)GH + ulc;
+#pragma unroll
+                for (int g = 0; g < G; ++g) gnext[nt][g] = *reinterpret_cast<const f32x4*>(gp + g * H);
+            }
+        }
+    };
+    fetch(0);
+    for (int s = 0; s < L; ++s) {
+        const int t = dir ? L - 1 - s : s;
+        f32x4 gv[NT][G];
+        float xb[NT][XKR];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) gv[nt][g] = gnext[nt][g];
+#pragma unroll
+            for (int j = 0; j < XKR; ++j) xb[nt][j] = 4 * j + q < cin ? xnext[nt][j] : 0.0f;
+        }
+        fetch(min(s + 1, L - 1));
+        if constexpr (XK > 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     gv[nt][g] = biasx[g];
 #pragma unroll
-                    for (int j = 0; j < XKR; ++j) gv[nt][g] = mfma16x16x4(wx[g][j], xb[j], gv[nt][g]);
+                    for (int j = 0; j < XKR; ++j) gv[nt][g] = mfma16x16x4(wx[g][j], xb[nt][j], gv[nt][g]);
                 }
-            } else {
-                const float* gp = gi + ((bn[nt] * L + t) * 2 + dir) * (size_t)GH + ul;
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    if (h4) gv[nt][g] = ul < H ? *reinterpret_cast<const f32x4*>(gp + g * H) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    else
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) gv[nt][g][i] = ul + i < H ? gp[g * H + i] : 0.0f;
-                }
-            }
         }
         const float* hc = hs + (s & 1) * NBLK * HP + n * HP + q;
         f32x4 acc[NT][G];
@@ -394,18 +410,9 @@ __global__ __launch_bounds__(512) void gen_rnn_mfma_kernel(const float* __restri
             hprev[nt] = hn;
             float* hnext = hs + ((s + 1) & 1) * NBLK * HP + (n + 16 * nt) * HP + ul;
             float* yp = y + (bn[nt] * L + t) * (size_t)(2 * H) + dir * H + ul;
-            if (h4) {
-                if (ul < H) {
-                    *reinterpret_cast<f32x4*>(hnext) = hn;
-                    if (valid[nt]) *reinterpret_cast<f32x4*>(yp) = hn;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (ul + i < H) {
-                        hnext[i] = hn[i];
-                        if (valid[nt]) yp[i] = hn[i];
-                    }
+            if (ul < H) {
+                *reinterpret_cast<f32x4*>(hnext) = hn;
+                if (valid[nt]) *reinterpret_cast<f32x4*>(yp) = hn;
             }
         }
         __syncthreads();
@@ -783,7 +790,7 @@ static int run_stack(GenericEngine* g, const Stack& S, const float* x, int B, hi
             const RnnL& R = S.rl[l];
             static const bool rnn_valu = [] { const char* e = getenv("TAE_GEN_RNN"); return e && !strcmp(e, "valu"); }();     // experiments: the vector-ALU kernel
             static const bool no_fuse = [] { const char* e = getenv("TAE_GEN_RNN_FUSE"); return e && e[0] == '0'; }();         // experiments: GI through HBM for every layer
-            const bool mfma = S.H <= 128 && !rnn_valu, fused = mfma && R.cin <= 8 && !no_fuse;
+            const bool mfma = S.H <= 128 && (S.H & 3) == 0 && !rnn_valu, fused = mfma && R.cin <= 8 && !no_fuse;
             float* y = bufs[l & 1];
             if (!fused) {
                 ConvL P{R.wih_t, R.bih, R.cin, 2 * GH, 1};
