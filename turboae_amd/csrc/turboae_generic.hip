@@ -189,6 +189,116 @@ __global__ __launch_bounds__(512) void gen_conv_mfma_kernel(const float* __restr
     }
 }
 
+// k = 1 (Linear heads, RNN input projections: the largest generic launches, K = 2 H -> 2 G H at every position): the same tiles
+// without taps / halo / masks, and software-pipelined - the 16-byte loads of input-channel chunk c + 1 (4 of x, 2 of W per thread)
+// are in flight while chunk c is multiplied, so a workgroup hides its own global latency instead of leaving that to its neighbour.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gen_proj_mfma_kernel(const float* __restrict__ x, int ldx, int cin, const float* __restrict__ wt,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int ldy, int coff, int cout,
+                                                            size_t np, int act) {
+    __shared__ __attribute__((aligned(16))) float xs[kMP * kMKP];
+    __shared__ __attribute__((aligned(16))) float ws[kMK * kMWP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
+    const size_t p0 = (size_t)blockIdx.x * kMP;
+    const int ch0 = blockIdx.y * kMC;
+    const bool xv = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    const bool wv = (cout & 3) == 0 && (reinterpret_cast<uintptr_t>(wt) & 15) == 0;
+    const bool yv = (ldy & 3) == 0 && (coff & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    f32x4 rx[4], rw[2];
+    auto fetch = [&](int c0) {
+        const int nc = min(kMK, cin - c0);
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            const int i = tid + 512 * e4, r = i / (kMK / 4), c = (i % (kMK / 4)) * 4;
+            const size_t p = p0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p < np && c < nc) {
+                const float* src = x + p * (size_t)ldx + c0 + c;
+                if (xv && c + 4 <= nc) v = *reinterpret_cast<const f32x4*>(src);
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = c + e < nc ? src[e] : 0.0f;
+            }
+            rx[e4] = v;
+        }
+#pragma unroll
+        for (int e4 = 0; e4 < 2; ++e4) {
+            const int i = tid + 512 * e4, m = (i % (kMC / 4)) * 4, c = i / (kMC / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c < nc && ch0 + m < cout) {
+                const float* src = wt + (size_t)(c0 + c) * cout + ch0 + m;
+                if (wv && ch0 + m + 4 <= cout) v = *reinterpret_cast<const f32x4*>(src);
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ch0 + m + e < cout ? src[e] : 0.0f;
+            }
+            rw[e4] = v;
+        }
+    };
+    f32x4 acc[8][2];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    fetch(0);
+    for (int c0 = 0; c0 < cin; c0 += kMK) {
+        const int kend = (min(kMK, cin - c0) + 3) & ~3;
+        __syncthreads();
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            const int i = tid + 512 * e4;
+            *reinterpret_cast<f32x4*>(xs + (i / (kMK / 4)) * kMKP + (i % (kMK / 4)) * 4) = rx[e4];
+        }
+#pragma unroll
+        for (int e4 = 0; e4 < 2; ++e4) {
+            const int i = tid + 512 * e4, m = (i % (kMC / 4)) * 4, c = i / (kMC / 4);
+            float* dst = ws + c * kMWP + (m >> 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[((m & 15) + e) * 8] = rw[e4][e];
+        }
+        __syncthreads();
+        if (c0 + kMK < cin) fetch(c0 + kMK);
+        const float* xr = xs + (wave * 32 + n) * kMKP + q;
+        const float* wr = ws + q * kMWP + n * 8;
+        for (int kk = 0; kk < kend; kk += 4) {
+            const float b0 = xr[kk], b1 = xr[16 * kMKP + kk];
+            const f32x4 alo = *reinterpret_cast<const f32x4*>(wr + kk * kMWP), ahi = *reinterpret_cast<const f32x4*>(wr + kk * kMWP + 4);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                acc[mt][0] = mfma16x16x4(alo[mt], b0, acc[mt][0]);
+                acc[mt][1] = mfma16x16x4(alo[mt], b1, acc[mt][1]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                acc[4 + mt][0] = mfma16x16x4(ahi[mt], b0, acc[4 + mt][0]);
+                acc[4 + mt][1] = mfma16x16x4(ahi[mt], b1, acc[4 + mt][1]);
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const size_t p = p0 + wave * 32 + nt * 16 + n;
+        if (p >= np) continue;
+        float* yr = y + p * (size_t)ldy + coff;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int ch = ch0 + mt * 16 + 4 * q;
+            if (ch >= cout) continue;
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t = acc[mt][nt][i] + (ch + i < cout ? bias[ch + i] : 0.0f);
+                if (act == 1) t = t > 0.0f ? t : expm1f(t);
+                v[i] = t;
+            }
+            if (yv && ch + 4 <= cout) *reinterpret_cast<f32x4*>(yr + ch) = v;
+            else
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ch + i < cout) yr[ch + i] = v[i];
+        }
+    }
+}
+
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // One (block, direction) of one recurrent layer; thread u owns hidden unit u.  gi (B, L, 2, G, H) holds W_ih x + b_ih for both
@@ -758,6 +868,11 @@ static hipError_t conv(const GenericEngine* g, const ConvL& C, const float* x, i
             lds_set = lds;
         }
         const dim3 grid((unsigned)((np + kMP - 1) / kMP), (C.cout + kMC - 1) / kMC);
+        static const bool no_proj = [] { const char* e = getenv("TAE_GEN_PROJ"); return e && e[0] == '0'; }();     // experiments: k = 1 on the general kernel
+        if (C.k == 1 && !no_proj) {
+            hipLaunchKernelGGL(gen_proj_mfma_kernel, grid, dim3(512), 0, st, x, ldx, C.cin, g->d_w + C.wt, g->d_w + C.bias, y, ldy, coff, C.cout, np, act);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL(gen_conv_mfma_kernel, grid, dim3(512), lds, st, x, ldx, C.cin, g->d_w + C.wt, g->d_w + C.bias, y, ldy, coff, C.cout, C.k, L, np, act);
         return hipGetLastError();
     }
