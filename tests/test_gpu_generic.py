@@ -98,12 +98,13 @@ def test_random_generic_configurations_match_oracle(gpu_device, case):
     assert np.abs(xd - xo).max() <= tol_x, np.abs(xd - xo).max()
 
 
-# r04: the generic recurrence runs on the fp32 matrix cores for H <= 128 (gen_rnn_mfma_kernel<G, KS>, KS = 8 / 16 / 25 / 32 k-steps),
-# 16 blocks per workgroup; above that on the vector-ALU kernel (1 / 4 / 8 blocks per workgroup by batch).  One case per
-# instantiation and edge: widths that are not multiples of 4 (scalar loads / stores), batches that leave a ragged last workgroup,
-# the last width of the MFMA kernel and the first of the vector-ALU one.
-@pytest.mark.parametrize("cell,H,B,L", [("lstm", 27, 5, 12), ("gru", 64, 37, 10), ("rnn", 100, 16, 9), ("lstm", 100, 33, 16), ("gru", 101, 3, 7),
-                                         ("lstm", 128, 17, 6), ("rnn", 126, 50, 5), ("lstm", 130, 9, 6), ("gru", 200, 4, 5), ("rnn", 7, 1, 1)])
+# r04: the generic recurrence runs on the fp32 matrix cores for H <= 128, H % 4 == 0 (gen_rnn_mfma_kernel<G, KS, 1, XK>, KS = 8 / 16 /
+# 25 / 32 k-steps, XK = 2 for first layers: input projection fused), 16 blocks per workgroup; other widths on the vector-ALU kernel
+# (1 / 4 / 8 blocks per workgroup by batch).  One case per instantiation and edge: widths that are no multiple of 4 (vector ALU),
+# batches that leave a ragged last workgroup, the last width of the MFMA kernel and the first of the vector-ALU one.
+@pytest.mark.parametrize("cell,H,B,L", [("lstm", 27, 5, 12), ("lstm", 28, 5, 12), ("gru", 64, 37, 10), ("rnn", 100, 16, 9), ("lstm", 100, 33, 16), ("gru", 101, 3, 7),
+                                         ("lstm", 128, 17, 6), ("rnn", 124, 50, 5), ("gru", 120, 18, 4), ("rnn", 126, 50, 5), ("lstm", 130, 9, 6),
+                                         ("gru", 200, 4, 5), ("rnn", 7, 1, 1), ("rnn", 4, 2, 3)])
 def test_generic_recurrence_kernels_every_instantiation(gpu_device, monkeypatch, cell, H, B, L):
     from turboae_amd import Channel_AE_HIP
     cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn=cell, dec_num_unit=H, enc_num_unit=20, block_len=L, num_iteration=2)
@@ -137,7 +138,7 @@ def test_generic_recurrence_does_not_depend_on_the_batch(gpu_device):
 
 @pytest.mark.parametrize("decoder", ["TurboAE_rate3_cnn", "TurboAE_rate3_rnn"])
 def test_three_independent_implementations_agree_on_the_trained_network(gpu_device, monkeypatch, decoder):
-    """TAE_FORCE_GENERIC=1 runs a standard configuration on the generic vector-ALU kernels: a third implementation next to the fp16-split
+    """TAE_FORCE_GENERIC=1 runs a standard configuration on the generic kernels (fp32 MFMA, one launch per layer): a third implementation next to the fp16-split
     and the fp32 MFMA kernels.  Reference-trained weights (CNN decoder) / random weights (GRU decoder), 1 000 blocks = 100 000 bits."""
     from dataclasses import replace
     from turboae_amd import Channel_AE_HIP

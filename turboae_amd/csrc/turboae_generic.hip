@@ -4,8 +4,11 @@
 // enc_num_layer != 2, an RNN encoder in front of the (then dense, decoders.py:173-176) CNN decoder - and `precision = f32` for the
 // variants whose MFMA kernels exist in the fp16-split arithmetic only (DenseSameShapeConv1d, kernel sizes 7 / 9).
 //
-// These are parity / coverage kernels, not the benchmark path: plain fp32 FMA chains on the vector ALU (an input tile staged in
-// LDS, weights streamed transposed so a wave's loads coalesce over output channels), activations round-trip through HBM between
+// One launch per layer, activations round-trip through HBM between layers, everything in plain fp32 (operands and accumulation: no
+// range window - this is also where the range fall-back lands for dense stacks and 7 / 9 taps).  Since r04 the multiplications run
+// on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: gen_conv_mfma_kernel, gen_proj_mfma_kernel, gen_rnn_mfma_kernel); the r03
+// vector-ALU kernels remain for recurrent widths above 128 / not a multiple of 4 and, behind TAE_GEN_CONV=valu / TAE_GEN_RNN=valu,
+// as the A/B baseline.  Not the benchmark path (DESIGN.md 3.9 has the numbers).
 // layers.  Every op follows the PyTorch definition the reference relies on:
 //   SameShapeConv1d / DenseSameShapeConv1d   cnn_utils.py:6-82       y[co,t] = b[co] + sum_ci sum_j W[co,ci,j] x[ci,t+j-k//2]; ELU
 //   torch.nn.GRU / LSTM / RNN (bidirectional, batch_first, n layers)   decoders.py:41-49, encoders.py:251-268
