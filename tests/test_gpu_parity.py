@@ -710,4 +710,6 @@ def test_width_104_is_no_longer_a_performance_cliff(gpu_device, monkeypatch):
     t_gen, x2 = ms(Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B))
     print(f"width 104, {B} blocks: MFMA {t_mfma:.2f} ms, generic {t_gen:.2f} ms")
     assert float((x1 - x2).abs().max()) <= 5e-5
-    assert t_gen >= 12.0 * t_mfma          # measured 17.9x at this size (3.53 vs 63.2 ms): the generic kernels do ~12 TFLOP/s at this width
+    # measured 4.7x at this size (3.8 vs 17.8 ms).  The generic kernels were vector-ALU code when this test was written (63.2 ms, 17.9x);
+    # they run on the fp32 matrix cores now, one launch per layer - what is left is f16x2 vs fp32 MFMA and fused vs layer-at-a-time.
+    assert t_gen >= 3.0 * t_mfma
