@@ -247,7 +247,7 @@ def time_other_config(name: str, cfg: TurboAEConfig, sd, B: int, dev, snr: float
     enc_tf = 2.0 * macs["enc"] * B * L / (enc_ms * 1e-3) / 1e12
     nb, lds = model.kernel_info()
     if cfg.generic:
-        kern = "generic fp32 MFMA kernels: tae::gen_conv_mfma_kernel" + (" / tae::gen_rnn_mfma_kernel" if cfg.decoder == "TurboAE_rate3_rnn" else "")
+        kern = "generic fp32 MFMA kernels: " + ("tae::gen_proj_mfma_kernel / tae::gen_rnn_mfma_kernel" if cfg.decoder == "TurboAE_rate3_rnn" else "tae::gen_conv_mfma_kernel")
     elif cfg.decoder == "TurboAE_rate3_rnn":
         kern = ("gru_rec_h / gru_proj_h / gru_head" if is_h2 else "gru_rec / gru_proj / gru_head") + f" x {2 * cfg.num_iteration} stacks (GRU decoder)"
     elif nb == 0:
