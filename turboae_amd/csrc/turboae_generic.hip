@@ -25,6 +25,10 @@
 #include "turboae_internal.hpp"
 #include "turboae_device.hpp"
 
+#ifndef TAE_GEN_MJ
+#define TAE_GEN_MJ 2        // taps of the weights staged together by gen_conv_mfma_kernel: 4 = 107 KB of LDS at k = 5 = one workgroup per CU, 17 % slower (profiles/r04_gen_mj_ab.txt)
+#endif
+
 namespace tae {
 
 namespace {
@@ -83,9 +87,9 @@ __global__ __launch_bounds__(256) void gen_conv_kernel(const float* __restrict__
 // Workgroup = 8 waves = 256 positions (FLATTENED over the batch, so short blocks fill tiles; a tap that would reach across a block
 // boundary is masked when the operand is read) x 128 output channels, 171 flops per staged float; wave = 32 positions x 128
 // channels = 16 accumulator tiles, 2 + 2 LDS reads per 16 MFMAs.  Input channels are staged 32 at a time (rows padded to 36 floats:
-// the 16 positions x 4 k of one operand read fall into 64 different banks), weights 32 channels x up to 4 taps x 128 outputs with
+// the 16 positions x 4 k of one operand read fall into 64 different banks), weights 32 channels x up to 2 taps x 128 outputs with
 // the outputs of a row permuted (channel 16 mt + n at n * 8 + mt) so that a lane's 8 A operands are two 16-byte reads.
-constexpr int kMP = 256, kMC = 128, kMK = 32, kMKP = 36, kMWP = 136, kMJ = 4;
+constexpr int kMP = 256, kMC = 128, kMK = 32, kMKP = 36, kMWP = 136, kMJ = TAE_GEN_MJ;
 
 __global__ __launch_bounds__(512) void gen_conv_mfma_kernel(const float* __restrict__ x, int ldx, int cin, const float* __restrict__ wt,
                                                             const float* __restrict__ bias, float* __restrict__ y, int ldy, int coff, int cout,
@@ -864,11 +868,9 @@ static hipError_t conv(const GenericEngine* g, const ConvL& C, const float* x, i
     if (!valu) {
         const size_t np = (size_t)B * L;
         const size_t lds = ((size_t)(kMP + C.k - 1) * kMKP + (size_t)std::min(C.k, kMJ) * kMK * kMWP) * sizeof(float);
-        static size_t lds_set = 0;
-        if (lds > lds_set) {
+        if (lds > 65536) {             // per device and cheap next to a launch of this size: no process-wide cache of "already set"
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gen_conv_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            lds_set = lds;
         }
         const dim3 grid((unsigned)((np + kMP - 1) / kMP), (C.cout + kMC - 1) / kMC);
         static const bool no_proj = [] { const char* e = getenv("TAE_GEN_PROJ"); return e && e[0] == '0'; }();     // experiments: k = 1 on the general kernel
