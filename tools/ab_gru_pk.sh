@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORICAL (r04): the TAE_GRU_PK code path was removed after this measurement (no gain); the script documents how profiles/r04_gru_pk_ab.txt was made.
 # A/B of the packed-fp32 gate arithmetic in gru_rec_h (-DTAE_GRU_PK=1 build in tools/probes/libs) against the in-tree library on one
 # box: GRU-decoder forward at 16 384 blocks, alternating; then the GRU tests on the variant.  -> gpurun_out/r04_gru_pk_ab.txt
 cd ${GRAFT_REPO_ROOT:-$(pwd)}; mkdir -p gpurun_out; out=gpurun_out/r04_gru_pk_ab.txt; : > $out
