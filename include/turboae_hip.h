@@ -53,7 +53,7 @@ typedef struct tae_config {
     int32_t block_len;        /* -block_len        get_args.py:122 */
     int32_t enc_num_layer;    /* -enc_num_layer    get_args.py:93  */
     int32_t enc_num_unit;     /* -enc_num_unit     get_args.py:98  (1..124 on the fused MFMA kernels - 1..100 in TAE_PREC_F32 and for RNN stacks -, independent of dec_num_unit: instantiated for 32 / 64 / 100 / 124, narrower stacks run embedded; above that to 1024: generic fp32 kernels) */
-    int32_t enc_kernel_size;  /* -enc_kernel_size  get_args.py:89  (1, 3, 5, 7, 9 on the fused kernels: 1 and 3 are embedded into 5 taps; 7 / 9 with TAE_PREC_F32 or dense stacks, and odd sizes 11..63: generic fp32 kernels) */
+    int32_t enc_kernel_size;  /* -enc_kernel_size  get_args.py:89  (1, 3, 5, 7, 9 on the fused kernels: 1 and 3 are embedded into 5 taps; 7 / 9 with TAE_PREC_F32, and odd sizes 11..63: generic fp32 kernels) */
     int32_t dec_num_layer;    /* -dec_num_layer    get_args.py:94  */
     int32_t dec_num_unit;     /* -dec_num_unit     get_args.py:97  (as enc_num_unit) */
     int32_t dec_kernel_size;  /* -dec_kernel_size  get_args.py:90  (as enc_kernel_size) */
