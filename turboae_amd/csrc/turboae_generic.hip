@@ -93,14 +93,18 @@ constexpr int kMP = 256, kMC = 128, kMK = 32, kMKP = 36, kMWP = 136, kMJ = TAE_G
 
 __global__ __launch_bounds__(512) void gen_conv_mfma_kernel(const float* __restrict__ x, int ldx, int cin, const float* __restrict__ wt,
                                                             const float* __restrict__ bias, float* __restrict__ y, int ldy, int coff, int cout,
-                                                            int k, int L, size_t np, int act) {
+                                                            int k, int L, size_t np, int act, unsigned ctiles, unsigned ntiles, int xcd) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int rows = kMP + k - 1, pad = k / 2;
     float* xs = sm;                                    // [rows][kMKP]: flattened positions p0 - pad ...
     float* ws = sm + rows * kMKP;                      // [taps staged][kMK][kMWP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
-    const size_t p0 = (size_t)blockIdx.x * kMP;
-    const int ch0 = blockIdx.y * kMC;
+    // 1-D grid, XCD-aware: workgroup i runs on XCD i % 8, so XCD k takes the k-th contiguous eighth of the (position tile, channel
+    // tile) list, channel tile fastest - the workgroups that share an activation tile follow each other on ONE L2
+    const unsigned per_xcd = gridDim.x / 8, tile = xcd ? (blockIdx.x % 8) * per_xcd + blockIdx.x / 8 : blockIdx.x;
+    if (tile >= ntiles) return;
+    const size_t p0 = (size_t)(tile / ctiles) * kMP;
+    const int ch0 = (int)(tile % ctiles) * kMC;
     const bool xv = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     const bool wv = (cout & 3) == 0 && (reinterpret_cast<uintptr_t>(wt) & 15) == 0;
     const bool yv = (ldy & 3) == 0 && (coff & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
@@ -201,12 +205,16 @@ __global__ __launch_bounds__(512) void gen_conv_mfma_kernel(const float* __restr
 // are in flight while chunk c is multiplied, so a workgroup hides its own global latency instead of leaving that to its neighbour.
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gen_proj_mfma_kernel(const float* __restrict__ x, int ldx, int cin, const float* __restrict__ wt,
                                                             const float* __restrict__ bias, float* __restrict__ y, int ldy, int coff, int cout,
-                                                            size_t np, int act) {
+                                                            size_t np, int act, unsigned ctiles, unsigned ntiles, int xcd) {
     __shared__ __attribute__((aligned(16))) float xs[kMP * kMKP];
     __shared__ __attribute__((aligned(16))) float ws[kMK * kMWP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
-    const size_t p0 = (size_t)blockIdx.x * kMP;
-    const int ch0 = blockIdx.y * kMC;
+    // 1-D grid, XCD-aware: workgroup i runs on XCD i % 8, so XCD k takes the k-th contiguous eighth of the (position tile, channel
+    // tile) list, channel tile fastest - the workgroups that share an activation tile follow each other on ONE L2
+    const unsigned per_xcd = gridDim.x / 8, tile = xcd ? (blockIdx.x % 8) * per_xcd + blockIdx.x / 8 : blockIdx.x;
+    if (tile >= ntiles) return;
+    const size_t p0 = (size_t)(tile / ctiles) * kMP;
+    const int ch0 = (int)(tile % ctiles) * kMC;
     const bool xv = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     const bool wv = (cout & 3) == 0 && (reinterpret_cast<uintptr_t>(wt) & 15) == 0;
     const bool yv = (ldy & 3) == 0 && (coff & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
@@ -872,13 +880,15 @@ static hipError_t conv(const GenericEngine* g, const ConvL& C, const float* x, i
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gen_conv_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        const dim3 grid((unsigned)((np + kMP - 1) / kMP), (C.cout + kMC - 1) / kMC);
+        const unsigned ctiles = (C.cout + kMC - 1) / kMC, ntiles = (unsigned)((np + kMP - 1) / kMP) * ctiles;
+        const dim3 grid((ntiles + 7) / 8 * 8);
+        static const int xcd = [] { const char* e = getenv("TAE_GEN_XCD"); return !(e && e[0] == '0'); }();     // experiments: 0 = tiles in launch order
         static const bool no_proj = [] { const char* e = getenv("TAE_GEN_PROJ"); return e && e[0] == '0'; }();     // experiments: k = 1 on the general kernel
         if (C.k == 1 && !no_proj) {
-            hipLaunchKernelGGL(gen_proj_mfma_kernel, grid, dim3(512), 0, st, x, ldx, C.cin, g->d_w + C.wt, g->d_w + C.bias, y, ldy, coff, C.cout, np, act);
+            hipLaunchKernelGGL(gen_proj_mfma_kernel, grid, dim3(512), 0, st, x, ldx, C.cin, g->d_w + C.wt, g->d_w + C.bias, y, ldy, coff, C.cout, np, act, ctiles, ntiles, xcd);
             return hipGetLastError();
         }
-        hipLaunchKernelGGL(gen_conv_mfma_kernel, grid, dim3(512), lds, st, x, ldx, C.cin, g->d_w + C.wt, g->d_w + C.bias, y, ldy, coff, C.cout, C.k, L, np, act);
+        hipLaunchKernelGGL(gen_conv_mfma_kernel, grid, dim3(512), lds, st, x, ldx, C.cin, g->d_w + C.wt, g->d_w + C.bias, y, ldy, coff, C.cout, C.k, L, np, act, ctiles, ntiles, xcd);
         return hipGetLastError();
     }
     const size_t lds = (size_t)(kConvPos + C.k - 1) * kConvCi * sizeof(float);
