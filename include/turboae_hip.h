@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TAE_ABI_VERSION 10
+#define TAE_ABI_VERSION 11
 
 #if defined(__GNUC__)
 #define TAE_API __attribute__((visibility("default")))
@@ -244,6 +244,13 @@ TAE_API int tae_eval_snr(tae_handle* h, float snr_db, int32_t batch, int32_t n_b
 
 /* Blocks per workgroup and dynamic LDS bytes of the fused kernels (for DESIGN / bench reporting). */
 TAE_API int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_t* lds_bytes);
+
+/* Debug overrides in effect (no reference counterpart).  Environment variables that change the arithmetic, the kernel family or a
+ * launch geometry (TAE_PRECISION, TAE_RANGE_CAL, TAE_FORCE_GENERIC, TAE_FORCE_SEGMENTED, TAE_SEG_T, TAE_FIXED_NB, TAE_NO_SUPER,
+ * TAE_GRU_*, TAE_GEN_*) are IGNORED unless TAE_DEBUG_KNOBS=1 is set beside them; every one that took effect in this process is
+ * listed here as "NAME=value;NAME=value" (empty string: none - the handle runs exactly what its tae_config asked for).
+ * Writes at most n bytes including the terminating NUL; returns the length the full list needs (without the NUL).  h may be NULL. */
+TAE_API int tae_overrides(tae_handle* h, char* buf, int32_t n);
 
 /* Measurement support (no reference counterpart; needs no handle): the rate a pure stream of v_mfma_f32_16x16x32_f16 sustains on
  * the current device for at least `min_ms` milliseconds - one 8-wave workgroup per CU (the decoder's residency), 16 independent

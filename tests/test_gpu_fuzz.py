@@ -35,6 +35,7 @@ def _check_shape_case(gpu_device, monkeypatch, case):
     from turboae_amd import Channel_AE_HIP
     case = dict(case)
     B, fixed_nb, wseed = case.pop("B"), case.pop("fixed_nb"), case.pop("wseed")
+    monkeypatch.setenv("TAE_DEBUG_KNOBS", "1")      # the library ignores its debug knobs without it
     monkeypatch.setenv("TAE_FIXED_NB", fixed_nb)
     cfg = TurboAEConfig(**case)
     L = cfg.block_len

@@ -109,6 +109,7 @@ def test_generic_recurrence_kernels_every_instantiation(gpu_device, monkeypatch,
     from turboae_amd import Channel_AE_HIP
     cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn=cell, dec_num_unit=H, enc_num_unit=20, block_len=L, num_iteration=2)
     if not cfg.generic:            # 2-layer GRUs up to 100 units have their own MFMA kernels: the testing knob puts them on these
+        monkeypatch.setenv("TAE_DEBUG_KNOBS", "1")      # the library ignores its debug knobs without it
         monkeypatch.setenv("TAE_FORCE_GENERIC", "1")
     wseed = 1000 + H
     sd = W.generate_state_dict(cfg, seed=wseed, gain=1.0)
@@ -150,6 +151,7 @@ def test_three_independent_implementations_agree_on_the_trained_network(gpu_devi
     B = 1000
     auto = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
     f32 = Channel_AE_HIP(replace(cfg, precision="f32"), sd, device=gpu_device, max_batch=B)
+    monkeypatch.setenv("TAE_DEBUG_KNOBS", "1")      # the library ignores its debug knobs without it
     monkeypatch.setenv("TAE_FORCE_GENERIC", "1")
     gen = Channel_AE_HIP(replace(cfg, precision="f32"), sd, device=gpu_device, max_batch=B)
     monkeypatch.delenv("TAE_FORCE_GENERIC")

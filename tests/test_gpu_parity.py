@@ -35,6 +35,7 @@ def run_both(cfg, sd, u, noise, dev):
 def test_forward_matches_oracle_u100(gpu_device, monkeypatch, B, fixed_nb):
     # TAE_FIXED_NB=1: always the fullest workgroups (3 blocks each); 0: blocks per workgroup picked per call
     # (small batches: 1 block each)
+    monkeypatch.setenv("TAE_DEBUG_KNOBS", "1")      # the library ignores its debug knobs without it
     monkeypatch.setenv("TAE_FIXED_NB", fixed_nb)
     cfg = TurboAEConfig()
     sd = W.generate_state_dict(cfg, seed=7, gain=1.0)
@@ -51,6 +52,7 @@ def test_forward_matches_oracle_u100(gpu_device, monkeypatch, B, fixed_nb):
 @pytest.mark.parametrize("fixed_nb", ["1", "0"])
 @pytest.mark.parametrize("U,L,nl_enc,nl_dec,iters", [(32, 100, 2, 5, 6), (64, 40, 1, 2, 2), (32, 64, 3, 1, 1), (100, 150, 5, 5, 2)])
 def test_forward_matches_oracle_shapes(gpu_device, monkeypatch, U, L, nl_enc, nl_dec, iters, fixed_nb):
+    monkeypatch.setenv("TAE_DEBUG_KNOBS", "1")      # the library ignores its debug knobs without it
     monkeypatch.setenv("TAE_FIXED_NB", fixed_nb)
     cfg = TurboAEConfig(block_len=L, enc_num_unit=U, dec_num_unit=U, enc_num_layer=nl_enc, dec_num_layer=nl_dec,
                         num_iteration=iters)
@@ -330,6 +332,7 @@ def test_segmented_path_is_bit_identical_to_fused(gpu_device, monkeypatch, seg_t
     ud, nd = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
     fused = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=7)
     xf, cf = fused(ud, nd)
+    monkeypatch.setenv("TAE_DEBUG_KNOBS", "1")      # the library ignores its debug knobs without it
     monkeypatch.setenv("TAE_FORCE_SEGMENTED", "1")
     if seg_t:
         monkeypatch.setenv("TAE_SEG_T", seg_t)
@@ -706,6 +709,7 @@ def test_width_104_is_no_longer_a_performance_cliff(gpu_device, monkeypatch):
         torch.cuda.synchronize()
         return a.elapsed_time(b), x
     t_mfma, x1 = ms(Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B))
+    monkeypatch.setenv("TAE_DEBUG_KNOBS", "1")      # the library ignores its debug knobs without it
     monkeypatch.setenv("TAE_FORCE_GENERIC", "1")
     t_gen, x2 = ms(Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B))
     print(f"width 104, {B} blocks: MFMA {t_mfma:.2f} ms, generic {t_gen:.2f} ms")

@@ -169,3 +169,72 @@ def test_calibration_does_not_change_in_window_results(gpu_device):
     assert torch.equal(xa, xb) and torch.equal(ca, cb)
     assert float((ca - cr).abs().max()) <= 2e-6 and float((xa - xr).abs().max()) <= 2e-6
     assert raw._eng.range_info()[:2] == ([], [])
+
+
+def test_fallback_twin_serves_every_batch_the_handle_accepts(gpu_device):
+    """tae_create calibrates on a synthetic batch of up to 768 blocks, which grows the handle's capacity past a
+    small max_batch; a C caller's B in (max_batch, 768] then passes check_batch, and a flagged call used to run on an fp32 twin whose
+    workspace was sized for max_batch only.  The raw C ABI call below (no tae_reserve) must be served by the twin, equal to an fp32
+    handle that was sized for the batch."""
+    import ctypes as C
+    from turboae_amd import Channel_AE_HIP
+    from turboae_amd.channel_ae import _ptr, _stream
+    cfg = TurboAEConfig(num_iteration=2)
+    sd = W.generate_state_dict(cfg, seed=7, gain=1.0)
+    B = 500
+    u, noise = _inputs(B, cfg.block_len)
+    ud, nd = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
+    exact = Channel_AE_HIP(TurboAEConfig(num_iteration=2, precision="f32"), sd, device=gpu_device, max_batch=B)
+    rx = (exact.enc(ud) + nd) * 2.0 ** 14                      # far above the calibrated window: every call is flagged
+    fb = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=100, range_fallback=True)
+    e = fb._eng
+    x1 = e._out(B, 1)
+    with torch.cuda.device(gpu_device):
+        _lib.check(e.lib.tae_decode(e.h, _ptr(rx), _ptr(x1), B, _stream()))      # B = 500 > max_batch = 100, accepted (cap = 768)
+    torch.cuda.synchronize()
+    assert fb.fell_back
+    assert torch.equal(x1, exact.dec(rx))
+
+
+def test_calibrate_range_takes_what_forward_takes(gpu_device):
+    """calibrate_range validates and routes its arguments exactly as forward does - (B, L, 1) punctured noise is
+    expanded, channel='fading' needs (and lays out) the coefficients, mismatched or half-given arguments raise instead of reading
+    out of bounds, and with is_variable_block_len the engine of the given length is the one calibrated."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(num_iteration=2)
+    sd = W.generate_state_dict(cfg, seed=7, gain=1.0)
+    B, L = 6, cfg.block_len
+    u, noise = _inputs(B, L)
+    ud, nd = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
+    m = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B, is_variable_block_len=True)
+    ref = m(ud, nd)
+    with pytest.raises(ValueError):
+        m.calibrate_range(ud)                                  # noise missing
+    with pytest.raises(ValueError):
+        m.calibrate_range(None, nd)
+    with pytest.raises(ValueError):
+        m.calibrate_range(ud, nd[:3])                          # batch mismatch
+    with pytest.raises(ValueError):
+        m.calibrate_range(ud, nd, fading=nd)                   # not a fading channel
+    m.calibrate_range(ud, nd[:, :, :1])                        # punctured pass: (B, L, 1), broadcast over the code symbols
+    m.calibrate_range(ud, nd)
+    m.calibrate_range()                                        # synthetic batch again
+    out = m(ud, nd)
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])      # O(1) network: same power-of-two window
+    # another block length: its own engine is calibrated, on its own shapes
+    L2 = 64
+    u2, n2 = _inputs(B, L2, seed=62)
+    u2d, n2d = torch.from_numpy(u2).to(gpu_device), torch.from_numpy(n2).to(gpu_device)
+    m.calibrate_range(u2d, n2d)
+    assert L2 in m._by_len and m._by_len[L2].range_word() == ("f16x2", 0)
+    m(u2d, n2d)
+    assert m._by_len[L2].range_word() == ("f16x2", 0)
+    # fading: the library reads [fading | noise]; calibrate_range builds that layout like forward
+    cf = TurboAEConfig(num_iteration=2, channel="fading")
+    mf = Channel_AE_HIP(cf, sd, device=gpu_device, max_batch=B)
+    nz, fh = mf.generate_noise(B, 2.0, seed=5)
+    with pytest.raises(ValueError):
+        mf.calibrate_range(ud, nz)                             # coefficients missing
+    mf.calibrate_range(ud, nz, fading=fh)
+    mf(ud, nz, fh)
+    assert mf._eng.range_word() == ("f16x2", 0)

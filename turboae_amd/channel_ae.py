@@ -179,14 +179,23 @@ class _Engine:
                                     "fp32-grade - calibrate on representative data (calibrate_range), use range_fallback=True or precision='f32'")
 
     def calibrate_range(self, u: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None) -> None:
-        """tae_calibrate_range: re-measure the per-layer exponents on the caller's batch (or the synthetic one)."""
+        """tae_calibrate_range: re-measure the per-layer exponents on the caller's batch (or, both None, the synthetic one).
+        `u` is a validated (B, L, 1) tensor on the device and `noise` the tensor the library expects for the configured channel
+        (Channel_AE_HIP._channel_input: (B, L, 3), or [fading | noise] for channel='fading') - Channel_AE_HIP.calibrate_range
+        builds both from what forward() takes."""
+        if (u is None) != (noise is None):
+            raise ValueError("calibrate_range needs input and fwd_noise together (or neither: the library's synthetic batch)")
         with torch.cuda.device(self.device):
             if u is None:
                 _lib.check(self.lib.tae_calibrate_range(self.h, None, None, 0))
             else:
-                uu, nn = self._in(u, 1, "u"), noise.to(self.device).contiguous().float()
+                B = int(u.shape[0])
+                want = B * self.cfg.block_len * 3 * (2 if self.cfg.channel == "fading" else 1)
+                if noise.numel() != want or noise.device != self.device or noise.dtype != torch.float32 or not noise.is_contiguous():
+                    raise ValueError(f"calibration noise must be {want} contiguous float32 values on {self.device}, got {noise.numel()}")
+                self.reserve(B)
                 torch.cuda.synchronize(self.device)
-                _lib.check(self.lib.tae_calibrate_range(self.h, _ptr(uu), _ptr(nn), int(uu.shape[0])))
+                _lib.check(self.lib.tae_calibrate_range(self.h, _ptr(u), _ptr(noise), B))
 
     def range_info(self):
         """(encoder exponents, decoder exponents, passes): per side one exponent per stack input, then one per (stack, layer)."""
@@ -410,9 +419,25 @@ class Channel_AE_HIP:
                 e.range_status()
         return any(e.fell_back for e in engines)
 
-    def calibrate_range(self, input: Optional[torch.Tensor] = None, fwd_noise: Optional[torch.Tensor] = None) -> None:
-        """Re-measure the fp16-split kernels' per-layer exponents on this batch (default: the library's synthetic batch)."""
-        self._eng.calibrate_range(input, fwd_noise)
+    def calibrate_range(self, input: Optional[torch.Tensor] = None, fwd_noise: Optional[torch.Tensor] = None,
+                        fading: Optional[torch.Tensor] = None) -> None:
+        """Re-measure the fp16-split kernels' per-layer exponents on this batch (default: the library's synthetic batch).  The
+        arguments are the ones forward() takes and go through the same checks: `input` (B, L, 1), `fwd_noise` (B, L, 3) or the
+        punctured pass's (B, L, 1), `fading` for channel='fading'; with is_variable_block_len the engine of input.shape[1] is the
+        one calibrated (every engine starts from the synthetic calibration of its own length)."""
+        if (input is None) != (fwd_noise is None):
+            raise ValueError("calibrate_range needs input and fwd_noise together (or neither: the library's synthetic batch)")
+        if input is None:
+            if fading is not None:
+                raise ValueError("fading coefficients given without input / fwd_noise")
+            for e in [self._eng] + list(self._by_len.values()):
+                e.calibrate_range()
+            return
+        e = self._engine_for(input.shape[1]) if input.dim() == 3 else self._eng
+        u = e._in(input, 1, "input")
+        if fwd_noise.shape[0] != u.shape[0]:
+            raise ValueError("input and fwd_noise batch sizes differ")
+        e.calibrate_range(u, self._channel_input(e, fwd_noise, fading))
 
     def forward(self, input: torch.Tensor, fwd_noise: torch.Tensor, fading: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         return self._forward_once(input, fwd_noise, fading)

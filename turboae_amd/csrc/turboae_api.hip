@@ -7,6 +7,8 @@
 #include <string.h>
 #include <stdlib.h>
 #include <math.h>
+#include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -26,6 +28,26 @@ int fail(int code, const std::string& msg) {
 
 namespace tae {
 int fail_msg(int code, const char* msg) { return fail(code, msg ? msg : "?"); }       // for the library's other translation units
+namespace {
+std::mutex g_knob_mu;
+std::vector<std::string> g_knobs;          // "NAME=value" of every debug knob that took effect in this process
+}
+const char* debug_knob(const char* name) {
+    const char* on = getenv("TAE_DEBUG_KNOBS");
+    if (!on || on[0] != '1' || on[1] != 0) return nullptr;
+    const char* v = getenv(name);
+    if (!v) return nullptr;
+    const std::string rec = std::string(name) + "=" + v;
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    if (std::find(g_knobs.begin(), g_knobs.end(), rec) == g_knobs.end()) g_knobs.push_back(rec);
+    return v;
+}
+std::string knob_report() {
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    std::string r;
+    for (const std::string& k : g_knobs) { if (!r.empty()) r += ';'; r += k; }
+    return r;
+}
 }
 
 namespace {
@@ -322,6 +344,7 @@ struct tae_handle {
     bool eval_noise_x2 = false;      // d_eval_noise holds fading coefficients + noise
     double* d_rnn_partials = nullptr;   // GRU encoder: per (chunk, stack, head workgroup) partial sums
     int32_t rnn_partial_slots = 0;
+    bool gru_l1_split = false; // f16x2 GRU stacks: layer 1 as projection kernel + recurrence kernel (r04) instead of the fused kernel
     int32_t rnn_chunk = 0;   // blocks per internal chunk (bounds the workspace)
     float* d_gxa = nullptr;  // (chunk, L, 8) natural-order panel
     float* d_gxb = nullptr;  // (chunk, L, 8) interleaved-order panel
@@ -676,7 +699,79 @@ void pack_gru_proj_h(const float* Wih, float scale, char* dst) {
                 }
 }
 
-size_t rnn_h_stack_bytes(size_t nout) { return 2 * kGHRec0B + kGHProjB + 2 * kGHRec1B + ((nout * 2 * kGH + nout) * 4 + 15) / 16 * 16; }
+// One direction of layer 1 for the fused kernel (turboae_gru_l1f.hip, tae::GruL1fLayout): W_ih1 and W_hh share ONE power-of-two
+// scale (their products meet in the same accumulators), the head tile has its own.
+void pack_gru_l1f_dir(const float* Wih, const float* Whh, const float* bih, const float* bhh, const float* Wlin, int nout, int d,
+                      float scale, float scale_h, char* dst) {
+    using Lay = tae::GruL1fLayout;
+    const int H = kGH;
+    memset(dst, 0, Lay::kDirB);
+    auto hh_unit = [](int sl, int kq, int j) { return j < 4 ? 16 * (2 * sl) + 4 * kq + j : 16 * (2 * sl + 1) + 4 * kq + (j - 4); };
+    // 32-k slab fragment pair: [lane][8 halves] hi at `hi`, lo at `lo`; w(m, kq, j) = weight of row slot m, k slot (kq, j)
+    auto slab = [&](size_t hi, size_t lo, auto&& w) {
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) put_split(dst, hi + lane * 16 + j * 2, lo + lane * 16 + j * 2, w(lane & 15, lane >> 4, j));
+    };
+    // K = 16 remainder fragment: [lane][4 hi halves | 4 lo halves]
+    auto rem = [&](size_t off, auto&& w) {
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 4; ++j) put_split(dst, off + lane * 16 + j * 2, off + lane * 16 + 8 + j * 2, w(lane & 15, lane >> 4, j));
+    };
+    const size_t lds0 = (size_t)6 * Lay::kUnitB + Lay::kRemB;
+    for (int ut = 0; ut < 6; ++ut) {
+        const size_t ub = (size_t)ut * Lay::kUnitB;
+        for (int g = 0; g < 3; ++g) {
+            auto row = [&](int m) { return (size_t)(g * H + 16 * ut + m); };
+            for (int sl = 0; sl < 3; ++sl)
+                slab(ub + (g * 7 + 2 * sl) * 1024, ub + (g * 7 + 2 * sl + 1) * 1024,
+                     [&](int m, int kq, int j) { return Whh[row(m) * H + hh_unit(sl, kq, j)] * scale; });
+            rem(ub + (g * 7 + 6) * 1024, [&](int m, int kq, int j) { return j == 0 ? Whh[row(m) * H + 96 + kq] * scale : 0.0f; });
+            for (int sl = 0; sl < 6; ++sl)
+                slab(ub + (21 + g * 7 + sl) * 1024, lds0 + ((size_t)(ut * 3 + g) * 6 + sl) * 1024,
+                     [&](int m, int kq, int j) { return Wih[row(m) * 2 * H + 32 * sl + 8 * kq + j] * scale; });
+            rem(ub + (21 + g * 7 + 6) * 1024,
+                [&](int m, int kq, int j) { return kq < 2 ? Wih[row(m) * 2 * H + 192 + 4 * kq + j] * scale : 0.0f; });
+        }
+    }
+    {   // remainder wave: mixed tile, row 4 qq + i = (r, z, n_h, n_i) of unit 96 + qq; then the head tile
+        const size_t rb = (size_t)6 * Lay::kUnitB;
+        auto rowh = [&](int m) { const int qq = m >> 2, i = m & 3; return i < 3 ? i * H + 96 + qq : -1; };
+        auto rowi = [&](int m) { const int qq = m >> 2, i = m & 3; return i < 2 ? i * H + 96 + qq : (i == 3 ? 2 * H + 96 + qq : -1); };
+        for (int sl = 0; sl < 3; ++sl)
+            slab(rb + (2 * sl) * 1024, rb + (2 * sl + 1) * 1024,
+                 [&](int m, int kq, int j) { return rowh(m) >= 0 ? Whh[(size_t)rowh(m) * H + hh_unit(sl, kq, j)] * scale : 0.0f; });
+        rem(rb + 6 * 1024, [&](int m, int kq, int j) { return (j == 0 && rowh(m) >= 0) ? Whh[(size_t)rowh(m) * H + 96 + kq] * scale : 0.0f; });
+        for (int sl = 0; sl < 6; ++sl)
+            slab(rb + (7 + 2 * sl) * 1024, rb + (8 + 2 * sl) * 1024,
+                 [&](int m, int kq, int j) { return rowi(m) >= 0 ? Wih[(size_t)rowi(m) * 2 * H + 32 * sl + 8 * kq + j] * scale : 0.0f; });
+        rem(rb + 19 * 1024,
+            [&](int m, int kq, int j) { return (kq < 2 && rowi(m) >= 0) ? Wih[(size_t)rowi(m) * 2 * H + 192 + 4 * kq + j] * scale : 0.0f; });
+        for (int sl = 0; sl < 3; ++sl)
+            slab(rb + (20 + 2 * sl) * 1024, rb + (21 + 2 * sl) * 1024,
+                 [&](int m, int kq, int j) { return m < nout ? Wlin[(size_t)m * 2 * H + d * H + hh_unit(sl, kq, j)] * scale_h : 0.0f; });
+        rem(rb + 26 * 1024, [&](int m, int kq, int j) { return (j == 0 && m < nout) ? Wlin[(size_t)m * 2 * H + d * H + 96 + kq] * scale_h : 0.0f; });
+    }
+    float* b = reinterpret_cast<float*>(dst + lds0 + (size_t)6 * 3 * 6 * 1024);
+    for (int ut = 0; ut < 6; ++ut)
+        for (int m = 0; m < 16; ++m) {
+            const int u = 16 * ut + m;
+            b[(ut * 4 + 0) * 16 + m] = (bih[u] + bhh[u]) * scale;
+            b[(ut * 4 + 1) * 16 + m] = (bih[H + u] + bhh[H + u]) * scale;
+            b[(ut * 4 + 2) * 16 + m] = bih[2 * H + u] * scale;
+            b[(ut * 4 + 3) * 16 + m] = bhh[2 * H + u] * scale;
+        }
+    for (int m = 0; m < 16; ++m) {
+        const int u = 96 + (m >> 2), i = m & 3;
+        b[6 * 64 + m] = (i < 2 ? bih[i * H + u] + bhh[i * H + u] : (i == 2 ? bhh[2 * H + u] : bih[2 * H + u])) * scale;
+    }
+    b[6 * 64 + 16] = 1.0f / scale;
+    b[6 * 64 + 17] = 1.0f / scale_h;
+}
+
+size_t rnn_h_stack_bytes(size_t nout) {
+    return 2 * kGHRec0B + kGHProjB + 2 * kGHRec1B + ((nout * 2 * kGH + nout) * 4 + 15) / 16 * 16 + 2 * (size_t)tae::GruL1fLayout::kDirB;
+}
+size_t rnn_h_l1f_offset(size_t nout) { return rnn_h_stack_bytes(nout) - 2 * (size_t)tae::GruL1fLayout::kDirB; }
 size_t rnn_h_packed_bytes(const std::vector<size_t>& nouts) {
     size_t n = 0;
     for (size_t nout : nouts) n += rnn_h_stack_bytes(nout);
@@ -730,11 +825,20 @@ void repack_rnn_h(const float* src, char* dst, size_t cin0, const std::vector<si
             b[7 * 16 + 1] = 1.0f / scale_h;
             b[7 * 16 + 2] = b[7 * 16 + 3] = 0.0f;
         }
+        const float* l1 = src;                                     // layer 1, two directions; the Linear head follows
         src += 2 * per1;
         dst += 2 * kGHRec1B;
         memcpy(dst, src, (nout * 2 * H + nout) * sizeof(float));
-        src += nout * 2 * H + nout;
         dst += ((nout * 2 * H + nout) * 4 + 15) / 16 * 16;
+        const float scale_h = pow2_scale(max_abs(src, nout * 2 * H));
+        for (int d = 0; d < 2; ++d) {
+            const float* p = l1 + d * per1;                         // weight_ih | weight_hh | bias_ih | bias_hh
+            const float scale = pow2_scale(fmaxf(max_abs(p, 3 * H * cin1), max_abs(p + 3 * H * cin1, 3 * H * H)));
+            pack_gru_l1f_dir(p, p + 3 * H * cin1, p + 3 * H * cin1 + 3 * H * H, p + 3 * H * cin1 + 3 * H * H + 3 * H, src, (int)nout, d,
+                             scale, scale_h, dst);
+            dst += tae::GruL1fLayout::kDirB;
+        }
+        src += nout * 2 * H + nout;
     }
 }
 
@@ -905,7 +1009,7 @@ bool choose_seg(int U, int L, int n_layer, int* T, int* T0, int* nseg, int* lds,
     }
     while (tmax >= 16 && seg_bytes(tmax) > 160 * 1024) tmax -= 16;
     if (tmax < 16) return false;
-    const char* cap = getenv("TAE_SEG_T");
+    const char* cap = tae::debug_knob("TAE_SEG_T");
     if (cap && atoi(cap) >= 1 && atoi(cap) < tmax) {      // testing knob: equal segments of at most this many centre positions
         tmax = atoi(cap);
         *nseg = (L + tmax - 1) / tmax;
@@ -1196,6 +1300,16 @@ int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_
     return TAE_OK;
 }
 
+// layer 1 of a GRU stack as one kernel (f16x2 path): `img` = the stack's two GruL1fLayout images
+tae::GruL1fParams l1f_params(const tae_handle* h, const char* img, int32_t Bc) {
+    tae::GruL1fParams F;
+    memset(&F, 0, sizeof(F));
+    F.w = img; F.w_dir_stride = (uint32_t)tae::GruL1fLayout::kDirB;
+    F.y0 = reinterpret_cast<const char*>(h->d_gy0); F.hpart = h->d_gy1;
+    F.B = Bc; F.L = h->cfg.block_len; F.ngroups = (Bc + 15) / 16;
+    return F;
+}
+
 // ENC_interRNN.forward before power_constraint (encoders.py:281-296): three GRU stacks on the decoder's kernels
 // (rec layer 0 -> projection -> rec layer 1 -> head in encoder mode), per internal chunk; every head workgroup leaves a
 // partial (sum, sumsq) that reduce_partials adds in fixed order.
@@ -1235,8 +1349,12 @@ int run_encoder_rnn(tae_handle* h, const float* u, float* xtx, double* stats, in
                 wl = reinterpret_cast<const float*>(w1 + kGHProjB + 2 * kGHRec1B);
                 R1.hpart = h->d_gy1;          // per-direction head products (the layer-1 recurrence contracts Y1 away)
                 TAE_HIP(tae::launch_gru_rec_h(true, R0, st));
-                TAE_HIP(tae::launch_gru_proj_h(PP, st));
-                TAE_HIP(tae::launch_gru_rec_h(false, R1, st));
+                if (h->gru_l1_split) {
+                    TAE_HIP(tae::launch_gru_proj_h(PP, st));
+                    TAE_HIP(tae::launch_gru_rec_h(false, R1, st));
+                } else {
+                    TAE_HIP(tae::launch_gru_l1f(l1f_params(h, wb + rnn_h_l1f_offset(1), Bc), st));
+                }
                 wb += rnn_h_stack_bytes(1);
             } else {
                 R0.w = w; R0.w_dir_stride = (uint32_t)kGL0Dir;
@@ -1285,11 +1403,15 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
             memset(&PP, 0, sizeof(PP));
                 const size_t npg = (size_t)((Bc + 15) / 16) * 16 * L;       // block-group-major rows incl. the padding blocks of the last group
                 PP.yin = h->d_gy0; PP.w = reinterpret_cast<const float*>(w1); PP.gi = h->d_ggi; PP.npos = npg; PP.B = Bc; PP.L = L;
-                TAE_HIP(tae::launch_gru_proj_h(PP, st));
                 tae::GruRecParams R1;
                 memset(&R1, 0, sizeof(R1));
                 R1.w = reinterpret_cast<const float*>(w1 + kGHProjB); R1.w_dir_stride = (uint32_t)kGHRec1B; R1.gi = h->d_ggi; R1.B = Bc; R1.L = L; R1.hpart = h->d_gy1;
-                TAE_HIP(tae::launch_gru_rec_h(false, R1, st));
+                if (h->gru_l1_split) {        // r04 form (debug knob): projection to HBM, then the block-split recurrence
+                    TAE_HIP(tae::launch_gru_proj_h(PP, st));
+                    TAE_HIP(tae::launch_gru_rec_h(false, R1, st));
+                } else {
+                    TAE_HIP(tae::launch_gru_l1f(l1f_params(h, wb + rnn_h_l1f_offset((size_t)nout), Bc), st));
+                }
                 const float* wl = reinterpret_cast<const float*>(w1 + kGHProjB + 2 * kGHRec1B);
                 tae::GruHeadParams HP;
                 memset(&HP, 0, sizeof(HP));
@@ -1383,7 +1505,7 @@ constexpr int kCalMaxPass = 5;
 
 // tae_config.range_calibration (0 = on), overridden by env TAE_RANGE_CAL=0|1 (testing knob: 0 reproduces the uncalibrated r03 arithmetic)
 bool range_calibration_on(const tae_config* c) {
-    if (const char* e = getenv("TAE_RANGE_CAL")) {
+    if (const char* e = tae::debug_knob("TAE_RANGE_CAL")) {
         if (e[0] == '0') return false;
         if (e[0] == '1') return true;
     }
@@ -1570,6 +1692,7 @@ int calibrate_range(tae_handle* h, const float* u_user, const float* noise_user,
 template <class F>
 int with_fallback(tae_handle* h, hipStream_t st, F&& call) {
     if (!h || !h->fb) return call(h);
+    if (h->fb->cap < h->cap) return fail(TAE_ESTATE, "internal: the fp32 fall-back handle's workspace is smaller than the main handle's");
     if (h->last_flags & 4u) return call(h->fb);
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
@@ -1668,13 +1791,14 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     h->Ud = cfg->dec_num_unit;
     (void)hipGetDevice(&h->device);
     if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || h->ncu < 1) h->ncu = 256;
-    const char* fixed_nb = getenv("TAE_FIXED_NB");
+    if (const char* e = tae::debug_knob("TAE_GRU_L1")) h->gru_l1_split = !strcmp(e, "split");     // r04 form of the f16x2 GRU layer 1
+    const char* fixed_nb = tae::debug_knob("TAE_FIXED_NB");
     h->fixed_nb = fixed_nb && fixed_nb[0] == '1';
     const int taps_e = cfg->enc_kernel_size, taps_d = cfg->dec_kernel_size;      // 5, 7 or 9 here (1 and 3 were embedded)
     const bool big_taps = taps_e > 5 || taps_d > 5;                               // f16x2 kernels only: no fp32 packing
     // precision of the conv kernels: config field, overridden by env TAE_PRECISION=f32|f16x2 (testing knob)
     int want_h2 = cfg->precision == TAE_PREC_F32 ? 0 : 1;
-    if (const char* pe = getenv("TAE_PRECISION")) {
+    if (const char* pe = tae::debug_knob("TAE_PRECISION")) {
         if (!strcmp(pe, "f32")) want_h2 = 0;
         else if (!strcmp(pe, "f16x2")) want_h2 = 1;
     }
@@ -1686,7 +1810,7 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     h->nbd = choose_nb(h->Ud, cfg->block_len, &h->lds_bytes_d, want_h2 != 0, taps_d, 2 * cfg->num_iteration * cfg->dec_num_layer);
     // Testing knobs (documented in DESIGN.md): TAE_FORCE_SEGMENTED=1 selects the long-block path even
     // when whole blocks fit; TAE_SEG_T=<n> caps the centre length of a segment.
-    const char* force_seg = getenv("TAE_FORCE_SEGMENTED");
+    const char* force_seg = tae::debug_knob("TAE_FORCE_SEGMENTED");
     if (force_seg && force_seg[0] == '1') h->nb = h->nbd = 0;
     if (cfg->dense) h->nb = h->nbd = 0;   // dense stacks run on the long-block kernels (one stack per launch)
     if (h->nb < 1 || h->nbd < 1) {
@@ -1705,7 +1829,7 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     }
     const Layout lo(h->U), lod(h->Ud);
     const int F = cfg->num_iter_ft;
-    const char* nosup = getenv("TAE_NO_SUPER");     // testing knob: force the padded-tile path
+    const char* nosup = tae::debug_knob("TAE_NO_SUPER");     // testing knob: force the padded-tile path
     h->super = (lo.sup && cfg->block_len % 4 == 0 && !(nosup && nosup[0] == '1')) ? 1 : 0;
     h->super_d = (lod.sup && cfg->block_len % 4 == 0 && !(nosup && nosup[0] == '1')) ? 1 : 0;
     h->enc_stride = (uint32_t)lo.stack_stride(cfg->enc_num_layer);
@@ -1865,6 +1989,12 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         fc.range_fallback = 0;
         rc = tae_create(&fc, user_weights, user_n_weights, &h->fb);
         if (rc != TAE_OK) { tae_destroy(h); return rc; }
+        // the synthetic calibration batch above may have grown h->cap past max_batch: the twin serves every batch h accepts
+        // (check_batch tests h->cap only; tae_reserve keeps the two in step from here on)
+        if (h->fb->cap < h->cap) {
+            rc = tae_reserve(h->fb, h->cap);
+            if (rc != TAE_OK) { tae_destroy(h); return rc; }
+        }
     }
     *out = h;
     return TAE_OK;
@@ -1926,12 +2056,15 @@ int tae_reserve(tae_handle* h, int32_t max_batch) {
         TAE_HIP(hipMalloc(&h->d_gxb, np * 8 * sizeof(float)));
         TAE_HIP(hipMalloc(&h->d_gy0, np * 200 * sizeof(float)));
         TAE_HIP(hipMalloc(&h->d_gy1, np * 200 * sizeof(float)));
-        TAE_HIP(hipMalloc(&h->d_ggi, np * 608 * sizeof(float)));
+        // GI (layer-1 input projections, 2.4 KB per position = 4 GB per 16 384-block chunk) exists only on the fp32 path and in the
+        // r04 split form of the f16x2 path: the fused layer-1 kernel (turboae_gru_l1f.hip) never writes it
+        const bool need_gi = h->prec != 1 || h->gru_l1_split;
+        if (need_gi) TAE_HIP(hipMalloc(&h->d_ggi, np * 608 * sizeof(float)));
         // rows of padding blocks (last block group) are never written; they are read next to valid rows by the K-padding
         // over-read of the projection GEMM (x zero weights), so they must hold finite values
         TAE_HIP(hipMemset(h->d_gy0, 0, np * 200 * sizeof(float)));
         TAE_HIP(hipMemset(h->d_gy1, 0, np * 200 * sizeof(float)));
-        TAE_HIP(hipMemset(h->d_ggi, 0, np * 608 * sizeof(float)));
+        if (need_gi) TAE_HIP(hipMemset(h->d_ggi, 0, np * 608 * sizeof(float)));
         if (h->cfg.enc_type == 1) {
             (void)hipFree(h->d_rnn_partials);
             h->d_rnn_partials = nullptr;
@@ -2175,6 +2308,16 @@ int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_t* lds_b
     if (blocks_per_workgroup) *blocks_per_workgroup = h->nbd;        // the decoder's (the dominant kernel)
     if (lds_bytes) *lds_bytes = h->nbd >= 1 ? (h->prec == 1 ? h->lds_bytes_hd : h->lds_bytes_d) : (h->prec == 1 ? h->dec_lds_h : h->dec_lds);
     return TAE_OK;
+}
+
+int tae_overrides(tae_handle*, char* buf, int32_t n) {
+    const std::string r = tae::knob_report();
+    if (buf && n > 0) {
+        const size_t m = std::min((size_t)n - 1, r.size());
+        memcpy(buf, r.data(), m);
+        buf[m] = 0;
+    }
+    return (int)r.size();
 }
 
 int tae_debug_split_f16(const float* x, size_t n, float scale, uint16_t* hi, uint16_t* lo) {

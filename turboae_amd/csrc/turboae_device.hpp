@@ -4,8 +4,28 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Timing-experiment bitmasks (the results become WRONG by construction; tools/build_variant.sh).  They exist only in builds made
+// with -DTAE_EXPERIMENT; in every other build they are the constant 0 and the code they guard is compiled out.
+//   TAE_X      (CNN kernels)           1 no layer barriers, 2 no panel writes, 4 no ELU, 8 no weight loads in loop, 16 no LDS reads in loop
+//   TAE_REC_X  (gru_rec_h)             1 no exp / rcp in the gates, 2 no LDS fragment reads, 4 no GI loads / Y0 stores, 8 no MFMAs
+//   TAE_PROJ_X (gru_proj_h)            1 no GI stores, 2 no K loop, 4 no Y0 staging loads
+#ifdef TAE_EXPERIMENT
 #ifndef TAE_X
-#define TAE_X 0   // timing-experiment bitmask (results become wrong): 1 no layer barriers, 2 no panel writes, 4 no ELU, 8 no weight loads in loop, 16 no LDS reads in loop
+#define TAE_X 0
+#endif
+#ifndef TAE_REC_X
+#define TAE_REC_X 0
+#endif
+#ifndef TAE_PROJ_X
+#define TAE_PROJ_X 0
+#endif
+#else
+#if defined(TAE_X) || defined(TAE_REC_X) || defined(TAE_PROJ_X)
+#error "TAE_X / TAE_REC_X / TAE_PROJ_X are timing experiments that break the results: build with -DTAE_EXPERIMENT as well"
+#endif
+#define TAE_X 0
+#define TAE_REC_X 0
+#define TAE_PROJ_X 0
 #endif
 
 namespace tae {

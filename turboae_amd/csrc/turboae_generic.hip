@@ -686,7 +686,7 @@ bool generic_needed(const tae_config* c) {
     // TAE_FORCE_GENERIC=1 (testing knob): run ANY configuration on the generic kernels - a third, independent implementation to hold
     // against the two MFMA arithmetics (tests/test_gpu_generic.py).  Read per call on purpose (the tests flip it between handles); a
     // handle's own choice is made once, in tae_create, and tae_create re-checks the blob size under the value it sees
-    if (const char* e = getenv("TAE_FORCE_GENERIC")) if (e[0] == '1') return true;
+    if (const char* e = tae::debug_knob("TAE_FORCE_GENERIC")) if (e[0] == '1') return true;
     const bool big_k = c->enc_kernel_size > 9 || c->dec_kernel_size > 9;
     const bool mid_k = c->enc_kernel_size > 5 || c->dec_kernel_size > 5;
     // channel widths: CNN stacks up to 124 on the fp16-split MFMA kernels (instantiated for 32 / 64 / 100 / 124 - the widths whose
@@ -872,7 +872,7 @@ int generic_reserve(GenericEngine* g, int32_t B) {
 
 static hipError_t conv(const GenericEngine* g, const ConvL& C, const float* x, int ldx, float* y, int ldy, int coff, int act, int B, hipStream_t st) {
     const int L = g->cfg.block_len;
-    static const bool valu = [] { const char* e = getenv("TAE_GEN_CONV"); return e && !strcmp(e, "valu"); }();     // experiments: the r03 vector-ALU kernel
+    static const bool valu = [] { const char* e = tae::debug_knob("TAE_GEN_CONV"); return e && !strcmp(e, "valu"); }();     // experiments: the r03 vector-ALU kernel
     if (!valu) {
         const size_t np = (size_t)B * L;
         const size_t lds = ((size_t)(kMP + C.k - 1) * kMKP + (size_t)std::min(C.k, kMJ) * kMK * kMWP) * sizeof(float);
@@ -882,8 +882,8 @@ static hipError_t conv(const GenericEngine* g, const ConvL& C, const float* x, i
         }
         const unsigned ctiles = (C.cout + kMC - 1) / kMC, ntiles = (unsigned)((np + kMP - 1) / kMP) * ctiles;
         const dim3 grid((ntiles + 7) / 8 * 8);
-        static const int xcd = [] { const char* e = getenv("TAE_GEN_XCD"); return !(e && e[0] == '0'); }();     // experiments: 0 = tiles in launch order
-        static const bool no_proj = [] { const char* e = getenv("TAE_GEN_PROJ"); return e && e[0] == '0'; }();     // experiments: k = 1 on the general kernel
+        static const int xcd = [] { const char* e = tae::debug_knob("TAE_GEN_XCD"); return !(e && e[0] == '0'); }();     // experiments: 0 = tiles in launch order
+        static const bool no_proj = [] { const char* e = tae::debug_knob("TAE_GEN_PROJ"); return e && e[0] == '0'; }();     // experiments: k = 1 on the general kernel
         if (C.k == 1 && !no_proj) {
             hipLaunchKernelGGL(gen_proj_mfma_kernel, grid, dim3(512), 0, st, x, ldx, C.cin, g->d_w + C.wt, g->d_w + C.bias, y, ldy, coff, C.cout, np, act, ctiles, ntiles, xcd);
             return hipGetLastError();
@@ -918,8 +918,8 @@ static int run_stack(GenericEngine* g, const Stack& S, const float* x, int B, hi
         float* bufs[2] = {g->d_p0, g->d_p1};
         for (size_t l = 0; l < S.rl.size(); ++l) {
             const RnnL& R = S.rl[l];
-            static const bool rnn_valu = [] { const char* e = getenv("TAE_GEN_RNN"); return e && !strcmp(e, "valu"); }();     // experiments: the vector-ALU kernel
-            static const bool no_fuse = [] { const char* e = getenv("TAE_GEN_RNN_FUSE"); return e && e[0] == '0'; }();         // experiments: GI through HBM for every layer
+            static const bool rnn_valu = [] { const char* e = tae::debug_knob("TAE_GEN_RNN"); return e && !strcmp(e, "valu"); }();     // experiments: the vector-ALU kernel
+            static const bool no_fuse = [] { const char* e = tae::debug_knob("TAE_GEN_RNN_FUSE"); return e && e[0] == '0'; }();         // experiments: GI through HBM for every layer
             const bool mfma = S.H <= 128 && (S.H & 3) == 0 && !rnn_valu, fused = mfma && R.cin <= 8 && !no_fuse;
             float* y = bufs[l & 1];
             if (!fused) {
@@ -936,7 +936,7 @@ static int run_stack(GenericEngine* g, const Stack& S, const float* x, int B, hi
             }
             const int threads = (S.H + 63) / 64 * 64;
             // blocks per workgroup: share the recurrent weights where the batch still fills the chip with workgroups
-            static const int nb_env = [] { const char* e = getenv("TAE_GEN_RNN_NB"); return e ? atoi(e) : 0; }();     // experiments: read once
+            static const int nb_env = [] { const char* e = tae::debug_knob("TAE_GEN_RNN_NB"); return e ? atoi(e) : 0; }();     // experiments: read once
             const int nb = nb_env ? nb_env : (B >= 4096 ? 8 : (B >= 1024 ? 4 : 1));
             if (nb == 8)
                 hipLaunchKernelGGL(gen_rnn_kernel<8>, dim3((B + 7) / 8, 2), dim3(threads), 8 * S.H * sizeof(float), st, S.cell, g->d_gi, g->d_w + R.whh_t[0],

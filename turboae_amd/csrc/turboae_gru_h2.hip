@@ -26,13 +26,6 @@
 #include "turboae_internal.hpp"
 #include "turboae_device.hpp"
 
-#ifndef TAE_PROJ_X
-#define TAE_PROJ_X 0      // timing experiments (results wrong): 1 no GI stores, 2 no K loop, 4 no Y0 staging loads
-#endif
-#ifndef TAE_REC_X
-#define TAE_REC_X 0       // timing experiments on the recurrence (results wrong): 1 no exp / rcp in the gates, 2 no LDS fragment reads in the
-#endif                    // step loop, 4 no GI loads (layer 1) / Y0 stores (layer 0), 8 no MFMAs
-
 namespace tae {
 
 using u32x4v = __attribute__((ext_vector_type(4))) uint32_t;
@@ -491,7 +484,7 @@ hipError_t launch_gru_rec_h(bool layer0, const GruRecParams& P, hipStream_t st) 
     const int lds = gru_rec_h_lds_bytes(layer0);
     int nw = 8;
     while (nw > 1 && 2 * ((P.B + 16 * nw - 1) / (16 * nw)) < 256) nw >>= 1;
-    static const int nw_env = [] { const char* e = getenv("TAE_GRU_NW"); return e ? atoi(e) : 0; }();     // experiments: read once
+    static const int nw_env = [] { const char* e = tae::debug_knob("TAE_GRU_NW"); return e ? atoi(e) : 0; }();     // experiments: read once
     if (nw_env == 1 || nw_env == 2 || nw_env == 4 || nw_env == 8) nw = nw_env;
     const dim3 grid((P.B + 16 * nw - 1) / (16 * nw), 2);
     const void* fn = layer0 ? reinterpret_cast<const void*>(gru_rec_h_kernel<true>) : reinterpret_cast<const void*>(gru_rec_h_kernel<false>);
@@ -513,8 +506,8 @@ static hipError_t launch_gru_proj_h_t(const GruProjParams& P, hipStream_t st) {
 }
 
 hipError_t launch_gru_proj_h(const GruProjParams& P, hipStream_t st) {
-    static const int npg = [] { const char* e = getenv("TAE_GRU_PROJ_PG"); return (e && atoi(e) == 2) ? 2 : 1; }();     // experiments
-    static const int nt = [] { const char* e = getenv("TAE_GRU_PROJ_NT"); return e ? atoi(e) : 1; }();
+    static const int npg = [] { const char* e = tae::debug_knob("TAE_GRU_PROJ_PG"); return (e && atoi(e) == 2) ? 2 : 1; }();     // experiments
+    static const int nt = [] { const char* e = tae::debug_knob("TAE_GRU_PROJ_NT"); return e ? atoi(e) : 1; }();
     if (npg == 2) return nt ? launch_gru_proj_h_t<2, true>(P, st) : launch_gru_proj_h_t<2, false>(P, st);
     return nt ? launch_gru_proj_h_t<1, true>(P, st) : launch_gru_proj_h_t<1, false>(P, st);
 }

@@ -106,6 +106,24 @@ struct GruHeadParams {
     float* xtx;           // (B, L, 3)
     double* partials;     // [gridDim.x][2]
 };
+// f16x2 layer 1 as one kernel (turboae_gru_l1f.hip): input projection + recurrence + this direction's half of the Linear head.
+// Weight image of one direction: 6 unit-wave register images (42 fragments of 1 KB: per gate W_hh {slab 0..2: hi, lo; remainder},
+// then per gate W_ih1 {slab 0..5 hi; remainder}) | remainder-wave image (27 fragments: W_hh 7, W_ih1 13, head 7) | LDS image
+// (W_ih1 lo [ut][gate][slab] | bias rows | 2^-S, 2^-S_head).
+struct GruL1fLayout {
+    static constexpr int kUnitB = 42 * 1024, kRemB = 27 * 1024;
+    static constexpr int kLdsImgB = 6 * 3 * 6 * 1024 + 6 * 4 * 64 + 64 + 16;
+    static constexpr int kDirB = 6 * kUnitB + kRemB + kLdsImgB;
+};
+struct GruL1fParams {
+    const char* w;         // two GruL1fLayout images (forward, backward)
+    uint32_t w_dir_stride; // bytes between them
+    const char* y0;        // layer-0 outputs as halves [pos'][hi 200 | lo 200], pos' = ((b / 16) L + t) 16 + b % 16
+    float* hpart;          // [pos'][dir][8]: this direction's share of the Linear head
+    int32_t B, L, ngroups; // ngroups = ceil(B / 16)
+};
+hipError_t launch_gru_l1f(const GruL1fParams& P, hipStream_t st);
+int gru_l1f_lds_bytes();
 hipError_t launch_gru_prep_enc(const float* u, const int32_t* perm, float* X, int B, int L, int interleaved, hipStream_t st);
 int gru_head_grid(size_t npos);
 hipError_t launch_gru_prep(const float* rx, const int32_t* perm, float* XA, float* XB, int B, int L, hipStream_t st);
@@ -155,6 +173,10 @@ void generic_destroy(GenericEngine* g);
 int generic_reserve(GenericEngine* g, int32_t B);
 int generic_encode(GenericEngine* g, const float* u, float* xtx, double* stats, const int32_t* perm, int32_t B, hipStream_t st);
 int generic_decode(GenericEngine* g, const float* rx, float* xdec, const int32_t* perm, const int32_t* inv, int32_t B, hipStream_t st);
+// Debug knobs: every environment variable that changes the arithmetic, the kernel family or a launch geometry goes through here.
+// It is inert (nullptr) unless TAE_DEBUG_KNOBS=1 is set in the same environment, and every override that took effect is recorded
+// for tae_overrides().
+const char* debug_knob(const char* name);
 int fail_msg(int code, const char* msg);          // turboae_api.hip: sets the calling thread's tae_last_error string
 int fused_lds_bytes(int U, int L, int nb);
 int fused_max_positions();
