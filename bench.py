@@ -103,6 +103,31 @@ def host_cpu_info():
     return {"model": model, "physical_cores": physical, "logical_cpus": logical or usable, "usable_cpus": usable}
 
 
+def host_l3_info():
+    """L3 geometry from sysfs: size of one L3 slice (a core complex) and how many CPUs share it - the evidence behind the CPU leg's
+    batch-size dependence (an activation set that leaves the reachable L3 slices streams from DRAM)."""
+    base = "/sys/devices/system/cpu/cpu0/cache"
+    try:
+        for idx in sorted(os.listdir(base)):
+            d = os.path.join(base, idx)
+            with open(os.path.join(d, "level")) as fh:
+                if fh.read().strip() != "3":
+                    continue
+            with open(os.path.join(d, "size")) as fh:
+                size = fh.read().strip()
+            with open(os.path.join(d, "shared_cpu_list")) as fh:
+                shared = fh.read().strip()
+            n = 0
+            for part in shared.split(","):
+                a, _, b = part.partition("-")
+                n += (int(b) - int(a) + 1) if b else 1
+            mb = float(size[:-1]) / (1024.0 if size.endswith("K") else 1.0) if size[-1] in "KM" else None
+            return {"l3_per_complex_MB": mb, "cpus_sharing_one_l3": n, "shared_cpu_list_cpu0": shared}
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def _time_forwards(fwd, warmups: int, runs: int):
     for _ in range(warmups):
         fwd()
@@ -175,22 +200,40 @@ def cpu_baseline_and_parity(cfg: TurboAEConfig, sd, u500: np.ndarray, noise500: 
            "cpu_model": info["model"], "physical_cores": info["physical_cores"], "logical_cpus": info["logical_cpus"],
            "usable_cpus": info["usable_cpus"], "torch": torch.__version__,
            "omp_binding": f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND', '-')} OMP_PLACES={os.environ.get('OMP_PLACES', '-')}"}
-    # larger batch at the best setting, then 1 thread on a smaller one - only while the budget lasts
-    if time.perf_counter() - t_start < 0.55 * budget_s:
+    # A larger batch (B = 2000), at ITS OWN best thread count.  r04 timed it at the B = 500 optimum and read 3.1x fewer bits/s: one
+    # conv layer's activations are B x L x 100 x 4 B in + the same out = 40 MB at B = 500 but 160 MB at B = 2000, against the L3 slices
+    # the bound threads can reach (l3_per_complex_MB x complexes spanned, below) - the big batch wants more complexes, i.e. more
+    # threads, not the B = 500 setting.  Fresh tensors, first-touched by the pool that uses them; sweep from `best` upwards.
+    out["l3"] = host_l3_info()
+    out["activation_MB_per_layer_B500"] = 2.0 * B * L * cfg.dec_num_unit * 4 / 1e6
+    if time.perf_counter() - t_start < 0.5 * budget_s:
         big = 4
-        ub, nb_ = ut.repeat(big, 1, 1), nt.repeat(big, 1, 1)
-        tb = _time_forwards(lambda: O.channel_ae_forward(ub, nb_, w, cd), 1, 3)
-        out["value_B2000"] = big * B * L / float(np.median(tb))
-    if time.perf_counter() - t_start < 0.8 * budget_s:
+        sweep_b = {}
+        left = lambda: budget_s * 0.85 - (time.perf_counter() - t_start)       # noqa: E731
+        for t in sorted({best, min(cap, 2 * best), min(cap, 4 * best), cap}):
+            if sweep_b and left() < 3.0 * big * (B * L / max(sweep_b.values())):
+                break
+            torch.set_num_threads(t)
+            ub, nb_ = ut.repeat(big, 1, 1).clone(), nt.repeat(big, 1, 1).clone()
+            tb = _time_forwards(lambda: O.channel_ae_forward(ub, nb_, w, cd), 1, 2)
+            sweep_b[t] = big * B * L / float(np.median(tb))
+        tb_best = max(sweep_b, key=lambda t: sweep_b[t])
+        out["value_B2000"] = sweep_b[tb_best]
+        out["cores_B2000"] = tb_best
+        out["value_B2000_at_B500_threads"] = sweep_b.get(best)
+        out["thread_sweep_B2000_bits_per_s"] = {str(k): v for k, v in sweep_b.items()}
+        out["b2000_over_b500"] = sweep_b[tb_best] / out["value"]
+        out["activation_MB_per_layer_B2000"] = big * out["activation_MB_per_layer_B500"]
+    if time.perf_counter() - t_start < 0.9 * budget_s:
         torch.set_num_threads(1)
-        u1, n1 = ut[:100], nt[:100]
+        u1, n1 = ut[:100].clone(), nt[:100].clone()
         t1 = _time_forwards(lambda: O.channel_ae_forward(u1, n1, w, cd), 1, 3)
         out["value_1_thread"] = 100 * L / float(np.median(t1))
     torch.set_num_threads(old_threads)
     out["sample"] = (f"median of {n_runs} forwards ({n_warm} warm-ups; thread sweep: {n_sweep} forwards per setting) of the first B={B} blocks of the benchmark's Philox stream (L={L}, "
                      f"enc{cfg.enc_num_layer}/dec{cfg.dec_num_layer}, {cfg.num_iteration} iters, trained weights) through "
                      f"oracle/turboae_oracle.py (PyTorch-CPU fp32) at {best} threads - best of the sweep {cands} on {info['model']} "
-                     f"({info['physical_cores']} physical cores); value_B2000: 4x that batch; value_1_thread: B=100 on one thread; "
+                     f"({info['physical_cores']} physical cores); value_B2000: 4x that batch at its own best thread count (cores_B2000); value_1_thread: B=100 on one thread; "
                      f"{time.perf_counter() - t_start:.0f} s of CPU work in total")
     return out, x_cpu.numpy(), c_cpu.numpy()
 
@@ -386,19 +429,235 @@ def measure_traffic_pmc(batch: int, block_len: int, snr: float, precision: str, 
                    "requests at 64 B, MI355X_MICROARCH.md HBM section); Infinity-Cache hits are counted by these counters"}
 
 
-def relaunch_distributed(n: int) -> int:
+def flatten_scalars(out) -> None:
+    """The driver keeps only the scalar top-level keys of the line: lift the secondary results (other BASELINE configs, the fp32
+    pass, the graph replay, the 12-point sweep, parity, the CPU leg) to scalars of their own; the nested objects stay as they are."""
+    rf = out.get("roofline", {})
+    out["roofline_frac"] = rf.get("frac")
+    out["roofline_kernel_ms"] = rf.get("kernel_ms")
+    out["roofline_traffic_gb"] = rf.get("traffic")
+    out["roofline_frac_of_sustained"] = rf.get("frac_of_sustained")
+    out["sustained_probe_tflops"] = rf.get("sustained_probe_tflops")
+    names = {"configs[0]": "cfg0_b500", "configs[2]": "cfg2_enc5", "configs[3]": "cfg3_l1000", "configs[4]": "cfg4_gru"}
+    for oc in rf.get("other_configs", []) or []:
+        key = next((v for k, v in names.items() if str(oc.get("config", "")).startswith(k)), None)
+        if key and "error" not in oc:
+            out[f"{key}_frac"] = oc["decoder_frac"]
+            out[f"{key}_enc_frac"] = oc["encoder_frac"]
+            out[f"{key}_bits_per_s"] = oc["bits_per_s"]
+            out[f"{key}_ms"] = oc["ms_per_forward"]
+            out[f"{key}_ber"] = oc["ber"]
+    for oc in rf.get("generic_configs", []) or []:
+        if "error" not in oc:
+            key = "lstm" if "lstm" in str(oc.get("config", "")) else "wide256"
+            out[f"{key}_bits_per_s"] = oc["bits_per_s"]
+            out[f"{key}_frac"] = oc["decoder_frac"]
+    rf["cfg0_b500_frac"], rf["cfg2_enc5_frac"] = out.get("cfg0_b500_frac"), out.get("cfg2_enc5_frac")
+    rf["cfg3_l1000_frac"], rf["cfg4_gru_frac"] = out.get("cfg3_l1000_frac"), out.get("cfg4_gru_frac")
+    r32 = out.get("roofline_f32")
+    if r32:
+        out["f32_bits_per_s"], out["f32_frac"], out["f32_ms_per_step"] = r32["value_bits_per_s"], r32["frac"], r32["ms_per_step"]
+    gr = out.get("graph_replay")
+    if gr:
+        out["graph_replay_ms"], out["graph_replay_bits_per_s"] = gr["ms_per_step"], gr["bits_per_s"]
+    sw = out.get("sweep_cfg1")
+    if sw and "error" not in sw:
+        out["sweep_cfg1_s"], out["sweep_cfg1_bits_per_s"] = sw["seconds"], sw["bits_per_s"]
+        if 2.0 in sw["snrs"]:
+            out["sweep_cfg1_ber_2dB"] = sw["ber"][sw["snrs"].index(2.0)]
+        out["sweep_cfg1_ber_first"], out["sweep_cfg1_ber_last"] = sw["ber"][0], sw["ber"][-1]
+    par = out.get("parity")
+    if par:
+        out["parity_decision_flips"] = par.get("decision_flips")
+        out["parity_max_abs_x_dec"] = par.get("max_abs_x_dec_gpu_vs_cpu")
+        out["parity_max_abs_codes"] = par.get("max_abs_codes_gpu_vs_cpu")
+        out["parity_ber_abs_diff"] = par.get("ber_abs_diff")
+        out["parity_decision_flips_f16x2_vs_f32"] = par.get("decision_flips_f16x2_vs_f32")
+    cpu = out.get("cpu_baseline")
+    if cpu:
+        out["cpu_baseline_bits_per_s"], out["cpu_baseline_cores"] = cpu["value"], cpu["cores"]
+        out["cpu_baseline_B2000_bits_per_s"], out["cpu_baseline_b2000_over_b500"] = cpu.get("value_B2000"), cpu.get("b2000_over_b500")
+    out["overrides"] = tae_overrides()
+
+
+def tae_overrides() -> str:
+    """Debug knobs in effect in this process (tae_overrides; empty = none)."""
+    import ctypes as C
+    from turboae_amd import _lib
+    buf = C.create_string_buffer(1024)
+    _lib.load().tae_overrides(None, buf, 1024)
+    return buf.value.decode()
+
+
+METRIC = "decoded info bits/sec @ block_len={L}, 6-iter rate-1/3 CNN; BER match"      # BASELINE.json's metric at the default L = 100
+PHASES = ("start", "device_ok", "pg_init", "pg_ready", "first_collective", "collectives_ok", "timed_pass", "extra_configs", "done")
+
+
+def _state_dir() -> str:
+    """Where the ranks of ONE launch leave their progress records: given by the launcher (TAE_BENCH_STATE_DIR), else derived from what
+    all ranks of a torch.distributed.run launch share - the agent's pid and the rendezvous port."""
+    d = os.environ.get("TAE_BENCH_STATE_DIR") or os.path.join("/tmp", f"tae_bench_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def read_rank_states(d: str, world: int):
+    out = []
+    for r in range(world):
+        try:
+            with open(os.path.join(d, f"rank{r}.json")) as fh:
+                out.append(json.load(fh))
+        except (OSError, ValueError):
+            out.append({"rank": r, "phase": "no record"})
+    return out
+
+
+def _pid_alive(pid) -> bool:
+    try:
+        os.kill(int(pid), 0)
+        return True
+    except (OSError, TypeError, ValueError):
+        return False
+
+
+def error_line(args, world: int, reason: str, states, extra=None):
+    """The ONE JSON line of a run that could not be measured: the contract's keys with value 0, the reason, how many ranks got their
+    process group up (`rccl_ranks_seen`) and every rank's last recorded phase."""
+    reached = [st.get("failed_in") if st.get("phase") == "failed" else st.get("phase") for st in states]
+    seen = sum(1 for ph in reached if ph in PHASES and PHASES.index(ph) >= PHASES.index("pg_ready"))
+    line = {"metric": METRIC.format(L=args.block_len), "value": 0.0, "unit": "bits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+            "dtype": "f16x2" if args.precision == "auto" else "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{1 if args.block_len == 100 else 3}] (not measured: see error)", "rank_states": states},
+            "error": reason, "rccl_ranks_seen": seen}
+    if extra:
+        line.update(extra)
+    return line
+
+
+class Guard:
+    """First-N>1-run hardening.  Every rank records its phase in a small file; a watchdog thread per rank turns
+    the three ways a multi-GPU launch dies silently - a peer that exits (the launcher then SIGTERMs the rest while they sit inside a
+    collective, where no Python signal handler can run), a rendezvous / collective that never completes, an exception on one rank -
+    into ONE JSON line with `error`, `rccl_ranks_seen` and the per-rank phases, printed by rank 0 (or, if rank 0 is the one that
+    died, by the lowest rank still alive).  The signal reaches the watchdog through signal.set_wakeup_fd: the C-level handler writes a
+    byte even while the main thread is blocked in RCCL / hipStreamSynchronize."""
+
+    def __init__(self, args, rank: int, world: int):
+        import signal
+        import threading
+        self.args, self.rank, self.world = args, rank, world
+        self.dir = _state_dir()
+        self.path = os.path.join(self.dir, f"rank{rank}.json")
+        self.phase_name, self.deadline, self.finished = "start", None, False
+        self.fallback = None                       # a complete result line: printed (plus the error) if a later, optional stage fails
+        self.lock = threading.Lock()
+        self.record("start")
+        self.active = world > 1 or os.environ.get("TAE_BENCH_FORCE_DIST") == "1"
+        if not self.active:
+            return
+        self.rfd, wfd = os.pipe()
+        os.set_blocking(wfd, False)
+        os.set_blocking(self.rfd, False)
+        signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
+        for sig in (signal.SIGTERM, signal.SIGINT):
+            signal.signal(sig, lambda *_: None)   # a Python-level handler must exist for the wake-up byte; the watchdog thread acts
+        threading.Thread(target=self._watch, daemon=True).start()
+
+    def record(self, phase: str, **kw):
+        self.phase_name = phase
+        rec = {"rank": self.rank, "pid": os.getpid(), "phase": phase, "t": round(time.time(), 3)}
+        rec.update(kw)
+        tmp = self.path + ".tmp"
+        try:
+            with open(tmp, "w") as fh:
+                json.dump(rec, fh)
+            os.replace(tmp, self.path)
+        except OSError:
+            pass
+
+    def phase(self, name: str, timeout=None):
+        """Enter a phase; with `timeout` the watchdog reports a failure if the NEXT phase is not entered within that many seconds."""
+        self.deadline = (time.monotonic() + timeout) if timeout else None
+        self.record(name)
+        die = os.environ.get("TAE_BENCH_TEST_DIE")          # test hook "rank:phase": that rank exits hard when it enters the phase
+        if die and die == f"{self.rank}:{name}":
+            os._exit(17)
+
+    def _watch(self):
+        import select
+        while not self.finished:
+            r, _, _ = select.select([self.rfd], [], [], 0.25)
+            if self.finished:
+                return
+            if r:
+                try:
+                    data = os.read(self.rfd, 64)
+                except OSError:
+                    data = b""
+                if data:
+                    self.fail(f"signal {data[0]} received during phase '{self.phase_name}' (the launcher stops the remaining ranks when one rank exits)")
+            if self.deadline is not None and time.monotonic() > self.deadline:
+                self.fail(f"phase '{self.phase_name}' did not complete within its time limit (hung rendezvous or collective)")
+
+    def is_reporter(self, states) -> bool:
+        if self.rank == 0:
+            return True
+        return not any(_pid_alive(states[r].get("pid")) for r in range(self.rank))
+
+    def fail(self, reason: str):
+        """Record the failure, print the error line if this rank is the reporter, and leave without running torch's teardown (a
+        destroy_process_group on a broken group can hang)."""
+        with self.lock:
+            if self.finished:
+                return
+            self.finished = True
+        self.record("failed", error=reason, failed_in=self.phase_name)
+        time.sleep(1.0 if self.rank == 0 else 0.2)           # let the other ranks write their last phase
+        states = read_rank_states(self.dir, self.world)
+        if self.is_reporter(states):
+            if self.fallback is not None:
+                line = dict(self.fallback)
+                line["error_after_headline"] = reason
+                line["config"] = dict(line.get("config", {}), rank_states=states)
+            else:
+                line = error_line(self.args, self.world, reason, states)
+            sys.stdout.write(json.dumps(line) + "\n")
+            sys.stdout.flush()
+        os._exit(3)
+
+    def done(self):
+        self.finished = True
+        self.record("done")
+
+
+def relaunch_distributed(n: int, args) -> int:
     """`python bench.py --gpus N` without a torch.distributed environment: start N ranks of this script, one per GPU, exactly as
-    the driver's documented launch line does; the exit code of the launcher is returned."""
+    the driver's documented launch line does (on a free port), pass their output through, and - should the launch end without
+    a JSON line (launcher failure, every reporter killed) - print the error line from the ranks' progress records here."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sdir = tempfile.mkdtemp(prefix="tae_bench_", dir="/tmp")
+    env["TAE_BENCH_STATE_DIR"] = sdir
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    saw_line = False
+    for line in proc.stdout:
+        saw_line = saw_line or line.startswith("{")
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if not saw_line:
+        print(json.dumps(error_line(args, n, f"the launch ended with exit code {rc} and no result line", read_rank_states(sdir, n))), flush=True)
+        rc = rc or 3
+    return rc
 
 
 def main():
@@ -422,6 +681,12 @@ def main():
     ap.add_argument("--graph-replays", type=int, default=20)
     ap.add_argument("--graph-multi", action="store_true", help="also time the hipGraph replay variant with more than one rank (RCCL all-reduce captured into the graph)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child passes (falls back to the committed figure, labelled)")
+    ap.add_argument("--dist-timeout", type=float, default=120.0, help="seconds allowed for the process-group rendezvous and, again, for the first collective (N > 1)")
+    ap.add_argument("--also-configs3", dest="also_configs3", action="store_true", default=None,
+                    help="after the timed pass also time BASELINE configs[3] (block_len 1000, 25000 blocks per GPU; plus its --strong form, 200000 blocks "
+                         "over the ranks, where that differs) and report it inside the same line (configs3, cfg3_*): default ON for N > 1 so ONE multi-GPU lease "
+                         "yields both configurations BASELINE.json names, OFF for N = 1 (roofline.other_configs already times that shape)")
+    ap.add_argument("--no-configs3", dest="also_configs3", action="store_false")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=75.0, help="wall-time bound of the CPU leg in seconds")
     ap.add_argument("--precision", choices=("auto", "f32"), default="auto",
@@ -436,25 +701,46 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-            sys.exit(relaunch_distributed(args.gpus))
+            sys.exit(relaunch_distributed(args.gpus, args))
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    guard = Guard(args, rank, world)
     # TAE_BENCH_BACKEND=gloo is a test hook: it lets N ranks share the GPUs that exist (rank % device_count) so the N > 1
     # code path can be exercised on a 1-GPU box (tests/test_gpu_sharded.py); the contract run uses RCCL, one GPU per rank.
     backend = os.environ.get("TAE_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if backend != "nccl":
-        local_rank %= torch.cuda.device_count()
+        local_rank %= ndev
+    elif local_world > ndev or local_rank >= ndev:
+        guard.fail(f"device_count {ndev} < {local_world} ranks on this node: one GPU per rank is required (RCCL)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    guard.phase("device_ok")
     dist = None
-    if world > 1 or os.environ.get("TAE_BENCH_FORCE_DIST") == "1":      # FORCE_DIST: run the RCCL init + collectives at world size 1 (test hook)
+    if guard.active:      # N > 1, or TAE_BENCH_FORCE_DIST=1: run the RCCL init + collectives at world size 1 (test hook)
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group(backend=backend)
+        tmo = datetime.timedelta(seconds=args.dist_timeout)
+        guard.phase("pg_init", timeout=args.dist_timeout + 15.0)
+        try:
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=dev, timeout=tmo)     # "nccl" is RCCL on ROCm
+            else:
+                dist.init_process_group(backend=backend, timeout=tmo)
+            guard.phase("pg_ready")
+            # the first collective, under the watchdog: a barrier and a count of the ranks it reached
+            guard.phase("first_collective", timeout=args.dist_timeout)
+            ones = torch.ones(1, dtype=torch.int64, device=dev)
+            dist.all_reduce(ones)
+            if int(ones.item()) != world:
+                guard.fail(f"the first all-reduce reached {int(ones.item())} of {world} ranks")
+            dist.barrier()
+            guard.phase("collectives_ok")
+        except Exception as e:         # port in use, peer unreachable, RCCL error, ...: still ONE JSON line
+            guard.fail(f"{type(e).__name__}: {e}")
 
     L = args.block_len
     cfg = TurboAEConfig(block_len=L, enc_num_layer=args.enc_layers, precision=args.precision)
@@ -474,9 +760,11 @@ def main():
     if B < 1:
         raise SystemExit("--strong: fewer blocks than ranks")
 
-    def timed_pass(precision: str):
-        """W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize; returns the measurements."""
+    def timed_pass(precision: str, cfg=cfg, B=B, first=first, global_blocks=global_blocks, n_steps=args.steps, n_warm=args.warmup, light=False):
+        """W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize; returns the measurements.  The defaults are
+        the headline workload; --also-configs3 calls it again for BASELINE configs[3] (light: no graph replay, no parity sample)."""
         from dataclasses import replace
+        L = cfg.block_len
         model = Channel_AE_HIP(replace(cfg, precision=precision), sd, device=dev, max_batch=max(B, PARITY_BLOCKS))
         # synthetic inputs generated on device, keyed by the GLOBAL block index (identical to the 1-GPU stream); excluded from the
         # timed region (inputs resident in HBM) but reported
@@ -486,7 +774,7 @@ def main():
         u, noise = model.generate_inputs(B, args.snr, seed=SEED, first_block=first)
         g1.record()
         counts = torch.zeros(2, dtype=torch.int64, device=dev)
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_steps)]
 
         def step(i=None):
             if i is not None:
@@ -508,13 +796,13 @@ def main():
             if dist is not None:
                 dist.barrier()
 
-        for _ in range(args.warmup):
+        for _ in range(n_warm):
             step()
         counts.zero_()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(n_steps):
             step(i)
         torch.cuda.synchronize()
         barrier()
@@ -542,7 +830,7 @@ def main():
         graph = None
         # N > 1: only on request (--graph-multi) - capturing RCCL collectives of several ranks into hipGraphs has never run on real
         # multi-GPU hardware from this repository (world size 1 only, tests/test_gpu_sharded.py), and the scaling run must not hang on it
-        if not args.no_graph and precision == args.precision and (dist is None or (backend == "nccl" and (world == 1 or args.graph_multi))):
+        if not light and not args.no_graph and precision == args.precision and (dist is None or (backend == "nccl" and (world == 1 or args.graph_multi))):
             n_rep = max(1, args.graph_replays)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -577,7 +865,7 @@ def main():
         # "BER match" sample: the first PARITY_BLOCKS blocks of the same Philox stream as ONE batch of their own (the power
         # constraint takes its statistics over the batch it is handed, encoders.py:107-108), compared with the CPU oracle below
         par = None
-        if rank == 0 and world == 1 and not args.no_parity:
+        if rank == 0 and world == 1 and not args.no_parity and not light:
             up, npar = model.generate_inputs(PARITY_BLOCKS, args.snr, seed=SEED, first_block=0)
             xd, codes = model(up, npar)
             torch.cuda.synchronize()
@@ -591,12 +879,19 @@ def main():
             probe = mfma_sustained_probe(150)          # same device, right before the timed pass
         except Exception as e:                         # a side measurement: never takes the headline line down
             print(f"bench.py: sustained-MFMA probe failed: {e}", file=sys.stderr)
-    if dist is not None:
-        dist.barrier()
-    main_res, main_par = timed_pass(args.precision)
-    f32_res = f32_par = None
-    if args.precision == "auto" and not args.no_f32_pass and main_res["mode"] == "f16x2":
-        f32_res, f32_par = timed_pass("f32")
+    # from here on every rank runs the same sequence of collectives; the watchdog bounds the whole measured part
+    guard.phase("timed_pass", timeout=(600.0 + 4.0 * (args.steps + args.warmup)) if guard.active else None)
+    try:
+        if dist is not None:
+            dist.barrier()
+        main_res, main_par = timed_pass(args.precision)
+        f32_res = f32_par = None
+        if args.precision == "auto" and not args.no_f32_pass and main_res["mode"] == "f16x2":
+            f32_res, f32_par = timed_pass("f32")
+    except (SystemExit, Exception) as e:
+        if not guard.active:
+            raise
+        guard.fail(f"{type(e).__name__}: {e}")
 
     pmc_live = {}
     if rank == 0 and world == 1 and not args.no_pmc and trained and args.enc_layers == 2:
@@ -655,7 +950,7 @@ def main():
                     "flops_per_launch": dec_flops_per_launch}
 
         out = {
-            "metric": f"decoded info bits/sec @ block_len={L}, 6-iter rate-1/3 CNN; BER match",      # BASELINE.json's metric at the default L = 100
+            "metric": METRIC.format(L=L),
             "value": value, "unit": "bits/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3, "ms_per_step_median": main_res["step_ms_median"], "ms_per_step_min": main_res["step_ms_min"],
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
@@ -746,7 +1041,45 @@ def main():
                     parity["decision_flips_f32"] = int((hard(f32_par["x_dec"]) != hard(x_cpu)).sum())
                     parity["max_abs_x_dec_gpu_f32_vs_cpu"] = float(np.abs(f32_par["x_dec"] - x_cpu).max())
             out["parity"] = parity
+        flatten_scalars(out)
+        guard.fallback = out                      # from here on a failure of the optional configs[3] stage still prints THIS line
+    # BASELINE configs[3] inside the same launch (all ranks: it has collectives of its own)
+    also3 = args.also_configs3 if args.also_configs3 is not None else (world > 1)
+    if also3 and L == 100 and cfg.enc_num_layer == 2:
+        guard.phase("extra_configs", timeout=900.0 if guard.active else None)
+        c3 = {}
+        try:
+            from dataclasses import replace
+            cfg3 = replace(cfg, block_len=1000)
+            k3, w3 = max(2, min(args.steps, 5)), 1
+            runs = [("weak", 25000, rank * 25000, world * 25000)]
+            if world not in (1, 8):               # the --strong form: 200 000 blocks over the ranks (= the weak shape at 8)
+                lo3, hi3 = (200000 * rank) // world, (200000 * (rank + 1)) // world
+                runs.append(("strong", hi3 - lo3, lo3, 200000))
+            for tag, b3, first3, glob3 in runs:
+                r3, _ = timed_pass(args.precision, cfg=cfg3, B=b3, first=first3, global_blocks=glob3, n_steps=k3, n_warm=w3, light=True)
+                bits3 = float(glob3) * 1000 * k3
+                dec_tf = 2.0 * cfg3.macs_per_bit()["dec"] * b3 * 1000 / (r3["dec_ms"] * 1e-3) / 1e12
+                peak3 = PEAK_F16_MFMA_TFLOPS / F16X2_PRODUCTS if r3["mode"] == "f16x2" else PEAK_FP32_MFMA_TFLOPS
+                c3[tag] = {"workload": f"BASELINE configs[3]: enc2/dec5, block_len=1000, {glob3} blocks over {world} GPU(s) ({b3} on rank {rank}), {tag} scaling",
+                           "value": bits3 / r3["elapsed"], "unit": "bits/s", "ms_per_step": r3["elapsed"] / k3 * 1e3, "steps": k3, "warmup": w3,
+                           "global_blocks": glob3, "ber": r3["counts"][0] / bits3, "decoder_ms": r3["dec_ms"], "decoder_frac": dec_tf / peak3,
+                           "rccl_ranks_seen": r3["ranks_seen"]}
+        except (SystemExit, Exception) as e:
+            if guard.active:
+                guard.fail(f"configs[3] stage: {type(e).__name__}: {e}")
+            c3["error"] = f"{type(e).__name__}: {e}"
+        if rank == 0:
+            out["configs3"] = c3
+            for tag in ("weak", "strong"):
+                if tag in c3:
+                    out[f"cfg3_{tag}_bits_per_s"] = c3[tag]["value"]
+                    out[f"cfg3_{tag}_ms_per_step"] = c3[tag]["ms_per_step"]
+                    out[f"cfg3_{tag}_decoder_frac"] = c3[tag]["decoder_frac"]
+    if rank == 0:
+        guard.finished = True                     # the line is about to be printed: the watchdog must not print a second one
         print(json.dumps(out), flush=True)
+    guard.done()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -91,3 +91,57 @@ def test_mean_std_from_stats_matches_torch():
     m, s = mean_std_from_stats(stats_from_tensor(x))
     assert m == pytest.approx(float(x.mean()), abs=1e-7)
     assert s == pytest.approx(float(x.std()), rel=1e-6)
+
+
+def test_bench_guard_turns_sigterm_and_hangs_into_one_error_line(tmp_path):
+    """bench.py's Guard (first-N>1-run hardening): a rank blocked in a call that never returns (stands in for a collective whose peer
+    died) still reports - the launcher's SIGTERM reaches the watchdog thread through signal.set_wakeup_fd, a hung phase through its
+    deadline; rank 0 prints ONE line with `error`, `rccl_ranks_seen` and every rank's last recorded phase; a non-zero rank stays
+    silent while rank 0 lives and takes over when it does not."""
+    import json
+    import signal
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, time, argparse\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import bench\n"
+        "rank, mode = int(sys.argv[1]), sys.argv[2]\n"
+        "args = argparse.Namespace(block_len=100, steps=2, warmup=1, strong=False, precision='auto')\n"
+        "g = bench.Guard(args, rank, 2)\n"
+        "g.phase('pg_init'); g.phase('pg_ready')\n"
+        "g.phase('first_collective', timeout=1.0 if mode == 'hang' else 60.0)\n"
+        "print('READY', flush=True)\n"
+        "time.sleep(120)\n")
+
+    def run(rank, mode, peer):
+        d = tmp_path / f"{rank}_{mode}_{peer['phase']}"
+        d.mkdir()
+        (d / f"rank{1 - rank}.json").write_text(json.dumps(dict(peer, rank=1 - rank)))
+        env = dict(os.environ, TAE_BENCH_STATE_DIR=str(d))
+        p = subprocess.Popen([sys.executable, "-c", script, str(rank), mode], stdout=subprocess.PIPE, text=True, env=env, cwd=root)
+        assert p.stdout.readline().strip() == "READY"
+        t0 = time.time()
+        if mode == "term":
+            p.send_signal(signal.SIGTERM)
+        rest, _ = p.communicate(timeout=60)
+        assert time.time() - t0 < 20.0 and p.returncode == 3
+        return [json.loads(l) for l in rest.splitlines() if l.startswith("{")]
+
+    dead = subprocess.Popen([sys.executable, "-c", "pass"])
+    dead.wait()
+    for mode in ("term", "hang"):
+        lines = run(0, mode, {"pid": dead.pid, "phase": "timed_pass"})
+        assert len(lines) == 1
+        res = lines[0]
+        assert res["value"] == 0.0 and res["n_gpus"] == 2 and res["unit"] == "bits/s" and res["metric"].startswith("decoded info bits/sec")
+        assert res["rccl_ranks_seen"] == 2                       # both ranks had their process group up
+        assert ("signal" if mode == "term" else "time limit") in res["error"]
+        st = res["config"]["rank_states"]
+        assert st[0]["phase"] == "failed" and st[0]["failed_in"] == "first_collective" and st[1]["phase"] == "timed_pass"
+    # rank 1: silent while rank 0's process exists (rank 0 reports), the reporter when it does not
+    assert run(1, "term", {"pid": os.getpid(), "phase": "timed_pass"}) == []
+    lines = run(1, "term", {"pid": dead.pid, "phase": "pg_init"})
+    assert len(lines) == 1 and lines[0]["rccl_ranks_seen"] == 1 and lines[0]["config"]["rank_states"][0]["phase"] == "pg_init"

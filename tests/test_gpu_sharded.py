@@ -225,3 +225,103 @@ def test_eval_sweep_hip_graph_captures_rccl_allreduce(gpu_device):
     assert p.exitcode == 0
     assert eager["bit_errors"] == graphed["bit_errors"] and eager["block_errors"] == graphed["block_errors"]
     assert eager["ber"] == graphed["ber"] and eager["bit_errors"][0] > eager["bit_errors"][1] > 0
+
+
+# ---- first-N>1-run hardening: every way a multi-rank launch can die still ends in ONE parsed JSON line ----------
+
+def _bench_lines(out):
+    import json
+    return [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("victim", [1, 0])
+def test_bench_rank_dies_mid_run_still_prints_one_error_line(gpu_device, victim):
+    """A rank exits hard when it enters the timed pass (test hook TAE_BENCH_TEST_DIE): the launcher SIGTERMs the survivor while it
+    sits inside a collective; its watchdog thread (signal.set_wakeup_fd) prints the error line - rank 0 if it is alive, otherwise
+    the lowest rank that is - with every rank's last phase, within a minute."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TAE_BENCH_BACKEND="gloo", TAE_BENCH_TEST_DIE=f"{victim}:timed_pass")
+    env.pop("TAE_BENCH_STATE_DIR", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2000"]
+    t0 = time.time()
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert time.time() - t0 < 60.0
+    assert out.returncode != 0
+    lines = _bench_lines(out)
+    assert len(lines) == 1, (out.stdout[-1500:], out.stderr[-1500:])
+    res = lines[0]
+    assert res["value"] == 0.0 and res["n_gpus"] == 2 and "error" in res and res["rccl_ranks_seen"] == 2
+    st = res["config"]["rank_states"]
+    assert st[victim]["phase"] == "timed_pass"                       # the last thing the dead rank recorded
+    assert st[1 - victim]["phase"] == "failed" and "signal" in st[1 - victim]["error"]
+
+
+def test_bench_port_busy_prints_an_error_line(gpu_device):
+    """Rendezvous port already taken (ranks started by hand, as a scheduler without torch.distributed.run would): rank 0's store
+    cannot bind, init_process_group raises, the line says so."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as holder:
+        holder.bind(("127.0.0.1", 0))
+        holder.listen(1)
+        port = holder.getsockname()[1]
+        env = dict(os.environ, TAE_BENCH_BACKEND="gloo", RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        t0 = time.time()
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2000",
+                              "--dist-timeout", "20"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert time.time() - t0 < 60.0
+    lines = _bench_lines(out)
+    assert out.returncode != 0 and len(lines) == 1, (out.stdout[-1500:], out.stderr[-1500:])
+    assert lines[0]["value"] == 0.0 and "error" in lines[0] and lines[0]["rccl_ranks_seen"] == 0
+    assert lines[0]["config"]["rank_states"][0]["failed_in"] == "pg_init"
+
+
+def test_bench_fewer_devices_than_ranks_prints_an_error_line(gpu_device):
+    """`python bench.py --gpus N` on a box with fewer than N GPUs (RCCL backend: one GPU per rank): every rank refuses before the
+    rendezvous, rank 0 prints the line, the self-relaunching parent passes it through."""
+    import subprocess
+    import sys
+    import time
+    n = torch.cuda.device_count() + 1
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TAE_BENCH_BACKEND", "TAE_BENCH_STATE_DIR")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert time.time() - t0 < 60.0
+    lines = _bench_lines(out)
+    assert out.returncode != 0 and len(lines) == 1, (out.stdout[-1500:], out.stderr[-1500:])
+    assert lines[0]["value"] == 0.0 and lines[0]["n_gpus"] == n and "device_count" in lines[0]["error"]
+
+
+def test_bench_also_configs3_in_the_same_launch(gpu_device):
+    """N > 1 runs BASELINE configs[3] (block_len 1000: 25 000 blocks per rank, and the --strong form, 200 000 blocks over the ranks)
+    after the headline pass and reports it inside the ONE line (`configs3`, flat `cfg3_*` scalars) - one multi-GPU lease yields both
+    configurations BASELINE.json names.  Two ranks share this box's GPU through the gloo hook."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TAE_BENCH_BACKEND="gloo")
+    env.pop("TAE_BENCH_STATE_DIR", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2000",
+           "--no-f32-pass"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = _bench_lines(out)
+    assert len(lines) == 1
+    res = lines[0]
+    assert res["n_gpus"] == 2 and res["value"] > 0 and "error" not in res
+    c3 = res["configs3"]
+    assert c3["weak"]["global_blocks"] == 50000 and c3["strong"]["global_blocks"] == 200000
+    for tag in ("weak", "strong"):
+        assert c3[tag]["rccl_ranks_seen"] == 2 and 1e-4 < c3[tag]["ber"] < 0.03 and c3[tag]["value"] > 0
+        assert res[f"cfg3_{tag}_bits_per_s"] == c3[tag]["value"] and 0.05 < res[f"cfg3_{tag}_decoder_frac"] < 1.0
+    assert res["roofline_frac"] == res["roofline"]["frac"] and res["overrides"] == ""

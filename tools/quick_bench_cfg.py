@@ -18,4 +18,6 @@ for _ in range(3):
     a.record(); xd, codes = model(u, noise); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
 ms = float(np.median(ts))
 fl = cfg.flops_per_bit() * B * L
-print(f"{decoder} L={L} B={B} enc{encl}: forward {ms:.2f} ms  {B*L/ms/1e3:.2f} Mbit/s  {fl/ms/1e9:.1f} TFLOP/s ({fl/ms/1e9/157.3:.3f} of fp32 MFMA peak)  kernel_info={model.kernel_info()}", flush=True)
+import hashlib
+sha = hashlib.sha256(xd.cpu().numpy().tobytes()).hexdigest()[:12]
+print(f"{decoder} L={L} B={B} enc{encl}: sha {sha} forward {ms:.2f} ms  {B*L/ms/1e3:.2f} Mbit/s  {fl/ms/1e9:.1f} TFLOP/s ({fl/ms/1e9/157.3:.3f} of fp32 MFMA peak)  kernel_info={model.kernel_info()}", flush=True)

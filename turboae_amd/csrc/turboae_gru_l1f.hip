@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "turboae_internal.hpp"
 #include "turboae_device.hpp"
 
@@ -70,6 +71,15 @@ __device__ __forceinline__ void mma3(f32x4 (&acc)[3], const h8 (&ah)[3], const h
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = mfma16x16x32h(ah[g], bh, acc[g]);
 }
+// ... the products of the hi fragments (registers) first, the lo fragments' last: they arrive from LDS during the first six
+__device__ __forceinline__ void mma3_lo_last(f32x4 (&acc)[3], const h8 (&ah)[3], const h8 (&al)[3], h8 bh, h8 bl) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = mfma16x16x32h(ah[g], bl, acc[g]);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = mfma16x16x32h(ah[g], bh, acc[g]);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = mfma16x16x32h(al[g], bh, acc[g]);
+}
 // K = 16 remainder slab: A = [4 hi | 4 lo] of the lane's k = 0..3, b1 = [lo | hi], b2 = [hi | 0] (gru_rec_h's mma_rem)
 __device__ __forceinline__ void mma3r(f32x4 (&acc)[3], const h8 (&ar)[3], h8 b1, h8 b2) {
 #pragma unroll
@@ -85,6 +95,29 @@ __device__ __forceinline__ void mma1(f32x4& acc, h8 ah, h8 al, h8 bh, h8 bl) {
 __device__ __forceinline__ void mma1r(f32x4& acc, h8 ar, h8 b1, h8 b2) {
     acc = mfma16x16x32h(ar, b1, acc);
     acc = mfma16x16x32h(ar, b2, acc);
+}
+
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, F, I + 1>(static_cast<F&&>(f));
+    }
+}
+
+// issue-order hint for one stage: ND LDS reads (operands of a LATER stage) first, then NM MFMAs with NV vector-ALU / transcendental
+// instructions after each
+template <int ND, int NM, int NV>
+__device__ __forceinline__ void pin() {
+#ifdef TAE_L1F_NOPIN
+    return;
+#endif
+    if (ND > 0) __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x402, NV, 0);
+    }
 }
 
 struct Ctx {
@@ -145,33 +178,57 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
         step_barrier();                                   // B1: y0 buffer 0 may be refilled
 #pragma unroll 1
         for (int s = 0; s < L; ++s) {
-            const lds_cptr hc = hb + (s & 1) * kHBsz;
+            // One step = ONE scheduling region, issue order pinned (left alone the scheduler puts every LDS read right in front of
+            // its first use - 11 exposed LDS latencies per step - and the gate arithmetic behind the last MFMA):
+            //   recurrence (the critical path): B fragments of h_{s-1} one slab ahead of their MFMAs;
+            //   projection of step s + 1 (off it): operands one slab ahead, and the gate arithmetic of step s dealt out between its
+            //   MFMAs, two vector-ALU instructions per MFMA - the matrix pipe never waits for the gates.
+            const lds_cptr hc = hb + (s & 1) * kHBsz, y = yb + ((s + 1) & 1) * kYBsz;
             f32x4 acc[3] = {gi[0], gi[1], *reinterpret_cast<lds_f4c*>(bias + 3 * 64)};
             const f32x4 gin = gi[2];
+            h8 xh[2], xl[2];                                   // B-fragment ring
+            xh[0] = lds_h8(hc); xl[0] = lds_h8(hc + 1024);
+            xh[1] = lds_h8(hc + 2048); xl[1] = lds_h8(hc + 3072);
+            mma3(acc, hh_hi[0], hh_lo[0], xh[0], xl[0]);
+            pin<5, 9, 0>();
+            xh[0] = lds_h8(hc + 4096); xl[0] = lds_h8(hc + 5120);
+            mma3(acc, hh_hi[1], hh_lo[1], xh[1], xl[1]);
+            pin<2, 9, 0>();
+            xh[1] = lds_h8(hc + 6144); xl[1] = lds_h8(hc + 7168);       // remainder slab: b1, b2
+            mma3(acc, hh_hi[2], hh_lo[2], xh[0], xl[0]);
+            pin<2, 9, 0>();
+            xh[0] = lds_h8(y); xl[0] = lds_h8(y + 1024);
 #pragma unroll
-            for (int sl = 0; sl < 3; ++sl) {
-                const h8 bh = lds_h8(hc + sl * 2048), bl = lds_h8(hc + sl * 2048 + 1024);
-                mma3(acc, hh_hi[sl], hh_lo[sl], bh, bl);
-            }
-            {
-                const h8 b1 = lds_h8(hc + 6144), b2 = lds_h8(hc + 7168);
-                mma3r(acc, hh_r, b1, b2);
-            }
-            proj(gi, yb + ((s + 1) & 1) * kYBsz);        // step s + 1's projection (s = L - 1: on stale rows, unused - no branch in the step)
+            for (int g = 0; g < 3; ++g) gi[g] = *reinterpret_cast<lds_f4c*>(bias + g * 64);
+            mma3r(acc, hh_r, xh[1], xl[1]);
+            pin<5, 6, 0>();
             f32x4 hn;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float r = sigm_f(acc[0][i] * inv);
-                const float z = sigm_f(acc[1][i] * inv);
-                const float nn = tanh_f(fmaf(r, acc[2][i] * inv, gin[i] * inv));
-                hn[i] = fmaf(z, h[i] - nn, nn);
-            }
-            h = hn;
             h4 nhi, nlo;
-            split4(hn, nhi, nlo);
-            const lds_ptr hn_w = hw + ((s + 1) & 1) * kHBsz;
-            *reinterpret_cast<lds_w2*>(hn_w) = __builtin_bit_cast(u32x2v, nhi);
-            *reinterpret_cast<lds_w2*>(hn_w + 1024) = __builtin_bit_cast(u32x2v, nlo);
+            static_for<6>([&](auto SL) {
+                constexpr int sl = decltype(SL)::value, cur = sl & 1, nxt = cur ^ 1;
+                // W_ih1 lo fragments of THIS slab (used by its last three MFMAs), B fragments of the NEXT one
+                h8 al[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) al[g] = lds_h8(wl + (g * 6 + sl) * 1024);
+                if (sl < 5) { xh[nxt] = lds_h8(y + (sl + 1) * 2048); xl[nxt] = lds_h8(y + (sl + 1) * 2048 + 1024); }
+                else { xh[nxt] = lds_h8(y + 12288); xl[nxt] = lds_h8(y + 13312); }
+                mma3_lo_last(gi, ih_hi[sl], al, xh[cur], xl[cur]);
+                if (sl < 4) {
+                    const int i = sl;
+                    const float r = sigm_f(acc[0][i] * inv);
+                    const float z = sigm_f(acc[1][i] * inv);
+                    const float nn = tanh_f(fmaf(r, acc[2][i] * inv, gin[i] * inv));
+                    hn[i] = fmaf(z, h[i] - nn, nn);
+                } else if (sl == 4) {
+                    h = hn;
+                    split4(hn, nhi, nlo);
+                    const lds_ptr hn_w = hw + ((s + 1) & 1) * kHBsz;
+                    *reinterpret_cast<lds_w2*>(hn_w) = __builtin_bit_cast(u32x2v, nhi);
+                    *reinterpret_cast<lds_w2*>(hn_w + 1024) = __builtin_bit_cast(u32x2v, nlo);
+                }
+                pin<5, 9, (sl < 4 ? 2 : (sl == 4 ? 1 : 0))>();
+            });
+            mma3r(gi, ih_r, xh[0], xl[0]);
             step_barrier();
         }
         step_barrier();                                   // the remainder wave's last head product has read the h buffer
