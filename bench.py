@@ -224,6 +224,14 @@ def cpu_baseline_and_parity(cfg: TurboAEConfig, sd, u500: np.ndarray, noise500: 
         out["thread_sweep_B2000_bits_per_s"] = {str(k): v for k, v in sweep_b.items()}
         out["b2000_over_b500"] = sweep_b[tb_best] / out["value"]
         out["activation_MB_per_layer_B2000"] = big * out["activation_MB_per_layer_B500"]
+        if left() > 2.5 * B * L / out["value"] * big:
+            # the same 2000 blocks as four batches of 500 at the B = 500 thread count: if THIS recovers the B = 500 rate, the drop above is
+            # the working set (activations past the reachable L3), not placement or first-touch of the inputs
+            torch.set_num_threads(best)
+            ub, nb_ = ut.repeat(big, 1, 1).clone(), nt.repeat(big, 1, 1).clone()
+            chunks = [(ub[i * B:(i + 1) * B], nb_[i * B:(i + 1) * B]) for i in range(big)]
+            tc = _time_forwards(lambda: [O.channel_ae_forward(a, b_, w, cd) for a, b_ in chunks], 1, 2)
+            out["value_B2000_as_4x500"] = big * B * L / float(np.median(tc))
     if time.perf_counter() - t_start < 0.9 * budget_s:
         torch.set_num_threads(1)
         u1, n1 = ut[:100].clone(), nt[:100].clone()
@@ -477,6 +485,7 @@ def flatten_scalars(out) -> None:
     if cpu:
         out["cpu_baseline_bits_per_s"], out["cpu_baseline_cores"] = cpu["value"], cpu["cores"]
         out["cpu_baseline_B2000_bits_per_s"], out["cpu_baseline_b2000_over_b500"] = cpu.get("value_B2000"), cpu.get("b2000_over_b500")
+        out["cpu_baseline_B2000_as_4x500_bits_per_s"] = cpu.get("value_B2000_as_4x500")
     out["overrides"] = tae_overrides()
 
 
@@ -549,7 +558,7 @@ class Guard:
         self.args, self.rank, self.world = args, rank, world
         self.dir = _state_dir()
         self.path = os.path.join(self.dir, f"rank{rank}.json")
-        self.phase_name, self.deadline, self.finished = "start", None, False
+        self.phase_name, self.deadline, self.finished, self.reporting = "start", None, False, False
         self.fallback = None                       # a complete result line: printed (plus the error) if a later, optional stage fails
         self.lock = threading.Lock()
         self.record("start")
@@ -609,11 +618,14 @@ class Guard:
         """Record the failure, print the error line if this rank is the reporter, and leave without running torch's teardown (a
         destroy_process_group on a broken group can hang)."""
         with self.lock:
-            if self.finished:
-                return
-            self.finished = True
+            first = not self.reporting
+            self.reporting = True
+        if not first:                     # the other thread (watchdog / main) is already reporting and will end the process
+            while True:
+                time.sleep(1.0)
+        self.finished = True
         self.record("failed", error=reason, failed_in=self.phase_name)
-        time.sleep(1.0 if self.rank == 0 else 0.2)           # let the other ranks write their last phase
+        time.sleep(0.5 if self.rank == 0 else 0.1)           # let the other ranks write their last phase
         states = read_rank_states(self.dir, self.world)
         if self.is_reporter(states):
             if self.fallback is not None:
@@ -1077,7 +1089,13 @@ def main():
                     out[f"cfg3_{tag}_ms_per_step"] = c3[tag]["ms_per_step"]
                     out[f"cfg3_{tag}_decoder_frac"] = c3[tag]["decoder_frac"]
     if rank == 0:
-        guard.finished = True                     # the line is about to be printed: the watchdog must not print a second one
+        with guard.lock:                          # the line is about to be printed: the watchdog must not print a second one
+            late = guard.reporting
+            guard.reporting = True
+        if late:
+            while True:
+                time.sleep(1.0)
+        guard.finished = True
         print(json.dumps(out), flush=True)
     guard.done()
     if dist is not None:

@@ -257,7 +257,10 @@ def test_bench_rank_dies_mid_run_still_prints_one_error_line(gpu_device, victim)
     assert res["value"] == 0.0 and res["n_gpus"] == 2 and "error" in res and res["rccl_ranks_seen"] == 2
     st = res["config"]["rank_states"]
     assert st[victim]["phase"] == "timed_pass"                       # the last thing the dead rank recorded
-    assert st[1 - victim]["phase"] == "failed" and "signal" in st[1 - victim]["error"]
+    # the survivor failed inside the timed pass: either its collective raised (gloo notices the closed connection) or the launcher's
+    # SIGTERM reached its watchdog first
+    assert st[1 - victim]["phase"] == "failed" and st[1 - victim]["failed_in"] in ("collectives_ok", "timed_pass")     # (rank 0 runs the MFMA probe first)
+    assert "signal" in st[1 - victim]["error"] or "Error" in st[1 - victim]["error"]
 
 
 def test_bench_port_busy_prints_an_error_line(gpu_device):

@@ -717,7 +717,11 @@ void pack_gru_l1f_dir(const float* Wih, const float* Whh, const float* bih, cons
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 4; ++j) put_split(dst, off + lane * 16 + j * 2, off + lane * 16 + 8 + j * 2, w(lane & 15, lane >> 4, j));
     };
-    const size_t lds0 = (size_t)6 * Lay::kUnitB + Lay::kRemB;
+    const size_t lo01 = (size_t)6 * Lay::kUnitB + Lay::kRemB, lds0 = lo01 + Lay::kLo01B;
+    // W_ih1 lo fragment of tile (ut, g), k-slab sl: slabs 0, 1 in the unit waves' register image, 2..5 in the LDS image
+    auto ih_lo_off = [&](int ut, int g, int sl) {
+        return sl < 2 ? lo01 + ((size_t)(ut * 3 + g) * 2 + sl) * 1024 : lds0 + ((size_t)(ut * 3 + g) * 4 + (sl - 2)) * 1024;
+    };
     for (int ut = 0; ut < 6; ++ut) {
         const size_t ub = (size_t)ut * Lay::kUnitB;
         for (int g = 0; g < 3; ++g) {
@@ -727,7 +731,7 @@ void pack_gru_l1f_dir(const float* Wih, const float* Whh, const float* bih, cons
                      [&](int m, int kq, int j) { return Whh[row(m) * H + hh_unit(sl, kq, j)] * scale; });
             rem(ub + (g * 7 + 6) * 1024, [&](int m, int kq, int j) { return j == 0 ? Whh[row(m) * H + 96 + kq] * scale : 0.0f; });
             for (int sl = 0; sl < 6; ++sl)
-                slab(ub + (21 + g * 7 + sl) * 1024, lds0 + ((size_t)(ut * 3 + g) * 6 + sl) * 1024,
+                slab(ub + (21 + g * 7 + sl) * 1024, ih_lo_off(ut, g, sl),
                      [&](int m, int kq, int j) { return Wih[row(m) * 2 * H + 32 * sl + 8 * kq + j] * scale; });
             rem(ub + (21 + g * 7 + 6) * 1024,
                 [&](int m, int kq, int j) { return kq < 2 ? Wih[row(m) * 2 * H + 192 + 4 * kq + j] * scale : 0.0f; });
@@ -751,7 +755,7 @@ void pack_gru_l1f_dir(const float* Wih, const float* Whh, const float* bih, cons
                  [&](int m, int kq, int j) { return m < nout ? Wlin[(size_t)m * 2 * H + d * H + hh_unit(sl, kq, j)] * scale_h : 0.0f; });
         rem(rb + 26 * 1024, [&](int m, int kq, int j) { return (j == 0 && m < nout) ? Wlin[(size_t)m * 2 * H + d * H + 96 + kq] * scale_h : 0.0f; });
     }
-    float* b = reinterpret_cast<float*>(dst + lds0 + (size_t)6 * 3 * 6 * 1024);
+    float* b = reinterpret_cast<float*>(dst + lds0 + (size_t)6 * 3 * 4 * 1024);
     for (int ut = 0; ut < 6; ++ut)
         for (int m = 0; m < 16; ++m) {
             const int u = 16 * ut + m;

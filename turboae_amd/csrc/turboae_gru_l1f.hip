@@ -7,15 +7,21 @@
 // LDS, which is why W_ih1 could not join them): 8 waves work on ONE group of 16 blocks (N = 16 columns of every MFMA) of one
 // direction,
 //   * 6 "unit" waves: wave ut owns units 16 ut .. 16 ut + 15, i.e. the r, z, n row tiles of those units.  Register-resident for the
-//     whole launch: W_hh hi + lo (3 tiles x (3 slabs x 8 + remainder 4) = 84 VGPRs) and W_ih1 hi (3 x (6 x 4 + 4) = 84); the W_ih1
-//     lo fragments (108 KB for the 18 tiles) stay in LDS.  Per step: 33 MFMAs of recurrence (on the critical path) + 60 of
+//     whole launch (168 VGPRs): W_hh hi + lo (3 tiles x (3 slabs x 8 + remainder 4)), W_ih1 hi of k-slabs 0..3 + remainder, W_ih1 lo
+//     of slabs 0, 1; the lo fragments of slabs 2, 3 come from LDS.  Per step: 33 MFMAs of recurrence (the critical path) + 42 of
 //     projection for the NEXT step (off it: they fill the pipe while the gates are computed and the other waves arrive);
-//   * the remainder wave: units 96..99 as one mixed row tile (row 4 qq + i = r, z, n_h, n_i of unit 96 + qq; everything in
-//     registers), plus the head tile: W_lin[:, dir H .. dir H + H) * h_t, 16 floats per position leave the kernel as before;
-//   * the staging wave: y0 of step s + 2 (16 rows of 800 bytes) from HBM into LDS in B-fragment order (loaded one step ahead).
-// h_t is exchanged through LDS as B fragments (hi | lo halves, 8 KB, double-buffered): one s_barrier per step.  Waves w and w + 4
-// share a SIMD, so the two light waves are 3 and 7 and every other SIMD carries two unit waves.
-// LDS: W_ih1 lo 110 592 + bias rows 1 616 + h 2 x 8 192 + y0 2 x 14 336 = 157 264 of 163 840 bytes.
+//   * the remainder wave: units 96..99 as one mixed row tile (row 4 qq + i = r, z, n_h, n_i of unit 96 + qq; all in registers),
+//     plus the head tile: W_lin[:, dir H .. dir H + H) * h_t - 16 floats per position leave the kernel, as before;
+//   * the staging wave: y0 rows (16 x 800 bytes per step) from HBM into LDS in B-fragment order, fetched a step ahead.
+// Waves w and w + 4 share a SIMD, so the two light waves are 3 and 7 and every other SIMD carries two unit waves.  To level the
+// SIMDs (r05 v1 had 2 x 93 MFMAs per step on three of them and 42 on the fourth, and ran at exactly the 81 % of the sustained
+// MFMA rate that split allows) the two light waves are also HELPERS: k-slabs 4 and 5 of the projection of EVERY unit tile
+// (1 + 5 unit tiles: 18 + 90 MFMAs, W_ih1 hi of those slabs in their registers, lo from LDS) are computed by them, two steps ahead
+// of the recurrence, and handed over through LDS as accumulator-init tiles (`pb`, which replace the unit waves' bias rows):
+// 2 x 75 MFMAs on every SIMD.
+// h_t is exchanged through LDS as B fragments (hi | lo halves, 8 KB, double-buffered): one s_barrier per step.
+// LDS: W_ih1 lo (slabs 2..5) 73 728 + bias rows 1 616 + h 2 x 8 192 + y0 2 x (10 240 + 4 096) + partial tiles 2 x 18 432
+//      = 157 264 of 163 840 bytes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -34,16 +40,21 @@ using lds_w4 = u32x4v __attribute__((address_space(3)));
 using lds_w2 = u32x2v __attribute__((address_space(3)));
 using lds_ptr = char __attribute__((address_space(3)))*;
 
-constexpr int kLdsW = 6 * 3 * 6 * 1024;             // W_ih1 lo fragments [ut][gate][slab][lane][8 halves]
+constexpr int kLdsW = 6 * 3 * 4 * 1024;             // W_ih1 lo fragments of k-slabs 2..5: [ut][gate][slab - 2][lane][8 halves]
 constexpr int kBiasB = 6 * 4 * 64 + 64 + 16;        // [ut][r, z, n_i, n_h][16] + remainder-tile init row + (2^-S, 2^-S_head, 0, 0)
 constexpr int kHB = kLdsW + kBiasB;                 // h exchange: 3 slabs x (hi | lo) + remainder (b1 | b2)
 constexpr int kHBsz = 8192;
-constexpr int kYB = kHB + 2 * kHBsz;                // y0 of a step: 6 slabs x (hi | lo) + remainder (b1 | b2)
-constexpr int kYBsz = 14336;
-constexpr int kLds = kYB + 2 * kYBsz;
-constexpr int kUnitB = 42 * 1024, kRemB = 27 * 1024;
+constexpr int kYM = kHB + 2 * kHBsz;                // y0 of a step, k-slabs 0..3 x (hi | lo) + remainder (b1 | b2): read by the owners' projection
+constexpr int kYMsz = 10240;
+constexpr int kYH = kYM + 2 * kYMsz;                // y0 of a step, k-slabs 4, 5 x (hi | lo): read by the helpers, two steps ahead
+constexpr int kYHsz = 4096;
+constexpr int kPB = kYH + 2 * kYHsz;                // helper partials = accumulator-init tiles [ut][r, z, n_i][lane][4 floats]
+constexpr int kPBsz = 18 * 1024;
+constexpr int kLds = kPB + 2 * kPBsz;
+constexpr int kUnitB = 42 * 1024, kRemB = 27 * 1024, kLo01B = 36 * 1024;
 static_assert(kLds <= 160 * 1024, "LDS budget");
-static_assert(kUnitB == GruL1fLayout::kUnitB && kRemB == GruL1fLayout::kRemB && kLdsW + kBiasB == GruL1fLayout::kLdsImgB, "host packing");
+static_assert(kUnitB == GruL1fLayout::kUnitB && kRemB == GruL1fLayout::kRemB && kLo01B == GruL1fLayout::kLo01B &&
+              kLdsW + kBiasB == GruL1fLayout::kLdsImgB, "host packing");
 
 __device__ __forceinline__ float sigm_f(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
@@ -128,11 +139,19 @@ struct Ctx {
     float inv, inv_head;
 };
 
+// Buffer parity: M[k & 1] / H[k & 1] hold the y0 fragments of step k, pb[k & 1] the partial tiles of step k, hb[k & 1] the B
+// fragments of h_{k-1}.  During step s
+//   unit waves   read hb[s], M[s + 1], pb[s + 1]              write hb[s + 1]
+//   helpers      read H[s + 2]                                write pb[s + 2]
+//   staging      (registers, fetched during step s - 1)       write M[s + 2], H[s + 3]
+// so nothing written in a step is read in it, and one barrier per step orders everything.
+
 // ---- unit wave ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
     const int lane = c.lane, L = c.L;
     const char* wr = c.wdir + (size_t)ut * kUnitB + lane * 16;
-    h8 hh_hi[3][3], hh_lo[3][3], hh_r[3], ih_hi[6][3], ih_r[3];       // [slab][gate]
+    const char* wlo = c.wdir + (size_t)6 * kUnitB + kRemB + (size_t)ut * (6 * 1024) + lane * 16;      // W_ih1 lo of slabs 0, 1: [gate][slab]
+    h8 hh_hi[3][3], hh_lo[3][3], hh_r[3], ih_hi[4][3], ih_lo[2][3], ih_r[3];       // [slab][gate]
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
 #pragma unroll
@@ -142,49 +161,49 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
         }
         hh_r[g] = glb_h8(wr + (g * 7 + 6) * 1024);
 #pragma unroll
-        for (int sl = 0; sl < 6; ++sl) ih_hi[sl][g] = glb_h8(wr + (21 + g * 7 + sl) * 1024);
+        for (int sl = 0; sl < 4; ++sl) ih_hi[sl][g] = glb_h8(wr + (21 + g * 7 + sl) * 1024);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) ih_lo[sl][g] = glb_h8(wlo + (g * 2 + sl) * 1024);
         ih_r[g] = glb_h8(wr + (21 + g * 7 + 6) * 1024);
     }
-    const lds_cptr wl = c.lds + ut * (18 * 1024) + lane * 16;           // W_ih1 lo: [gate][slab] of this unit tile
-    const lds_cptr bias = c.lds + kLdsW + ut * 256 + c.q * 16;          // rows r, z, n_i, n_h
-    const lds_cptr hb = c.lds + kHB + lane * 16, yb = c.lds + kYB + lane * 16;
+    const lds_cptr wl = c.lds + ut * (12 * 1024) + lane * 16;           // W_ih1 lo of slabs 2..5: [gate][slab - 2] of this unit tile
+    const lds_cptr bias_nh = c.lds + kLdsW + ut * 256 + 3 * 64 + c.q * 16;
+    const lds_cptr hb = c.lds + kHB + lane * 16, ym = c.lds + kYM + lane * 16;
+    const lds_cptr pb = c.lds + kPB + ut * (3 * 1024) + lane * 16;
     const lds_ptr hw = (lds_ptr)(c.lds + kHB + (ut >> 1) * 2048 + lane * 16 + (ut & 1) * 8);
     const float inv = c.inv;
-
-    // gi = b + W_ih1 * y0 (r, z, n_i rows of this unit tile) from the staged fragments at `y`
-    auto proj = [&](f32x4 (&gi)[3], lds_cptr y) {
-#pragma unroll
-        for (int g = 0; g < 3; ++g) gi[g] = *reinterpret_cast<lds_f4c*>(bias + g * 64);
-#pragma unroll
-        for (int sl = 0; sl < 6; ++sl) {
-            const h8 bh = lds_h8(y + sl * 2048), bl = lds_h8(y + sl * 2048 + 1024);
-            h8 al[3];
-#pragma unroll
-            for (int g = 0; g < 3; ++g) al[g] = lds_h8(wl + (g * 6 + sl) * 1024);
-            mma3(gi, ih_hi[sl], al, bh, bl);
-        }
-        const h8 b1 = lds_h8(y + 12288), b2 = lds_h8(y + 13312);
-        mma3r(gi, ih_r, b1, b2);
-    };
 
     for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
         // h_{-1} = 0: this wave's slots of buffer 0
         *reinterpret_cast<lds_w2*>(hw) = u32x2v{0, 0};
         *reinterpret_cast<lds_w2*>(hw + 1024) = u32x2v{0, 0};
         step_barrier();                                   // B0: y0 of steps 0 and 1 staged, h buffer 0 cleared
+        step_barrier();                                   // B1: the helpers' partial tiles of steps 0 and 1 are in pb
         f32x4 gi[3];
-        proj(gi, yb);
+        {   // the owner's share of step 0's projection
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gi[g] = *reinterpret_cast<lds_f4c*>(pb + g * 1024);
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const h8 bh = lds_h8(ym + sl * 2048), bl = lds_h8(ym + sl * 2048 + 1024);
+                h8 al[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) al[g] = sl < 2 ? ih_lo[sl < 2 ? sl : 0][g] : lds_h8(wl + (g * 4 + sl - 2) * 1024);
+                mma3(gi, ih_hi[sl], al, bh, bl);
+            }
+            mma3r(gi, ih_r, lds_h8(ym + 8192), lds_h8(ym + 9216));
+        }
         f32x4 h = {0.f, 0.f, 0.f, 0.f};
-        step_barrier();                                   // B1: y0 buffer 0 may be refilled
+        step_barrier();                                   // B2: M[0], pb[0] may be refilled
 #pragma unroll 1
         for (int s = 0; s < L; ++s) {
-            // One step = ONE scheduling region, issue order pinned (left alone the scheduler puts every LDS read right in front of
-            // its first use - 11 exposed LDS latencies per step - and the gate arithmetic behind the last MFMA):
+            // One step = ONE scheduling region with a pinned issue order:
             //   recurrence (the critical path): B fragments of h_{s-1} one slab ahead of their MFMAs;
-            //   projection of step s + 1 (off it): operands one slab ahead, and the gate arithmetic of step s dealt out between its
-            //   MFMAs, two vector-ALU instructions per MFMA - the matrix pipe never waits for the gates.
-            const lds_cptr hc = hb + (s & 1) * kHBsz, y = yb + ((s + 1) & 1) * kYBsz;
-            f32x4 acc[3] = {gi[0], gi[1], *reinterpret_cast<lds_f4c*>(bias + 3 * 64)};
+            //   the owner's share of step s + 1's projection (off it): B fragments one slab ahead, the gate arithmetic of step s dealt
+            //   out between its MFMAs (two vector-ALU instructions per MFMA): the matrix pipe never waits for the gates.
+            const int p1 = (s + 1) & 1;
+            const lds_cptr hc = hb + (s & 1) * kHBsz, y = ym + p1 * kYMsz, pbn = pb + p1 * kPBsz;
+            f32x4 acc[3] = {gi[0], gi[1], *reinterpret_cast<lds_f4c*>(bias_nh)};
             const f32x4 gin = gi[2];
             h8 xh[2], xl[2];                                   // B-fragment ring
             xh[0] = lds_h8(hc); xl[0] = lds_h8(hc + 1024);
@@ -199,43 +218,69 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
             pin<2, 9, 0>();
             xh[0] = lds_h8(y); xl[0] = lds_h8(y + 1024);
 #pragma unroll
-            for (int g = 0; g < 3; ++g) gi[g] = *reinterpret_cast<lds_f4c*>(bias + g * 64);
+            for (int g = 0; g < 3; ++g) gi[g] = *reinterpret_cast<lds_f4c*>(pbn + g * 1024);       // helpers' partial (bias + slabs 4, 5)
             mma3r(acc, hh_r, xh[1], xl[1]);
             pin<5, 6, 0>();
             f32x4 hn;
-            h4 nhi, nlo;
-            static_for<6>([&](auto SL) {
+            static_for<4>([&](auto SL) {
                 constexpr int sl = decltype(SL)::value, cur = sl & 1, nxt = cur ^ 1;
-                // W_ih1 lo fragments of THIS slab (used by its last three MFMAs), B fragments of the NEXT one
-                h8 al[3];
+                if (sl < 3) { xh[nxt] = lds_h8(y + (sl + 1) * 2048); xl[nxt] = lds_h8(y + (sl + 1) * 2048 + 1024); }
+                else { xh[nxt] = lds_h8(y + 8192); xl[nxt] = lds_h8(y + 9216); }
+                if constexpr (sl < 2) {
+                    mma3_lo_last(gi, ih_hi[sl], ih_lo[sl], xh[cur], xl[cur]);
+                } else {
+                    h8 al[3];                                  // lo fragments of THIS slab, used by its last three MFMAs
 #pragma unroll
-                for (int g = 0; g < 3; ++g) al[g] = lds_h8(wl + (g * 6 + sl) * 1024);
-                if (sl < 5) { xh[nxt] = lds_h8(y + (sl + 1) * 2048); xl[nxt] = lds_h8(y + (sl + 1) * 2048 + 1024); }
-                else { xh[nxt] = lds_h8(y + 12288); xl[nxt] = lds_h8(y + 13312); }
-                mma3_lo_last(gi, ih_hi[sl], al, xh[cur], xl[cur]);
-                if (sl < 4) {
-                    const int i = sl;
-                    const float r = sigm_f(acc[0][i] * inv);
-                    const float z = sigm_f(acc[1][i] * inv);
-                    const float nn = tanh_f(fmaf(r, acc[2][i] * inv, gin[i] * inv));
-                    hn[i] = fmaf(z, h[i] - nn, nn);
-                } else if (sl == 4) {
-                    h = hn;
-                    split4(hn, nhi, nlo);
-                    const lds_ptr hn_w = hw + ((s + 1) & 1) * kHBsz;
-                    *reinterpret_cast<lds_w2*>(hn_w) = __builtin_bit_cast(u32x2v, nhi);
-                    *reinterpret_cast<lds_w2*>(hn_w + 1024) = __builtin_bit_cast(u32x2v, nlo);
+                    for (int g = 0; g < 3; ++g) al[g] = lds_h8(wl + (g * 4 + sl - 2) * 1024);
+                    mma3_lo_last(gi, ih_hi[sl], al, xh[cur], xl[cur]);
                 }
-                pin<5, 9, (sl < 4 ? 2 : (sl == 4 ? 1 : 0))>();
+                const int i = sl;
+                const float r = sigm_f(acc[0][i] * inv);
+                const float z = sigm_f(acc[1][i] * inv);
+                const float nn = tanh_f(fmaf(r, acc[2][i] * inv, gin[i] * inv));
+                hn[i] = fmaf(z, h[i] - nn, nn);
+                pin<(sl < 2 ? 2 : 5), 9, 2>();
             });
+            h = hn;
+            h4 nhi, nlo;
+            split4(hn, nhi, nlo);
+            const lds_ptr hn_w = hw + p1 * kHBsz;
+            *reinterpret_cast<lds_w2*>(hn_w) = __builtin_bit_cast(u32x2v, nhi);
+            *reinterpret_cast<lds_w2*>(hn_w + 1024) = __builtin_bit_cast(u32x2v, nlo);
             mma3r(gi, ih_r, xh[0], xl[0]);
+            pin<0, 6, 1>();
             step_barrier();
         }
         step_barrier();                                   // the remainder wave's last head product has read the h buffer
     }
 }
 
-// ---- remainder wave: units 96..99 + the head tile ----------------------------------------------------------------------------
+// Helper share of the projection: for NU unit tiles starting at u0, tile (ut, g) <- bias + W_ih1[rows, k-slabs 4, 5] * y0, written
+// to `pbw` as accumulator-init tiles.  `yh`: this step's H fragments; A hi fragments in registers, lo from LDS.
+template <int NU>
+__device__ __forceinline__ void helper_partials(const h8 (&a_hi)[NU][2][3], lds_cptr lds, int lane, int u0, int q, lds_cptr yh, lds_ptr pbw) {
+    const h8 b4h = lds_h8(yh), b4l = lds_h8(yh + 1024), b5h = lds_h8(yh + 2048), b5l = lds_h8(yh + 3072);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int ut = u0 + u;
+        const lds_cptr wl = lds + ut * (12 * 1024) + lane * 16;
+        const lds_cptr bias = lds + kLdsW + ut * 256 + q * 16;
+        f32x4 acc[3];
+        h8 al4[3], al5[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            acc[g] = *reinterpret_cast<lds_f4c*>(bias + g * 64);
+            al4[g] = lds_h8(wl + (g * 4 + 2) * 1024);
+            al5[g] = lds_h8(wl + (g * 4 + 3) * 1024);
+        }
+        mma3_lo_last(acc, a_hi[u][0], al4, b4h, b4l);
+        mma3_lo_last(acc, a_hi[u][1], al5, b5h, b5l);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4 __attribute__((address_space(3)))*>(pbw + (ut * 3 + g) * 1024) = acc[g];
+    }
+}
+
+// ---- remainder wave: units 96..99 + the head tile + helper for unit tile 0 -------------------------------------------------
 __device__ __forceinline__ void rem_wave(const Ctx& c) {
     const int lane = c.lane, L = c.L, n = c.n, q = c.q, dir = c.dir;
     const char* wr = c.wdir + (size_t)6 * kUnitB + lane * 16;
@@ -249,20 +294,31 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) { hd_hi[sl] = glb_h8(wr + (20 + 2 * sl) * 1024); hd_lo[sl] = glb_h8(wr + (21 + 2 * sl) * 1024); }
     hd_r = glb_h8(wr + 26 * 1024);
+    h8 hp_hi[1][2][3];                                                  // helper: W_ih1 hi of k-slabs 4, 5 of unit tile 0
+#pragma unroll
+    for (int u = 0; u < 1; ++u)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) hp_hi[u][sl][g] = glb_h8(c.wdir + (size_t)u * kUnitB + (21 + g * 7 + 4 + sl) * 1024 + lane * 16);
     const lds_cptr bias = c.lds + kLdsW + 6 * 256 + q * 16;             // init row: (r, z, b_hn, b_in) of unit 96 + q
-    const lds_cptr hb = c.lds + kHB + lane * 16, yb = c.lds + kYB + lane * 16;
+    const lds_cptr hb = c.lds + kHB + lane * 16, ym = c.lds + kYM + lane * 16, yh = c.lds + kYH + lane * 16;
     const lds_ptr hw = (lds_ptr)(c.lds + kHB + 6144 + lane * 16);
+    const lds_ptr pbw = (lds_ptr)(c.lds + kPB + lane * 16);
     const float inv = c.inv, inv_head = c.inv_head;
 
-    auto proj = [&](f32x4& gi, lds_cptr y) {
-        gi = *reinterpret_cast<lds_f4c*>(bias);
+    // this wave's own tile: bias + k-slabs 4, 5 (at helper time, two steps ahead) ...
+    auto own_part = [&](lds_cptr yhk) {
+        f32x4 g = *reinterpret_cast<lds_f4c*>(bias);
+        mma1(g, ih_hi[4], ih_lo[4], lds_h8(yhk), lds_h8(yhk + 1024));
+        mma1(g, ih_hi[5], ih_lo[5], lds_h8(yhk + 2048), lds_h8(yhk + 3072));
+        return g;
+    };
+    // ... + k-slabs 0..3 and the remainder (one step ahead, like the unit waves)
+    auto own_main = [&](f32x4& gi, lds_cptr y) {
 #pragma unroll
-        for (int sl = 0; sl < 6; ++sl) {
-            const h8 bh = lds_h8(y + sl * 2048), bl = lds_h8(y + sl * 2048 + 1024);
-            mma1(gi, ih_hi[sl], ih_lo[sl], bh, bl);
-        }
-        const h8 b1 = lds_h8(y + 12288), b2 = lds_h8(y + 13312);
-        mma1r(gi, ih_r, b1, b2);
+        for (int sl = 0; sl < 4; ++sl) mma1(gi, ih_hi[sl], ih_lo[sl], lds_h8(y + sl * 2048), lds_h8(y + sl * 2048 + 1024));
+        mma1r(gi, ih_r, lds_h8(y + 8192), lds_h8(y + 9216));
     };
     // head products of the state in h buffer `hc` -> hpart[(grp L + t) 16 + n][dir][8]
     auto head = [&](lds_cptr hc, const __amdgpu_buffer_rsrc_t& rs, int t) {
@@ -283,13 +339,18 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
         *reinterpret_cast<lds_w4*>(hw) = u32x4v{0, 0, 0, 0};
         *reinterpret_cast<lds_w4*>(hw + 1024) = u32x4v{0, 0, 0, 0};
         step_barrier();                                   // B0
-        f32x4 gi;
-        proj(gi, yb);
-        float hr = 0.0f;
+        helper_partials<1>(hp_hi, c.lds, lane, 0, q, yh, pbw);                             // steps 0 and 1
+        __builtin_amdgcn_sched_barrier(0);
+        helper_partials<1>(hp_hi, c.lds, lane, 0, q, yh + kYHsz, pbw + kPBsz);
+        f32x4 gi = own_part(yh), gp1 = own_part(yh + kYHsz);                            // own tile: partials of steps 0 and 1
         step_barrier();                                   // B1
+        own_main(gi, ym);
+        float hr = 0.0f;
+        step_barrier();                                   // B2
 #pragma unroll 1
         for (int s = 0; s < L; ++s) {
-            const lds_cptr hc = hb + (s & 1) * kHBsz;
+            const int p0 = s & 1, p1 = p0 ^ 1;
+            const lds_cptr hc = hb + p0 * kHBsz;
             f32x4 acc = gi;
 #pragma unroll
             for (int sl = 0; sl < 3; ++sl) {
@@ -300,7 +361,10 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
                 const h8 b1 = lds_h8(hc + 6144), b2 = lds_h8(hc + 7168);
                 mma1r(acc, hh_r, b1, b2);
             }
-            proj(gi, yb + ((s + 1) & 1) * kYBsz);
+            gi = gp1;                                                                    // own tile, step s + 1
+            own_main(gi, ym + p1 * kYMsz);
+            gp1 = own_part(yh + p0 * kYHsz);                                             // own tile, step s + 2
+            helper_partials<1>(hp_hi, c.lds, lane, 0, q, yh + p0 * kYHsz, pbw + p0 * kPBsz);   // unit tile 0, step s + 2
             if (s > 0) head(hc, rs, dir ? L - s : s - 1);          // Linear head on h_{s-1} (the state this step started from)
             const float r = sigm_f(acc[0] * inv);
             const float z = sigm_f(acc[1] * inv);
@@ -309,7 +373,7 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
             const _Float16 hi = (_Float16)hr;
             const _Float16 lo = (_Float16)(hr - (float)hi);
             const h8 b1 = {lo, 0, 0, 0, hi, 0, 0, 0}, b2 = {hi, 0, 0, 0, 0, 0, 0, 0};
-            const lds_ptr hn_w = hw + ((s + 1) & 1) * kHBsz;
+            const lds_ptr hn_w = hw + p1 * kHBsz;
             *reinterpret_cast<lds_w4*>(hn_w) = __builtin_bit_cast(u32x4v, b1);
             *reinterpret_cast<lds_w4*>(hn_w + 1024) = __builtin_bit_cast(u32x4v, b2);
             step_barrier();
@@ -319,48 +383,84 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
     }
 }
 
-// ---- staging wave: y0 rows of one step -> B fragments in LDS ------------------------------------------------------------------
-struct YRow { u32x4v v[12]; u32x2v rh, rl; };
+// ---- staging wave: y0 rows -> B fragments in LDS; helper for unit tiles 1..5 ------------------------------------------------------
+struct YM { u32x4v v[8]; u32x2v rh, rl; };            // k-slabs 0..3 (hi, lo) + the K = 16 remainder of one step
+struct YH { u32x4v v[4]; };                           // k-slabs 4, 5 (hi, lo)
 
-__device__ __forceinline__ void y_load(YRow& r, __amdgpu_buffer_rsrc_t rs, uint32_t v0, uint32_t vr, uint32_t so) {
+// lane (n, kq) supplies k = 32 sl + 8 kq .. + 7 of block n: bytes plane * 400 + sl * 64 + kq * 16 of the block's 800-byte row
+__device__ __forceinline__ void ym_load(YM& r, __amdgpu_buffer_rsrc_t rs, uint32_t v0, uint32_t vr, uint32_t so) {
 #pragma unroll
-    for (int sl = 0; sl < 6; ++sl) {
+    for (int sl = 0; sl < 4; ++sl) {
         r.v[2 * sl] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + sl * 64, so, 0);
         r.v[2 * sl + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + 400 + sl * 64, so, 0);
     }
     r.rh = __builtin_amdgcn_raw_buffer_load_b64(rs, vr, so, 0);               // out-of-range lanes read zeros
     r.rl = __builtin_amdgcn_raw_buffer_load_b64(rs, vr + 400, so, 0);
 }
-__device__ __forceinline__ void y_store(const YRow& r, lds_ptr y) {
+__device__ __forceinline__ void yh_load(YH& r, __amdgpu_buffer_rsrc_t rs, uint32_t v0, uint32_t so) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) *reinterpret_cast<lds_w4*>(y + i * 1024) = r.v[i];
-    *reinterpret_cast<lds_w4*>(y + 12288) = u32x4v{r.rl.x, r.rl.y, r.rh.x, r.rh.y};       // b1 = [lo | hi]
-    *reinterpret_cast<lds_w4*>(y + 13312) = u32x4v{r.rh.x, r.rh.y, 0, 0};                 // b2 = [hi | 0]
+    for (int sl = 0; sl < 2; ++sl) {
+        r.v[2 * sl] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + (4 + sl) * 64, so, 0);
+        r.v[2 * sl + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + 400 + (4 + sl) * 64, so, 0);
+    }
+}
+__device__ __forceinline__ void ym_store(const YM& r, lds_ptr y) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<lds_w4*>(y + i * 1024) = r.v[i];
+    *reinterpret_cast<lds_w4*>(y + 8192) = u32x4v{r.rl.x, r.rl.y, r.rh.x, r.rh.y};        // b1 = [lo | hi]
+    *reinterpret_cast<lds_w4*>(y + 9216) = u32x4v{r.rh.x, r.rh.y, 0, 0};                  // b2 = [hi | 0]
+}
+__device__ __forceinline__ void yh_store(const YH& r, lds_ptr y) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<lds_w4*>(y + i * 1024) = r.v[i];
 }
 
 __device__ __forceinline__ void stage_wave(const Ctx& c) {
     const int lane = c.lane, L = c.L, n = c.n, q = c.q, dir = c.dir;
-    const lds_ptr yw = (lds_ptr)(c.lds + kYB + lane * 16);
-    // lane (n, kq) supplies k = 32 sl + 8 kq .. + 7 of block n: bytes plane * 400 + sl * 64 + kq * 16 of the block's row
+    h8 hp_hi[5][2][3];                                                  // helper: W_ih1 hi of k-slabs 4, 5 of unit tiles 1..5
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) hp_hi[u][sl][g] = glb_h8(c.wdir + (size_t)(1 + u) * kUnitB + (21 + g * 7 + 4 + sl) * 1024 + lane * 16);
+    const lds_cptr yh = c.lds + kYH + lane * 16;
+    const lds_ptr ymw = (lds_ptr)(c.lds + kYM + lane * 16), yhw = (lds_ptr)(c.lds + kYH + lane * 16);
+    const lds_ptr pbw = (lds_ptr)(c.lds + kPB + lane * 16);
     const uint32_t v0 = (uint32_t)(n * 800 + q * 16);
     const uint32_t vr = q < 2 ? (uint32_t)(n * 800 + 384 + q * 8) : 0x80000000u;        // remainder k = 192 + 4 kq .. + 3 (kq < 2)
     for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(c.P.y0) + (size_t)grp * L * (16 * 800), 0, L * 16 * 800, 0x00020000);
-        const auto so = [&](int s) { return (uint32_t)__builtin_amdgcn_readfirstlane(dir ? L - 1 - s : s) * (16 * 800u); };
-        YRow r0, r1;
-        y_load(r0, rs, v0, vr, so(0));
-        y_load(r1, rs, v0, vr, so(L > 1 ? 1 : 0));
-        y_store(r0, yw);
-        y_store(r1, yw + kYBsz);
-        if (L > 2) y_load(r0, rs, v0, vr, so(2));
+        // byte offset of step k's 16 rows (steps past the end: the last step again - fetched, never used)
+        const auto so = [&](int k) { k = k < L ? k : L - 1; return (uint32_t)__builtin_amdgcn_readfirstlane(dir ? L - 1 - k : k) * (16 * 800u); };
+        YM m0;
+        YH h0, h1;
+        // one set of row registers, refilled in turn (register pressure: the helper's 120 weight registers stay live here)
+        ym_load(m0, rs, v0, vr, so(0)); yh_load(h0, rs, v0, so(0)); yh_load(h1, rs, v0, so(1));
+        ym_store(m0, ymw); yh_store(h0, yhw); yh_store(h1, yhw + kYHsz);
+        __builtin_amdgcn_sched_barrier(0);
+        ym_load(m0, rs, v0, vr, so(1)); yh_load(h0, rs, v0, so(2));
+        ym_store(m0, ymw + kYMsz);
+        __builtin_amdgcn_sched_barrier(0);
         step_barrier();                                   // B0
-        step_barrier();                                   // B1
+        helper_partials<5>(hp_hi, c.lds, lane, 1, q, yh, pbw);                             // steps 0 and 1
+        __builtin_amdgcn_sched_barrier(0);
+        helper_partials<5>(hp_hi, c.lds, lane, 1, q, yh + kYHsz, pbw + kPBsz);
+        __builtin_amdgcn_sched_barrier(0);
+        ym_load(m0, rs, v0, vr, so(2));
+        yh_load(h1, rs, v0, so(3));
+        step_barrier();                                   // B1: every helper has read H[0]
+        yh_store(h0, yhw);                                // H[0] <- step 2
+        step_barrier();                                   // B2
 #pragma unroll 1
         for (int s = 0; s < L; ++s) {
-            // r0 holds y0 of step s + 2 (fetched a step ago): into buffer s & 1, whose last reader (the projection of step s) passed
-            // the previous barrier; then fetch step s + 3
-            if (s + 2 < L) y_store(r0, yw + (s & 1) * kYBsz);
-            if (s + 3 < L) y_load(r0, rs, v0, vr, so(s + 3));
+            const int p0 = s & 1, p1 = p0 ^ 1;
+            // m0 / h1 hold M(s + 2) / H(s + 3), fetched a step ago
+            ym_store(m0, ymw + p0 * kYMsz);
+            yh_store(h1, yhw + p1 * kYHsz);
+            ym_load(m0, rs, v0, vr, so(s + 3));
+            yh_load(h1, rs, v0, so(s + 4));
+            helper_partials<5>(hp_hi, c.lds, lane, 1, q, yh + p0 * kYHsz, pbw + p0 * kPBsz);   // unit tiles 1..5, step s + 2
             step_barrier();
         }
         step_barrier();
@@ -374,7 +474,7 @@ __global__ __launch_bounds__(512) void gru_l1f_kernel(GruL1fParams P) {
     const int dir = blockIdx.y;
     const char* wdir = P.w + (size_t)dir * P.w_dir_stride;
     {
-        const f32x4* src = reinterpret_cast<const f32x4*>(wdir + 6 * kUnitB + kRemB);
+        const f32x4* src = reinterpret_cast<const f32x4*>(wdir + 6 * kUnitB + kRemB + kLo01B);
         for (int i = tid; i < (kLdsW + kBiasB) / 16; i += 512) reinterpret_cast<f32x4*>(smem)[i] = src[i];
     }
     __syncthreads();

@@ -108,12 +108,13 @@ struct GruHeadParams {
 };
 // f16x2 layer 1 as one kernel (turboae_gru_l1f.hip): input projection + recurrence + this direction's half of the Linear head.
 // Weight image of one direction: 6 unit-wave register images (42 fragments of 1 KB: per gate W_hh {slab 0..2: hi, lo; remainder},
-// then per gate W_ih1 {slab 0..5 hi; remainder}) | remainder-wave image (27 fragments: W_hh 7, W_ih1 13, head 7) | LDS image
-// (W_ih1 lo [ut][gate][slab] | bias rows | 2^-S, 2^-S_head).
+// then per gate W_ih1 hi {slab 0..5; remainder}) | remainder-wave image (27 fragments: W_hh 7, W_ih1 13, head 7) | W_ih1 lo of
+// k-slabs 0, 1 [ut][gate][slab] (unit waves' registers) | LDS image (W_ih1 lo of k-slabs 2..5 [ut][gate][slab - 2] | bias rows |
+// 2^-S, 2^-S_head).
 struct GruL1fLayout {
-    static constexpr int kUnitB = 42 * 1024, kRemB = 27 * 1024;
-    static constexpr int kLdsImgB = 6 * 3 * 6 * 1024 + 6 * 4 * 64 + 64 + 16;
-    static constexpr int kDirB = 6 * kUnitB + kRemB + kLdsImgB;
+    static constexpr int kUnitB = 42 * 1024, kRemB = 27 * 1024, kLo01B = 6 * 3 * 2 * 1024;
+    static constexpr int kLdsImgB = 6 * 3 * 4 * 1024 + 6 * 4 * 64 + 64 + 16;
+    static constexpr int kDirB = 6 * kUnitB + kRemB + kLo01B + kLdsImgB;
 };
 struct GruL1fParams {
     const char* w;         // two GruL1fLayout images (forward, backward)
