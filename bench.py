@@ -297,6 +297,7 @@ def time_other_config(name: str, cfg: TurboAEConfig, sd, B: int, dev, snr: float
     dec_tf = 2.0 * macs["dec"] * B * L / (dec_ms * 1e-3) / 1e12
     enc_tf = 2.0 * macs["enc"] * B * L / (enc_ms * 1e-3) / 1e12
     nb, lds = model.kernel_info()
+    variants = list(model.kernel_variants())
     if cfg.generic:
         kern = "generic fp32 MFMA kernels: " + ("tae::gen_proj_mfma_kernel / tae::gen_rnn_mfma_kernel" if cfg.decoder == "TurboAE_rate3_rnn" else "tae::gen_conv_mfma_kernel")
     elif cfg.decoder == "TurboAE_rate3_rnn":
@@ -308,7 +309,7 @@ def time_other_config(name: str, cfg: TurboAEConfig, sd, B: int, dev, snr: float
     out = {"config": name, "blocks": B, "block_len": L, "weights": weights, "arithmetic": mode, "ms_per_forward": fwd_ms,
            "bits_per_s": B * L / (fwd_ms * 1e-3), "dominant_kernel": kern, "decoder_ms": dec_ms, "decoder_tflops": dec_tf,
            "decoder_frac": dec_tf / peak, "encoder_plus_norm_ms": enc_ms, "encoder_frac": enc_tf / peak, "peak": peak,
-           "ber": int(counts[0].item()) / (float(B) * L * runs), "blocks_per_workgroup": nb}
+           "ber": int(counts[0].item()) / (float(B) * L * runs), "blocks_per_workgroup": nb, "_variants": variants}
     del model
     torch.cuda.empty_cache()
     return out
@@ -334,6 +335,12 @@ def other_configs(dev, snr: float, sd_trained):
     c0 = TurboAEConfig()
     sd0, w0 = (sd_trained, "trained") if sd_trained is not None else (W.generate_state_dict(c0, seed=SEED, gain=1.0), "random-init")
     res.append(time_other_config("configs[0] shape: enc2/dec5, block_len=100, batch=500", c0, sd0, 500, dev, snr, w0, runs=9))
+    # configs[1] shape on a network whose last conv layers stay below 1/4: the both-expm1-branches twin of the production kernels
+    # (dec_kernel_h<100,5,false,true>), VERDICT r04 item 4 - must cost what the plain instantiation costs
+    if sd_trained is not None:
+        r = time_other_config("configs[1] shape, last conv layers x 2^-5 (both-branch head twin): enc2/dec5, block_len=100, batch=50000", c0,
+                              W.scale_last_layers(sd_trained, c0, 2.0 ** -5), 50000, dev, snr, "trained, last layers rescaled")
+        res.append(r)
     c4 = TurboAEConfig(decoder="TurboAE_rate3_rnn")
     sd4, w4 = fixture(TRAINED_GRU, c4)
     res.append(time_other_config("configs[4]: TurboAE_rate3_rnn (GRU decoder), block_len=100, batch=16384", c4, sd4, 16384, dev, snr, w4))
@@ -446,7 +453,11 @@ def flatten_scalars(out) -> None:
     out["roofline_traffic_gb"] = rf.get("traffic")
     out["roofline_frac_of_sustained"] = rf.get("frac_of_sustained")
     out["sustained_probe_tflops"] = rf.get("sustained_probe_tflops")
-    names = {"configs[0]": "cfg0_b500", "configs[2]": "cfg2_enc5", "configs[3]": "cfg3_l1000", "configs[4]": "cfg4_gru"}
+    names = {"configs[0]": "cfg0_b500", "configs[2]": "cfg2_enc5", "configs[3]": "cfg3_l1000", "configs[4]": "cfg4_gru",
+             "configs[1] shape, last conv layers": "cfg1_head2"}
+    for oc in list(rf.get("other_configs", []) or []) + list(rf.get("generic_configs", []) or []):
+        if "_variants" in oc:
+            oc["kernel_variants_enc_dec"] = oc.pop("_variants")
     for oc in rf.get("other_configs", []) or []:
         key = next((v for k, v in names.items() if str(oc.get("config", "")).startswith(k)), None)
         if key and "error" not in oc:
@@ -462,6 +473,10 @@ def flatten_scalars(out) -> None:
             out[f"{key}_frac"] = oc["decoder_frac"]
     rf["cfg0_b500_frac"], rf["cfg2_enc5_frac"] = out.get("cfg0_b500_frac"), out.get("cfg2_enc5_frac")
     rf["cfg3_l1000_frac"], rf["cfg4_gru_frac"] = out.get("cfg3_l1000_frac"), out.get("cfg4_gru_frac")
+    if out.get("cfg1_head2_ms") and rf.get("kernel_ms"):
+        h2 = next(oc for oc in rf["other_configs"] if str(oc.get("config", "")).startswith("configs[1] shape, last conv layers"))
+        out["cfg1_head2_decoder_ms"] = h2["decoder_ms"]
+        out["cfg1_head2_decoder_over_plain"] = h2["decoder_ms"] / rf["kernel_ms"]
     r32 = out.get("roofline_f32")
     if r32:
         out["f32_bits_per_s"], out["f32_frac"], out["f32_ms_per_step"] = r32["value_bits_per_s"], r32["frac"], r32["ms_per_step"]

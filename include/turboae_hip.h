@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TAE_ABI_VERSION 11
+#define TAE_ABI_VERSION 12
 
 #if defined(__GNUC__)
 #define TAE_API __attribute__((visibility("default")))
@@ -244,6 +244,12 @@ TAE_API int tae_eval_snr(tae_handle* h, float snr_db, int32_t batch, int32_t n_b
 
 /* Blocks per workgroup and dynamic LDS bytes of the fused kernels (for DESIGN / bench reporting). */
 TAE_API int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_t* lds_bytes);
+
+/* Which instantiation of the fp16-split whole-block kernels this handle's production launches use (no reference counterpart): 1 when
+ * one of that side's last conv layers stayed below 1/4 in calibration, so its Linear heads evaluate both expm1 branches per value
+ * (a twin of the plain kernel with the same registers and no scratch - not the calibration instantiation); 0 otherwise, and always 0
+ * for fp32 / generic / long-block / GRU handles.  Either pointer may be NULL. */
+TAE_API int tae_kernel_variants(tae_handle* h, int32_t* enc_both_branch_heads, int32_t* dec_both_branch_heads);
 
 /* Debug overrides in effect (no reference counterpart).  Environment variables that change the arithmetic, the kernel family or a
  * launch geometry (TAE_PRECISION, TAE_RANGE_CAL, TAE_FORCE_GENERIC, TAE_FORCE_SEGMENTED, TAE_SEG_T, TAE_FIXED_NB, TAE_NO_SUPER,

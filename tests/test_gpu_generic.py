@@ -25,7 +25,7 @@ GEN = [n for n in sorted(MANIFEST["cases"]) if n.startswith("gen_")]
 
 def _run(gpu_device, cfg, meta, name):
     from turboae_amd import Channel_AE_HIP
-    sd = W.generate_state_dict(cfg, seed=meta["weight_seed"], gain=meta["gain"])
+    sd = W.golden_state_dict(cfg, meta)
     g = np.load(os.path.join(GOLD, name + ".npz"))
     model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=meta["B"])
     xd, codes = model(torch.from_numpy(g["u"]).to(gpu_device), torch.from_numpy(g["noise"]).to(gpu_device))

@@ -97,7 +97,7 @@ def test_forward_matches_reference_golden(gpu_device, name):
     from turboae_amd import Channel_AE_HIP
     meta = MANIFEST["cases"][name]
     cfg = TurboAEConfig(**meta["config"])
-    sd = W.generate_state_dict(cfg, seed=meta["weight_seed"], gain=meta["gain"])
+    sd = W.golden_state_dict(cfg, meta)
     g = np.load(os.path.join(GOLD, name + ".npz"))
     model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=meta["B"], is_interleave=meta.get("is_interleave", 1))
     quantised = cfg.train_channel_mode == "block_norm_ste"
@@ -123,7 +123,7 @@ def test_decoder_stage_taps_match_reference(gpu_device, name, precision):
     from turboae_amd import Channel_AE_HIP
     meta = MANIFEST["cases"][name]
     cfg = replace(TurboAEConfig(**meta["config"]), precision=precision)
-    sd = W.generate_state_dict(cfg, seed=meta["weight_seed"], gain=meta["gain"])
+    sd = W.golden_state_dict(cfg, meta)
     g = np.load(os.path.join(GOLD, name + ".npz"))
     model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=meta["B"])
     rx = torch.from_numpy(g["codes"] + g["noise"]).to(gpu_device)          # channel_ae.py:42 on the reference's own codes
@@ -465,7 +465,7 @@ def test_rnn_decoder_matches_reference_golden_and_oracle(gpu_device, name, prec)
     meta = MANIFEST["cases"][name]
     cfg = replace(TurboAEConfig(**meta["config"]), precision=prec)      # f16x2 kernels (default) and the fp32-MFMA kernels
     assert cfg.decoder == "TurboAE_rate3_rnn"
-    sd = W.generate_state_dict(cfg, seed=meta["weight_seed"], gain=meta["gain"])
+    sd = W.golden_state_dict(cfg, meta)
     g = np.load(os.path.join(GOLD, name + ".npz"))
     model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=meta["B"])
     xd, codes = model(torch.from_numpy(g["u"]).to(gpu_device), torch.from_numpy(g["noise"]).to(gpu_device))

@@ -22,7 +22,7 @@ CASES = sorted(MANIFEST["cases"])
 def test_oracle_matches_reference_fixture(name):
     meta = MANIFEST["cases"][name]
     cfg = TurboAEConfig(**meta["config"])
-    sd = W.generate_state_dict(cfg, seed=meta["weight_seed"], gain=meta["gain"])
+    sd = W.golden_state_dict(cfg, meta)
     g = np.load(os.path.join(GOLD, name + ".npz"))
     taps, state = {}, {}
     fading = torch.from_numpy(g["fading"]) if "fading" in g.files else None

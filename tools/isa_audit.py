@@ -35,9 +35,12 @@ DEFAULT_LIB = os.path.join(ROOT, "turboae_amd", "lib", "libturboae_hip.so")
 CSRC = os.path.join(ROOT, "turboae_amd", "csrc")
 
 # demangled-name prefixes of the kernels bench.py times (headline line + roofline.other_configs), production instantiations only
-BENCH_KERNELS = [r"tae::dec_kernel_h<100, 5, false>", r"tae::enc_kernel_h<100, 5, 0>", r"tae::seg_kernel_h<100, 5>",
+BENCH_KERNELS = [r"tae::dec_kernel_h<100, 5, false", r"tae::enc_kernel_h<100, 5, 0", r"tae::seg_kernel_h<100, 5>",
                  r"tae::dec_kernel<100, 5, false>", r"tae::enc_kernel<100, 5>",
-                 r"tae::gru_rec_h_kernel<", r"tae::gru_proj_h_kernel<", r"tae::gru_head_part_kernel"]
+                 r"tae::gru_rec_h_kernel<true>", r"tae::(anonymous namespace)::gru_l1f_kernel", r"tae::gru_head_part_kernel",
+                 # roofline.generic_configs (LSTM decoder, 256-wide CNN pair) and what bench.py times beside the kernels above
+                 r"tae::(anonymous namespace)::gen_conv_mfma_kernel", r"tae::(anonymous namespace)::gen_proj_mfma_kernel",
+                 r"tae::(anonymous namespace)::gen_rnn_mfma_kernel", r"tae::normalize_kernel", r"tae::count_errors_vec4_kernel"]
 MEM_ASM = re.compile(r"\b(global_load|global_store|global_atomic|buffer_load|buffer_store|buffer_atomic|flat_load|flat_store|flat_atomic|"
                      r"scratch_load|scratch_store|ds_read|ds_write|ds_load|ds_store|ds_bpermute|ds_permute|s_load|s_buffer_load|"
                      r"tbuffer_load|tbuffer_store)", re.I)

@@ -12,7 +12,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TAE_LIB", os.path.join(_HERE, "lib", "libturboae_hip.so"))   # TAE_LIB: kernel-variant experiments
 
-TAE_ABI_VERSION = 11
+TAE_ABI_VERSION = 12
 
 
 class TaeConfig(C.Structure):
@@ -65,6 +65,7 @@ SIGNATURES = {
     "tae_eval_snr": (C.c_int, [_P, C.c_float, C.c_int32, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64, _P, _P]),
     "tae_kernel_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tae_overrides": (C.c_int, [_P, C.c_char_p, C.c_int32]),
+    "tae_kernel_variants": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tae_range_status": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tae_calibrate_range": (C.c_int, [_P, _P, _P, C.c_int32]),
     "tae_range_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, C.c_int32, C.POINTER(C.c_int32)]),

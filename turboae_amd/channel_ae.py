@@ -150,6 +150,18 @@ class _Engine:
         _lib.check(self.lib.tae_kernel_info(self.h, C.byref(nb), C.byref(lds)))
         return nb.value, lds.value
 
+    def kernel_variants(self) -> Tuple[bool, bool]:
+        """(encoder, decoder): True where the production launches use the both-expm1-branches head instantiation (tae_kernel_variants)."""
+        e, d = C.c_int32(), C.c_int32()
+        _lib.check(self.lib.tae_kernel_variants(self.h, C.byref(e), C.byref(d)))
+        return bool(e.value), bool(d.value)
+
+    def overrides(self) -> str:
+        """Debug knobs in effect in this process ("NAME=value;..."; empty: none) - tae_overrides."""
+        buf = C.create_string_buffer(2048)
+        self.lib.tae_overrides(self.h, buf, 2048)
+        return buf.value.decode()
+
     def range_word(self) -> Tuple[str, int]:
         """('f16x2' | 'f32', bits): the arithmetic in use and the TAE_RANGE_* bits raised since the last call (_lib.RANGE_HIGH:
         a scaled activation left the fp16 range - results invalid; RANGE_LOW: data far below the calibrated window - results no
@@ -363,6 +375,12 @@ class Channel_AE_HIP:
 
     def kernel_info(self):
         return self._eng.kernel_info()
+
+    def kernel_variants(self):
+        return self._eng.kernel_variants()
+
+    def overrides(self) -> str:
+        return self._eng.overrides()
 
     def reserve(self, max_batch: int) -> None:
         """Grow the library's workspace to `max_batch` blocks per call now (tae_reserve) instead of on first use - needed

@@ -1174,12 +1174,13 @@ tae::FusedParams base_params(const tae_handle* h, int32_t B, bool decoder) {
     P.x_low = decoder && h->calibrated && !h->calibrating ? ldexpf(h->dec_r_low, ax) : 0.0f;
     P.cal = h->calibrating ? h->d_cal + (decoder ? cal_dec_offset(h) : 0) : nullptr;
     P.cal_r = (int32_t)cal_dec_r(h);
-    {   // see FusedParams::track; a side needs the full instantiation when one of its last layers asked for both expm1 branches
+    {   // see FusedParams::track / head2
         const std::vector<int>& K = decoder ? h->dec_kind : h->enc_kind;
         const int nl = decoder ? h->cfg.dec_num_layer : h->cfg.enc_num_layer;
-        bool full = h->calibrating;
-        for (size_t i = 0; i < K.size(); ++i) full = full || ((int)(i % nl) == nl - 1 && K[i] == 2);
-        P.track = full ? 2 : (decoder ? 1 : (h->calibrated ? 0 : 2));
+        bool both = false;
+        for (size_t i = 0; i < K.size(); ++i) both = both || ((int)(i % nl) == nl - 1 && K[i] == 2);
+        P.track = h->calibrating ? 2 : (decoder ? 1 : (h->calibrated ? 0 : 2));
+        P.head2 = both ? 1 : 0;          // production launch with both-branch heads: its own (spill-free) instantiation, not the full one
     }
     return P;
 }
@@ -2311,6 +2312,14 @@ int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_t* lds_b
     }
     if (blocks_per_workgroup) *blocks_per_workgroup = h->nbd;        // the decoder's (the dominant kernel)
     if (lds_bytes) *lds_bytes = h->nbd >= 1 ? (h->prec == 1 ? h->lds_bytes_hd : h->lds_bytes_d) : (h->prec == 1 ? h->dec_lds_h : h->dec_lds);
+    return TAE_OK;
+}
+
+int tae_kernel_variants(tae_handle* h, int32_t* enc_both, int32_t* dec_both) {
+    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
+    const bool whole = !h->gen && h->prec == 1;
+    if (enc_both) *enc_both = (whole && h->cfg.enc_type == 0 && h->nb >= 1) ? base_params(h, 1, false).head2 : 0;
+    if (dec_both) *dec_both = (whole && h->cfg.dec_type == 0 && h->nbd >= 1) ? base_params(h, 1, true).head2 : 0;
     return TAE_OK;
 }
 

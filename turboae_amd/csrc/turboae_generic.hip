@@ -208,7 +208,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                             size_t np, int act, unsigned ctiles, unsigned ntiles, int xcd) {
     __shared__ __attribute__((aligned(16))) float xs[kMP * kMKP];
     __shared__ __attribute__((aligned(16))) float ws[kMK * kMWP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // 1-D grid, XCD-aware: workgroup i runs on XCD i % 8, so XCD k takes the k-th contiguous eighth of the (position tile, channel
     // tile) list, channel tile fastest - the workgroups that share an activation tile follow each other on ONE L2
     const unsigned per_xcd = gridDim.x / 8, tile = xcd ? (blockIdx.x % 8) * per_xcd + blockIdx.x / 8 : blockIdx.x;
@@ -289,14 +290,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         }
     }
+    // the lane index again, from mbcnt: nothing lane-dependent has to stay live across the K loop for the epilogue (at the 128
+    // registers of two workgroups per CU that one value was spilled: 8 bytes of scratch per lane for a single reload)
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), n_e = lane_e & 15, q_e = lane_e >> 4;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const size_t p = p0 + wave * 32 + nt * 16 + n;
+        const size_t p = p0 + wave * 32 + nt * 16 + n_e;
         if (p >= np) continue;
         float* yr = y + p * (size_t)ldy + coff;
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
-            const int ch = ch0 + mt * 16 + 4 * q;
+            const int ch = ch0 + mt * 16 + 4 * q_e;
             if (ch >= cout) continue;
             f32x4 v;
 #pragma unroll

@@ -397,7 +397,7 @@ __device__ __forceinline__ const float* dense_tail(const float* wpack, uint32_t 
 // (the first layer's packed 2^-(S + A_x) undoes it).
 // `l0_slabs` > 0: the first layer walks that many K slabs instead of the tap_geo count (encoder stacks: C_in = 1 folds all taps
 // into ONE slab, see fold_enc_input).
-template <int U, int PT, int C0, int NC, int TRACK = 1, class Epi>
+template <int U, int PT, int C0, int NC, int TRACK = 1, bool HEAD2 = (TRACK == 2), class Epi>
 __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint32_t soff, uint32_t snext, int n_layer, char* smem,
                                             const PanelsH& pn, const XPlane& xin, const TileH<PT>& tc, int g, int lane,
                                             WeightStreamH<U, C0, NC>& ws, const RangeH& rg, Epi epi, int l0_slabs = 0) {
@@ -514,10 +514,12 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
         hmax = fmaxf(hmax * inv_scale, 1.0f - __expf(-hneg * inv_scale));
     }
     // Which expm1 the last layer gets is a COMPILE-TIME property of the instantiation (a run-time choice - two copies of the head, or
-    // a wave-uniform branch per tile - spilled 10 / 48 registers): TRACK == 2, the "full" instantiation (calibration launches, tap
-    // export, and every launch of a network one of whose last layers stays below 1: the host decides, FusedParams::track), evaluates
-    // both branches per value; the production instantiations keep r03's exp2 - 1 (3e-8 absolute against a layer maximum >= 1).
-    constexpr int HEAD_KIND = (TAE_ELU_MODE == 0) ? 0 : ((TAE_ELU_MODE == 1 || TRACK == 2) ? 2 : 0);
+    // a wave-uniform branch per tile - spilled 10 / 48 registers): HEAD2 instantiations evaluate both branches per value - the "full"
+    // one (TRACK == 2: calibration launches, tap export) and, since r05, a production twin of the plain kernels for networks one of
+    // whose last layers stays below 1/4 (the host decides, FusedParams::head2; it carries none of the calibration bookkeeping, so a
+    // full-size launch does not run the spilling instantiation); the plain instantiations keep r03's exp2 - 1 (3e-8 absolute against a
+    // layer maximum >= 1/4).
+    constexpr int HEAD_KIND = (TAE_ELU_MODE == 0) ? 0 : ((TAE_ELU_MODE == 1 || HEAD2) ? 2 : 0);
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         f32x4 w4[8];
@@ -734,7 +736,7 @@ __device__ __forceinline__ void range_check_inputs(uint32_t* slot, float low, ui
 
 // =============================================================================================
 // Decoder: DEC_LargeCNN.forward (decoders.py:206-269)
-template <int U, int PT, int C0, int NC, bool TAPS>
+template <int U, int PT, int C0, int NC, bool TAPS, bool HEAD2>
 __device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, const PanelsH& pn, const TileH<PT>& tc, int g, int lane, int blk0) {
     const int L = P.L;
     const int n_stack = 2 * P.n_iter;
@@ -754,7 +756,7 @@ __device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, con
         const int* ptab = (s & 1) ? pn.PERM : pn.INV;
         const RangeH rg{range_rows(pn.RNG) + s * P.n_layer * 8};
         if (s + 1 < n_stack) {
-            run_stack_h<U, PT, C0, NC, TAPS ? 2 : 1>(wpack, s * sstride, (s + 1) * sstride, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
+            run_stack_h<U, PT, C0, NC, TAPS ? 2 : 1, HEAD2>(wpack, s * sstride, (s + 1) * sstride, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
                                        [&](int p, int f, float v) {
                 if (f < F) {
                     if (extrinsic) v -= Xin.read(tc.row(p), 2 + f) * xinv;     // decoders.py:235-236,246-247
@@ -765,7 +767,7 @@ __device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, con
                 }
             });
         } else {
-            run_stack_h<U, PT, C0, NC, TAPS ? 2 : 1>(wpack, s * sstride, 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
+            run_stack_h<U, PT, C0, NC, TAPS ? 2 : 1, HEAD2>(wpack, s * sstride, 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
                                        [&](int p, int f, float v) {
                 if (f == 0) xdec[tc.blk(p) * L + ptab[tc.t(p)]] = 1.0f / (1.0f + expf(-v));   // decoders.py:262-267
             });
@@ -774,7 +776,7 @@ __device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, con
     report_range_x(xmax, xinv, range_flags(pn.RNG), range_cal(pn.RNG));
 }
 
-template <int U, int PT, bool TAPS = false>
+template <int U, int PT, bool TAPS = false, bool HEAD2 = TAPS>
 __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -828,8 +830,8 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
         TileH<T> tc;
         make_tiles_h<T>(tc, pn.ROWT, gs.gt0, lane, L, npos, pad);
         __syncthreads();
-        if (!upper) dec_body_h<U, T, 0, Split<U>::CTA, TAPS>(P, smem, pn, tc, gs.gt0, lane, blk0);
-        else dec_body_h<U, T, Split<U>::CTA, Split<U>::CTB, TAPS>(P, smem, pn, tc, gs.gt0, lane, blk0);
+        if (!upper) dec_body_h<U, T, 0, Split<U>::CTA, TAPS, HEAD2>(P, smem, pn, tc, gs.gt0, lane, blk0);
+        else dec_body_h<U, T, Split<U>::CTA, Split<U>::CTB, TAPS, HEAD2>(P, smem, pn, tc, gs.gt0, lane, blk0);
     };
     dispatch_tiles<PT>(gs.live, run);
     // every stack ends with a barrier: all rows are in place.  Row i = (stack i / n_layer, layer i % n_layer); the last layer of a stack has no panel
@@ -838,7 +840,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
 
 // =============================================================================================
 // Encoder before power normalisation: ENC_interCNN.forward (encoders.py:362-373)
-template <int U, int PT, int C0, int NC, int TRACK>
+template <int U, int PT, int C0, int NC, int TRACK, bool HEAD2>
 __device__ __forceinline__ void enc_body_h(const FusedParams& P, char* smem, const PanelsH& pn, const TileH<PT>& tc, int g, int lane,
                                            int blk0, double& sum, double& sumsq) {
     const int L = P.L;
@@ -852,7 +854,7 @@ __device__ __forceinline__ void enc_body_h(const FusedParams& P, char* smem, con
     for (int s = 0; s < 3; ++s) {
         const XPlane Xin = (s == 2) ? pn.XB : pn.XA;
         const RangeH rg{range_rows(pn.RNG) + s * P.n_layer * 8};
-        run_stack_h<U, PT, C0, NC, TRACK>(wpack, s * sstride, s < 2 ? (s + 1) * sstride : 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
+        run_stack_h<U, PT, C0, NC, TRACK, HEAD2>(wpack, s * sstride, s < 2 ? (s + 1) * sstride : 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
                                    [&](int p, int f, float v) {
             if (f == 0) {
                 v = act_apply(v, act);                                     // enc_act (encoders.py:364)
@@ -867,7 +869,7 @@ __device__ __forceinline__ void enc_body_h(const FusedParams& P, char* smem, con
 // TRACK = 0: no range bookkeeping (2: all of it, the last layers' maxima included).  The encoder's inputs are bit patterns - the calibration batch samples exactly the
 // distribution every later call draws from - so once a handle is calibrated its encoder panels cannot leave their window unless the
 // weights change; the host launches the tracking instantiation only for calibration passes and for uncalibrated handles.
-template <int U, int PT, int TRACK>
+template <int U, int PT, int TRACK, bool HEAD2 = (TRACK == 2)>
 __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -911,8 +913,8 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
         TileH<T> tc;
         make_tiles_h<T>(tc, pn.ROWT, gs.gt0, lane, L, npos, pad);
         __syncthreads();
-        if (!upper) enc_body_h<U, T, 0, Split<U>::CTA, TRACK>(P, smem, pn, tc, gs.gt0, lane, blk0, sum, sumsq);
-        else enc_body_h<U, T, Split<U>::CTA, Split<U>::CTB, TRACK>(P, smem, pn, tc, gs.gt0, lane, blk0, sum, sumsq);
+        if (!upper) enc_body_h<U, T, 0, Split<U>::CTA, TRACK, HEAD2>(P, smem, pn, tc, gs.gt0, lane, blk0, sum, sumsq);
+        else enc_body_h<U, T, Split<U>::CTA, Split<U>::CTB, TRACK, HEAD2>(P, smem, pn, tc, gs.gt0, lane, blk0, sum, sumsq);
     };
     dispatch_tiles<PT>(gs.live, run);
     if (TAE_RANGE_BOOK == 1 && TRACK) range_finish(pn.RNG, 3 * P.n_layer, 1, [&](int i) { return plain_tail<U>(P.wpack, P.stack_stride, P.n_layer, P.taps, i); });
@@ -1111,19 +1113,24 @@ template <int U>
 hipError_t launch_fused_h_u(bool decoder, const FusedParams& P, int grid, hipStream_t st) {
     constexpr int PT = 5;
     auto kd = dec_kernel_h<U, PT>;
+    auto kd2 = dec_kernel_h<U, PT, false, true>;   // production twin with both expm1 branches in the heads (FusedParams::head2)
     auto kt = dec_kernel_h<U, PT, true>;       // the instantiation for tae_decode_taps (exports every stack's extrinsic outputs) and for
                                                // calibration launches (also tracks the last layers' ELU maxima)
     auto ke = enc_kernel_h<U, PT, 0>;
+    auto ke2 = enc_kernel_h<U, PT, 0, true>;
     auto ket = enc_kernel_h<U, PT, 2>;
     const bool taps = decoder && (P.tap_out != nullptr || P.cal != nullptr || P.track == 2);
     const bool etrack = !decoder && (P.track != 0 || P.cal != nullptr);
-    const void* fn = decoder ? (taps ? reinterpret_cast<const void*>(kt) : reinterpret_cast<const void*>(kd))
-                             : (etrack ? reinterpret_cast<const void*>(ket) : reinterpret_cast<const void*>(ke));
+    const bool h2 = P.head2 != 0;
+    const void* fn = decoder ? (taps ? reinterpret_cast<const void*>(kt) : (h2 ? reinterpret_cast<const void*>(kd2) : reinterpret_cast<const void*>(kd)))
+                             : (etrack ? reinterpret_cast<const void*>(ket) : (h2 ? reinterpret_cast<const void*>(ke2) : reinterpret_cast<const void*>(ke)));
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes);
     if (e != hipSuccess) return e;
     if (taps) hipLaunchKernelGGL(kt, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
+    else if (decoder && h2) hipLaunchKernelGGL(kd2, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
     else if (decoder) hipLaunchKernelGGL(kd, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
     else if (etrack) hipLaunchKernelGGL(ket, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
+    else if (h2) hipLaunchKernelGGL(ke2, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
     else hipLaunchKernelGGL(ke, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
     return hipGetLastError();
 }

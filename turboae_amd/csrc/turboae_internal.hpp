@@ -40,7 +40,9 @@ struct FusedParams {
     int32_t cal_r;
     int32_t track;          // which instantiation of the f16x2 whole-block kernels: 0 = no range bookkeeping (calibrated encoders), 1 = the
                             // panels (production decoder), 2 = full: + the last layers' maxima, both expm1 branches in the heads (calibration
-                            // launches, uncalibrated encoders, networks whose last layers stay below 1)
+                            // launches, uncalibrated encoders)
+    int32_t head2;          // f16x2 whole-block kernels, track < 2: 1 = the instantiation whose Linear heads evaluate both expm1 branches (one of
+                            // this side's last conv layers stays below 1/4: exp2 - 1 alone is not relatively accurate there)
 };
 
 // Arguments of the per-stack segmented kernel used when a block does not fit one workgroup.

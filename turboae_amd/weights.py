@@ -166,6 +166,41 @@ def generate_state_dict(cfg: TurboAEConfig, seed: int = 20190001, gain: float = 
     return out
 
 
+def scale_last_layers(state_dict: Dict[str, object], cfg: TurboAEConfig, factor: float, encoder: bool = True,
+                      decoder_stacks=None) -> Dict[str, np.ndarray]:
+    """Copy of a CNN `state_dict` with the LAST conv layer of the chosen stacks (all three encoder stacks when `encoder`, the
+    decoder stacks listed in `decoder_stacks` as (iteration, half) pairs, default all) scaled by `factor` - weight and bias - and
+    the Linear layer behind it by 1 / factor.  Exactly the same function where that layer is in the linear part of its ELU, a
+    slightly different network elsewhere; what it is for: a last layer whose activations stay below 1 (factor < 1) makes the
+    fp16-split kernels evaluate both expm1 branches in that head (test / bench case for that instantiation)."""
+    out = {k: np.array(v, dtype=np.float32, copy=True) for k, v in state_dict.items()}
+    f = np.float32(factor)
+    if encoder:
+        for s in (1, 2, 3):
+            out[f"enc.enc_cnn_{s}.cnns.{cfg.enc_num_layer - 1}.weight"] *= f
+            out[f"enc.enc_cnn_{s}.cnns.{cfg.enc_num_layer - 1}.bias"] *= f
+            out[f"enc.enc_linear_{s}.weight"] /= f
+    if decoder_stacks is None:
+        decoder_stacks = [(it, h) for it in range(cfg.num_iteration) for h in (1, 2)]
+    for it, h in decoder_stacks:
+        out[f"dec.dec{h}_cnns.{it}.cnns.{cfg.dec_num_layer - 1}.weight"] *= f
+        out[f"dec.dec{h}_cnns.{it}.cnns.{cfg.dec_num_layer - 1}.bias"] *= f
+        out[f"dec.dec{h}_outputs.{it}.weight"] /= f
+    return out
+
+
+def golden_state_dict(cfg: TurboAEConfig, meta: Dict[str, object]) -> Dict[str, np.ndarray]:
+    """Weights of a tests/golden/MANIFEST.json case: the portable generator at (weight_seed, gain), then the case's
+    `last_layer_scale` = {"factor", "encoder", "decoder_stacks"} if it has one (scale_last_layers)."""
+    sd = generate_state_dict(cfg, seed=int(meta["weight_seed"]), gain=float(meta["gain"]))
+    t = meta.get("last_layer_scale")
+    if t:
+        stacks = t.get("decoder_stacks")
+        sd = scale_last_layers(sd, cfg, float(t["factor"]), bool(t.get("encoder", True)),
+                               None if stacks is None else [tuple(x) for x in stacks])
+    return sd
+
+
 def save_blob(path: str, cfg: TurboAEConfig, state_dict: Dict[str, object]) -> None:
     """Flat little-endian fp32 blob + JSON manifest (``<path>.json``)."""
     import json
