@@ -79,10 +79,12 @@ typedef struct tae_config {
     int32_t dec_rnn;          /* -dec_rnn (get_args.py:80, decoders.py:27-32): the cell of DEC_LargeRNN (dec_type = 1) */
     int32_t range_calibration;/* fp16-split conv kernels (no reference counterpart: the reference's fp32 F.conv1d, cnn_utils.py:36-46, has 24
                                  significant bits at any magnitude; an fp16 hi/lo pair has them only for values in about [2^-3, 2^16)):
-                                 0 (default) = tae_create / tae_set_interleaver / tae_set_channel_opts run the handle's own forward on a
-                                 synthetic batch, measure every layer's largest activation and store each panel times a per-layer power of
-                                 two that puts that maximum at [2^10, 2^11) (see tae_calibrate_range); 1 = no calibration, every exponent 0
-                                 (fp32-grade only while activations are O(1); testing / A-B) */
+                                 0 (default) = tae_create, the FIRST tae_set_interleaver after it and a tae_set_channel_opts that changes what
+                                 the decoder receives run the handle's own forward on a synthetic batch, measure every layer's largest
+                                 activation and store each panel times a per-layer power of two that puts that maximum at [2^10, 2^11)
+                                 (see tae_calibrate_range; later permutations keep the measurement, and a calibration on the caller's
+                                 own data is kept until the caller replaces it); 1 = no calibration, every exponent 0 (fp32-grade only
+                                 while activations are O(1); testing / A-B) */
     int32_t range_fallback;   /* 1: every compute entry point (tae_forward / encode / encode_prenorm / decode / eval_snr) waits for its
                                  launches, reads the range word and, if an activation left the window (above the fp16 range, or a
                                  workgroup's data 2^7 below the calibration maximum), runs the call again on an fp32 twin of the handle
@@ -286,7 +288,11 @@ TAE_API int tae_range_status(tae_handle* h, int32_t* precision, int32_t* overflo
  * NULL for the built-in synthetic batch (Bernoulli bits; the configured channel's own kind of noise at 0 dB).  Runs the forward a
  * few times on the NULL stream, rewrites the packed bias / scale tails (the weight fragments are untouched), SYNCHRONISES the
  * device, clears the range word.  Every exponent is a power of two: a different calibration batch moves where the floor and the
- * ceiling of the fp16 pairs sit, never the rounding of a value inside the window.  No-op for fp32 / GRU-only / generic handles. */
+ * ceiling of the fp16 pairs sit, never the rounding of a value inside the window.  No-op for fp32 / GRU-only / generic handles.
+ * A calibration on the caller's data stays in force through later tae_set_interleaver / tae_set_channel_opts calls (they re-measure
+ * only a synthetic calibration); call again - with data, or with NULLs to return to the synthetic batch - after such a change.
+ * Inputs: a calibrated handle's encoder runs without range bookkeeping on the assumption that u holds bits (0 / 1, as
+ * Channel_AE.forward's input does); soft or scaled inputs belong to a handle created with range_calibration = 1 or TAE_PREC_F32. */
 TAE_API int tae_calibrate_range(tae_handle* h, const float* u, const float* noise, int32_t B);
 
 /* Diagnostics: the exponents in use.  *n_encoder / *n_decoder = number of int32 values per side (0: not calibrated): first one

@@ -238,3 +238,55 @@ def test_calibrate_range_takes_what_forward_takes(gpu_device):
     mf.calibrate_range(ud, nz, fading=fh)
     mf(ud, nz, fh)
     assert mf._eng.range_word() == ("f16x2", 0)
+
+
+def test_user_calibration_survives_interleaver_and_channel_changes(gpu_device):
+    """tae_set_interleaver / tae_set_channel_opts used to re-run the synthetic calibration every time - with
+    -is_same_interleaver 0 on every forward - and silently replaced a calibration made on the caller's data.  Now: the synthetic
+    calibration is repeated once, with the first installed permutation; later permutations keep it; a user calibration stays until
+    the caller replaces it."""
+    from turboae_amd import Channel_AE_HIP
+    from turboae_amd.interleaver import rand_interleaver
+    cfg = TurboAEConfig(num_iteration=2)
+    sd = W.generate_state_dict(cfg, seed=7, gain=1.0)
+    B, L = 6, cfg.block_len
+    u, noise = _inputs(B, L)
+    ud, nd = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
+    m = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    m(ud, nd)                                             # installs the seed-0 permutation: the one synthetic re-measurement
+    synthetic = m._eng.range_info()
+    m._eng.set_interleaver(rand_interleaver(L, 5))        # another permutation: kept
+    assert m._eng.range_info() == synthetic
+    big = nd * 64.0                                       # the caller's channel is 36 dB noisier than the synthetic batch's
+    m.calibrate_range(ud, big)
+    user = m._eng.range_info()
+    assert user[1] != synthetic[1]                        # the decoder's exponents moved to the caller's data
+    m._eng.set_interleaver(rand_interleaver(L, 6))
+    assert m._eng.range_info() == user
+    m(ud, big)
+    assert m._eng.range_word() == ("f16x2", 0)            # in-window on that data; the synthetic window would have raised HIGH
+    m.calibrate_range()                                   # back to the synthetic batch on request
+    assert m._eng.range_info()[1] == synthetic[1]
+
+
+def test_range_rows_beyond_one_per_thread(gpu_device):
+    """range_finish gave one thread to each (stack, layer) row and stopped at the workgroup's 512 threads; a decoder
+    with 2 x 52 iterations x 5 layers = 520 rows left the last ones unchecked and uncalibrated (exponent 0).  Small-activation
+    network: every panel row, the last stacks' included, gets a non-zero exponent, and the result is fp32-grade."""
+    from turboae_amd import Channel_AE_HIP
+    from tests._fuzz_cases import scale_layers, balanced
+    cfg = TurboAEConfig(num_iteration=52, enc_num_unit=32, dec_num_unit=32, block_len=12)
+    sd = scale_layers(W.generate_state_dict(cfg, seed=11, gain=1.0), cfg, balanced(cfg.enc_num_layer, 0.05), balanced(cfg.dec_num_layer, 0.05))
+    B = 3
+    u, noise = _inputs(B, cfg.block_len)
+    m = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    enc_a, dec_a, _ = m._eng.range_info()
+    n_stack, nl = 2 * cfg.num_iteration, cfg.dec_num_layer
+    panels = dec_a[len(dec_a) - n_stack * nl:]            # one exponent per (stack, layer) behind the stack-input exponents
+    assert len(panels) == 520
+    for s in range(n_stack):
+        assert all(panels[s * nl + l] != 0 for l in range(nl - 1)), (s, panels[s * nl:(s + 1) * nl])       # layers 0..3 hold ~0.05^k: scaled up
+    xd, codes = m(torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device))
+    assert m._eng.range_word() == ("f16x2", 0)
+    x64, c64 = _oracle64(cfg, sd, u, noise)
+    assert float((codes.cpu().double() - c64).abs().max()) <= 5e-6 and float((xd.cpu().double() - x64).abs().max()) <= 2e-5

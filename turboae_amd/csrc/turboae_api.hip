@@ -366,6 +366,8 @@ struct tae_handle {
     uint32_t* d_cal = nullptr;                      // calibration launches: per-layer / per-stack maxima (float bits), encoder then decoder
     bool calibrating = false;
     bool calibrated = false;
+    bool cal_user = false;     // the current exponents were measured on the caller's data (tae_calibrate_range(u, noise)): never replaced silently
+    bool cal_perm = false;     // ... on the synthetic batch with an installed (post-create) permutation
     int cal_passes = 0;
     // ---- tae_config.range_fallback: fp32 twin of this handle and what the last flagged call did
     tae_handle* fb = nullptr;
@@ -1629,7 +1631,9 @@ int calibrate_range(tae_handle* h, const float* u_user, const float* noise_user,
                 else if (decoder && h->cfg.dense) mx = both(word(o + 1 + (size_t)ns * nl + s), rmax);
                 else if (decoder) {
                     // plain long-block decoder: the same ONE exponent the whole-block kernel would use (the union of what the stacks
-                    // stage is what that kernel's planes see), so both paths stay bit-identical on blocks either can run
+                    // stage is what that kernel's planes see), so both paths stay bit-identical on blocks either can run - for networks whose
+                    // last layers stay at or above 1/4 (the long-block kernels always use exp2 - 1 in their heads; the whole-block
+                    // kernels switch to both expm1 branches below that, FusedParams::head2, and tae_decode_taps always does)
                     mx = rmax;
                     for (int k = 0; k < ns; ++k) mx = both(word(o + 1 + (size_t)ns * nl + k), mx);
                 }
@@ -2095,8 +2099,16 @@ int tae_set_interleaver(tae_handle* h, const int32_t* p, int32_t L) {
     TAE_HIP(hipMemcpy(h->d_perm, p, L * sizeof(int32_t), hipMemcpyHostToDevice));
     TAE_HIP(hipMemcpy(h->d_inv, inv.data(), L * sizeof(int32_t), hipMemcpyHostToDevice));
     if (h->fb) { const int rc_f = tae_set_interleaver(h->fb, p, L); if (rc_f != TAE_OK) return rc_f; }
-    // the extrinsic values a trained decoder exchanges depend on the permutation: measure the ranges again
-    if (h->calibrated) return calibrate_range(h, nullptr, nullptr, 0);
+    // The extrinsic values a trained decoder exchanges depend on the permutation: the synthetic calibration made at create (identity
+    // permutation) is repeated ONCE, with the first permutation the caller installs.  Later permutations keep it - another random
+    // permutation of the same network moves a layer maximum by far less than the window (2^-7 .. 2^5 around it; both ends stay
+    // checked per launch), and -is_same_interleaver 0 installs one per forward (r04 re-measured on every one of them: two forward
+    // passes of up to 768 blocks each time) - and a calibration on the caller's own data is never discarded behind its back.
+    if (h->calibrated && !h->cal_user && !h->cal_perm) {
+        const int rc = calibrate_range(h, nullptr, nullptr, 0);
+        h->cal_perm = rc == TAE_OK;
+        return rc;
+    }
     return TAE_OK;
 }
 
@@ -2136,7 +2148,7 @@ int tae_set_channel_opts(tae_handle* h, const tae_channel_opts* o) {
                           a.enc_truncate_limit == b.enc_truncate_limit && a.enc_value_limit == b.enc_value_limit &&
                           a.enc_quantize_level == b.enc_quantize_level && a.rec_quantize_limit == b.rec_quantize_limit &&
                           a.rec_quantize_level == b.rec_quantize_level;
-        if (same || !h->calibrated || h->dec_tails.empty()) return (int)TAE_OK;
+        if (same || !h->calibrated || h->cal_user || h->dec_tails.empty()) return (int)TAE_OK;      // (a user calibration stays: the caller re-measures)
         if (check_handle(h) != TAE_OK) return (int)TAE_OK;      // no device context here: the next tae_set_interleaver / tae_calibrate_range measures
         return calibrate_range(h, nullptr, nullptr, 0);
     };
@@ -2363,7 +2375,12 @@ int tae_calibrate_range(tae_handle* h, const float* u, const float* noise, int32
     { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
     if ((u == nullptr) != (noise == nullptr)) return fail(TAE_EINVAL, "u and noise must be given together (both NULL: the synthetic batch)");
     if (u && B < 1) return fail(TAE_EINVAL, "batch must be >= 1");
-    return calibrate_range(h, u, noise, B);
+    const int rc = calibrate_range(h, u, noise, B);
+    if (rc == TAE_OK) {
+        h->cal_user = u != nullptr;           // the caller's data define the window from here on (a synthetic re-measurement gives it back)
+        if (!u) h->cal_perm = true;
+    }
+    return rc;
 }
 
 int tae_range_info(tae_handle* h, int32_t* n_encoder, int32_t* n_decoder, int32_t* exponents, int32_t capacity, int32_t* passes) {

@@ -288,20 +288,22 @@ __device__ __forceinline__ void range_note_layer(const RangeH& rg, int l, float 
 // 2^A_out | low-side threshold | high-side threshold) - `tail_of(i)` returns it, or nullptr for a row that holds no panel.
 template <class TailOf>
 __device__ __forceinline__ void range_finish(uint32_t* rng, int n_rows, int cal_base, TailOf tail_of) {
-    const int i = threadIdx.x;
-    if (i >= n_rows) return;
-    const float* tail = tail_of(i);
-    if (tail == nullptr) return;
-    const uint32_t* r = range_rows(rng) + i * 8;
-    uint32_t mb = 0u;
+    // strided: 2 * num_iteration * dec_num_layer rows may exceed the workgroup's 512 threads (60 iterations x 5 layers: ADVICE r04 -
+    // rows past 512 used to stay unchecked and uncalibrated)
+    for (int i = threadIdx.x; i < n_rows; i += kThreads) {
+        const float* tail = tail_of(i);
+        if (tail == nullptr) continue;
+        const uint32_t* r = range_rows(rng) + i * 8;
+        uint32_t mb = 0u;
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) mb = max(mb, r[w]);
-    const float m = __uint_as_float(mb);
-    const uint32_t f = (!(m <= tail[3]) ? 1u : 0u) | ((m < tail[2]) ? 2u : 0u);
-    uint32_t* flags = range_flags(rng);
-    if (f != 0u && flags != nullptr) atomicOr(flags, f);
-    uint32_t* cal = range_cal(rng);
-    if (cal != nullptr) atomicMax(cal + cal_base + i, __float_as_uint(m / tail[1]));
+        for (int w = 0; w < kWaves; ++w) mb = max(mb, r[w]);
+        const float m = __uint_as_float(mb);
+        const uint32_t f = (!(m <= tail[3]) ? 1u : 0u) | ((m < tail[2]) ? 2u : 0u);
+        uint32_t* flags = range_flags(rng);
+        if (f != 0u && flags != nullptr) atomicOr(flags, f);
+        uint32_t* cal = range_cal(rng);
+        if (cal != nullptr) atomicMax(cal + cal_base + i, __float_as_uint(m / tail[1]));
+    }
 }
 
 // Layer epilogue for 4 accumulator values: ELU(acc * 2^-S') * 2^A, running max of |.| (range report), split into fp16
