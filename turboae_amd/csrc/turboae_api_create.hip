@@ -1,62 +1,10 @@
-// libturboae_hip.so - host side of the C ABI declared in include/turboae_hip.h.
-// Owns the packed weights, the interleaver tables and the workspace; every compute entry point is
-// a short sequence of asynchronous kernel launches on the caller's stream (graph-capturable).
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <string.h>
-#include <stdlib.h>
-#include <math.h>
-#include <algorithm>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "../../include/turboae_hip.h"
-#include "turboae_internal.hpp"
-
-namespace {
-
-thread_local std::string g_err;
-
-int fail(int code, const std::string& msg) {
-    g_err = msg;
-    return code;
-}
-
-}  // namespace
+// libturboae_hip.so, host side 1 of 3 - the handle's life cycle (see turboae_host.hpp): configuration checks, weight packing into the
+// kernels' fragment layouts, range calibration of the fp16-split kernels, and tae_num_weights / tae_create / tae_destroy / tae_reserve.
+#include "turboae_host.hpp"
 
 namespace tae {
-int fail_msg(int code, const char* msg) { return fail(code, msg ? msg : "?"); }       // for the library's other translation units
+namespace host {
 namespace {
-std::mutex g_knob_mu;
-std::vector<std::string> g_knobs;          // "NAME=value" of every debug knob that took effect in this process
-}
-const char* debug_knob(const char* name) {
-    const char* on = getenv("TAE_DEBUG_KNOBS");
-    if (!on || on[0] != '1' || on[1] != 0) return nullptr;
-    const char* v = getenv(name);
-    if (!v) return nullptr;
-    const std::string rec = std::string(name) + "=" + v;
-    std::lock_guard<std::mutex> lk(g_knob_mu);
-    if (std::find(g_knobs.begin(), g_knobs.end(), rec) == g_knobs.end()) g_knobs.push_back(rec);
-    return v;
-}
-std::string knob_report() {
-    std::lock_guard<std::mutex> lk(g_knob_mu);
-    std::string r;
-    for (const std::string& k : g_knobs) { if (!r.empty()) r += ';'; r += k; }
-    return r;
-}
-}
-
-namespace {
-
-#define TAE_HIP(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e__ = (expr);                                                                   \
-        if (e__ != hipSuccess) return fail(TAE_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
-    } while (0)
 
 struct Layout {   // must mirror tae::Geo<U> in turboae_kernels.hip
     int U, CT, CP, nch_mid, midf, l0f, sup, sfm, sf0;
@@ -159,34 +107,7 @@ struct LayoutH {   // must mirror tae::GeoH<U> / tae::tap_geo<U>(taps)
 };
 
 // fp32 -> fp16 bits, round to nearest even, denormals kept (the device side uses v_cvt_f16_f32 in the default mode)
-inline uint16_t f2h(float f) {
-    uint32_t x;
-    memcpy(&x, &f, 4);
-    const uint32_t sign = (x >> 16) & 0x8000u;
-    x &= 0x7fffffffu;
-    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
-    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                 // rounds to >= 65520 -> inf
-    if (x < 0x33000001u) return (uint16_t)sign;                               // <= 2^-25 -> 0 (ties to even)
-    int e = (int)(x >> 23) - 127;
-    uint32_t m = (x & 0x7fffffu) | 0x800000u;
-    int shift = e >= -14 ? 13 : 13 + (-14 - e);                               // denormal: more bits dropped
-    const uint32_t half = 1u << (shift - 1), rest = m & ((1u << shift) - 1);
-    uint32_t r = m >> shift;
-    if (rest > half || (rest == half && (r & 1u))) ++r;
-    if (e >= -14) return (uint16_t)(sign | (uint32_t)(((e + 15) << 10) + (r - 0x400u)));   // carry propagates into the exponent
-    return (uint16_t)(sign | r);
-}
-inline float h2f(uint16_t h) {
-    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
-    const int e = (h >> 10) & 0x1f;
-    const uint32_t m = h & 0x3ffu;
-    float v;
-    if (e == 0) v = ldexpf((float)m, -24);
-    else if (e == 31) v = m ? NAN : INFINITY;
-    else v = ldexpf((float)(m | 0x400u), e - 25);
-    return sign ? -v : v;
-}
-
+// (f2h / h2f: turboae_host.hpp)
 inline float pow2_scale(float maxabs) {       // power of two that brings maxabs into [2^13, 2^14)
     if (!(maxabs > 0.0f) || !std::isfinite(maxabs)) return 1.0f;
     int e = 0;
@@ -216,15 +137,6 @@ void pack_conv_h(const float* W, int U, int cin, int cin_pad, int nslab, int CT,
                     dst[base + 512] = lo;
                 }
 }
-
-// The tail of one packed layer as the host keeps it for the range calibration (calibrate_range below): the layer's accumulators carry
-// 2^(S + A_in) (S: the weights' own power-of-two scale, A_in: exponent of the panel / stack inputs it reads), its ELU output is
-// stored * 2^A_out.  Device tail = bias * 2^(S + A_in) [CP] | 2^-(S + A_in) | 2^A_out | low-side threshold | high-side threshold | ELU kind | 3 spare.
-struct TailRef {
-    uint32_t off = 0;              // byte offset of the tail inside the side's packed buffer
-    int S = 0;
-    std::vector<float> bias_s;     // bias * 2^S, padded to CP
-};
 
 void tail_values(const TailRef& t, int A_in, int A_out, float low, float high, int elu_kind, std::vector<float>& out) {
     const size_t CP = t.bias_s.size();
@@ -295,89 +207,8 @@ size_t pack_stack_h(const float* src, const LayoutH& lo, int n_layer, int cin0, 
     return (size_t)(s - src);
 }
 
+
 }  // namespace
-
-struct tae_handle {
-    tae_config cfg;
-    int device = 0;
-    // per side (encoder / decoder): channel width, blocks per workgroup of the whole-block kernels (0: long-block path), LDS bytes
-    int U = 0, nb = 0, lds_bytes = 0;            // encoder
-    int Ud = 0, nbd = 0, lds_bytes_d = 0;        // decoder
-    int ncu = 256;           // compute units of the device (workgroups resident at once: one per CU)
-    bool fixed_nb = false;   // TAE_FIXED_NB=1: always nb blocks per workgroup (testing knob)
-    // long-block (segmented) path, used when a whole block does not fit one workgroup (nb == 0)
-    int enc_T = 0, enc_nseg = 0, enc_lds = 0, dec_T = 0, dec_nseg = 0, dec_lds = 0;
-    int enc_T0 = 0, dec_T0 = 0;      // centre length of segment 0 (no left halo: up to H + 3 more than the others)
-    uint32_t enc_stride = 0, dec_stride = 0;
-    uint32_t enc_bytes = 0, dec_bytes = 0;
-    int super = 0, super_d = 0;   // remainder channels via super-tiles (U % 16 == 4 and block_len % 4 == 0), encoder / decoder
-    // f16x2 representation of the whole-block kernels (prec == 1); the fp32 packs above stay resident for the long-block path
-    int prec = 0;            // 0: v_mfma_f32_16x16x4_f32 on fp32 operands; 1: 3 x v_mfma_f32_16x16x32_f16 on hi/lo halves
-    int lds_bytes_h = 0, lds_bytes_hd = 0, enc_lds_h = 0, dec_lds_h = 0;
-    uint32_t enc_stride_h = 0, dec_stride_h = 0, enc_bytes_h = 0, dec_bytes_h = 0;
-    char* d_wenc_h = nullptr;
-    char* d_wdec_h = nullptr;
-    uint32_t* d_flags = nullptr;   // bit 0: an activation left the fp16 range (f16x2 kernels clamp and report)
-    float* d_wenc = nullptr;
-    float* d_wdec = nullptr;
-    int32_t* d_perm = nullptr;
-    int32_t* d_inv = nullptr;
-    // workspace
-    int32_t cap = 0;
-    float* d_xtx = nullptr;
-    float* d_rx = nullptr;
-    double* d_partials = nullptr;
-    double* d_stats = nullptr;
-    float* d_e0 = nullptr;   // long-block path: extrinsic exchange buffers (B, L, 8)
-    float* d_e1 = nullptr;
-    // GRU decoder (dec_type = 1): canonical decoder weights uploaded as they are + per-chunk workspace
-    float* d_wrnn = nullptr;
-    char* d_wrnn_h = nullptr;   // f16x2 packing of the same (prec == 1)
-    float* d_wernn = nullptr;   // GRU encoder (enc_type = 1): the three ENC_interRNN stacks, packed like the decoder's
-    char* d_wernn_h = nullptr;
-    // tae_eval_snr workspace (grown on demand)
-    float* d_eval_u = nullptr;       // bits of one decode group (kept for the error count)
-    float* d_eval_noise = nullptr;   // noise of one batch
-    float* d_eval_xdec = nullptr;    // decisions of one decode group
-    int64_t eval_group_blocks = 0;
-    int32_t eval_batch = 0;
-    bool eval_noise_x2 = false;      // d_eval_noise holds fading coefficients + noise
-    double* d_rnn_partials = nullptr;   // GRU encoder: per (chunk, stack, head workgroup) partial sums
-    int32_t rnn_partial_slots = 0;
-    bool gru_l1_split = false; // f16x2 GRU stacks: layer 1 as projection kernel + recurrence kernel (r04) instead of the fused kernel
-    int32_t rnn_chunk = 0;   // blocks per internal chunk (bounds the workspace)
-    float* d_gxa = nullptr;  // (chunk, L, 8) natural-order panel
-    float* d_gxb = nullptr;  // (chunk, L, 8) interleaved-order panel
-    float* d_gy0 = nullptr;  // (chunk, L, 2H) layer-0 outputs
-    float* d_gy1 = nullptr;  // (chunk, L, 2H) layer-1 outputs
-    float* d_ggi = nullptr;  // (chunk, L, 2, 19, 16) layer-1 input projections in gate-tile order
-    tae::NormOpts nopts;       // encoder-output / channel variant (tae_set_channel_opts)
-    tae_noise_opts noise_opts; // generator tae_eval_snr draws from (tae_set_noise_opts; default AWGN)
-    tae::GenericEngine* gen = nullptr;   // generic fp32 kernels (configurations outside the MFMA kernels' envelope)
-    // ---- range calibration of the fp16-split conv kernels (calibrate_range): per-layer activation exponents
-    std::vector<TailRef> enc_tails, dec_tails;      // [stack * n_layer + l]; empty: the side has no fp16-split conv stacks
-    std::vector<int> enc_A, dec_A;                  // exponent of every layer's OUTPUT panel ([stack * n_layer + l]; unused for the last layer)
-    std::vector<int> enc_Ax, dec_Ax;                // exponent of every stack's input planes (whole-block decoder: all equal)
-    std::vector<float> enc_low, dec_low;            // low-side threshold per layer (0: not checked)
-    std::vector<float> enc_high, dec_high;          // high-side threshold per layer: 65504, or 2^-3 * 2^A for a layer whose ELU runs as a polynomial
-    std::vector<int> enc_kind, dec_kind;            // ELU branch per layer (turboae_h2.hip, TAE_ELU_MODE 2): 0 exp2, 1 polynomial, 2 both
-    float dec_r_low = 0.0f;                         // 2^-7 of the largest received value of the calibration batch (0: not checked); x_low = this * 2^A_x
-    int enc_min_values = 0, dec_min_values = 0;     // values of one panel a workgroup holds at least (positions x real channels)
-    uint32_t* d_cal = nullptr;                      // calibration launches: per-layer / per-stack maxima (float bits), encoder then decoder
-    bool calibrating = false;
-    bool calibrated = false;
-    bool cal_user = false;     // the current exponents were measured on the caller's data (tae_calibrate_range(u, noise)): never replaced silently
-    bool cal_perm = false;     // ... on the synthetic batch with an installed (post-create) permutation
-    int cal_passes = 0;
-    // ---- tae_config.range_fallback: fp32 twin of this handle and what the last flagged call did
-    tae_handle* fb = nullptr;
-    uint32_t last_flags = 0;                         // range bits accumulated since the last tae_range_status (bit 2: a call was re-run in fp32)
-};
-
-namespace {
-
-// Instantiated kernel widths / the width a configured one runs at (0: too wide)
-inline int kernel_width(int u) { return u <= 32 ? 32 : (u <= 64 ? 64 : (u <= 100 ? 100 : (u <= 124 ? 124 : 0))); }
 
 int check_cfg(const tae_config* c) {
     if (!c) return fail(TAE_EINVAL, "config is NULL");
@@ -500,10 +331,7 @@ size_t pack_stack_h_dense(const float* src, const LayoutH& lo, int n_layer, int 
 // Gate rows of one direction in 19 MFMA row tiles: tile 3*ut + g = gate g (r, z, n) of units 16*ut + m;
 // remainder tile 18, row 4*qq + i = gate i of unit 96 + qq.  `slot3` says what the remainder's 4th row holds:
 // nothing (-1) or the n gate again (layer-0 input projection), in which case row i = 2 is empty instead.
-constexpr int kGH = 100, kGRT = 19, kGKP = 13;
-constexpr size_t kGRecF = (size_t)kGRT * kGKP * 128, kGXF = (size_t)kGRT * 128, kGB0 = 25 * 16, kGB1 = 7 * 16;
-constexpr size_t kGProjF = 2 * 25 * (size_t)kGRT * 128, kGPB = 2 * (size_t)kGRT * 16;
-constexpr size_t kGL0Dir = kGRecF + kGXF + kGB0, kGL1Dir = kGRecF + kGB1;
+// (fragment geometry constants kGH, kGRT, kGRecF, ... : turboae_host.hpp - the launch code indexes the packed buffers with them)
 
 inline int gru_row(int T, int m, bool n_in_slot3) {
     if (T < 18) return (T % 3) * kGH + 16 * (T / 3) + m;
@@ -620,9 +448,7 @@ std::vector<size_t> dec_rnn_nouts(size_t F, int n_iter) {
 }
 
 // ---- GRU decoder, f16x2 representation (turboae_gru_h2.hip) -----------------------------------------------
-constexpr size_t kGHTileB = 3 * 2048 + 1024, kGHFragB = 19 * kGHTileB, kGHNiB = 6 * 1024;
-constexpr size_t kGHRec0B = kGHFragB + kGHNiB + 25 * 64 + 16, kGHRec1B = kGHFragB + kGHTileB + 7 * 64 + 16;
-constexpr size_t kGHProjDirB = 7 * 19 * 2048, kGHProjB = 2 * kGHProjDirB + 2 * 19 * 64 + 16;
+// (kGHTileB, kGHRec0B, kGHProjB, ... : turboae_host.hpp)
 
 inline void put_split(char* dst, size_t hi_off, size_t lo_off, float w) {
     const uint16_t hi = f2h(w), lo = f2h(w - h2f(hi));
@@ -979,526 +805,6 @@ bool needs_embedding(const tae_config* c) {
            (c->dec_type == 0 ? kernel_width(c->dec_num_unit) : 100) != c->dec_num_unit;
 }
 
-// `h2`: size for the f16x2 kernels' panels (the arithmetic that will run); `taps` > 5 exists there only
-int choose_nb(int U, int L, int* lds_out, bool h2 = false, int taps = 5, int range_layers = 0) {
-    const int max_pos = tae::fused_max_positions();
-    int nb = max_pos / L;
-    auto bytes = [&](int n) { return h2 ? tae::fused_lds_bytes_h(U, L, n, taps, range_layers) : tae::fused_lds_bytes(U, L, n); };
-    while (nb >= 1 && bytes(nb) > 160 * 1024) --nb;
-    if (nb < 1) return 0;
-    *lds_out = bytes(nb);
-    return nb;
-}
-
-// Segment geometry of the long-block path.  A workgroup holds at most fused_max_positions() panel positions: T centre
-// positions + H halo positions per side (+ up to 3 alignment rows); halos that would lie outside the block are not walked
-// (the kernels clip the panel to [0, L)).  Segments are BALANCED (block_len 1000, H = 10: 4 x 250, 17 / 18 / 18 / 17 position
-// tiles).  Measured on MI355X (tools/seg_ab.sh, 25 000 blocks of 1000): balanced 4 x 250 412-419 ms per forward; panel-filling
-// segments with a short last one (310 + 297 + 297 + 96, T0 = T + H + 3) 434-441 ms although they walk 7 % fewer tile rows
-// (full 20-tile workgroups run every SIMD at 5 tiles and clock lower; the short workgroup still pays the fixed prologue);
-// 5 x 200 445 ms, 6 x 167 440 ms, 8 x 125 (two workgroups per CU) 545 ms.  T0 (segment 0 may own more centre positions, it
-// has no left halo) is kept in the kernel interface and set to T.
-bool choose_seg(int U, int L, int n_layer, int* T, int* T0, int* nseg, int* lds, bool dense = false, bool h2 = false, int taps = 5) {
-    const int H = (taps / 2) * n_layer;
-    auto seg_bytes = [&](int t) { return h2 ? tae::seg_lds_bytes_h(U, t, n_layer, taps) : tae::seg_lds_bytes(U, t, n_layer); };
-    int tmax = tae::fused_max_positions() - 2 * H - 3;    // 3 alignment rows: panel origin floored to a multiple of 4
-    if (dense) {
-        // every earlier layer's output stays resident (n_layer - 1 panels): a segment is one position group (5 tiles) at most
-        tmax = 80 - 2 * H - 3;
-        while (tmax >= 8 && tae::seg_lds_bytes_h_dense(U, tmax, n_layer) > 160 * 1024) tmax -= 4;
-        if (tmax < 8) return false;
-        *nseg = (L + tmax - 1) / tmax;
-        *T = (L + *nseg - 1) / *nseg;
-        *T0 = *T;
-        *lds = tae::seg_lds_bytes_h_dense(U, *T, n_layer);
-        return true;
-    }
-    while (tmax >= 16 && seg_bytes(tmax) > 160 * 1024) tmax -= 16;
-    if (tmax < 16) return false;
-    const char* cap = tae::debug_knob("TAE_SEG_T");
-    if (cap && atoi(cap) >= 1 && atoi(cap) < tmax) {      // testing knob: equal segments of at most this many centre positions
-        tmax = atoi(cap);
-        *nseg = (L + tmax - 1) / tmax;
-        *T = (L + *nseg - 1) / *nseg;
-        *T0 = *T;
-        *lds = seg_bytes(*T);
-        return true;
-    }
-    *nseg = (L + tmax - 1) / tmax;
-    *T = (L + *nseg - 1) / *nseg;      // balanced segments
-    *T0 = *T;
-    *lds = seg_bytes(*T);
-    return true;
-}
-
-// Blocks per workgroup for one call of the whole-block f16x2 kernels.  One workgroup is resident per CU and its time
-// is set by the most loaded of its 4 position groups (group_span in turboae_h2.hip): measured on MI355X, about
-// 0.33 + 0.135 * tiles (ms per decoder workgroup: 2 tiles 0.60, 5 tiles 1.00), i.e. proportional to 5 + 2 * tiles.
-// A large batch wants the fullest workgroups (3 blocks of 100 -> 5 tiles per group); a batch that would leave CUs
-// idle is cheaper spread thinner (500 blocks: 250 workgroups x 4 tiles instead of 167 x 5; <= 256 blocks: one block
-// per workgroup, 2 tiles).  Results do not depend on the choice (blocks never see each other).
-int nb_for_batch(const tae_handle* h, int32_t B, int nb_max) {
-    if (h->fixed_nb || h->prec != 1) return nb_max;
-    const int L = h->cfg.block_len;
-    int best = nb_max;
-    long best_cost = -1;
-    for (int nb = nb_max; nb >= 1; --nb) {              // ties keep the larger nb (fewer passes over the weights)
-        const long grid = ((long)B + nb - 1) / nb;
-        const long rounds = (grid + h->ncu - 1) / h->ncu;
-        const long ntile = ((long)nb * L + 15) / 16;
-        const long cost = rounds * (5 + 2 * ((ntile + 3) / 4));
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nb; }
-    }
-    return best;
-}
-
-// Grid of one call of the whole-block f16x2 kernels: full rounds of ncu workgroups with nb blocks each, and the blocks that are
-// left (less than one round's worth) dealt nb_tail per workgroup with nb_tail chosen like nb_for_batch does: the last, partial
-// round then costs 5 + 2 * ceil(tiles(nb_tail) / 4) instead of a full workgroup time (50 000 blocks on 256 CUs: 65 rounds of
-// 256 x 3 blocks + 80 single-block workgroups instead of 27 three-block ones).  Returns the grid size.
-int tail_geometry(const tae_handle* h, int32_t B, int nb, tae::FusedParams* P) {
-    P->n_full = -1;
-    P->nb_tail = nb;
-    const int grid = (B + nb - 1) / nb;
-    if (h->fixed_nb || nb <= 1 || grid <= h->ncu) return grid;       // a single round is nb_for_batch's business
-    const int n_full = (B / nb) / h->ncu * h->ncu;                    // whole rounds of full workgroups
-    const int rest = B - n_full * nb;                                 // < ncu * nb + nb blocks
-    if (rest <= 0) return grid;
-    const int L = h->cfg.block_len;
-    int best = nb;
-    long best_cost = -1;
-    for (int t = nb; t >= 1; --t) {
-        const long g = ((long)rest + t - 1) / t, rounds = (g + h->ncu - 1) / h->ncu;
-        const long ntile = ((long)t * L + 15) / 16;
-        const long cost = rounds * (5 + 2 * ((ntile + 3) / 4));
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = t; }
-    }
-    if (best == nb) return grid;
-    P->n_full = n_full;
-    P->nb_tail = best;
-    return n_full + (rest + best - 1) / best;
-}
-
-// A handle's weights, workspace and kernel launches live on the device that was current at tae_create: a call made with another
-// current device would launch there on foreign pointers (a fault, or silent peer traffic over xGMI).  One handle per GPU; a process
-// that drives several GPUs makes the handle's device current before calling (hipSetDevice / torch.cuda.device).
-int check_handle(tae_handle* h) {
-    if (!h) return fail(TAE_EINVAL, "handle is NULL");
-    int cur = -1;
-    if (hipGetDevice(&cur) != hipSuccess || cur != h->device)
-        return fail(TAE_ESTATE, "handle belongs to device " + std::to_string(h->device) + " but the calling thread's current device is " +
-                                    std::to_string(cur) + " (make the handle's device current first)");
-    return TAE_OK;
-}
-
-int check_batch(tae_handle* h, int32_t B) {
-    const int rc = check_handle(h);
-    if (rc != TAE_OK) return rc;
-    if (B < 1) return fail(TAE_EINVAL, "batch must be >= 1");
-    if (B > h->cap) return fail(TAE_ESTATE, "batch exceeds reserved workspace; call tae_reserve first");
-    return TAE_OK;
-}
-
-tae_noise_opts default_noise_opts() {
-    tae_noise_opts o;
-    o.struct_size = (int32_t)sizeof(tae_noise_opts);
-    o.kind = TAE_NOISE_AWGN;
-    o.vv = 5.0f; o.radar_prob = 0.05f; o.radar_power = 5.0f;      // get_args.py:53-56
-    o.p_gg = 0.8f; o.p_bb = 0.8f;                                  // channels.py:60-61,86-87
-    return o;
-}
-
-int check_noise_opts(const tae_noise_opts* o) {
-    if (o->struct_size != (int32_t)sizeof(tae_noise_opts)) return fail(TAE_EINVAL, "tae_noise_opts.struct_size mismatch (ABI)");
-    if (o->kind < TAE_NOISE_AWGN || o->kind > TAE_NOISE_FADING) return fail(TAE_EINVAL, "tae_noise_opts.kind must be one of TAE_NOISE_*");
-    if (o->kind == TAE_NOISE_TDIST && !(o->vv > 2.0f)) return fail(TAE_EINVAL, "t-dist needs vv > 2 (the reference scales by sqrt((vv - 2) / vv), channels.py:41)");
-    if (o->kind == TAE_NOISE_RADAR && !(o->radar_prob >= 0.0f && o->radar_prob <= 1.0f)) return fail(TAE_EINVAL, "radar_prob must be in [0, 1]");
-    if ((o->kind == TAE_NOISE_GE || o->kind == TAE_NOISE_GE_AWGN) && !(o->p_gg >= 0.0f && o->p_gg <= 1.0f && o->p_bb >= 0.0f && o->p_bb <= 1.0f))
-        return fail(TAE_EINVAL, "Gilbert-Elliott transition probabilities must be in [0, 1]");
-    return TAE_OK;
-}
-
-// host-side derivation of the generator's constants from test_sigma (channels.py:27-31,62-63,88-89; utils.py:69-76)
-int make_noise_gen(const tae_noise_opts* o, float test_sigma, tae::NoiseGen* g) {
-    const bool mask = o->kind == TAE_NOISE_BEC || o->kind == TAE_NOISE_BSC || o->kind == TAE_NOISE_GE;
-    if (mask && !(test_sigma >= 0.0f && test_sigma <= 1.0f)) return fail(TAE_EINVAL, "bec / bsc / ge: test_sigma is a probability in [0, 1]");
-    const double sigma = pow(10.0, -(double)test_sigma / 20.0);          // snr_db2sigma
-    const double snr_back = -20.0 * log10(sigma);                       // snr_sigma2db
-    g->kind = o->kind;
-    g->sigma = mask ? 0.0f : (float)sigma;
-    g->p = mask ? test_sigma : 0.0f;
-    g->s_good = (float)pow(10.0, -(snr_back + 1.0) / 20.0);
-    g->s_bad = (float)pow(10.0, -(snr_back - 1.0) / 20.0);
-    g->vv = o->vv; g->radar_prob = o->radar_prob; g->radar_power = o->radar_power; g->p_gg = o->p_gg; g->p_bb = o->p_bb;
-    return TAE_OK;
-}
-
-tae::NormOpts default_norm_opts() {
-    tae::NormOpts o;
-    memset(&o, 0, sizeof(o));
-    o.std = 1.0f;
-    o.enc_value_limit = 1.0f;
-    o.enc_quantize_level = 2.0f;
-    o.rec_quantize_limit = 1.0f;
-    o.rec_quantize_level = 2.0f;
-    return o;
-}
-
-// Calibration array (tae_handle::d_cal, uint32 float bits): encoder part [0] unused | [1 + s * nl + l] layer maxima | then one slot per
-// stack (unused: encoder inputs are +-1); decoder part at cal_dec_offset: [0] max |stack input| of the whole-block kernel |
-// [1 + s * nl + l] | [1 + n_stack * nl + s] max |extrinsic value| stack s staged on the long-block path | [cal_dec_r] max |received value|.
-constexpr float kRangeLow = 8.0f;        // low end of the window in scaled units (packed into the tails / launch parameters)
-constexpr int kRangeTarget = 11;         // calibrated maxima land in [2^10, 2^11)
-constexpr int kRangeMinValues = 2048;    // panels with fewer values per workgroup are not low-checked
-size_t cal_dec_offset(const tae_handle* h) { return 1 + 3 * (size_t)h->cfg.enc_num_layer + 3; }
-size_t cal_dec_r(const tae_handle* h) { return 1 + 2 * (size_t)h->cfg.num_iteration * ((size_t)h->cfg.dec_num_layer + 1); }     // relative to the decoder part
-size_t cal_words(const tae_handle* h) { return cal_dec_offset(h) + cal_dec_r(h) + 1; }
-
-tae::FusedParams base_params(const tae_handle* h, int32_t B, bool decoder) {
-    tae::FusedParams P;
-    memset(&P, 0, sizeof(P));
-    P.perm = h->d_perm;
-    P.inv = h->d_inv;
-    P.B = B;
-    P.L = h->cfg.block_len;
-    P.nb = decoder ? h->nbd : h->nb;
-    P.taps = decoder ? h->cfg.dec_kernel_size : h->cfg.enc_kernel_size;
-    P.n_iter = h->cfg.num_iteration;
-    P.F = h->cfg.num_iter_ft;
-    P.extrinsic = h->cfg.extrinsic;
-    P.act = h->cfg.enc_act;
-    P.lds_bytes = decoder ? h->lds_bytes_d : h->lds_bytes;
-    P.super = decoder ? h->super_d : h->super;
-    // stack-input planes of the fp16-split kernels: the encoder's are +-1 (exponent 0), the whole-block decoder has one exponent
-    const int ax = decoder && !h->dec_Ax.empty() ? h->dec_Ax[0] : 0;
-    P.x_scale = ldexpf(1.0f, ax);
-    P.x_inv = ldexpf(1.0f, -ax);
-    P.x_low = decoder && h->calibrated && !h->calibrating ? ldexpf(h->dec_r_low, ax) : 0.0f;
-    P.cal = h->calibrating ? h->d_cal + (decoder ? cal_dec_offset(h) : 0) : nullptr;
-    P.cal_r = (int32_t)cal_dec_r(h);
-    {   // see FusedParams::track / head2
-        const std::vector<int>& K = decoder ? h->dec_kind : h->enc_kind;
-        const int nl = decoder ? h->cfg.dec_num_layer : h->cfg.enc_num_layer;
-        bool both = false;
-        for (size_t i = 0; i < K.size(); ++i) both = both || ((int)(i % nl) == nl - 1 && K[i] == 2);
-        P.track = h->calibrating ? 2 : (decoder ? 1 : (h->calibrated ? 0 : 2));
-        P.head2 = both ? 1 : 0;          // production launch with both-branch heads: its own (spill-free) instantiation, not the full one
-    }
-    return P;
-}
-
-tae::SegParams seg_params(const tae_handle* h, int32_t B, bool decoder) {
-    tae::SegParams P;
-    memset(&P, 0, sizeof(P));
-    P.perm = h->d_perm;
-    P.inv = h->d_inv;
-    P.B = B;
-    P.L = h->cfg.block_len;
-    P.F = h->cfg.num_iter_ft;
-    P.extrinsic = h->cfg.extrinsic;
-    P.act = h->cfg.enc_act;
-    P.super = decoder ? h->super_d : h->super;
-    P.taps = decoder ? h->cfg.dec_kernel_size : h->cfg.enc_kernel_size;
-    P.dense = h->cfg.dense;
-    for (int s = 0; s < 3; ++s) P.x_scale[s] = (!decoder && (size_t)s < h->enc_Ax.size()) ? ldexpf(1.0f, h->enc_Ax[s]) : 1.0f;
-    P.x_low = 0.0f;                      // decoder: per launch (run_decoder_long), the exponent is the stack's
-    P.cal = h->calibrating ? h->d_cal + (decoder ? cal_dec_offset(h) : 0) : nullptr;
-    P.cal_r = (int32_t)cal_dec_r(h);
-    return P;
-}
-
-int run_encoder_long(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st) {
-    tae::SegParams P = seg_params(h, B, false);
-    P.wpack = h->d_wenc;
-    P.in = u;
-    P.out = xtx;
-    P.partials = h->d_partials;
-    P.mode = 0;
-    P.T = h->enc_T;
-    P.T0 = h->enc_T0;
-    P.nseg = h->enc_nseg;
-    P.n_layer = h->cfg.enc_num_layer;
-    P.stack_stride = h->enc_stride;
-    P.wpack_bytes = h->enc_bytes;
-    P.lds_bytes = h->enc_lds;
-    const int grid = 3 * B * h->enc_nseg;
-    if (h->prec == 1) {
-        P.wpack = reinterpret_cast<const float*>(h->d_wenc_h);
-        P.stack_stride = h->enc_stride_h;
-        P.wpack_bytes = h->enc_bytes_h;
-        P.lds_bytes = h->enc_lds_h;
-        P.flags = h->d_flags;
-        TAE_HIP(tae::launch_seg_h(h->U, P, grid, st));
-    } else
-    TAE_HIP(tae::launch_seg(h->U, P, grid, st));
-    TAE_HIP(tae::launch_reduce_partials(h->d_partials, grid, (double)B * h->cfg.block_len * 3.0, stats, st));
-    return TAE_OK;
-}
-
-int run_decoder_long(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st, float* tap_out = nullptr) {
-    tae::SegParams P = seg_params(h, B, true);
-    P.wpack = h->d_wdec;
-    P.in = rx;
-    P.out = xdec;
-    P.mode = 1;
-    P.T = h->dec_T;
-    P.T0 = h->dec_T0;
-    P.nseg = h->dec_nseg;
-    P.n_layer = h->cfg.dec_num_layer;
-    P.stack_stride = h->dec_stride;
-    P.wpack_bytes = h->dec_bytes;
-    P.lds_bytes = h->dec_lds;
-    const int n_stack = 2 * h->cfg.num_iteration;
-    const int grid = B * h->dec_nseg;
-    if (h->prec == 1) {
-        P.wpack = reinterpret_cast<const float*>(h->d_wdec_h);
-        P.stack_stride = h->dec_stride_h;
-        P.wpack_bytes = h->dec_bytes_h;
-        P.lds_bytes = h->dec_lds_h;
-        P.flags = h->d_flags;
-    }
-    for (int s = 0; s < n_stack; ++s) {
-        P.stack = s;
-        P.last = (s == n_stack - 1);
-        P.x_scale[0] = (size_t)s < h->dec_Ax.size() ? ldexpf(1.0f, h->dec_Ax[s]) : 1.0f;
-        P.x_low = (size_t)s < h->dec_Ax.size() && h->calibrated && !h->calibrating ? ldexpf(h->dec_r_low, h->dec_Ax[s]) : 0.0f;
-        P.cal_x = 1 + n_stack * h->cfg.dec_num_layer + s;
-        P.eprev = (s & 1) ? h->d_e0 : h->d_e1;
-        P.ecur = (s & 1) ? h->d_e1 : h->d_e0;
-        if (h->prec == 1) TAE_HIP(tae::launch_seg_h(h->Ud, P, grid, st));
-        else TAE_HIP(tae::launch_seg(h->Ud, P, grid, st));
-        if (tap_out && !P.last) {       // (B, L, 8) exchange rows -> compact (B, L, F)
-            const size_t F = (size_t)h->cfg.num_iter_ft, rows = (size_t)B * h->cfg.block_len;
-            TAE_HIP(hipMemcpy2DAsync(tap_out + (size_t)s * rows * F, F * sizeof(float), P.ecur, 8 * sizeof(float), F * sizeof(float), rows,
-                                     hipMemcpyDeviceToDevice, st));
-        }
-    }
-    return TAE_OK;
-}
-
-int run_encoder_rnn(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st);
-
-int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st) {
-    if (h->gen) return tae::generic_encode(h->gen, u, xtx, stats, h->d_perm, B, st);
-    if (h->cfg.enc_type == 1) return run_encoder_rnn(h, u, xtx, stats, B, st);
-    if (h->nb < 1) return run_encoder_long(h, u, xtx, stats, B, st);
-    tae::FusedParams P = base_params(h, B, false);
-    P.wpack = h->d_wenc;
-    P.in = u;
-    P.out = xtx;
-    P.partials = h->d_partials;
-    P.n_layer = h->cfg.enc_num_layer;
-    P.stack_stride = h->enc_stride;
-    P.wpack_bytes = h->enc_bytes;
-    P.nb = nb_for_batch(h, B, h->nb);
-    P.n_full = -1;
-    int grid = (B + P.nb - 1) / P.nb;
-    if (h->prec == 1) {
-        grid = tail_geometry(h, B, P.nb, &P);
-        P.wpack = reinterpret_cast<const float*>(h->d_wenc_h);
-        P.stack_stride = h->enc_stride_h;
-        P.wpack_bytes = h->enc_bytes_h;
-        P.lds_bytes = P.nb == h->nb ? h->lds_bytes_h : tae::fused_lds_bytes_h(h->U, h->cfg.block_len, P.nb, P.taps, 3 * h->cfg.enc_num_layer);
-        P.flags = h->d_flags;
-        TAE_HIP(tae::launch_fused_h(h->U, false, P, grid, st));
-    } else
-    TAE_HIP(tae::launch_fused(h->U, false, P, grid, st));
-    TAE_HIP(tae::launch_reduce_partials(h->d_partials, grid, (double)B * h->cfg.block_len * 3.0, stats, st));
-    return TAE_OK;
-}
-
-// layer 1 of a GRU stack as one kernel (f16x2 path): `img` = the stack's two GruL1fLayout images
-tae::GruL1fParams l1f_params(const tae_handle* h, const char* img, int32_t Bc) {
-    tae::GruL1fParams F;
-    memset(&F, 0, sizeof(F));
-    F.w = img; F.w_dir_stride = (uint32_t)tae::GruL1fLayout::kDirB;
-    F.y0 = reinterpret_cast<const char*>(h->d_gy0); F.hpart = h->d_gy1;
-    F.B = Bc; F.L = h->cfg.block_len; F.ngroups = (Bc + 15) / 16;
-    return F;
-}
-
-// ENC_interRNN.forward before power_constraint (encoders.py:281-296): three GRU stacks on the decoder's kernels
-// (rec layer 0 -> projection -> rec layer 1 -> head in encoder mode), per internal chunk; every head workgroup leaves a
-// partial (sum, sumsq) that reduce_partials adds in fixed order.
-int run_encoder_rnn(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st) {
-    const int L = h->cfg.block_len, H = 100;
-    int slot = 0;
-    {   // every head launch writes gru_head_grid(npos) partial-sum slots: check the whole call BEFORE anything is launched
-        long need = 0;
-        for (int32_t c0 = 0; c0 < B; c0 += h->rnn_chunk) {
-            const int32_t Bc = (B - c0 < h->rnn_chunk) ? B - c0 : h->rnn_chunk;
-            const size_t npos = h->prec == 1 ? (size_t)((Bc + 15) / 16) * 16 * L : (size_t)Bc * L;
-            need += 3L * tae::gru_head_grid(npos);
-        }
-        if (need > h->rnn_partial_slots) return fail(TAE_ESTATE, "internal: GRU-encoder partial-sum slots exceeded");
-    }
-    for (int32_t c0 = 0; c0 < B; c0 += h->rnn_chunk) {
-        const int32_t Bc = (B - c0 < h->rnn_chunk) ? B - c0 : h->rnn_chunk;
-        const size_t np = (size_t)Bc * L, npg = (size_t)((Bc + 15) / 16) * 16 * L;
-        const float* w = h->d_wernn;
-        const char* wb = h->d_wernn_h;
-        for (int s = 0; s < 3; ++s) {
-            TAE_HIP(tae::launch_gru_prep_enc(u + (size_t)c0 * L, h->d_perm, h->d_gxa, Bc, L, s == 2 ? 1 : 0, st));
-            tae::GruRecParams R0, R1;
-            tae::GruProjParams PP;
-            memset(&PP, 0, sizeof(PP));
-            tae::GruHeadParams HP;
-            memset(&R0, 0, sizeof(R0)); memset(&R1, 0, sizeof(R1)); memset(&HP, 0, sizeof(HP));
-            R0.x = h->d_gxa; R0.B = Bc; R0.L = L; R0.y = h->d_gy0;
-            R1.gi = h->d_ggi; R1.B = Bc; R1.L = L; R1.y = h->d_gy1;
-            PP.yin = h->d_gy0; PP.gi = h->d_ggi; PP.B = Bc; PP.L = L;
-            const float* wl;
-            if (h->prec == 1) {
-                R0.w = reinterpret_cast<const float*>(wb); R0.w_dir_stride = (uint32_t)kGHRec0B;
-                const char* w1 = wb + 2 * kGHRec0B;
-                PP.w = reinterpret_cast<const float*>(w1); PP.npos = npg;
-                R1.w = reinterpret_cast<const float*>(w1 + kGHProjB); R1.w_dir_stride = (uint32_t)kGHRec1B;
-                wl = reinterpret_cast<const float*>(w1 + kGHProjB + 2 * kGHRec1B);
-                R1.hpart = h->d_gy1;          // per-direction head products (the layer-1 recurrence contracts Y1 away)
-                TAE_HIP(tae::launch_gru_rec_h(true, R0, st));
-                if (h->gru_l1_split) {
-                    TAE_HIP(tae::launch_gru_proj_h(PP, st));
-                    TAE_HIP(tae::launch_gru_rec_h(false, R1, st));
-                } else {
-                    TAE_HIP(tae::launch_gru_l1f(l1f_params(h, wb + rnn_h_l1f_offset(1), Bc), st));
-                }
-                wb += rnn_h_stack_bytes(1);
-            } else {
-                R0.w = w; R0.w_dir_stride = (uint32_t)kGL0Dir;
-                const float* w1 = w + 2 * kGL0Dir;
-                PP.w = w1; PP.npos = np;
-                R1.w = w1 + kGProjF + kGPB; R1.w_dir_stride = (uint32_t)kGL1Dir;
-                wl = w1 + kGProjF + kGPB + 2 * kGL1Dir;
-                TAE_HIP(tae::launch_gru_rec(true, R0, st));
-                TAE_HIP(tae::launch_gru_proj(PP, st));
-                TAE_HIP(tae::launch_gru_rec(false, R1, st));
-                w += rnn_packed_stack_floats(1);
-            }
-            HP.y = h->d_gy1; HP.w = wl; HP.b = wl + 2 * H; HP.npos = h->prec == 1 ? npg : np; HP.L = L; HP.F = 1; HP.nout = 1;
-            HP.grouped = h->prec == 1 ? 1 : 0; HP.B = Bc;
-            HP.enc_stack = s; HP.act = h->cfg.enc_act; HP.xtx = xtx + (size_t)c0 * L * 3;
-            HP.partials = h->d_rnn_partials + (size_t)slot * 2;
-            if (h->prec == 1) TAE_HIP(tae::launch_gru_head_part(HP, st));
-            else TAE_HIP(tae::launch_gru_head(HP, st));
-            slot += tae::gru_head_grid(HP.npos);
-        }
-    }
-    TAE_HIP(tae::launch_reduce_partials(h->d_rnn_partials, slot, (double)B * L * 3.0, stats, st));
-    return TAE_OK;
-}
-
-// DEC_LargeRNN.forward (decoders.py:84-149): per half-iteration rec(layer 0) -> proj -> rec(layer 1) -> head
-int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st) {
-    const int L = h->cfg.block_len, F = h->cfg.num_iter_ft, H = 100, n_iter = h->cfg.num_iteration;
-    for (int32_t c0 = 0; c0 < B; c0 += h->rnn_chunk) {
-        const int32_t Bc = (B - c0 < h->rnn_chunk) ? B - c0 : h->rnn_chunk;
-        const size_t np = (size_t)Bc * L;
-        TAE_HIP(tae::launch_gru_prep(rx + (size_t)c0 * L * 3, h->d_perm, h->d_gxa, h->d_gxb, Bc, L, st));
-        if (h->prec == 1) {
-            // f16x2 kernels: layer 0 writes Y0 as halves straight into the projection's operand layout
-            const char* wb = h->d_wrnn_h;
-            for (int s = 0; s < 2 * n_iter; ++s) {
-                const bool odd = (s & 1) != 0, last = (s == 2 * n_iter - 1);
-                const int nout = last ? 1 : F;
-                const float* xin = odd ? h->d_gxb : h->d_gxa;
-                tae::GruRecParams R0;
-                memset(&R0, 0, sizeof(R0));
-                R0.w = reinterpret_cast<const float*>(wb); R0.w_dir_stride = (uint32_t)kGHRec0B; R0.x = xin; R0.B = Bc; R0.L = L; R0.y = h->d_gy0;
-                TAE_HIP(tae::launch_gru_rec_h(true, R0, st));
-                const char* w1 = wb + 2 * kGHRec0B;
-                tae::GruProjParams PP;
-            memset(&PP, 0, sizeof(PP));
-                const size_t npg = (size_t)((Bc + 15) / 16) * 16 * L;       // block-group-major rows incl. the padding blocks of the last group
-                PP.yin = h->d_gy0; PP.w = reinterpret_cast<const float*>(w1); PP.gi = h->d_ggi; PP.npos = npg; PP.B = Bc; PP.L = L;
-                tae::GruRecParams R1;
-                memset(&R1, 0, sizeof(R1));
-                R1.w = reinterpret_cast<const float*>(w1 + kGHProjB); R1.w_dir_stride = (uint32_t)kGHRec1B; R1.gi = h->d_ggi; R1.B = Bc; R1.L = L; R1.hpart = h->d_gy1;
-                if (h->gru_l1_split) {        // r04 form (debug knob): projection to HBM, then the block-split recurrence
-                    TAE_HIP(tae::launch_gru_proj_h(PP, st));
-                    TAE_HIP(tae::launch_gru_rec_h(false, R1, st));
-                } else {
-                    TAE_HIP(tae::launch_gru_l1f(l1f_params(h, wb + rnn_h_l1f_offset((size_t)nout), Bc), st));
-                }
-                const float* wl = reinterpret_cast<const float*>(w1 + kGHProjB + 2 * kGHRec1B);
-                tae::GruHeadParams HP;
-                memset(&HP, 0, sizeof(HP));
-                HP.y = h->d_gy1; HP.w = wl; HP.b = wl + (size_t)nout * 2 * H; HP.xcur = xin;
-                HP.xnext = odd ? h->d_gxa : h->d_gxb; HP.xdec = xdec + (size_t)c0 * L;
-                HP.ptab = odd ? h->d_perm : h->d_inv;
-                HP.npos = npg; HP.L = L; HP.F = F; HP.nout = nout; HP.extrinsic = h->cfg.extrinsic; HP.last = last ? 1 : 0;
-                HP.grouped = 1; HP.B = Bc; HP.enc_stack = -1; HP.act = h->cfg.dec_act;
-                TAE_HIP(tae::launch_gru_head_part(HP, st));
-                wb += rnn_h_stack_bytes((size_t)nout);
-            }
-            continue;
-        }
-        const float* w = h->d_wrnn;
-        for (int s = 0; s < 2 * n_iter; ++s) {
-            const bool odd = (s & 1) != 0, last = (s == 2 * n_iter - 1);
-            const int nout = last ? 1 : F;
-            const float* xin = odd ? h->d_gxb : h->d_gxa;
-            tae::GruRecParams R0;
-            memset(&R0, 0, sizeof(R0));
-            R0.w = w; R0.w_dir_stride = (uint32_t)kGL0Dir; R0.x = xin; R0.B = Bc; R0.L = L; R0.y = h->d_gy0;
-            TAE_HIP(tae::launch_gru_rec(true, R0, st));
-            const float* w1 = w + 2 * kGL0Dir;
-            tae::GruProjParams PP;
-            memset(&PP, 0, sizeof(PP));
-            PP.yin = h->d_gy0; PP.w = w1; PP.gi = h->d_ggi; PP.npos = np; PP.B = Bc; PP.L = L;
-            TAE_HIP(tae::launch_gru_proj(PP, st));
-            tae::GruRecParams R1;
-            memset(&R1, 0, sizeof(R1));
-            R1.w = w1 + kGProjF + kGPB; R1.w_dir_stride = (uint32_t)kGL1Dir; R1.gi = h->d_ggi; R1.B = Bc; R1.L = L; R1.y = h->d_gy1;
-            TAE_HIP(tae::launch_gru_rec(false, R1, st));
-            const float* wl = w1 + kGProjF + kGPB + 2 * kGL1Dir;
-            tae::GruHeadParams HP;
-            memset(&HP, 0, sizeof(HP));
-            HP.y = h->d_gy1; HP.w = wl; HP.b = wl + (size_t)nout * 2 * H; HP.xcur = xin;
-            HP.xnext = odd ? h->d_gxa : h->d_gxb; HP.xdec = xdec + (size_t)c0 * L;
-            HP.ptab = odd ? h->d_perm : h->d_inv;     // dec1 -> interleave (row inv[t]); dec2 -> deinterleave (row p[i])
-            HP.npos = np; HP.L = L; HP.F = F; HP.nout = nout; HP.extrinsic = h->cfg.extrinsic; HP.last = last ? 1 : 0;
-            HP.enc_stack = -1; HP.act = h->cfg.dec_act;
-            TAE_HIP(tae::launch_gru_head(HP, st));
-            w += rnn_packed_stack_floats((size_t)nout);
-        }
-    }
-    return TAE_OK;
-}
-
-int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st, float* tap_out = nullptr) {
-    if (h->gen) {
-        if (tap_out) return fail(TAE_EINVAL, "tae_decode_taps: no tap export on the generic fp32 kernels");
-        return tae::generic_decode(h->gen, rx, xdec, h->d_perm, h->d_inv, B, st);
-    }
-    if (h->cfg.dec_type == 1) {
-        if (tap_out) return fail(TAE_EINVAL, "tae_decode_taps: the GRU decoder has no tap export");
-        return run_decoder_rnn(h, rx, xdec, B, st);
-    }
-    if (h->nbd < 1) return run_decoder_long(h, rx, xdec, B, st, tap_out);
-    tae::FusedParams P = base_params(h, B, true);
-    P.tap_out = tap_out;
-    P.wpack = h->d_wdec;
-    P.in = rx;
-    P.out = xdec;
-    P.n_layer = h->cfg.dec_num_layer;
-    P.stack_stride = h->dec_stride;
-    P.wpack_bytes = h->dec_bytes;
-    P.nb = nb_for_batch(h, B, h->nbd);
-    P.n_full = -1;
-    int grid = (B + P.nb - 1) / P.nb;
-    if (h->prec == 1) {
-        grid = tail_geometry(h, B, P.nb, &P);
-        P.wpack = reinterpret_cast<const float*>(h->d_wdec_h);
-        P.stack_stride = h->dec_stride_h;
-        P.wpack_bytes = h->dec_bytes_h;
-        P.lds_bytes = P.nb == h->nbd ? h->lds_bytes_hd : tae::fused_lds_bytes_h(h->Ud, h->cfg.block_len, P.nb, P.taps, 2 * h->cfg.num_iteration * h->cfg.dec_num_layer);
-        P.flags = h->d_flags;
-        TAE_HIP(tae::launch_fused_h(h->Ud, true, P, grid, st));
-        return TAE_OK;
-    }
-    TAE_HIP(tae::launch_fused(h->Ud, true, P, grid, st));
-    return TAE_OK;
-}
 
 // ---- range calibration of the fp16-split conv kernels ---------------------------------------------------------------------
 // The reference convolves in fp32 (cnn_utils.py:36-46: F.conv1d on fp32 tensors), 24 significant bits at any magnitude; an fp16
@@ -1697,33 +1003,13 @@ int calibrate_range(tae_handle* h, const float* u_user, const float* noise_user,
 }
 
 // tae_config.range_fallback: run `call` on the fp16-split handle, wait for it, read the range word, and if a launch left the window
-// run the same call on the fp32 twin - from then on every call goes there (a network that left the window once will again).
-template <class F>
-int with_fallback(tae_handle* h, hipStream_t st, F&& call) {
-    if (!h || !h->fb) return call(h);
-    if (h->fb->cap < h->cap) return fail(TAE_ESTATE, "internal: the fp32 fall-back handle's workspace is smaller than the main handle's");
-    if (h->last_flags & 4u) return call(h->fb);
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-        return fail(TAE_ESTATE, "a handle created with range_fallback synchronises after every call and cannot be captured into a hipGraph");
-    int rc = call(h);
-    if (rc != TAE_OK) return rc;
-    uint32_t f = 0;
-    TAE_HIP(hipStreamSynchronize(st));
-    TAE_HIP(hipMemcpy(&f, h->d_flags, sizeof(f), hipMemcpyDeviceToHost));
-    if ((f & 3u) == 0u) return TAE_OK;
-    TAE_HIP(hipMemset(h->d_flags, 0, sizeof(f)));
-    h->last_flags |= (f & 3u) | 4u;
-    return call(h->fb);
-}
 
-}  // namespace
+}  // namespace host
+}  // namespace tae
+
+using namespace tae::host;
 
 extern "C" {
-
-int tae_abi_version(void) { return TAE_ABI_VERSION; }
-
-const char* tae_last_error(void) { return g_err.c_str(); }
 
 size_t tae_num_weights(const tae_config* cfg) {
     if (check_cfg(cfg) != TAE_OK) return 0;
@@ -2083,320 +1369,6 @@ int tae_reserve(tae_handle* h, int32_t max_batch) {
         }
     }
     h->cap = max_batch;
-    return TAE_OK;
-}
-
-int tae_set_interleaver(tae_handle* h, const int32_t* p, int32_t L) {
-    if (!h || !p) return fail(TAE_EINVAL, "NULL argument");
-    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
-    if (L != h->cfg.block_len) return fail(TAE_EINVAL, "interleaver length must equal block_len");
-    std::vector<int32_t> inv(L, -1);
-    for (int i = 0; i < L; ++i) {
-        if (p[i] < 0 || p[i] >= L || inv[p[i]] != -1) return fail(TAE_EINVAL, "p is not a permutation of 0..L-1");
-        inv[p[i]] = i;   // interleavers.py:29-33
-    }
-    TAE_HIP(hipDeviceSynchronize());
-    TAE_HIP(hipMemcpy(h->d_perm, p, L * sizeof(int32_t), hipMemcpyHostToDevice));
-    TAE_HIP(hipMemcpy(h->d_inv, inv.data(), L * sizeof(int32_t), hipMemcpyHostToDevice));
-    if (h->fb) { const int rc_f = tae_set_interleaver(h->fb, p, L); if (rc_f != TAE_OK) return rc_f; }
-    // The extrinsic values a trained decoder exchanges depend on the permutation: the synthetic calibration made at create (identity
-    // permutation) is repeated ONCE, with the first permutation the caller installs.  Later permutations keep it - another random
-    // permutation of the same network moves a layer maximum by far less than the window (2^-7 .. 2^5 around it; both ends stay
-    // checked per launch), and -is_same_interleaver 0 installs one per forward (r04 re-measured on every one of them: two forward
-    // passes of up to 768 blocks each time) - and a calibration on the caller's own data is never discarded behind its back.
-    if (h->calibrated && !h->cal_user && !h->cal_perm) {
-        const int rc = calibrate_range(h, nullptr, nullptr, 0);
-        h->cal_perm = rc == TAE_OK;
-        return rc;
-    }
-    return TAE_OK;
-}
-
-int tae_set_noise_opts(tae_handle* h, const tae_noise_opts* o) {
-    if (!h) return fail(TAE_EINVAL, "handle is NULL");
-    if (h->fb) { const int rc_f = tae_set_noise_opts(h->fb, o); if (rc_f != TAE_OK) return rc_f; }
-    if (!o) { h->noise_opts = default_noise_opts(); return TAE_OK; }
-    const int rc = check_noise_opts(o);
-    if (rc != TAE_OK) return rc;
-    h->noise_opts = *o;
-    return TAE_OK;
-}
-
-int tae_generate_noise(tae_handle* h, const tae_noise_opts* opts, float test_sigma, float* noise, float* fading_h, int32_t B,
-                       int64_t first_block, uint64_t seed, void* stream) {
-    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
-    if (!opts || !noise) return fail(TAE_EINVAL, "NULL argument");
-    if (B < 1 || first_block < 0) return fail(TAE_EINVAL, "bad block range");
-    int rc = check_noise_opts(opts);
-    if (rc != TAE_OK) return rc;
-    if (opts->kind == TAE_NOISE_FADING && !fading_h) return fail(TAE_EINVAL, "TAE_NOISE_FADING writes the fading coefficients: fading_h is NULL");
-    tae::NoiseGen g;
-    rc = make_noise_gen(opts, test_sigma, &g);
-    if (rc != TAE_OK) return rc;
-    TAE_HIP(tae::launch_gen_noise(g, noise, fading_h, (size_t)B, (size_t)first_block, h->cfg.block_len, seed, (hipStream_t)stream));
-    return TAE_OK;
-}
-
-int tae_set_channel_opts(tae_handle* h, const tae_channel_opts* o) {
-    if (!h) return fail(TAE_EINVAL, "handle is NULL");
-    if (h->fb) { const int rc_f = tae_set_channel_opts(h->fb, o); if (rc_f != TAE_OK) return rc_f; }
-    const tae::NormOpts before = h->nopts;
-    // what the decoder receives changes class with these fields (not with the running mean / std of norm_mode 2): measure again
-    auto recalibrate = [&]() {
-        const tae::NormOpts& a = before; const tae::NormOpts& b = h->nopts;
-        const bool same = a.norm_mode == b.norm_mode && a.ste == b.ste && a.channel == b.channel && a.rec_quantize == b.rec_quantize &&
-                          a.enc_truncate_limit == b.enc_truncate_limit && a.enc_value_limit == b.enc_value_limit &&
-                          a.enc_quantize_level == b.enc_quantize_level && a.rec_quantize_limit == b.rec_quantize_limit &&
-                          a.rec_quantize_level == b.rec_quantize_level;
-        if (same || !h->calibrated || h->cal_user || h->dec_tails.empty()) return (int)TAE_OK;      // (a user calibration stays: the caller re-measures)
-        if (check_handle(h) != TAE_OK) return (int)TAE_OK;      // no device context here: the next tae_set_interleaver / tae_calibrate_range measures
-        return calibrate_range(h, nullptr, nullptr, 0);
-    };
-    if (!o) { h->nopts = default_norm_opts(); return recalibrate(); }
-    if (o->struct_size != (int32_t)sizeof(tae_channel_opts)) return fail(TAE_EINVAL, "tae_channel_opts.struct_size mismatch (ABI)");
-    if (o->norm_mode < 0 || o->norm_mode > 2) return fail(TAE_EINVAL, "norm_mode must be 0, 1 or 2");
-    if (o->norm_mode == 2 && !(o->std > 0.0f)) return fail(TAE_EINVAL, "fixed std must be > 0");
-    if (o->channel < 0 || o->channel > 3) return fail(TAE_EINVAL, "channel must be 0 (additive), 1 (bec), 2 (bsc/ge) or 3 (fading)");
-    if (o->ste && (!(o->enc_value_limit > 0.0f) || o->enc_quantize_level < 2.0f)) return fail(TAE_EINVAL, "bad STE quantiser parameters");
-    if (o->rec_quantize && (!(o->rec_quantize_limit > 0.0f) || o->rec_quantize_level < 2.0f)) return fail(TAE_EINVAL, "bad receive quantiser parameters");
-    tae::NormOpts n;
-    n.norm_mode = o->norm_mode; n.mean = o->mean; n.std = o->std;
-    n.ste = o->ste; n.enc_value_limit = o->enc_value_limit; n.enc_quantize_level = o->enc_quantize_level;
-    n.enc_truncate_limit = o->enc_truncate_limit;
-    n.channel = o->channel; n.rec_quantize = o->rec_quantize;
-    n.rec_quantize_limit = o->rec_quantize_limit; n.rec_quantize_level = o->rec_quantize_level;
-    h->nopts = n;
-    return recalibrate();
-}
-
-int tae_encode_prenorm(tae_handle* h, const float* u, float* x_tx, double* stats3, int32_t B, void* stream) {
-    int rc = check_batch(h, B);
-    if (rc != TAE_OK) return rc;
-    if (!u || !x_tx || !stats3) return fail(TAE_EINVAL, "NULL tensor");
-    return with_fallback(h, (hipStream_t)stream, [&](tae_handle* e) { return run_encoder(e, u, x_tx, stats3, B, (hipStream_t)stream); });
-}
-
-int tae_normalize(tae_handle* h, const float* x_tx, const double* stats3, const float* noise, float* codes, float* received,
-                  int32_t B, void* stream) {
-    int rc = check_batch(h, B);
-    if (rc != TAE_OK) return rc;
-    if (!x_tx || !stats3) return fail(TAE_EINVAL, "NULL tensor");
-    if ((received != nullptr) != (noise != nullptr)) return fail(TAE_EINVAL, "noise and received must be given together");
-    if (!codes && !received) return fail(TAE_EINVAL, "nothing to write");
-    TAE_HIP(tae::launch_normalize(x_tx, stats3, noise, codes, received, (size_t)B * h->cfg.block_len * 3, h->nopts, (hipStream_t)stream));
-    return TAE_OK;
-}
-
-int tae_encode(tae_handle* h, const float* u, float* codes, int32_t B, void* stream) {
-    int rc = check_batch(h, B);
-    if (rc != TAE_OK) return rc;
-    if (!u || !codes) return fail(TAE_EINVAL, "NULL tensor");
-    return with_fallback(h, (hipStream_t)stream, [&](tae_handle* e) {
-        const int r = run_encoder(e, u, e->d_xtx, e->d_stats, B, (hipStream_t)stream);
-        if (r != TAE_OK) return r;
-        return tae_normalize(e, e->d_xtx, e->d_stats, nullptr, codes, nullptr, B, stream);
-    });
-}
-
-int tae_decode(tae_handle* h, const float* received, float* x_dec, int32_t B, void* stream) {
-    int rc = check_batch(h, B);
-    if (rc != TAE_OK) return rc;
-    if (!received || !x_dec) return fail(TAE_EINVAL, "NULL tensor");
-    return with_fallback(h, (hipStream_t)stream, [&](tae_handle* e) { return run_decoder(e, received, x_dec, B, (hipStream_t)stream); });
-}
-
-int tae_decode_taps(tae_handle* h, const float* received, float* x_dec, float* taps, int32_t B, void* stream) {
-    int rc = check_batch(h, B);
-    if (rc != TAE_OK) return rc;
-    if (!received || !x_dec || !taps) return fail(TAE_EINVAL, "NULL tensor");
-    if (h->cfg.dense) return fail(TAE_EINVAL, "tae_decode_taps: not built for DenseSameShapeConv1d stacks");
-    return run_decoder(h, received, x_dec, B, (hipStream_t)stream, taps);
-}
-
-int tae_forward(tae_handle* h, const float* u, const float* noise, float* x_dec, float* codes, int32_t B, void* stream) {
-    int rc = check_batch(h, B);
-    if (rc != TAE_OK) return rc;
-    if (!u || !noise || !x_dec) return fail(TAE_EINVAL, "NULL tensor");
-    hipStream_t st = (hipStream_t)stream;
-    return with_fallback(h, st, [&](tae_handle* e) {
-        int r = run_encoder(e, u, e->d_xtx, e->d_stats, B, st);
-        if (r != TAE_OK) return r;
-        r = tae_normalize(e, e->d_xtx, e->d_stats, noise, codes, e->d_rx, B, stream);
-        if (r != TAE_OK) return r;
-        return run_decoder(e, e->d_rx, x_dec, B, st);
-    });
-}
-
-// One SNR point of trainer.test (trainer.py:160-217) on the device: per batch generate inputs -> encoder -> power constraint with
-// that batch's statistics -> AWGN; the received blocks of a group of batches are decoded in one call (the decoder never mixes
-// blocks) and the errors are counted per batch.
-static int eval_snr_impl(tae_handle* h, float snr_db, int32_t batch, int32_t n_batches, int64_t first_block, uint64_t seed_bits,
-                         uint64_t seed_noise, uint64_t* counts, void* stream);
-int tae_eval_snr(tae_handle* h, float snr_db, int32_t batch, int32_t n_batches, int64_t first_block, uint64_t seed_bits,
-                 uint64_t seed_noise, uint64_t* counts, void* stream) {
-    return with_fallback(h, (hipStream_t)stream, [&](tae_handle* e) {
-        return eval_snr_impl(e, snr_db, batch, n_batches, first_block, seed_bits, seed_noise, counts, stream);
-    });
-}
-static int eval_snr_impl(tae_handle* h, float snr_db, int32_t batch, int32_t n_batches, int64_t first_block, uint64_t seed_bits,
-                         uint64_t seed_noise, uint64_t* counts, void* stream) {
-    if (!h || !counts) return fail(TAE_EINVAL, "NULL argument");
-    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
-    if (batch < 1 || n_batches < 1 || first_block < 0) return fail(TAE_EINVAL, "bad batch geometry");
-    // the generator must produce what the configured channel consumes (channel_ae.py:41-56): masks for bec / bsc / ge, fading
-    // coefficients for fading, additive noise otherwise
-    const int nk = h->noise_opts.kind;
-    const bool mask_kind = nk == TAE_NOISE_BEC || nk == TAE_NOISE_BSC || nk == TAE_NOISE_GE;
-    if ((h->nopts.channel == 1 || h->nopts.channel == 2) != mask_kind || (h->nopts.channel == 3) != (nk == TAE_NOISE_FADING))
-        return fail(TAE_EINVAL, "tae_eval_snr: the noise generator (tae_set_noise_opts) does not match the channel (tae_set_channel_opts)");
-    const size_t noise_mult = nk == TAE_NOISE_FADING ? 2 : 1;      // fading: coefficients followed by the noise
-    hipStream_t st = (hipStream_t)stream;
-    const size_t L = h->cfg.block_len;
-    int64_t group = (24576 + batch - 1) / batch;           // batches per decoder call: about 24 576 blocks
-    if (group > n_batches) group = n_batches;
-    if (group * batch > h->cap || group * batch > h->eval_group_blocks || batch > h->eval_batch || (noise_mult == 2 && !h->eval_noise_x2)) {
-        // workspace growth: synchronises and allocates (first call for a geometry only - afterwards the call only enqueues work)
-        int rc = tae_reserve(h, (int32_t)(group * batch));
-        if (rc != TAE_OK) return rc;
-        TAE_HIP(hipDeviceSynchronize());
-        (void)hipFree(h->d_eval_u); (void)hipFree(h->d_eval_noise); (void)hipFree(h->d_eval_xdec);
-        h->d_eval_u = h->d_eval_noise = h->d_eval_xdec = nullptr;
-        h->eval_group_blocks = 0; h->eval_batch = 0;
-        TAE_HIP(hipMalloc(&h->d_eval_u, (size_t)group * batch * L * sizeof(float)));
-        TAE_HIP(hipMalloc(&h->d_eval_xdec, (size_t)group * batch * L * sizeof(float)));
-        TAE_HIP(hipMalloc(&h->d_eval_noise, noise_mult * (size_t)batch * L * 3 * sizeof(float)));
-        h->eval_noise_x2 = noise_mult == 2;
-        h->eval_group_blocks = group * batch;
-        h->eval_batch = batch;
-    }
-    TAE_HIP(hipMemsetAsync(counts, 0, (size_t)n_batches * 2 * sizeof(uint64_t), st));
-    for (int64_t g0 = 0; g0 < n_batches; g0 += group) {
-        const int64_t ng = g0 + group <= n_batches ? group : n_batches - g0;
-        for (int64_t i = 0; i < ng; ++i) {
-            float* u = h->d_eval_u + (size_t)i * batch * L;
-            const int64_t fb = first_block + (g0 + i) * batch;
-            int rc = tae_generate_inputs(h, u, nk == TAE_NOISE_AWGN ? h->d_eval_noise : nullptr, batch, fb, seed_bits, seed_noise, snr_db, stream);
-            if (rc != TAE_OK) return rc;
-            if (nk != TAE_NOISE_AWGN) {
-                float* nz = h->d_eval_noise + (noise_mult - 1) * (size_t)batch * L * 3;
-                rc = tae_generate_noise(h, &h->noise_opts, snr_db, nz, nk == TAE_NOISE_FADING ? h->d_eval_noise : nullptr, batch, fb, seed_noise, stream);
-                if (rc != TAE_OK) return rc;
-            }
-            rc = run_encoder(h, u, h->d_xtx, h->d_stats, batch, st);
-            if (rc != TAE_OK) return rc;
-            rc = tae_normalize(h, h->d_xtx, h->d_stats, h->d_eval_noise, nullptr, h->d_rx + (size_t)i * batch * L * 3, batch, stream);
-            if (rc != TAE_OK) return rc;
-        }
-        int rc = run_decoder(h, h->d_rx, h->d_eval_xdec, (int32_t)(ng * batch), st);
-        if (rc != TAE_OK) return rc;
-        for (int64_t i = 0; i < ng; ++i)
-            TAE_HIP(tae::launch_count_errors(h->d_eval_xdec + (size_t)i * batch * L, h->d_eval_u + (size_t)i * batch * L, batch, (int)L,
-                                             (unsigned long long*)(counts + 2 * (g0 + i)), st));
-    }
-    return TAE_OK;
-}
-
-int tae_count_errors(tae_handle* h, const float* x_dec, const float* u, int32_t B, uint64_t* counts2, void* stream) {
-    if (!h || !x_dec || !u || !counts2) return fail(TAE_EINVAL, "NULL argument");
-    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
-    if (B < 1) return fail(TAE_EINVAL, "batch must be >= 1");
-    TAE_HIP(tae::launch_count_errors(x_dec, u, B, h->cfg.block_len, (unsigned long long*)counts2, (hipStream_t)stream));
-    return TAE_OK;
-}
-
-int tae_generate_inputs(tae_handle* h, float* u, float* noise, int32_t B, int64_t first_block, uint64_t seed_bits,
-                        uint64_t seed_noise, float snr_db, void* stream) {
-    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
-    if (B < 1 || first_block < 0) return fail(TAE_EINVAL, "bad block range");
-    if (!u && !noise) return fail(TAE_EINVAL, "nothing to write");
-    const float sigma = (float)pow(10.0, -(double)snr_db / 20.0);   // utils.py:69-70
-    const size_t L = h->cfg.block_len;
-    TAE_HIP(tae::launch_gen_inputs(u, noise, (size_t)B * L, (size_t)first_block * L, seed_bits, seed_noise, sigma, (hipStream_t)stream));
-    return TAE_OK;
-}
-
-int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_t* lds_bytes) {
-    if (!h) return fail(TAE_EINVAL, "handle is NULL");
-    if (h->gen) {          // generic fp32 kernels: no fused geometry to report
-        if (blocks_per_workgroup) *blocks_per_workgroup = 0;
-        if (lds_bytes) *lds_bytes = 0;
-        return TAE_OK;
-    }
-    if (blocks_per_workgroup) *blocks_per_workgroup = h->nbd;        // the decoder's (the dominant kernel)
-    if (lds_bytes) *lds_bytes = h->nbd >= 1 ? (h->prec == 1 ? h->lds_bytes_hd : h->lds_bytes_d) : (h->prec == 1 ? h->dec_lds_h : h->dec_lds);
-    return TAE_OK;
-}
-
-int tae_kernel_variants(tae_handle* h, int32_t* enc_both, int32_t* dec_both) {
-    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
-    const bool whole = !h->gen && h->prec == 1;
-    if (enc_both) *enc_both = (whole && h->cfg.enc_type == 0 && h->nb >= 1) ? base_params(h, 1, false).head2 : 0;
-    if (dec_both) *dec_both = (whole && h->cfg.dec_type == 0 && h->nbd >= 1) ? base_params(h, 1, true).head2 : 0;
-    return TAE_OK;
-}
-
-int tae_overrides(tae_handle*, char* buf, int32_t n) {
-    const std::string r = tae::knob_report();
-    if (buf && n > 0) {
-        const size_t m = std::min((size_t)n - 1, r.size());
-        memcpy(buf, r.data(), m);
-        buf[m] = 0;
-    }
-    return (int)r.size();
-}
-
-int tae_debug_split_f16(const float* x, size_t n, float scale, uint16_t* hi, uint16_t* lo) {
-    if (!x || !hi || !lo) return fail(TAE_EINVAL, "NULL argument");
-    for (size_t i = 0; i < n; ++i) {
-        const float w = x[i] * scale;
-        hi[i] = f2h(w);
-        lo[i] = f2h(w - h2f(hi[i]));
-    }
-    return TAE_OK;
-}
-
-int tae_range_status(tae_handle* h, int32_t* precision, int32_t* overflow) {
-    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
-    if (precision) *precision = h->prec;
-    if (overflow) {
-        uint32_t f = 0;
-        // the launches whose flag is read may sit on any stream (torch side streams are non-blocking: the null-stream copy
-        // below does not order behind them) - wait for the whole device first
-        TAE_HIP(hipDeviceSynchronize());
-        TAE_HIP(hipMemcpy(&f, h->d_flags, sizeof(f), hipMemcpyDeviceToHost));
-        if (f) TAE_HIP(hipMemset(h->d_flags, 0, sizeof(f)));
-        *overflow = (int32_t)((f & 3u) | h->last_flags);
-        h->last_flags &= 4u;           // the fall-back is permanent, the range bits it reacted to are reported once
-    }
-    return TAE_OK;
-}
-
-int tae_calibrate_range(tae_handle* h, const float* u, const float* noise, int32_t B) {
-    { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
-    if ((u == nullptr) != (noise == nullptr)) return fail(TAE_EINVAL, "u and noise must be given together (both NULL: the synthetic batch)");
-    if (u && B < 1) return fail(TAE_EINVAL, "batch must be >= 1");
-    const int rc = calibrate_range(h, u, noise, B);
-    if (rc == TAE_OK) {
-        h->cal_user = u != nullptr;           // the caller's data define the window from here on (a synthetic re-measurement gives it back)
-        if (!u) h->cal_perm = true;
-    }
-    return rc;
-}
-
-int tae_range_info(tae_handle* h, int32_t* n_encoder, int32_t* n_decoder, int32_t* exponents, int32_t capacity, int32_t* passes) {
-    if (!h) return fail(TAE_EINVAL, "handle is NULL");
-    const int32_t ne = (int32_t)(h->enc_A.size() + h->enc_Ax.size()), nd = (int32_t)(h->dec_A.size() + h->dec_Ax.size());
-    if (n_encoder) *n_encoder = h->calibrated ? ne : 0;
-    if (n_decoder) *n_decoder = h->calibrated ? nd : 0;
-    if (passes) *passes = h->cal_passes;
-    if (exponents && h->calibrated) {
-        if (capacity < ne + nd) return fail(TAE_EINVAL, "tae_range_info: capacity too small");
-        int32_t* o = exponents;
-        for (int v : h->enc_Ax) *o++ = v;
-        for (int v : h->enc_A) *o++ = v;
-        for (int v : h->dec_Ax) *o++ = v;
-        for (int v : h->dec_A) *o++ = v;
-    }
     return TAE_OK;
 }
 

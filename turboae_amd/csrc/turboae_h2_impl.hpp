@@ -14,7 +14,7 @@
 // is the 5*U contiguous halves starting at row t-2 of each plane: a B fragment (8 consecutive k) is two
 // ds_read_b64 per plane.
 //
-// Packed stack (bytes), written by turboae_api.hip::pack_stack_h:
+// Packed stack (bytes), written by turboae_api_create.hip::pack_stack_h:
 //   per layer: A fragments [slab][channel tile][hi | lo][lane][8 halves] | bias * 2^S [CP] fp32 | 2^-S x 4 fp32
 //   then Linear weights [8][CP] fp32 | bias [8] fp32
 // where 2^S is the layer's power-of-two weight scale (max |w| * 2^S in [2^13, 2^14)).
@@ -212,7 +212,7 @@ struct WeightStreamH {
 // ---- range bookkeeping of the fp16-split representation ------------------------------------------------------------
 // hi + lo carries a value to 2^-22 relative only while its lo half is a NORMAL fp16 number, i.e. for |x| >= 2^-3; below that
 // the pair has an absolute floor of 2^-25, and above 65504 it overflows.  fp32 has neither limit, so every panel is stored
-// SCALED: layer l writes ELU(v) * 2^A_l with a per-layer exponent the host calibrates (turboae_api.hip::calibrate_range) so
+// SCALED: layer l writes ELU(v) * 2^A_l with a per-layer exponent the host calibrates (turboae_api_create.hip::calibrate_range) so
 // that the layer's largest activation lands in [2^10, 2^11): 2^5 of headroom above, and every value down to 2^-13 of the
 // maximum keeps the full 2^-22 (the floor is then 2^-35 of the maximum - far below the fp32 accumulation noise of the dot
 // products that consume it).  The next layer's accumulators carry 2^(S + A_l) (its bias is pre-scaled, its 2^-(S + A_l) comes
@@ -313,7 +313,7 @@ __device__ __forceinline__ void range_finish(uint32_t* rng, int n_rows, int cal_
 // TAE_ELU_MODE (A/B builds): 0 = exp2 only (r03: absolute error 3e-8 * c), 1 = both expm1 branches per value (elu1's own
 // arithmetic: +9 vector-ALU instructions per value, measured +7 % decoder time - the epilogues of the two waves of a SIMD
 // coincide behind the layer barrier, so their vector-ALU time is exposed), 2 (default) = the host picks per LAYER from the
-// layer's calibrated maximum M (tail[4]; calibrate_range in turboae_api.hip):
+// layer's calibrated maximum M (tail[4]; calibrate_range in turboae_api_create.hip):
 //   kind 1, M <= 2^-5: x (1 + x/2 + x^2/6 + x^3/24) for both signs of x, no exp2 - truncation x^4/120 <= 1.3e-7 relative up to
 //     |x| = 1/16; the layer's high-side threshold is lowered to |x| = 1/8 (2e-6) so that data which outgrows the polynomial
 //     raises TAE_RANGE_HIGH instead of losing accuracy silently;
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
     // The workgroup's position tiles are dealt out evenly over the 4 position groups and a group walks only its own
     // tiles (3 blocks of 100 = 19 tiles -> 5, 5, 5, 4; 2 blocks -> 4, 3, 3, 3; 1 block -> 2, 2, 2, 1): tiles that hold no
     // block are never computed, and a small batch can be spread over more workgroups at a lower cost each (the host
-    // picks blocks per workgroup per call, choose_nb_for_batch in turboae_api.hip).
+    // picks blocks per workgroup per call, nb_for_batch in turboae_api_launch.hip).
     const GroupSpan gs = group_span(npos, g);
     const bool upper = __builtin_amdgcn_readfirstlane(h) != 0;
     auto run = [&](auto pt) {

@@ -29,7 +29,7 @@ struct FusedParams {
     int32_t super;          // 1: remainder channels via super-tiles (needs U % 16 == 4 and block_len % 4 == 0)
     uint32_t* flags;        // f16x2 kernels: bit 0 set when an activation left the fp16 range (stack_stride is in BYTES there)
     int32_t n_full, nb_tail; // f16x2 whole-block kernels: workgroups [0, n_full) own nb blocks each, the rest nb_tail each (the last
-                            // partial round of workgroups runs thinner, see tail_geometry in turboae_api.hip); n_full < 0: all own nb
+                            // partial round of workgroups runs thinner, see tail_geometry in turboae_api_launch.hip); n_full < 0: all own nb
     float* tap_out;         // decoder, debug instantiation only (tae_decode_taps): [2*n_iter-1][B][L][F] extrinsic outputs of every
                             // non-final stack in the producing stack's own position order (before the (de)interleave scatter)
     // f16x2 kernels: the stack-input planes hold value * x_scale (a power of two; x_inv = 1 / x_scale); a workgroup whose largest
@@ -180,7 +180,7 @@ int generic_decode(GenericEngine* g, const float* rx, float* xdec, const int32_t
 // It is inert (nullptr) unless TAE_DEBUG_KNOBS=1 is set in the same environment, and every override that took effect is recorded
 // for tae_overrides().
 const char* debug_knob(const char* name);
-int fail_msg(int code, const char* msg);          // turboae_api.hip: sets the calling thread's tae_last_error string
+int fail_msg(int code, const char* msg);          // turboae_api_entry.hip: sets the calling thread's tae_last_error string
 int fused_lds_bytes(int U, int L, int nb);
 int fused_max_positions();
 

@@ -62,7 +62,7 @@ struct WeightStream {
 // `HS` = head-combine scratch [kHeadSlots][8] floats: the upper channel half parks its partial
 // Linear outputs there and the lower half adds them in a fixed order.
 //
-// Packed stack layout (floats), written by turboae_api.hip::pack_stack:
+// Packed stack layout (floats), written by turboae_api_create.hip::pack_stack:
 //   per layer: A fragments [chunk][...] (see load_w) | bias [CP];  then Linear weights [8][CP] | bias [8]
 // SUPER: this (upper-half) wave additionally computes the 4 remainder channels of its position group with
 // two super-tiles (see super_accumulate); its NC then excludes the padded last channel tile.
