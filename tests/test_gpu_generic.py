@@ -35,8 +35,12 @@ def _run(gpu_device, cfg, meta, name):
 @pytest.mark.parametrize("name", GEN)
 def test_generic_configurations_match_reference_golden(gpu_device, name):
     assert len(GEN) >= 9
+    from dataclasses import replace
     meta = MANIFEST["cases"][name]
     cfg = TurboAEConfig(**meta["config"])
+    if not cfg.generic:      # r05: LSTM / RNN decoders behind the CNN encoder have unit-split f16x2 kernels; precision = f32 keeps them here
+        assert name in ("gen_dec_lstm", "gen_dec_rnn_tanh")
+        cfg = replace(cfg, precision="f32")
     assert cfg.generic
     model, g, xd, codes = _run(gpu_device, cfg, meta, name)
     assert model.range_status() == ("f32", False) and model.kernel_info() == (0, 0)
@@ -49,6 +53,50 @@ def test_generic_configurations_match_reference_golden(gpu_device, name):
     u = torch.from_numpy(g["u"]).to(gpu_device)
     assert torch.equal(model.enc(u).cpu(), torch.from_numpy(codes))
     assert torch.equal(model.dec(torch.from_numpy(codes + g["noise"]).to(gpu_device)).cpu(), torch.from_numpy(xd))
+
+
+@pytest.mark.parametrize("name", ["gen_dec_lstm", "gen_dec_rnn_tanh"])
+def test_lstm_and_rnn_decoders_on_the_unit_split_f16x2_kernels(gpu_device, name):
+    """`-dec_rnn lstm | rnn` (decoders.py:27-32) behind the CNN encoder run on turboae_rnn_u.hip in the default
+    arithmetic - the reference's golden vectors, the GRU tests' tolerances; the generic fp32 kernels stay the second implementation
+    (precision = f32) and agree with it."""
+    from dataclasses import replace
+    meta = MANIFEST["cases"][name]
+    cfg = TurboAEConfig(**meta["config"])
+    assert not cfg.generic and cfg.decoder == "TurboAE_rate3_rnn" and cfg.dec_rnn in ("lstm", "rnn")
+    model, g, xd, codes = _run(gpu_device, cfg, meta, name)
+    assert model.range_status() == ("f16x2", False)
+    assert np.abs(codes - g["codes"]).max() <= 1e-5
+    d = np.abs(xd - g["x_dec"]).max()
+    assert d <= 5e-5, d
+    flips = (xd > 0.5) != (g["x_dec"] > 0.5)
+    assert np.all(np.abs(g["logits"][flips]) < 2e-4)
+    _, _, xd32, codes32 = _run(gpu_device, replace(cfg, precision="f32"), meta, name)
+    assert np.abs(xd - xd32).max() <= 5e-5 and np.abs(codes - codes32).max() <= 1e-5
+
+
+@pytest.mark.parametrize("cell,B,L", [("lstm", 37, 100), ("rnn", 70, 33), ("lstm", 5, 7)])
+def test_lstm_rnn_unit_split_kernels_batch_independence_and_oracle(gpu_device, cell, B, L):
+    """100-unit LSTM / RNN decoders (the width the kernels are built for; the goldens above run narrower cells embedded in it): against
+    the float64-free oracle, ragged batches (partial groups of 32 blocks), sub-batches bit for bit, determinism."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn=cell, block_len=L, num_iteration=2)
+    assert not cfg.generic
+    sd = W.generate_state_dict(cfg, seed=500 + L, gain=1.0)
+    u = philox.random_bits(9, 0, B * L).reshape(B, L, 1)
+    noise = (np.float32(O.snr_db2sigma(1.0)) * philox.random_normal(9, 0, B * L * 3)).reshape(B, L, 3).astype(np.float32)
+    xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict(), {})
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    ud, nd = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
+    xd, codes = model(ud, nd)
+    assert model.range_status() == ("f16x2", False)
+    assert np.abs(codes.cpu().numpy() - co.numpy()).max() <= 1e-5
+    d = np.abs(xd.cpu().numpy() - xo.numpy()).max()
+    assert d <= 6e-5, d
+    rx = codes + nd
+    assert torch.equal(model.dec(rx), xd)                                  # run to run
+    for lo, hi in ((0, 1), (B // 2, B // 2 + 3), (B - 2, B)):
+        assert torch.equal(model.dec(rx[lo:hi].contiguous()), xd[lo:hi]), (lo, hi)
 
 
 @pytest.mark.parametrize("name", ["fwd_dense_u100_L100_b3_it2", "fwd_dense_k3_k1_u32_L64", "var_kernel_e7_d9", "var_kernel_e9_d7_L500"])
@@ -171,10 +219,13 @@ def test_three_independent_implementations_agree_on_the_trained_network(gpu_devi
         assert 4e-3 < ber < 1e-2, ber            # the trained network's operating point at 2 dB (reference: 6.4e-3)
 
 
-def test_generic_path_runs_the_eval_sweep_and_every_entry_point(gpu_device):
-    """evaluate.test, tae_eval_snr and the hipGraph form on an LSTM decoder (all launches are plain kernels on the caller's stream)"""
+@pytest.mark.parametrize("precision", ["f32", "auto"])
+def test_generic_path_runs_the_eval_sweep_and_every_entry_point(gpu_device, precision):
+    """evaluate.test, tae_eval_snr and the hipGraph form on an LSTM decoder (all launches are plain kernels on the caller's stream): on
+    the generic fp32 kernels (precision f32) and on the unit-split f16x2 kernels (auto)"""
     from turboae_amd import Channel_AE_HIP, evaluate
-    cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="lstm", enc_num_unit=16, dec_num_unit=12, num_iteration=1, block_len=20)
+    cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="lstm", enc_num_unit=16, dec_num_unit=12, num_iteration=1, block_len=20, precision=precision)
+    assert cfg.generic == (precision == "f32")
     model = Channel_AE_HIP(cfg, W.generate_state_dict(cfg, seed=3, gain=1.0), device=gpu_device, max_batch=40)
     res = evaluate.test(model, snr_test_start=0.0, snr_test_end=2.0, snr_points=2, num_block=80, batch_size=40, seed=4, verbose=False)
     gr = evaluate.test(model, snr_test_start=0.0, snr_test_end=2.0, snr_points=2, num_block=80, batch_size=40, seed=4, verbose=False, hip_graph=True)

@@ -76,7 +76,10 @@ class TurboAEConfig:
         enc_max, dec_max = (100 if enc_rnn else cnn_max), (100 if dec_rnn else cnn_max)
         if max(ks) > 9 or self.enc_num_unit > enc_max or self.dec_num_unit > dec_max or self.num_iter_ft > 6:
             return True
-        if (enc_rnn and self.enc_rnn != "gru") or (dec_rnn and self.dec_rnn != "gru"):
+        if enc_rnn and self.enc_rnn != "gru":
+            return True
+        # LSTM / vanilla-RNN decoder: unit-split f16x2 kernels (csrc/turboae_rnn_u.hip) behind the CNN encoder; fp32 and RNN-encoder pairings stay generic
+        if dec_rnn and self.dec_rnn != "gru" and (self.precision == "f32" or enc_rnn):
             return True
         if enc_rnn and (self.enc_num_layer != 2 or not dec_rnn):
             return True

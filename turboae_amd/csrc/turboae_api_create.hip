@@ -251,11 +251,11 @@ int check_cfg(const tae_config* c) {
 
 // canonical GRU stack: per layer l and direction d: weight_ih (3H,cin) weight_hh (3H,H) bias_ih (3H) bias_hh (3H);
 // then Linear (nout,2H), bias (nout)   (turboae_amd/weights.py canonical_entries)
-size_t rnn_stack_floats(size_t H, size_t cin0, size_t nout) {
+size_t rnn_stack_floats(size_t H, size_t cin0, size_t nout, size_t G = 3) {
     size_t n = 0;
     for (int l = 0; l < 2; ++l) {
         const size_t cin = l == 0 ? cin0 : 2 * H;
-        n += 2 * (3 * H * cin + 3 * H * H + 3 * H + 3 * H);
+        n += 2 * (G * H * cin + G * H * H + G * H + G * H);
     }
     return n + nout * 2 * H + nout;
 }
@@ -600,6 +600,113 @@ void pack_gru_l1f_dir(const float* Wih, const float* Whh, const float* bih, cons
     b[6 * 64 + 17] = 1.0f / scale_h;
 }
 
+// ---- LSTM / vanilla-RNN decoder stacks, unit-split f16x2 layouts (turboae_rnn_u.hip, tae::RnnULayout) ---------------------------------
+// One direction of one layer.  Gate rows: tile (ut, g) row m = gate g of unit 16 ut + m; remainder tile row 4 qq + g = gate g of unit
+// 96 + qq.  `Wx` (layer 0: W_ih (G H, cin), cin <= 8) rides as one K = 16 slab; `Wlin` (layer 1) gives the head tile of direction d.
+void pack_rnn_u_dir(int G, const float* Wx, int cin, const float* Whh, const float* bih, const float* bhh, const float* Wlin, int nout,
+                    int d, float scale, float scale_h, char* dst) {
+    const int H = kGH;
+    const size_t dirb = tae::RnnULayout::dir_bytes(G);
+    memset(dst, 0, dirb);
+    auto hh_unit = [](int sl, int kq, int j) { return j < 4 ? 16 * (2 * sl) + 4 * kq + j : 16 * (2 * sl + 1) + 4 * kq + (j - 4); };
+    auto slab = [&](size_t hi, size_t lo, auto&& w) {
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) put_split(dst, hi + lane * 16 + j * 2, lo + lane * 16 + j * 2, w(lane & 15, lane >> 4, j));
+    };
+    auto rem = [&](size_t off, auto&& w) {
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 4; ++j) put_split(dst, off + lane * 16 + j * 2, off + lane * 16 + 8 + j * 2, w(lane & 15, lane >> 4, j));
+    };
+    auto tile = [&](size_t base, auto&& row) {       // 8 fragments of one gate tile: W_hh slabs, remainder, input slab
+        for (int sl = 0; sl < 3; ++sl)
+            slab(base + (2 * sl) * 1024, base + (2 * sl + 1) * 1024,
+                 [&](int m, int kq, int j) { return row(m) >= 0 ? Whh[(size_t)row(m) * H + hh_unit(sl, kq, j)] * scale : 0.0f; });
+        rem(base + 6 * 1024, [&](int m, int kq, int j) { return (j == 0 && row(m) >= 0) ? Whh[(size_t)row(m) * H + 96 + kq] * scale : 0.0f; });
+        if (Wx) rem(base + 7 * 1024, [&](int m, int kq, int j) { return (kq < 2 && 4 * kq + j < cin && row(m) >= 0) ? Wx[(size_t)row(m) * cin + 4 * kq + j] * scale : 0.0f; });
+    };
+    for (int ut = 0; ut < 6; ++ut)
+        for (int g = 0; g < G; ++g) tile(((size_t)ut * G + g) * 8 * 1024, [&](int m) { return g * H + 16 * ut + m; });
+    const size_t rb = (size_t)6 * G * 8 * 1024;
+    auto rrow = [&](int m) { const int qq = m >> 2, g = m & 3; return g < G ? g * H + 96 + qq : -1; };
+    tile(rb, rrow);
+    if (Wlin) {
+        for (int sl = 0; sl < 3; ++sl)
+            slab(rb + (8 + 2 * sl) * 1024, rb + (9 + 2 * sl) * 1024,
+                 [&](int m, int kq, int j) { return m < nout ? Wlin[(size_t)m * 2 * H + d * H + hh_unit(sl, kq, j)] * scale_h : 0.0f; });
+        rem(rb + 14 * 1024, [&](int m, int kq, int j) { return (j == 0 && m < nout) ? Wlin[(size_t)m * 2 * H + d * H + 96 + kq] * scale_h : 0.0f; });
+    }
+    float* b = reinterpret_cast<float*>(dst + rb + 15 * 1024);
+    if (Wx) {      // layer 0: accumulators start at b_ih + b_hh (layer 1: at GI, which carries both)
+        for (int ut = 0; ut < 6; ++ut)
+            for (int g = 0; g < G; ++g)
+                for (int m = 0; m < 16; ++m) b[(ut * G + g) * 16 + m] = (bih[g * H + 16 * ut + m] + bhh[g * H + 16 * ut + m]) * scale;
+        for (int m = 0; m < 16; ++m) b[6 * G * 16 + m] = rrow(m) >= 0 ? (bih[rrow(m)] + bhh[rrow(m)]) * scale : 0.0f;
+    }
+    b[6 * G * 16 + 16] = 1.0f / scale;
+    b[6 * G * 16 + 17] = 1.0f / scale_h;
+}
+// layer-1 W_ih (G H, 2H) of both directions -> [dir][slab 7][tile][hi | lo][lane][8 halves] | bias rows (b_ih + b_hh) | 2^-S
+void pack_rnn_u_proj(int G, const float* l1, size_t per1, char* dst) {
+    const int H = kGH, CTT = 6 * G + 1;
+    const size_t cin1 = 2 * H, dirb = (size_t)7 * CTT * 2048;
+    const float scale = pow2_scale(fmaxf(max_abs(l1, (size_t)G * H * cin1), max_abs(l1 + per1, (size_t)G * H * cin1)));
+    float* pb = reinterpret_cast<float*>(dst + 2 * dirb);
+    for (int d = 0; d < 2; ++d) {
+        const float* Wih = l1 + d * per1;
+        const float* bih = Wih + (size_t)G * H * cin1 + (size_t)G * H * H;
+        const float* bhh = bih + G * H;
+        for (int T = 0; T < CTT; ++T)
+            for (int m = 0; m < 16; ++m) {
+                const int row = T < 6 * G ? (T % G) * H + 16 * (T / G) + m : ((m & 3) < G ? (m & 3) * H + 96 + (m >> 2) : -1);
+                pb[(d * CTT + T) * 16 + m] = row >= 0 ? (bih[row] + bhh[row]) * scale : 0.0f;
+                for (int sl = 0; sl < 7; ++sl)
+                    for (int kq = 0; kq < 4; ++kq)
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = 32 * sl + 8 * kq + j, lane = kq * 16 + m;
+                            const float w = (row >= 0 && k < 2 * H) ? Wih[(size_t)row * cin1 + k] * scale : 0.0f;
+                            const size_t o = d * dirb + ((size_t)(sl * CTT + T) * 2) * 1024 + lane * 16 + j * 2;
+                            put_split(dst, o, o + 1024, w);
+                        }
+            }
+    }
+    pb[2 * CTT * 16] = 1.0f / scale;
+}
+size_t rnn_u_stack_bytes(size_t nout, int G) {
+    return 4 * tae::RnnULayout::dir_bytes(G) + tae::RnnULayout::proj_bytes(G) + ((nout * 2 * kGH + nout) * 4 + 15) / 16 * 16;
+}
+// canonical LSTM / RNN decoder -> per stack: L0 {dir image} x 2 | PROJ | L1 {dir image} x 2 | Linear w | b; gimul[2 s + d] = 2^S of L1 dir d
+void repack_rnn_u(const float* src, char* dst, size_t cin0, const std::vector<size_t>& nouts, int G, std::vector<float>& gimul) {
+    const size_t H = kGH, cin1 = 2 * H, GH = (size_t)G * H;
+    const size_t per0 = GH * cin0 + GH * H + 2 * GH, per1 = GH * cin1 + GH * H + 2 * GH, dirb = tae::RnnULayout::dir_bytes(G);
+    gimul.assign(2 * nouts.size(), 1.0f);
+    for (size_t s = 0; s < nouts.size(); ++s) {
+        const size_t nout = nouts[s];
+        for (int d = 0; d < 2; ++d) {
+            const float* p = src + d * per0;           // weight_ih | weight_hh | bias_ih | bias_hh
+            const float scale = pow2_scale(fmaxf(max_abs(p, GH * cin0), max_abs(p + GH * cin0, GH * H)));
+            pack_rnn_u_dir(G, p, (int)cin0, p + GH * cin0, p + GH * cin0 + GH * H, p + GH * cin0 + GH * H + GH, nullptr, 0, d, scale, 1.0f, dst + d * dirb);
+        }
+        src += 2 * per0;
+        dst += 2 * dirb;
+        const float* l1 = src;
+        pack_rnn_u_proj(G, l1, per1, dst);
+        dst += tae::RnnULayout::proj_bytes(G);
+        const float* wlin = l1 + 2 * per1;
+        const float scale_h = pow2_scale(max_abs(wlin, nout * 2 * H));
+        for (int d = 0; d < 2; ++d) {
+            const float* p = l1 + d * per1;
+            const float scale = pow2_scale(max_abs(p + GH * cin1, GH * H));
+            gimul[2 * s + d] = scale;
+            pack_rnn_u_dir(G, nullptr, 0, p + GH * cin1, nullptr, nullptr, wlin, (int)nout, d, scale, scale_h, dst + d * dirb);
+        }
+        dst += 2 * dirb;
+        src += 2 * per1;
+        memcpy(dst, src, (nout * 2 * H + nout) * sizeof(float));
+        src += nout * 2 * H + nout;
+        dst += ((nout * 2 * H + nout) * 4 + 15) / 16 * 16;
+    }
+}
+
 size_t rnn_h_stack_bytes(size_t nout) {
     return 2 * kGHRec0B + kGHProjB + 2 * kGHRec1B + ((nout * 2 * kGH + nout) * 4 + 15) / 16 * 16 + 2 * (size_t)tae::GruL1fLayout::kDirB;
 }
@@ -692,7 +799,7 @@ void walk_weights(const tae_config* c, Fn&& f) {
     for (int it = 0; it < c->num_iteration; ++it)
         for (int half = 0; half < 2; ++half) {
             const size_t nout = (half == 1 && it == c->num_iteration - 1) ? 1 : F;
-            if (c->dec_type == 1) { f(false, rnn_stack_floats(U, 2 + F, nout), 0, 0); continue; }
+            if (c->dec_type == 1) { f(false, rnn_stack_floats(U, 2 + F, nout, (size_t)cell_gates(c->dec_rnn)), 0, 0); continue; }
             for (int l = 0; l < c->dec_num_layer; ++l) {
                 f(true, U, c->dense ? 2 + F + l * U : (l == 0 ? 2 + F : U), (size_t)c->dec_kernel_size);
                 f(false, U, 0, 0);
@@ -735,27 +842,28 @@ std::vector<float> embed_weights(const tae_config* c, const float* w, tae_config
     };
     // 2-layer bidirectional GRU(cin0 -> H) + Linear(2H -> nout) widened to H2 = 100 units: gate rows g*H + u -> g*H2 + u, the
     // layer-1 / Linear input columns (forward | backward halves) likewise.  A unit with zero weights and biases has
-    // r = z = 1/2, n = tanh(0) = 0, so h' = (1 - z) n + z h stays at its initial 0 and feeds nothing.
-    auto rnn = [&](size_t H, size_t H2, size_t cin0, size_t nout) {
+    // r = z = 1/2, n = tanh(0) = 0, so h' = (1 - z) n + z h stays at its initial 0 and feeds nothing (LSTM: i = f = o = 1/2, g = 0, so
+    // c and h stay 0; vanilla RNN: h = tanh(0) = 0).
+    auto rnn = [&](size_t H, size_t H2, size_t cin0, size_t nout, size_t NG = 3) {
         auto col2 = [&](size_t c2) -> long { const size_t half = c2 / H2, u = c2 % H2; return u < H ? (long)(half * H + u) : -1; };
         for (int l = 0; l < 2; ++l) {
             const size_t cin = l == 0 ? cin0 : 2 * H, cin2 = l == 0 ? cin0 : 2 * H2;
             for (int d = 0; d < 2; ++d) {
-                for (size_t g = 0; g < 3; ++g)                        // weight_ih (3H, cin)
+                for (size_t g = 0; g < NG; ++g)                       // weight_ih (G H, cin): G = 3 gates of a GRU, 4 of an LSTM, 1 of a vanilla RNN
                     for (size_t u = 0; u < H2; ++u)
                         for (size_t c2 = 0; c2 < cin2; ++c2) {
                             const long cc = l == 0 ? (long)c2 : col2(c2);
                             out.push_back(u < H && cc >= 0 ? w[(g * H + u) * cin + (size_t)cc] : 0.0f);
                         }
-                w += 3 * H * cin;
-                for (size_t g = 0; g < 3; ++g)                        // weight_hh (3H, H)
+                w += NG * H * cin;
+                for (size_t g = 0; g < NG; ++g)                       // weight_hh (G H, H)
                     for (size_t u = 0; u < H2; ++u)
                         for (size_t c2 = 0; c2 < H2; ++c2) out.push_back(u < H && c2 < H ? w[(g * H + u) * H + c2] : 0.0f);
-                w += 3 * H * H;
-                for (int b = 0; b < 2; ++b) {                         // bias_ih, bias_hh (3H)
-                    for (size_t g = 0; g < 3; ++g)
+                w += NG * H * H;
+                for (int b = 0; b < 2; ++b) {                         // bias_ih, bias_hh (G H)
+                    for (size_t g = 0; g < NG; ++g)
                         for (size_t u = 0; u < H2; ++u) out.push_back(u < H ? w[g * H + u] : 0.0f);
-                    w += 3 * H;
+                    w += NG * H;
                 }
             }
         }
@@ -788,7 +896,7 @@ std::vector<float> embed_weights(const tae_config* c, const float* w, tae_config
         for (int it = 0; it < c->num_iteration; ++it)
             for (int half = 0; half < 2; ++half) {
                 const size_t nout = (half == 1 && it == c->num_iteration - 1) ? 1 : F;
-                if (c->dec_type == 1) { rnn(U, U2, 2 + F, nout); continue; }
+                if (c->dec_type == 1) { rnn(U, U2, 2 + F, nout, (size_t)cell_gates(c->dec_rnn)); continue; }
                 for (int l = 0; l < c->dec_num_layer; ++l) {
                     if (c->dense) conv(U, U2, 2 + F + l * U, false, ks, ks2);
                     else conv(U, U2, l == 0 ? 2 + F : U, l != 0, ks, ks2);
@@ -1239,7 +1347,18 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     }
     TAE_HIP_H(hipMemcpy(h->d_wenc, penc.data(), penc.size() * sizeof(float), hipMemcpyHostToDevice));
     TAE_HIP_H(hipMemcpy(h->d_wdec, pdec.data(), pdec.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (cfg->dec_type == 1) {
+    h->dec_gates = cfg->dec_type == 1 ? cell_gates(cfg->dec_rnn) : 3;
+    if (cfg->dec_type == 1 && h->dec_gates != 3) {
+        // LSTM / vanilla-RNN decoder (generic_needed left it here: CNN encoder, precision auto): unit-split f16x2 kernels only
+        if (h->prec != 1) { tae_destroy(h); return fail(TAE_EINVAL, "internal: the LSTM / RNN decoder kernels exist in the fp16-split arithmetic only"); }
+        const std::vector<size_t> nouts = dec_rnn_nouts((size_t)F, cfg->num_iteration);
+        size_t bytes = 0;
+        for (size_t nout : nouts) bytes += rnn_u_stack_bytes(nout, h->dec_gates);
+        std::vector<char> pu(bytes, 0);
+        repack_rnn_u(dec_src, pu.data(), 2 + (size_t)F, nouts, h->dec_gates, h->rnn_u_gimul);
+        TAE_HIP_H(hipMalloc(&h->d_wrnn_u, pu.size()));
+        TAE_HIP_H(hipMemcpy(h->d_wrnn_u, pu.data(), pu.size(), hipMemcpyHostToDevice));
+    } else if (cfg->dec_type == 1) {
         const size_t nrnn = (size_t)(weights + n_weights - dec_src);
         (void)nrnn;
         const std::vector<size_t> nouts = dec_rnn_nouts((size_t)F, cfg->num_iteration);
@@ -1307,7 +1426,7 @@ int tae_destroy(tae_handle* h) {
     (void)hipFree(h->d_wrnn); (void)hipFree(h->d_gxa); (void)hipFree(h->d_gxb); (void)hipFree(h->d_gy0); (void)hipFree(h->d_gy1);
     (void)hipFree(h->d_ggi);
     (void)hipFree(h->d_wenc_h); (void)hipFree(h->d_wdec_h); (void)hipFree(h->d_flags); (void)hipFree(h->d_wrnn_h);
-    (void)hipFree(h->d_wernn); (void)hipFree(h->d_wernn_h); (void)hipFree(h->d_rnn_partials);
+    (void)hipFree(h->d_wernn); (void)hipFree(h->d_wernn_h); (void)hipFree(h->d_rnn_partials); (void)hipFree(h->d_wrnn_u);
     (void)hipFree(h->d_eval_u); (void)hipFree(h->d_eval_noise); (void)hipFree(h->d_eval_xdec);
     delete h;
     return TAE_OK;
@@ -1346,20 +1465,23 @@ int tae_reserve(tae_handle* h, int32_t max_batch) {
         int32_t chunk = 16384;
         while (chunk > 128 && (size_t)chunk * h->cfg.block_len > (size_t)16384 * 100) chunk -= 128;
         h->rnn_chunk = max_batch < chunk ? max_batch : chunk;
-        const size_t np = (size_t)((h->rnn_chunk + 15) / 16 * 16) * h->cfg.block_len;     // whole block groups (f16x2 path layout)
+        const size_t np = (size_t)((h->rnn_chunk + 31) / 32 * 32) * h->cfg.block_len;     // whole block groups (16 per GRU workgroup, 32 per LSTM / RNN one)
         TAE_HIP(hipMalloc(&h->d_gxa, np * 8 * sizeof(float)));
         TAE_HIP(hipMalloc(&h->d_gxb, np * 8 * sizeof(float)));
         TAE_HIP(hipMalloc(&h->d_gy0, np * 200 * sizeof(float)));
         TAE_HIP(hipMalloc(&h->d_gy1, np * 200 * sizeof(float)));
         // GI (layer-1 input projections, 2.4 KB per position = 4 GB per 16 384-block chunk) exists only on the fp32 path and in the
         // r04 split form of the f16x2 path: the fused layer-1 kernel (turboae_gru_l1f.hip) never writes it
-        const bool need_gi = h->prec != 1 || h->gru_l1_split;
-        if (need_gi) TAE_HIP(hipMalloc(&h->d_ggi, np * 608 * sizeof(float)));
+        const bool need_gi = h->prec != 1 || h->gru_l1_split || h->dec_gates != 3;
+        const size_t gi_row = (size_t)2 * (6 * h->dec_gates + 1) * 16;          // floats per position: 2 directions x row tiles x 16 rows (GRU: 608)
+        if (need_gi) TAE_HIP(hipMalloc(&h->d_ggi, np * gi_row * sizeof(float)));
+        TAE_HIP(hipMemset(h->d_gxa, 0, np * 8 * sizeof(float)));
+        TAE_HIP(hipMemset(h->d_gxb, 0, np * 8 * sizeof(float)));
         // rows of padding blocks (last block group) are never written; they are read next to valid rows by the K-padding
         // over-read of the projection GEMM (x zero weights), so they must hold finite values
         TAE_HIP(hipMemset(h->d_gy0, 0, np * 200 * sizeof(float)));
         TAE_HIP(hipMemset(h->d_gy1, 0, np * 200 * sizeof(float)));
-        if (need_gi) TAE_HIP(hipMemset(h->d_ggi, 0, np * 608 * sizeof(float)));
+        if (need_gi) TAE_HIP(hipMemset(h->d_ggi, 0, np * gi_row * sizeof(float)));
         if (h->cfg.enc_type == 1) {
             (void)hipFree(h->d_rnn_partials);
             h->d_rnn_partials = nullptr;

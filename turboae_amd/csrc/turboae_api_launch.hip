@@ -487,6 +487,47 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
     return TAE_OK;
 }
 
+// DEC_LargeRNN.forward with an LSTM / vanilla-RNN cell (decoders.py:27-32,84-149) on the unit-split f16x2 kernels (turboae_rnn_u.hip):
+// per half-iteration rec(layer 0) -> projection GEMM -> rec(layer 1, head tile fused) -> gru_head_part
+int run_decoder_rnn_u(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st) {
+    const int L = h->cfg.block_len, F = h->cfg.num_iter_ft, H = 100, n_iter = h->cfg.num_iteration, G = h->dec_gates;
+    const size_t dirb = tae::RnnULayout::dir_bytes(G), projb = tae::RnnULayout::proj_bytes(G);
+    for (int32_t c0 = 0; c0 < B; c0 += h->rnn_chunk) {
+        const int32_t Bc = (B - c0 < h->rnn_chunk) ? B - c0 : h->rnn_chunk;
+        TAE_HIP(tae::launch_gru_prep(rx + (size_t)c0 * L * 3, h->d_perm, h->d_gxa, h->d_gxb, Bc, L, st));
+        const char* wb = h->d_wrnn_u;
+        const size_t npg = (size_t)((Bc + 15) / 16) * 16 * L;        // block-group-major rows incl. the padding blocks of the last group of 16
+        for (int s = 0; s < 2 * n_iter; ++s) {
+            const bool odd = (s & 1) != 0, last = (s == 2 * n_iter - 1);
+            const int nout = last ? 1 : F;
+            const float* xin = odd ? h->d_gxb : h->d_gxa;
+            tae::RnnUParams R;
+            memset(&R, 0, sizeof(R));
+            R.w = wb; R.w_dir_stride = (uint32_t)dirb; R.x = xin; R.y0 = reinterpret_cast<char*>(h->d_gy0);
+            R.B = Bc; R.L = L; R.ngroups = (Bc + 31) / 32;
+            TAE_HIP(tae::launch_rnn_rec_u(G, true, R, st));
+            tae::RnnProjParams PP;
+            memset(&PP, 0, sizeof(PP));
+            PP.yin = h->d_gy0; PP.w = reinterpret_cast<const float*>(wb + 2 * dirb); PP.gi = h->d_ggi; PP.npos = npg;
+            PP.gi_mul[0] = h->rnn_u_gimul[2 * s]; PP.gi_mul[1] = h->rnn_u_gimul[2 * s + 1];
+            TAE_HIP(tae::launch_rnn_proj_u(G, PP, st));
+            R.w = wb + 2 * dirb + projb; R.x = nullptr; R.gi = h->d_ggi; R.y0 = nullptr; R.hpart = h->d_gy1;
+            TAE_HIP(tae::launch_rnn_rec_u(G, false, R, st));
+            const float* wl = reinterpret_cast<const float*>(wb + 4 * dirb + projb);
+            tae::GruHeadParams HP;
+            memset(&HP, 0, sizeof(HP));
+            HP.y = h->d_gy1; HP.w = wl; HP.b = wl + (size_t)nout * 2 * H; HP.xcur = xin;
+            HP.xnext = odd ? h->d_gxa : h->d_gxb; HP.xdec = xdec + (size_t)c0 * L;
+            HP.ptab = odd ? h->d_perm : h->d_inv;
+            HP.npos = npg; HP.L = L; HP.F = F; HP.nout = nout; HP.extrinsic = h->cfg.extrinsic; HP.last = last ? 1 : 0;
+            HP.grouped = 1; HP.B = Bc; HP.enc_stack = -1; HP.act = h->cfg.dec_act;
+            TAE_HIP(tae::launch_gru_head_part(HP, st));
+            wb += rnn_u_stack_bytes((size_t)nout, G);
+        }
+    }
+    return TAE_OK;
+}
+
 int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st, float* tap_out) {
     if (h->gen) {
         if (tap_out) return fail(TAE_EINVAL, "tae_decode_taps: no tap export on the generic fp32 kernels");
@@ -494,6 +535,7 @@ int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStrea
     }
     if (h->cfg.dec_type == 1) {
         if (tap_out) return fail(TAE_EINVAL, "tae_decode_taps: the GRU decoder has no tap export");
+        if (h->dec_gates != 3) return run_decoder_rnn_u(h, rx, xdec, B, st);
         return run_decoder_rnn(h, rx, xdec, B, st);
     }
     if (h->nbd < 1) return run_decoder_long(h, rx, xdec, B, st, tap_out);

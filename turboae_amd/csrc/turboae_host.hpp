@@ -97,6 +97,9 @@ struct tae_handle {
     float* d_gy0 = nullptr;  // (chunk, L, 2H) layer-0 outputs
     float* d_gy1 = nullptr;  // (chunk, L, 2H) layer-1 outputs
     float* d_ggi = nullptr;  // (chunk, L, 2, 19, 16) layer-1 input projections in gate-tile order
+    int dec_gates = 3;           // recurrent decoder cell: 3 GRU (turboae_gru*.hip), 4 LSTM / 1 vanilla RNN (turboae_rnn_u.hip, f16x2 only)
+    char* d_wrnn_u = nullptr;    // LSTM / RNN decoder stacks in the unit-split layouts
+    std::vector<float> rnn_u_gimul;   // [stack][dir]: scale the projection kernel folds into GI (the layer-1 recurrence's own 2^S)
     tae::NormOpts nopts;       // encoder-output / channel variant (tae_set_channel_opts)
     tae_noise_opts noise_opts; // generator tae_eval_snr draws from (tae_set_noise_opts; default AWGN)
     tae::GenericEngine* gen = nullptr;   // generic fp32 kernels (configurations outside the MFMA kernels' envelope)
@@ -131,6 +134,9 @@ constexpr size_t kGL0Dir = kGRecF + kGXF + kGB0, kGL1Dir = kGRecF + kGB1;
 constexpr size_t kGHTileB = 3 * 2048 + 1024, kGHFragB = 19 * kGHTileB, kGHNiB = 6 * 1024;
 constexpr size_t kGHRec0B = kGHFragB + kGHNiB + 25 * 64 + 16, kGHRec1B = kGHFragB + kGHTileB + 7 * 64 + 16;
 constexpr size_t kGHProjDirB = 7 * 19 * 2048, kGHProjB = 2 * kGHProjDirB + 2 * 19 * 64 + 16;
+// gates of a recurrent cell (tae_config.enc_rnn / dec_rnn): GRU 3 (r, z, n), LSTM 4 (i, f, g, o), vanilla RNN 1
+inline int cell_gates(int rnn) { return rnn == 1 ? 4 : (rnn == 2 ? 1 : 3); }
+size_t rnn_u_stack_bytes(size_t nout, int G);     // packed LSTM / RNN decoder stack (turboae_rnn_u.hip layouts)
 size_t rnn_packed_stack_floats(size_t nout);
 size_t rnn_h_stack_bytes(size_t nout);
 size_t rnn_h_l1f_offset(size_t nout);

@@ -126,6 +126,33 @@ struct GruL1fParams {
     int32_t B, L, ngroups; // ngroups = ceil(B / 16)
 };
 hipError_t launch_gru_l1f(const GruL1fParams& P, hipStream_t st);
+
+// LSTM / vanilla-RNN cells of DEC_LargeRNN in the unit-split f16x2 layout (turboae_rnn_u.hip).  Weight image of one direction of one
+// layer (G gates): 6 unit-wave register images (per gate 8 fragments of 1 KB: W_hh {slab 0..2: hi, lo; remainder}, the layer-0 input
+// slab) | remainder-wave image (mixed tile: 7 + input slab; head tile: 7) | LDS image (bias rows [ut][gate][16], remainder row, 2^-S,
+// 2^-S_head).
+struct RnnULayout {
+    static constexpr size_t dir_bytes(int G) { return (size_t)(6 * G * 8 + 15) * 1024 + (size_t)((6 * G * 64 + 64 + 16 + 15) / 16 * 16); }
+    static constexpr size_t proj_bytes(int G) { return (size_t)2 * 7 * (6 * G + 1) * 2048 + (size_t)2 * (6 * G + 1) * 64 + 16; }
+};
+struct RnnUParams {
+    const char* w;          // two RnnULayout images (forward, backward)
+    uint32_t w_dir_stride;
+    const float* x;         // layer 0: stack-input panel (B, L, 8)
+    const float* gi;        // layer 1: projections [(g16 L + t) 2 + dir][6 G + 1][lane][4], already times the recurrence's 2^S
+    char* y0;               // layer 0: outputs as halves [pos'][hi 200 | lo 200], pos' = ((b / 16) L + t) 16 + b % 16
+    float* hpart;           // layer 1: [pos'][dir][8] this direction's share of the Linear head
+    int32_t B, L, ngroups;  // ngroups = ceil(B / 32)
+};
+struct RnnProjParams {
+    const float* yin;       // layer-0 outputs (halves)
+    const float* w;         // A fragments [dir][slab 7][tile][hi | lo][lane][8 halves] | bias rows [dir][tile][16] | 2^-S
+    float* gi;
+    size_t npos;            // positions incl. the padding blocks of the last group of 16
+    float gi_mul[2];        // per direction: the layer-1 recurrence's own power-of-two scale
+};
+hipError_t launch_rnn_rec_u(int gates, bool layer0, const RnnUParams& P, hipStream_t st);
+hipError_t launch_rnn_proj_u(int gates, const RnnProjParams& P, hipStream_t st);
 int gru_l1f_lds_bytes();
 hipError_t launch_gru_prep_enc(const float* u, const int32_t* perm, float* X, int B, int L, int interleaved, hipStream_t st);
 int gru_head_grid(size_t npos);

@@ -1,0 +1,481 @@
+// LSTM / vanilla-RNN cells of DEC_LargeRNN (decoders.py:27-32: `-dec_rnn lstm | rnn`, 2 layers, bidirectional, batch_first) in the
+// f16x2 representation, in the unit-split layout gru_l1f_kernel proved for the GRU (turboae_gru_l1f.hip).  Through r04 these cells ran
+// on the generic fp32 kernels only (turboae_generic.hip: 9.9 M bits/s for the LSTM decoder, 3.8x behind the GRU's).
+//
+// PyTorch cells (the arithmetic lives in ATen, third-party to the reference), gate order i, f, g, o:
+//   LSTM  i = s(W_ii x + b_ii + W_hi h + b_hi), f likewise, g = tanh(...), o = s(...);  c' = f c + i g;  h' = o tanh(c');  h_0 = c_0 = 0
+//   RNN   h' = tanh(W_ih x + b_ih + W_hh h + b_hh)
+// A GRU needs W_ih1 next to W_hh on the chip because its n gate keeps the two products apart; here all gate pre-activations are
+// plain sums, and 4 gates x (W_hh + W_ih1) = 480 KB of fp16 pairs per direction do not fit one CU's registers + LDS.  So:
+//   rnn_proj_u   GI = W_ih1 * Y0 + b_ih + b_hh for all positions and both directions as one f16x2 GEMM on conv_accumulate_h
+//                (gru_proj_h with the row-tile count as a template parameter: 6 G + 1 tiles per direction), written in the
+//                recurrence's accumulator layout, pre-multiplied by the recurrence's own power-of-two scale;
+//   rnn_rec_u    one workgroup = 32 blocks (two N tiles) of one direction, 8 waves: six unit waves own 16 hidden units each = G gate
+//                row tiles, W_hh hi + lo in registers for the whole launch (G x 28 VGPRs); the remainder wave owns units 96..99 as one
+//                mixed tile (row 4 qq + g) and, in layer 1, the Linear head tile; h_t is exchanged through LDS as B fragments (one
+//                barrier per step).  Layer 0 contracts its K = 2 + F inputs as one more K = 16 slab (staged by the eighth wave);
+//                layer 1 starts its accumulators from GI (fetched one step ahead).  Layer 0 writes Y0 as halves in the GRU path's
+//                layout, layer 1 the per-direction head products - so gru_head_part closes the stack unchanged.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
+#include "turboae_internal.hpp"
+#include "turboae_device.hpp"
+
+namespace tae {
+
+namespace {
+
+using u32x4v = __attribute__((ext_vector_type(4))) uint32_t;
+using lds_q4 = const u32x4v __attribute__((address_space(3)));
+using lds_f4c = const f32x4 __attribute__((address_space(3)));
+using lds_w4 = u32x4v __attribute__((address_space(3)));
+using lds_w2 = u32x2v __attribute__((address_space(3)));
+using lds_ptr = char __attribute__((address_space(3)))*;
+
+constexpr int kNT = 2;                              // N tiles (of 16 blocks) per workgroup
+constexpr int kHBsz = kNT * 8192;                   // h exchange of one step: per N tile 3 slabs x (hi | lo) + remainder (b1 | b2)
+constexpr int kXBsz = kNT * 2048;                   // layer 0: x_t as the K = 16 slab's (b1 | b2) per N tile
+
+template <int G> struct Geo {
+    static constexpr int kBiasB = 6 * G * 64 + 64 + 16;          // [ut][gate][16] + remainder-tile row + (2^-S, 2^-S_head, 0, 0)
+    static constexpr int kHB = (kBiasB + 15) / 16 * 16;
+    static constexpr int kXB = kHB + 2 * kHBsz;
+    static constexpr int kLds = kXB + 2 * kXBsz;
+    static constexpr int kFragU = G * 8;                          // fragments of a unit wave: per gate W_hh {3 x (hi, lo), remainder} + the input slab
+    static constexpr int kFragR = 8 + 7;                          // remainder wave: mixed tile {7 + input slab} + head tile 7
+    static constexpr int kDirB = (6 * kFragU + kFragR) * 1024 + kHB;
+};
+static_assert(Geo<4>::kDirB == RnnULayout::dir_bytes(4) && Geo<1>::kDirB == RnnULayout::dir_bytes(1), "host packing");
+
+__device__ __forceinline__ float sigm_f(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float tanh_f(float x) {
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)), 1.0f);
+}
+__device__ __forceinline__ h8 lds_h8(lds_cptr p) { return __builtin_bit_cast(h8, *reinterpret_cast<lds_q4*>(p)); }
+__device__ __forceinline__ h8 glb_h8(const char* p) { return __builtin_bit_cast(h8, *reinterpret_cast<const u32x4v*>(p)); }
+
+// LDS writes of this wave are done and visible, then the workgroup barrier (LDS-only fence: global loads / stores stay in flight)
+__device__ __forceinline__ void step_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int N, class F, int I = 0>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, F, I + 1>(static_cast<F&&>(f));
+    }
+}
+
+// one 32-k slab over G gate tiles: hi*lo, lo*hi, hi*hi, each product across the gates (independent chains)
+template <int G>
+__device__ __forceinline__ void mma_g(f32x4 (&acc)[G], const h8 (&ah)[G], const h8 (&al)[G], h8 bh, h8 bl) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = mfma16x16x32h(ah[g], bl, acc[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = mfma16x16x32h(al[g], bh, acc[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = mfma16x16x32h(ah[g], bh, acc[g]);
+}
+// K = 16 slab: A = [4 hi | 4 lo] of the lane's k = 0..3, b1 = [lo | hi], b2 = [hi | 0] (gru_rec_h's mma_rem)
+template <int G>
+__device__ __forceinline__ void mma_gr(f32x4 (&acc)[G], const h8 (&ar)[G], h8 b1, h8 b2) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = mfma16x16x32h(ar[g], b1, acc[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = mfma16x16x32h(ar[g], b2, acc[g]);
+}
+
+// cell arithmetic on the de-scaled pre-activations of one (unit, block): returns h', updates c (LSTM)
+template <int G>
+__device__ __forceinline__ float cell(const float (&a)[G], float& c) {
+    if constexpr (G == 4) {
+        const float ig = sigm_f(a[0]), fg = sigm_f(a[1]), gg = tanh_f(a[2]), og = sigm_f(a[3]);
+        c = fmaf(fg, c, ig * gg);
+        return og * tanh_f(c);
+    } else {
+        return tanh_f(a[0]);
+    }
+}
+
+struct Ctx {
+    const RnnUParams& P;
+    const char* wdir;
+    lds_cptr lds;
+    int lane, n, q, dir, L;
+    float inv, inv_head;
+};
+
+// ---- unit wave: units 16 ut .. 16 ut + 15, G gate tiles -------------------------------------------------------------------------
+template <int G, bool LAYER0>
+__device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
+    using GE = Geo<G>;
+    constexpr int CTT = 6 * G + 1;
+    const int lane = c.lane, L = c.L, n = c.n, q = c.q, dir = c.dir;
+    const char* wr = c.wdir + (size_t)ut * GE::kFragU * 1024 + lane * 16;
+    h8 hh_hi[3][G], hh_lo[3][G], hh_r[G], xw[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            hh_hi[sl][g] = glb_h8(wr + (g * 8 + 2 * sl) * 1024);
+            hh_lo[sl][g] = glb_h8(wr + (g * 8 + 2 * sl + 1) * 1024);
+        }
+        hh_r[g] = glb_h8(wr + (g * 8 + 6) * 1024);
+        xw[g] = LAYER0 ? glb_h8(wr + (g * 8 + 7) * 1024) : h8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const lds_cptr bias = c.lds + ut * (G * 64) + q * 16;
+    const lds_cptr hb = c.lds + GE::kHB + lane * 16, xb = c.lds + GE::kXB + lane * 16;
+    const lds_ptr hw = (lds_ptr)(c.lds + GE::kHB + (ut >> 1) * 2048 + lane * 16 + (ut & 1) * 8);
+    const float inv = c.inv;
+
+    for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
+        // layer 1: GI tiles of this wave, [(g16 L + t) 2 + dir][CTT][lane][4 floats]; layer 0: Y0 rows of the two block groups
+        __amdgpu_buffer_rsrc_t rs[kNT];
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+            const size_t g16 = (size_t)grp * kNT + nt;
+            rs[nt] = LAYER0 ? __builtin_amdgcn_make_buffer_rsrc(c.P.y0 + g16 * L * (16 * 800), 0, L * 16 * 800, 0x00020000)
+                            : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.P.gi) + g16 * L * 2 * (CTT * 256), 0, L * 2 * CTT * 1024, 0x00020000);
+        }
+        const uint32_t v_gi = (uint32_t)((G * ut) * 1024 + lane * 16);
+        const uint32_t v_y = (uint32_t)(n * 800 + (dir * 100 + 16 * ut + 4 * q) * 2);
+        f32x4 gi[kNT][G];
+        auto fetch_gi = [&](int s, int nt) {
+            const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(((dir ? L - 1 - s : s) * 2 + dir) * (CTT * 1024));
+#pragma unroll
+            for (int g = 0; g < G; ++g) gi[nt][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs[nt], v_gi + g * 1024, so, 0));
+        };
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+            *reinterpret_cast<lds_w2*>(hw + nt * 8192) = u32x2v{0, 0};          // h_{-1} = 0: this wave's slots of buffer 0
+            *reinterpret_cast<lds_w2*>(hw + nt * 8192 + 1024) = u32x2v{0, 0};
+            if (!LAYER0) fetch_gi(0, nt);
+        }
+        f32x4 cs[kNT];
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) cs[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        step_barrier();                                   // B0: h buffer 0 cleared, x of step 0 staged
+#pragma unroll 1
+        for (int s = 0; s < L; ++s) {
+            const int p0 = s & 1, p1 = p0 ^ 1;
+            const int t = dir ? L - 1 - s : s;
+            f32x4 acc[kNT][G];
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                const lds_cptr hc = hb + p0 * kHBsz + nt * 8192;
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[nt][g] = LAYER0 ? *reinterpret_cast<lds_f4c*>(bias + g * 64) : gi[nt][g];
+                if (!LAYER0) fetch_gi(s + 1 < L ? s + 1 : s, nt);            // next step's tiles into the registers just consumed
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl) mma_g<G>(acc[nt], hh_hi[sl], hh_lo[sl], lds_h8(hc + sl * 2048), lds_h8(hc + sl * 2048 + 1024));
+                mma_gr<G>(acc[nt], hh_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
+                if (LAYER0) {
+                    const lds_cptr xc = xb + p0 * kXBsz + nt * 2048;
+                    mma_gr<G>(acc[nt], xw, lds_h8(xc), lds_h8(xc + 1024));
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                f32x4 hn;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float a[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) a[g] = acc[nt][g][i] * inv;
+                    float cc = cs[nt][i];
+                    hn[i] = cell<G>(a, cc);
+                    cs[nt][i] = cc;
+                }
+                h4 nhi, nlo;
+                split4(hn, nhi, nlo);
+                const lds_ptr hn_w = hw + p1 * kHBsz + nt * 8192;
+                *reinterpret_cast<lds_w2*>(hn_w) = __builtin_bit_cast(u32x2v, nhi);
+                *reinterpret_cast<lds_w2*>(hn_w + 1024) = __builtin_bit_cast(u32x2v, nlo);
+                if (LAYER0) {        // Y0 as halves [pos'][hi 200 | lo 200] (the projection kernel's operand)
+                    const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(t * (16 * 800));
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nhi), rs[nt], v_y, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nlo), rs[nt], v_y + 400, so, 0);
+                }
+            }
+            step_barrier();
+        }
+        step_barrier();                                   // the remainder wave's last head product has read the h buffer
+    }
+}
+
+// ---- remainder wave: units 96..99 as one mixed tile (row 4 qq + g = gate g of unit 96 + qq) + the head tile (layer 1) ---------------
+template <int G, bool LAYER0>
+__device__ __forceinline__ void rem_wave(const Ctx& c) {
+    using GE = Geo<G>;
+    constexpr int CTT = 6 * G + 1;
+    const int lane = c.lane, L = c.L, n = c.n, q = c.q, dir = c.dir;
+    const char* wr = c.wdir + (size_t)6 * GE::kFragU * 1024 + lane * 16;
+    h8 hh_hi[3], hh_lo[3], hh_r, xw, hd_hi[3], hd_lo[3], hd_r;
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) { hh_hi[sl] = glb_h8(wr + (2 * sl) * 1024); hh_lo[sl] = glb_h8(wr + (2 * sl + 1) * 1024); }
+    hh_r = glb_h8(wr + 6 * 1024);
+    xw = glb_h8(wr + 7 * 1024);
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) { hd_hi[sl] = glb_h8(wr + (8 + 2 * sl) * 1024); hd_lo[sl] = glb_h8(wr + (9 + 2 * sl) * 1024); }
+    hd_r = glb_h8(wr + 14 * 1024);
+    const lds_cptr bias = c.lds + 6 * (G * 64) + q * 16;
+    const lds_cptr hb = c.lds + GE::kHB + lane * 16, xb = c.lds + GE::kXB + lane * 16;
+    const lds_ptr hw = (lds_ptr)(c.lds + GE::kHB + 6144 + lane * 16);
+    const float inv = c.inv, inv_head = c.inv_head;
+    auto mma1 = [](f32x4& a, h8 ah, h8 al, h8 bh, h8 bl) {
+        a = mfma16x16x32h(ah, bl, a); a = mfma16x16x32h(al, bh, a); a = mfma16x16x32h(ah, bh, a);
+    };
+    auto mma1r = [](f32x4& a, h8 ar, h8 b1, h8 b2) { a = mfma16x16x32h(ar, b1, a); a = mfma16x16x32h(ar, b2, a); };
+
+    for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
+        __amdgpu_buffer_rsrc_t rs[kNT], rs_h[kNT];
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+            const size_t g16 = (size_t)grp * kNT + nt;
+            rs[nt] = LAYER0 ? __builtin_amdgcn_make_buffer_rsrc(c.P.y0 + g16 * L * (16 * 800), 0, L * 16 * 800, 0x00020000)
+                            : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.P.gi) + g16 * L * 2 * (CTT * 256), 0, L * 2 * CTT * 1024, 0x00020000);
+            rs_h[nt] = __builtin_amdgcn_make_buffer_rsrc(c.P.hpart + g16 * L * 256, 0, L * 1024, 0x00020000);
+        }
+        const uint32_t v_gi = (uint32_t)((6 * G) * 1024 + lane * 16);
+        const uint32_t v_y = (uint32_t)(n * 800 + (dir * 100 + 96 + q) * 2);
+        const uint32_t v_h = q < 2 ? (uint32_t)(n * 64 + dir * 32 + q * 16) : 0x80000000u;
+        f32x4 gi[kNT];
+        auto fetch_gi = [&](int s, int nt) {
+            const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(((dir ? L - 1 - s : s) * 2 + dir) * (CTT * 1024));
+            gi[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs[nt], v_gi, so, 0));
+        };
+        auto head = [&](lds_cptr hc, int nt, int t) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) mma1(a, hd_hi[sl], hd_lo[sl], lds_h8(hc + sl * 2048), lds_h8(hc + sl * 2048 + 1024));
+            mma1r(a, hd_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, a * inv_head), rs_h[nt], v_h, (uint32_t)t * 1024u, 0);
+        };
+        float cs[kNT];
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+            *reinterpret_cast<lds_w4*>(hw + nt * 8192) = u32x4v{0, 0, 0, 0};
+            *reinterpret_cast<lds_w4*>(hw + nt * 8192 + 1024) = u32x4v{0, 0, 0, 0};
+            cs[nt] = 0.0f;
+            if (!LAYER0) fetch_gi(0, nt);
+        }
+        step_barrier();                                   // B0
+#pragma unroll 1
+        for (int s = 0; s < L; ++s) {
+            const int p0 = s & 1, p1 = p0 ^ 1;
+            const int t = dir ? L - 1 - s : s;
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                const lds_cptr hc = hb + p0 * kHBsz + nt * 8192;
+                f32x4 acc = LAYER0 ? *reinterpret_cast<lds_f4c*>(bias) : gi[nt];
+                if (!LAYER0) fetch_gi(s + 1 < L ? s + 1 : s, nt);
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl) mma1(acc, hh_hi[sl], hh_lo[sl], lds_h8(hc + sl * 2048), lds_h8(hc + sl * 2048 + 1024));
+                mma1r(acc, hh_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
+                if (LAYER0) {
+                    const lds_cptr xc = xb + p0 * kXBsz + nt * 2048;
+                    mma1r(acc, xw, lds_h8(xc), lds_h8(xc + 1024));
+                } else if (s > 0) {
+                    head(hc, nt, dir ? L - s : s - 1);        // Linear head on h_{s-1} (the state this step started from)
+                }
+                float a[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) a[g] = acc[g] * inv;
+                const float hr = cell<G>(a, cs[nt]);
+                const _Float16 hi = (_Float16)hr;
+                const _Float16 lo = (_Float16)(hr - (float)hi);
+                const h8 b1 = {lo, 0, 0, 0, hi, 0, 0, 0}, b2 = {hi, 0, 0, 0, 0, 0, 0, 0};
+                const lds_ptr hn_w = hw + p1 * kHBsz + nt * 8192;
+                *reinterpret_cast<lds_w4*>(hn_w) = __builtin_bit_cast(u32x4v, b1);
+                *reinterpret_cast<lds_w4*>(hn_w + 1024) = __builtin_bit_cast(u32x4v, b2);
+                if (LAYER0) {
+                    const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(t * (16 * 800));
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, hi), rs[nt], v_y, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, lo), rs[nt], v_y + 400, so, 0);
+                }
+            }
+            step_barrier();
+        }
+        if (!LAYER0) {
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) head(hb + (L & 1) * kHBsz + nt * 8192, nt, dir ? 0 : L - 1);
+        }
+        step_barrier();
+    }
+}
+
+// ---- eighth wave: layer 0 stages x_t (B, L, 8) as the input slab's B fragments; layer 1 only keeps the barrier count ------------------
+template <int G, bool LAYER0>
+__device__ __forceinline__ void stage_wave(const Ctx& c) {
+    using GE = Geo<G>;
+    const int lane = c.lane, L = c.L, n = c.n, q = c.q, dir = c.dir;
+    const lds_ptr xw = (lds_ptr)(c.lds + GE::kXB + lane * 16);
+    for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
+        // lane (n, kq) supplies k = 4 kq .. 4 kq + 3 of block n (kq < 2: the panel is 8 wide)
+        auto stage = [&](int s, int buf) {
+            const int t = dir ? L - 1 - s : s;
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                const size_t b = (size_t)grp * (16 * kNT) + nt * 16 + n;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (q < 2 && b < (size_t)c.P.B) v = *reinterpret_cast<const f32x4*>(c.P.x + (b * L + t) * 8 + 4 * q);
+                h4 hi, lo;
+                split4(v, hi, lo);
+                const u32x2v h2 = __builtin_bit_cast(u32x2v, hi), l2 = __builtin_bit_cast(u32x2v, lo);
+                *reinterpret_cast<lds_w4*>(xw + buf * kXBsz + nt * 2048) = u32x4v{l2.x, l2.y, h2.x, h2.y};          // b1 = [lo | hi]
+                *reinterpret_cast<lds_w4*>(xw + buf * kXBsz + nt * 2048 + 1024) = u32x4v{h2.x, h2.y, 0, 0};          // b2 = [hi | 0]
+            }
+        };
+        if (LAYER0) stage(0, 0);
+        step_barrier();                                   // B0
+#pragma unroll 1
+        for (int s = 0; s < L; ++s) {
+            if (LAYER0 && s + 1 < L) stage(s + 1, (s + 1) & 1);
+            step_barrier();
+        }
+        step_barrier();
+    }
+}
+
+template <int G, bool LAYER0>
+__global__ __launch_bounds__(512) void rnn_rec_u_kernel(RnnUParams P) {
+    using GE = Geo<G>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y;
+    const char* wdir = P.w + (size_t)dir * P.w_dir_stride;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(wdir + (size_t)(6 * GE::kFragU + GE::kFragR) * 1024);
+        for (int i = tid; i < GE::kHB / 16; i += 512) reinterpret_cast<f32x4*>(smem)[i] = src[i];
+    }
+    __syncthreads();
+    const float inv = *reinterpret_cast<const float*>(smem + 6 * G * 64 + 64);
+    const float inv_head = *reinterpret_cast<const float*>(smem + 6 * G * 64 + 68);
+    const Ctx c{P, wdir, (lds_cptr)smem, lane, lane & 15, lane >> 4, dir, P.L, inv, inv_head};
+    if (wave == 3) rem_wave<G, LAYER0>(c);
+    else if (wave == 7) stage_wave<G, LAYER0>(c);
+    else unit_wave<G, LAYER0>(c, wave < 3 ? wave : wave - 1);
+}
+
+// ---- layer-1 input projections: GI = (W_ih1 * Y0 + b) * gi_mul as an f16x2 GEMM, CTT row tiles per direction -------------------------
+// Workgroup = 4 waves, 80 positions (5 tiles) staged in LDS as hi / lo planes of 200 halves; wave = (direction, half of the row tiles),
+// passes of <= 5 tiles.  A fragments [slab 7][tile CTT][hi | lo][lane][8 halves] per direction, then the bias rows and 2^-S.
+constexpr int kPT = 5, kProjSlabs = 7;
+constexpr int kProjPos = 16 * kPT, kPlaneB = kProjPos * 400 + 512, kProjLds = 2 * kPlaneB;
+
+template <int CTT, int C0, int NC>
+__device__ __forceinline__ void proj_pass(const RnnProjParams& P, const char* smem, int dir, int lane, size_t p0) {
+    const int n = lane & 15, kq = lane >> 4;
+    constexpr uint32_t DIRB = kProjSlabs * CTT * 2048u;
+    const char* wb = reinterpret_cast<const char*>(P.w);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wb), 0, (int)(2 * DIRB + 2 * CTT * 64 + 16), 0x00020000);
+    const uint32_t voff = (uint32_t)lane * 16u, soff = (uint32_t)dir * DIRB;
+    const float* bias = reinterpret_cast<const float*>(wb + 2 * DIRB) + dir * (CTT * 16);
+    const float mul = reinterpret_cast<const float*>(wb + 2 * DIRB)[2 * CTT * 16] * P.gi_mul[dir];
+    uint32_t bh[kPT], bl[kPT];
+#pragma unroll
+    for (int p = 0; p < kPT; ++p) {
+        bh[p] = (uint32_t)((p * 16 + n) * 400 + 16 * kq);
+        bl[p] = bh[p] + (uint32_t)kPlaneB;
+    }
+    OpsHA<NC> a0;
+    load_wh<CTT, C0, NC>(a0, rsrc, voff, soff);
+    f32x4 acc[kPT][NC];
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + (C0 + ct) * 16 + 4 * kq);
+#pragma unroll
+        for (int p = 0; p < kPT; ++p) acc[p][ct] = bv;
+    }
+    conv_accumulate_h<CTT, C0, NC, kPT, kProjSlabs>(acc, a0, rsrc, voff, soff, smem, bh, bl);
+#pragma unroll
+    for (int p = 0; p < kPT; ++p) {
+        const size_t pos = p0 + p * 16 + n;
+        if (pos < P.npos) {
+            float* dst = P.gi + ((pos >> 4) * 2 + dir) * (size_t)(CTT * 256) + (size_t)C0 * 256 + (n * 4 + kq) * 4;
+#pragma unroll
+            for (int ct = 0; ct < NC; ++ct) __builtin_nontemporal_store(acc[p][ct] * mul, reinterpret_cast<f32x4*>(dst + ct * 256));
+        }
+    }
+}
+
+template <int CTT>
+__global__ __launch_bounds__(256, 2) void rnn_proj_u_kernel(RnnProjParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t p0 = (size_t)blockIdx.x * kProjPos;
+    const int np = (int)min((size_t)kProjPos, P.npos - p0);
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(P.yin) + p0 * 800);
+        for (int i = tid; i < kProjLds / 16; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        for (int i = tid; i < np * 50; i += 256) {      // Y0 rows are halves [hi 200 | lo 200]: 25 16-byte pieces per plane
+            const int pos = i / 50, c = i - pos * 50, plane = c >= 25 ? 1 : 0, cc = c - plane * 25;
+            *reinterpret_cast<f32x4*>(smem + plane * kPlaneB + pos * 400 + cc * 16) = src[i];
+        }
+    }
+    __syncthreads();
+    const int dir = wave >> 1;
+    constexpr int H0 = (CTT + 1) / 2, H1 = CTT - H0;
+    if ((wave & 1) == 0) {
+        static_for<(H0 + 4) / 5>([&](auto I) {
+            constexpr int c0 = 5 * decltype(I)::value, nc = H0 - c0 < 5 ? H0 - c0 : 5;
+            proj_pass<CTT, c0, nc>(P, smem, dir, lane, p0);
+        });
+    } else {
+        static_for<(H1 + 4) / 5>([&](auto I) {
+            constexpr int c0 = 5 * decltype(I)::value, nc = H1 - c0 < 5 ? H1 - c0 : 5;
+            proj_pass<CTT, H0 + c0, nc>(P, smem, dir, lane, p0);
+        });
+    }
+}
+
+template <int G, bool LAYER0>
+hipError_t launch_rec(const RnnUParams& P, hipStream_t st) {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    constexpr int lds = Geo<G>::kLds;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_rec_u_kernel<G, LAYER0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    const dim3 grid((unsigned)std::min(P.ngroups, std::max(1, ncu / 2)), 2);       // one workgroup per CU, half of them per direction
+    hipLaunchKernelGGL((rnn_rec_u_kernel<G, LAYER0>), grid, dim3(512), lds, st, P);
+    return hipGetLastError();
+}
+
+template <int CTT>
+hipError_t launch_proj(const RnnProjParams& P, hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_proj_u_kernel<CTT>), hipFuncAttributeMaxDynamicSharedMemorySize, kProjLds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((rnn_proj_u_kernel<CTT>), dim3((unsigned)((P.npos + kProjPos - 1) / kProjPos)), dim3(256), kProjLds, st, P);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_rnn_rec_u(int gates, bool layer0, const RnnUParams& P, hipStream_t st) {
+    if (gates == 4) return layer0 ? launch_rec<4, true>(P, st) : launch_rec<4, false>(P, st);
+    if (gates == 1) return layer0 ? launch_rec<1, true>(P, st) : launch_rec<1, false>(P, st);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_rnn_proj_u(int gates, const RnnProjParams& P, hipStream_t st) {
+    if (gates == 4) return launch_proj<25>(P, st);
+    if (gates == 1) return launch_proj<7>(P, st);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace tae
