@@ -302,8 +302,10 @@ def time_other_config(name: str, cfg: TurboAEConfig, sd, B: int, dev, snr: float
     variants = list(model.kernel_variants())
     if cfg.generic:
         kern = "generic fp32 MFMA kernels: " + ("tae::gen_proj_mfma_kernel / tae::gen_rnn_mfma_kernel" if cfg.decoder == "TurboAE_rate3_rnn" else "tae::gen_conv_mfma_kernel")
+    elif cfg.decoder == "TurboAE_rate3_rnn" and cfg.dec_rnn != "gru":
+        kern = f"rnn_rec_u<layer 0> / rnn_proj_u / rnn_rec_u<layer 1> / gru_head_part x {2 * cfg.num_iteration} stacks ({cfg.dec_rnn.upper()} decoder, unit-split f16x2 kernels)"
     elif cfg.decoder == "TurboAE_rate3_rnn":
-        kern = ("gru_rec_h / gru_proj_h / gru_head" if is_h2 else "gru_rec / gru_proj / gru_head") + f" x {2 * cfg.num_iteration} stacks (GRU decoder)"
+        kern = ("gru_rec_h<layer 0> / gru_l1f / gru_head_part" if is_h2 else "gru_rec / gru_proj / gru_head") + f" x {2 * cfg.num_iteration} stacks (GRU decoder)"
     elif nb == 0:
         kern = ("tae::seg_kernel_h<100,5>" if is_h2 else "tae::seg_kernel<100,5>") + f" x {2 * cfg.num_iteration} launches (long-block decoder)"
     else:
@@ -350,12 +352,16 @@ def other_configs(dev, snr: float, sd_trained):
 
 
 def generic_configs(dev, snr: float):
-    """Two configurations outside the f16x2 kernels' envelope, on the library's generic fp32 MFMA kernels: an LSTM
-    decoder (`-dec_rnn lstm`) and a 256-wide CNN pair.  Random-init weights (no reference-trained fixture): timing only."""
+    """Other cells / widths the reference's parser accepts (random-init weights, no reference-trained fixture: timing only): the LSTM
+    decoder (`-dec_rnn lstm`) on its unit-split f16x2 kernels (r05) and, for comparison, on the generic fp32 MFMA kernels
+    (precision f32), and a 256-wide CNN pair (generic kernels)."""
+    from dataclasses import replace
     res = []
     cl = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="lstm")
-    res.append(time_other_config("-dec_rnn lstm (DEC_LargeRNN, LSTM cell), block_len=100, batch=16384", cl,
-                                 W.generate_state_dict(cl, seed=SEED, gain=1.0), 16384, dev, snr, "random-init", runs=3))
+    sdl = W.generate_state_dict(cl, seed=SEED, gain=1.0)
+    res.append(time_other_config("-dec_rnn lstm (DEC_LargeRNN, LSTM cell), block_len=100, batch=16384", cl, sdl, 16384, dev, snr, "random-init", runs=3))
+    res.append(time_other_config("-dec_rnn lstm on the generic fp32 kernels (precision f32), block_len=100, batch=16384", replace(cl, precision="f32"), sdl,
+                                 16384, dev, snr, "random-init", runs=3))
     cw = TurboAEConfig(enc_num_unit=256, dec_num_unit=256)
     res.append(time_other_config("-enc_num_unit 256 -dec_num_unit 256, block_len=100, batch=2048", cw,
                                  W.generate_state_dict(cw, seed=SEED, gain=1.0), 2048, dev, snr, "random-init", runs=3))
@@ -470,7 +476,8 @@ def flatten_scalars(out) -> None:
             out[f"{key}_ber"] = oc["ber"]
     for oc in rf.get("generic_configs", []) or []:
         if "error" not in oc:
-            key = "lstm" if "lstm" in str(oc.get("config", "")) else "wide256"
+            name = str(oc.get("config", ""))
+            key = "lstm_generic_f32" if "generic fp32" in name else ("lstm" if "lstm" in name else "wide256")
             out[f"{key}_bits_per_s"] = oc["bits_per_s"]
             out[f"{key}_frac"] = oc["decoder_frac"]
     rf["cfg0_b500_frac"], rf["cfg2_enc5_frac"] = out.get("cfg0_b500_frac"), out.get("cfg2_enc5_frac")

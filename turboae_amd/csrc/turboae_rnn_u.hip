@@ -144,7 +144,7 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
             rs[nt] = LAYER0 ? __builtin_amdgcn_make_buffer_rsrc(c.P.y0 + g16 * L * (16 * 800), 0, L * 16 * 800, 0x00020000)
                             : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.P.gi) + g16 * L * 2 * (CTT * 256), 0, L * 2 * CTT * 1024, 0x00020000);
         }
-        const uint32_t v_gi = (uint32_t)((G * ut) * 1024 + lane * 16);
+        const uint32_t v_gi = (uint32_t)((G * ut) * 1024 + (n * 4 + q) * 16);        // the projection's D layout: block n major, row quad q minor
         const uint32_t v_y = (uint32_t)(n * 800 + (dir * 100 + 16 * ut + 4 * q) * 2);
         f32x4 gi[kNT][G];
         auto fetch_gi = [&](int s, int nt) {
@@ -243,7 +243,7 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
                             : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.P.gi) + g16 * L * 2 * (CTT * 256), 0, L * 2 * CTT * 1024, 0x00020000);
             rs_h[nt] = __builtin_amdgcn_make_buffer_rsrc(c.P.hpart + g16 * L * 256, 0, L * 1024, 0x00020000);
         }
-        const uint32_t v_gi = (uint32_t)((6 * G) * 1024 + lane * 16);
+        const uint32_t v_gi = (uint32_t)((6 * G) * 1024 + (n * 4 + q) * 16);
         const uint32_t v_y = (uint32_t)(n * 800 + (dir * 100 + 96 + q) * 2);
         const uint32_t v_h = q < 2 ? (uint32_t)(n * 64 + dir * 32 + q * 16) : 0x80000000u;
         f32x4 gi[kNT];
