@@ -970,7 +970,7 @@ def main():
             if isinstance(live, dict):
                 traffic, traffic_how = live["bytes_per_launch"] / 1e9, live
             else:
-                pmc_dir = next((d for d in (("r04_pmc_f16x2", "r03_pmc_f16x2", "r02_pmc_f16x2") if is_h2 else ("r01_pmc",))
+                pmc_dir = next((d for d in (("r05_pmc_f16x2", "r04_pmc_f16x2", "r03_pmc_f16x2", "r02_pmc_f16x2") if is_h2 else ("r01_pmc",))
                                 if os.path.isfile(os.path.join(ROOT, "profiles", d, "traffic.json"))), "r01_pmc")
                 tpath = os.path.join(ROOT, "profiles", pmc_dir, "traffic.json")
                 if os.path.isfile(tpath) and cfg.enc_num_layer == 2 and L == 100:
