@@ -29,6 +29,18 @@
 #include "turboae_internal.hpp"
 #include "turboae_device.hpp"
 
+// timing experiments on this kernel (results wrong; -DTAE_EXPERIMENT builds only): 1 linear gates (no exp / rcp), 2 no step barrier,
+// 4 no projection MFMAs in the unit waves' step, 8 no recurrence MFMAs in the unit waves' step, 16 no y0 loads in the staging wave's step,
+// 32 no helper partials in the step loops, 64 no LDS stores of the staged rows
+#if defined(TAE_EXPERIMENT) && defined(TAE_L1F_X)
+constexpr int kL1fX = TAE_L1F_X;
+#else
+#ifdef TAE_L1F_X
+#error "TAE_L1F_X is a timing experiment that breaks the results: build with -DTAE_EXPERIMENT as well"
+#endif
+constexpr int kL1fX = 0;
+#endif
+
 namespace tae {
 
 namespace {
@@ -57,9 +69,11 @@ static_assert(kUnitB == GruL1fLayout::kUnitB && kRemB == GruL1fLayout::kRemB && 
               kLdsW + kBiasB == GruL1fLayout::kLdsImgB, "host packing");
 
 __device__ __forceinline__ float sigm_f(float x) {
+    if (kL1fX & 1) return fmaf(x, 0.25f, 0.5f);
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
 }
 __device__ __forceinline__ float tanh_f(float x) {
+    if (kL1fX & 1) return x * 0.5f;
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)), 1.0f);
 }
 __device__ __forceinline__ h8 lds_h8(lds_cptr p) { return __builtin_bit_cast(h8, *reinterpret_cast<lds_q4*>(p)); }
@@ -69,10 +83,15 @@ __device__ __forceinline__ h8 glb_h8(const char* p) { return __builtin_bit_cast(
 // staging wave's loads / the head stores are meant to stay in flight across steps.
 __device__ __forceinline__ void step_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
+    if (!(kL1fX & 2)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// timing experiments: keep the operands alive, issue no MFMA
+__device__ __forceinline__ void skip3(f32x4 (&acc)[3], const h8 (&a)[3], h8 b0, h8 b1) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) asm volatile("" : "+v"(acc[g]) : "v"(a[g]), "v"(b0), "v"(b1));
+}
 // one 32-k slab, three gate tiles: hi*lo, lo*hi, hi*hi, each product over the three accumulators (independent chains)
 __device__ __forceinline__ void mma3(f32x4 (&acc)[3], const h8 (&ah)[3], const h8 (&al)[3], h8 bh, h8 bl) {
 #pragma unroll
@@ -208,18 +227,18 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
             h8 xh[2], xl[2];                                   // B-fragment ring
             xh[0] = lds_h8(hc); xl[0] = lds_h8(hc + 1024);
             xh[1] = lds_h8(hc + 2048); xl[1] = lds_h8(hc + 3072);
-            mma3(acc, hh_hi[0], hh_lo[0], xh[0], xl[0]);
+            if (kL1fX & 8) skip3(acc, hh_hi[0], xh[0], xl[0]); else mma3(acc, hh_hi[0], hh_lo[0], xh[0], xl[0]);
             pin<5, 9, 0>();
             xh[0] = lds_h8(hc + 4096); xl[0] = lds_h8(hc + 5120);
-            mma3(acc, hh_hi[1], hh_lo[1], xh[1], xl[1]);
+            if (kL1fX & 8) skip3(acc, hh_hi[1], xh[1], xl[1]); else mma3(acc, hh_hi[1], hh_lo[1], xh[1], xl[1]);
             pin<2, 9, 0>();
             xh[1] = lds_h8(hc + 6144); xl[1] = lds_h8(hc + 7168);       // remainder slab: b1, b2
-            mma3(acc, hh_hi[2], hh_lo[2], xh[0], xl[0]);
+            if (kL1fX & 8) skip3(acc, hh_hi[2], xh[0], xl[0]); else mma3(acc, hh_hi[2], hh_lo[2], xh[0], xl[0]);
             pin<2, 9, 0>();
             xh[0] = lds_h8(y); xl[0] = lds_h8(y + 1024);
 #pragma unroll
             for (int g = 0; g < 3; ++g) gi[g] = *reinterpret_cast<lds_f4c*>(pbn + g * 1024);       // helpers' partial (bias + slabs 4, 5)
-            mma3r(acc, hh_r, xh[1], xl[1]);
+            if (kL1fX & 8) skip3(acc, hh_r, xh[1], xl[1]); else mma3r(acc, hh_r, xh[1], xl[1]);
             pin<5, 6, 0>();
             f32x4 hn;
             static_for<4>([&](auto SL) {
@@ -227,12 +246,12 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
                 if (sl < 3) { xh[nxt] = lds_h8(y + (sl + 1) * 2048); xl[nxt] = lds_h8(y + (sl + 1) * 2048 + 1024); }
                 else { xh[nxt] = lds_h8(y + 8192); xl[nxt] = lds_h8(y + 9216); }
                 if constexpr (sl < 2) {
-                    mma3_lo_last(gi, ih_hi[sl], ih_lo[sl], xh[cur], xl[cur]);
+                    if (kL1fX & 4) skip3(gi, ih_hi[sl], xh[cur], xl[cur]); else mma3_lo_last(gi, ih_hi[sl], ih_lo[sl], xh[cur], xl[cur]);
                 } else {
                     h8 al[3];                                  // lo fragments of THIS slab, used by its last three MFMAs
 #pragma unroll
                     for (int g = 0; g < 3; ++g) al[g] = lds_h8(wl + (g * 4 + sl - 2) * 1024);
-                    mma3_lo_last(gi, ih_hi[sl], al, xh[cur], xl[cur]);
+                    if (kL1fX & 4) skip3(gi, al, xh[cur], xl[cur]); else mma3_lo_last(gi, ih_hi[sl], al, xh[cur], xl[cur]);
                 }
                 const int i = sl;
                 const float r = sigm_f(acc[0][i] * inv);
@@ -247,7 +266,7 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
             const lds_ptr hn_w = hw + p1 * kHBsz;
             *reinterpret_cast<lds_w2*>(hn_w) = __builtin_bit_cast(u32x2v, nhi);
             *reinterpret_cast<lds_w2*>(hn_w + 1024) = __builtin_bit_cast(u32x2v, nlo);
-            mma3r(gi, ih_r, xh[0], xl[0]);
+            if (kL1fX & 4) skip3(gi, ih_r, xh[0], xl[0]); else mma3r(gi, ih_r, xh[0], xl[0]);
             pin<0, 6, 1>();
             step_barrier();
         }
@@ -364,7 +383,7 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
             gi = gp1;                                                                    // own tile, step s + 1
             own_main(gi, ym + p1 * kYMsz);
             gp1 = own_part(yh + p0 * kYHsz);                                             // own tile, step s + 2
-            helper_partials<1>(hp_hi, c.lds, lane, 0, q, yh + p0 * kYHsz, pbw + p0 * kPBsz);   // unit tile 0, step s + 2
+            if (!(kL1fX & 32)) helper_partials<1>(hp_hi, c.lds, lane, 0, q, yh + p0 * kYHsz, pbw + p0 * kPBsz);   // unit tile 0, step s + 2
             if (s > 0) head(hc, rs, dir ? L - s : s - 1);          // Linear head on h_{s-1} (the state this step started from)
             const float r = sigm_f(acc[0] * inv);
             const float z = sigm_f(acc[1] * inv);
@@ -456,11 +475,9 @@ __device__ __forceinline__ void stage_wave(const Ctx& c) {
         for (int s = 0; s < L; ++s) {
             const int p0 = s & 1, p1 = p0 ^ 1;
             // m0 / h1 hold M(s + 2) / H(s + 3), fetched a step ago
-            ym_store(m0, ymw + p0 * kYMsz);
-            yh_store(h1, yhw + p1 * kYHsz);
-            ym_load(m0, rs, v0, vr, so(s + 3));
-            yh_load(h1, rs, v0, so(s + 4));
-            helper_partials<5>(hp_hi, c.lds, lane, 1, q, yh + p0 * kYHsz, pbw + p0 * kPBsz);   // unit tiles 1..5, step s + 2
+            if (!(kL1fX & 64)) { ym_store(m0, ymw + p0 * kYMsz); yh_store(h1, yhw + p1 * kYHsz); }
+            if (!(kL1fX & 16)) { ym_load(m0, rs, v0, vr, so(s + 3)); yh_load(h1, rs, v0, so(s + 4)); }
+            if (!(kL1fX & 32)) helper_partials<5>(hp_hi, c.lds, lane, 1, q, yh + p0 * kYHsz, pbw + p0 * kPBsz);   // unit tiles 1..5, step s + 2
             step_barrier();
         }
         step_barrier();
