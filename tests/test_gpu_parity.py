@@ -717,3 +717,25 @@ def test_width_104_is_no_longer_a_performance_cliff(gpu_device, monkeypatch):
     # measured 4.7x at this size (3.8 vs 17.8 ms).  The generic kernels were vector-ALU code when this test was written (63.2 ms, 17.9x);
     # they run on the fp32 matrix cores now, one launch per layer - what is left is f16x2 vs fp32 MFMA and fused vs layer-at-a-time.
     assert t_gen >= 3.0 * t_mfma
+
+
+def test_debug_knobs_are_inert_without_the_master_switch(gpu_device, monkeypatch):
+    """an environment variable that changes the arithmetic or the kernel family (TAE_PRECISION, TAE_FORCE_GENERIC,
+    TAE_GRU_L1, ...) does nothing unless TAE_DEBUG_KNOBS=1 stands beside it, and every override that took effect is reported by
+    tae_overrides - a stray variable in a deployment cannot silently switch a handle."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(num_iteration=1)
+    sd = W.generate_state_dict(cfg, seed=1, gain=1.0)
+    monkeypatch.delenv("TAE_DEBUG_KNOBS", raising=False)
+    monkeypatch.setenv("TAE_PRECISION", "f32")
+    monkeypatch.setenv("TAE_FORCE_GENERIC", "1")
+    plain = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4)
+    assert plain.range_status()[0] == "f16x2" and plain.kernel_info()[0] > 0          # both ignored
+    assert "TAE_PRECISION" not in plain.overrides() and "TAE_FORCE_GENERIC" not in plain.overrides()
+    monkeypatch.delenv("TAE_FORCE_GENERIC")
+    monkeypatch.setenv("TAE_DEBUG_KNOBS", "1")
+    forced = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4)
+    assert forced.range_status()[0] == "f32"
+    assert "TAE_PRECISION=f32" in forced.overrides().split(";")
+    monkeypatch.setenv("TAE_DEBUG_KNOBS", "yes")                                      # anything but exactly "1" is off
+    assert Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4).range_status()[0] == "f16x2"
