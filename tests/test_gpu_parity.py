@@ -726,16 +726,24 @@ def test_debug_knobs_are_inert_without_the_master_switch(gpu_device, monkeypatch
     from turboae_amd import Channel_AE_HIP
     cfg = TurboAEConfig(num_iteration=1)
     sd = W.generate_state_dict(cfg, seed=1, gain=1.0)
+    import ctypes as C
+    from turboae_amd import _lib
+
+    def overrides():                 # process-wide list (earlier tests of this process may have used knobs legitimately)
+        buf = C.create_string_buffer(4096)
+        _lib.load().tae_overrides(None, buf, 4096)
+        return set(x for x in buf.value.decode().split(";") if x)
+    before = overrides()
     monkeypatch.delenv("TAE_DEBUG_KNOBS", raising=False)
     monkeypatch.setenv("TAE_PRECISION", "f32")
     monkeypatch.setenv("TAE_FORCE_GENERIC", "1")
     plain = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4)
     assert plain.range_status()[0] == "f16x2" and plain.kernel_info()[0] > 0          # both ignored
-    assert "TAE_PRECISION" not in plain.overrides() and "TAE_FORCE_GENERIC" not in plain.overrides()
+    assert overrides() == before                                                       # ... and nothing recorded
     monkeypatch.delenv("TAE_FORCE_GENERIC")
     monkeypatch.setenv("TAE_DEBUG_KNOBS", "1")
     forced = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4)
     assert forced.range_status()[0] == "f32"
-    assert "TAE_PRECISION=f32" in forced.overrides().split(";")
+    assert "TAE_PRECISION=f32" in forced.overrides().split(";") and overrides() - before == {"TAE_PRECISION=f32"}
     monkeypatch.setenv("TAE_DEBUG_KNOBS", "yes")                                      # anything but exactly "1" is off
     assert Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=4).range_status()[0] == "f16x2"
