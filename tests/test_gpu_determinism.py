@@ -13,7 +13,10 @@ CASES = [("cnn_f16x2", dict(), 6000), ("cnn_f32", dict(precision="f32"), 3000), 
          ("gru_dec_f16x2_two_waves_per_simd", dict(decoder="TurboAE_rate3_rnn", num_iteration=2), 8192),
          ("gru_dec_f32", dict(decoder="TurboAE_rate3_rnn", num_iteration=2, precision="f32"), 4096),
          ("gru_enc_dec", dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", num_iteration=1), 4096),
-         ("generic_rnn", dict(decoder="TurboAE_rate3_rnn", dec_rnn="rnn", dec_num_unit=24, num_iteration=2), 96)]
+         ("generic_rnn", dict(decoder="TurboAE_rate3_rnn", dec_rnn="rnn", dec_num_unit=24, num_iteration=2, precision="f32"), 96),
+         # r05: unit-split f16x2 recurrences - eight cooperating waves per workgroup, h exchanged through LDS behind one barrier per step
+         ("lstm_dec_unit_split", dict(decoder="TurboAE_rate3_rnn", dec_rnn="lstm", num_iteration=2), 8192 + 40),
+         ("rnn_dec_unit_split", dict(decoder="TurboAE_rate3_rnn", dec_rnn="rnn", num_iteration=2), 4096)]
 
 
 @pytest.mark.parametrize("name,over,B", CASES, ids=[c[0] for c in CASES])

@@ -13,8 +13,10 @@ cases = [("cnn f16x2 50000x100", TurboAEConfig(), 50000), ("cnn f32 20000x100", 
          ("gru dec f16x2 16384", TurboAEConfig(decoder="TurboAE_rate3_rnn"), 16384), ("gru dec f32 4096", TurboAEConfig(decoder="TurboAE_rate3_rnn", precision="f32"), 4096),
          ("gru enc+dec f16x2 4096", TurboAEConfig(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", num_iteration=2), 4096),
          ("dense f16x2 2000", TurboAEConfig(encoder="TurboAE_rate3_cnn_dense", decoder="TurboAE_rate3_cnn_dense", num_iteration=2), 2000),
-         ("B=500 f16x2", TurboAEConfig(), 500), ("generic lstm 64", TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="lstm", dec_num_unit=32, num_iteration=2), 64),
-         ("generic lstm H=100 4096 (fp32 MFMA)", TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="lstm", num_iteration=2), 4096),
+         ("B=500 f16x2", TurboAEConfig(), 500), ("generic lstm 64", TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="lstm", dec_num_unit=32, num_iteration=2, precision="f32"), 64),
+         ("generic lstm H=100 4096 (fp32 MFMA)", TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="lstm", num_iteration=2, precision="f32"), 4096),
+         ("lstm H=100 16400 (unit-split f16x2)", TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="lstm", num_iteration=2), 16400),
+         ("rnn H=100 8192 (unit-split f16x2)", TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="rnn", num_iteration=2), 8192),
          ("generic widths 256 1024 (fp32 MFMA)", TurboAEConfig(enc_num_unit=256, dec_num_unit=256, num_iteration=2), 1024),
          ("generic rnn H=130 2048 (vector ALU)", TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="rnn", dec_num_unit=130, num_iteration=2), 2048)]
 bad = 0
