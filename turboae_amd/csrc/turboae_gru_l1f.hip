@@ -57,9 +57,15 @@ constexpr int kBiasB = 6 * 4 * 64 + 64 + 16;        // [ut][r, z, n_i, n_h][16] 
 constexpr int kHB = kLdsW + kBiasB;                 // h exchange: 3 slabs x (hi | lo) + remainder (b1 | b2)
 constexpr int kHBsz = 8192;
 constexpr int kYM = kHB + 2 * kHBsz;                // y0 of a step, k-slabs 0..3 x (hi | lo) + remainder (b1 | b2): read by the owners' projection
-constexpr int kYMsz = 10240;
+#ifndef TAE_L1F_HS
+#define TAE_L1F_HS 2
+#endif
+constexpr int kHS = TAE_L1F_HS;                     // k-slabs of every unit tile's projection the helpers compute (the last kHS of 6);
+                                                    // 1 measured 2 % slower than 2 (profiles/r05_gru_l1f_hs1_ab.txt): the staging wave's SIMD idles less than the unit waves' gain
+constexpr int kMS = 6 - kHS;                        // ... and the owners' share
+constexpr int kYMsz = (2 * kMS + 2) * 1024;
 constexpr int kYH = kYM + 2 * kYMsz;                // y0 of a step, k-slabs 4, 5 x (hi | lo): read by the helpers, two steps ahead
-constexpr int kYHsz = 4096;
+constexpr int kYHsz = 2 * kHS * 1024;
 constexpr int kPB = kYH + 2 * kYHsz;                // helper partials = accumulator-init tiles [ut][r, z, n_i][lane][4 floats]
 constexpr int kPBsz = 18 * 1024;
 constexpr int kLds = kPB + 2 * kPBsz;
@@ -170,7 +176,7 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
     const int lane = c.lane, L = c.L;
     const char* wr = c.wdir + (size_t)ut * kUnitB + lane * 16;
     const char* wlo = c.wdir + (size_t)6 * kUnitB + kRemB + (size_t)ut * (6 * 1024) + lane * 16;      // W_ih1 lo of slabs 0, 1: [gate][slab]
-    h8 hh_hi[3][3], hh_lo[3][3], hh_r[3], ih_hi[4][3], ih_lo[2][3], ih_r[3];       // [slab][gate]
+    h8 hh_hi[3][3], hh_lo[3][3], hh_r[3], ih_hi[kMS][3], ih_lo[2][3], ih_r[3];       // [slab][gate]
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
 #pragma unroll
@@ -180,7 +186,7 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
         }
         hh_r[g] = glb_h8(wr + (g * 7 + 6) * 1024);
 #pragma unroll
-        for (int sl = 0; sl < 4; ++sl) ih_hi[sl][g] = glb_h8(wr + (21 + g * 7 + sl) * 1024);
+        for (int sl = 0; sl < kMS; ++sl) ih_hi[sl][g] = glb_h8(wr + (21 + g * 7 + sl) * 1024);
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) ih_lo[sl][g] = glb_h8(wlo + (g * 2 + sl) * 1024);
         ih_r[g] = glb_h8(wr + (21 + g * 7 + 6) * 1024);
@@ -203,14 +209,14 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
 #pragma unroll
             for (int g = 0; g < 3; ++g) gi[g] = *reinterpret_cast<lds_f4c*>(pb + g * 1024);
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl) {
+            for (int sl = 0; sl < kMS; ++sl) {
                 const h8 bh = lds_h8(ym + sl * 2048), bl = lds_h8(ym + sl * 2048 + 1024);
                 h8 al[3];
 #pragma unroll
                 for (int g = 0; g < 3; ++g) al[g] = sl < 2 ? ih_lo[sl < 2 ? sl : 0][g] : lds_h8(wl + (g * 4 + sl - 2) * 1024);
                 mma3(gi, ih_hi[sl], al, bh, bl);
             }
-            mma3r(gi, ih_r, lds_h8(ym + 8192), lds_h8(ym + 9216));
+            mma3r(gi, ih_r, lds_h8(ym + kMS * 2048), lds_h8(ym + kMS * 2048 + 1024));
         }
         f32x4 h = {0.f, 0.f, 0.f, 0.f};
         step_barrier();                                   // B2: M[0], pb[0] may be refilled
@@ -241,10 +247,9 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
             if (kL1fX & 8) skip3(acc, hh_r, xh[1], xl[1]); else mma3r(acc, hh_r, xh[1], xl[1]);
             pin<5, 6, 0>();
             f32x4 hn;
-            static_for<4>([&](auto SL) {
+            static_for<kMS>([&](auto SL) {
                 constexpr int sl = decltype(SL)::value, cur = sl & 1, nxt = cur ^ 1;
-                if (sl < 3) { xh[nxt] = lds_h8(y + (sl + 1) * 2048); xl[nxt] = lds_h8(y + (sl + 1) * 2048 + 1024); }
-                else { xh[nxt] = lds_h8(y + 8192); xl[nxt] = lds_h8(y + 9216); }
+                xh[nxt] = lds_h8(y + (sl + 1) * 2048); xl[nxt] = lds_h8(y + (sl + 1) * 2048 + 1024);      // (the slab after the last one is the remainder's b1 | b2)
                 if constexpr (sl < 2) {
                     if (kL1fX & 4) skip3(gi, ih_hi[sl], xh[cur], xl[cur]); else mma3_lo_last(gi, ih_hi[sl], ih_lo[sl], xh[cur], xl[cur]);
                 } else {
@@ -253,12 +258,14 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
                     for (int g = 0; g < 3; ++g) al[g] = lds_h8(wl + (g * 4 + sl - 2) * 1024);
                     if (kL1fX & 4) skip3(gi, al, xh[cur], xl[cur]); else mma3_lo_last(gi, ih_hi[sl], al, xh[cur], xl[cur]);
                 }
-                const int i = sl;
-                const float r = sigm_f(acc[0][i] * inv);
-                const float z = sigm_f(acc[1][i] * inv);
-                const float nn = tanh_f(fmaf(r, acc[2][i] * inv, gin[i] * inv));
-                hn[i] = fmaf(z, h[i] - nn, nn);
-                pin<(sl < 2 ? 2 : 5), 9, 2>();
+                if constexpr (sl < 4) {
+                    const int i = sl;
+                    const float r = sigm_f(acc[0][i] * inv);
+                    const float z = sigm_f(acc[1][i] * inv);
+                    const float nn = tanh_f(fmaf(r, acc[2][i] * inv, gin[i] * inv));
+                    hn[i] = fmaf(z, h[i] - nn, nn);
+                    pin<(sl < 2 ? 2 : 5), 9, 2>();
+                } else pin<5, 9, 0>();
             });
             h = hn;
             h4 nhi, nlo;
@@ -266,7 +273,7 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
             const lds_ptr hn_w = hw + p1 * kHBsz;
             *reinterpret_cast<lds_w2*>(hn_w) = __builtin_bit_cast(u32x2v, nhi);
             *reinterpret_cast<lds_w2*>(hn_w + 1024) = __builtin_bit_cast(u32x2v, nlo);
-            if (kL1fX & 4) skip3(gi, ih_r, xh[0], xl[0]); else mma3r(gi, ih_r, xh[0], xl[0]);
+            if (kL1fX & 4) skip3(gi, ih_r, xh[kMS & 1], xl[kMS & 1]); else mma3r(gi, ih_r, xh[kMS & 1], xl[kMS & 1]);
             pin<0, 6, 1>();
             step_barrier();
         }
@@ -277,23 +284,25 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
 // Helper share of the projection: for NU unit tiles starting at u0, tile (ut, g) <- bias + W_ih1[rows, k-slabs 4, 5] * y0, written
 // to `pbw` as accumulator-init tiles.  `yh`: this step's H fragments; A hi fragments in registers, lo from LDS.
 template <int NU>
-__device__ __forceinline__ void helper_partials(const h8 (&a_hi)[NU][2][3], lds_cptr lds, int lane, int u0, int q, lds_cptr yh, lds_ptr pbw) {
-    const h8 b4h = lds_h8(yh), b4l = lds_h8(yh + 1024), b5h = lds_h8(yh + 2048), b5l = lds_h8(yh + 3072);
+__device__ __forceinline__ void helper_partials(const h8 (&a_hi)[NU][kHS][3], lds_cptr lds, int lane, int u0, int q, lds_cptr yh, lds_ptr pbw) {
+    h8 bh[kHS], bl[kHS];
+#pragma unroll
+    for (int j = 0; j < kHS; ++j) { bh[j] = lds_h8(yh + j * 2048); bl[j] = lds_h8(yh + j * 2048 + 1024); }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int ut = u0 + u;
         const lds_cptr wl = lds + ut * (12 * 1024) + lane * 16;
         const lds_cptr bias = lds + kLdsW + ut * 256 + q * 16;
         f32x4 acc[3];
-        h8 al4[3], al5[3];
+        h8 al[kHS][3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             acc[g] = *reinterpret_cast<lds_f4c*>(bias + g * 64);
-            al4[g] = lds_h8(wl + (g * 4 + 2) * 1024);
-            al5[g] = lds_h8(wl + (g * 4 + 3) * 1024);
+#pragma unroll
+            for (int j = 0; j < kHS; ++j) al[j][g] = lds_h8(wl + (g * 4 + kMS - 2 + j) * 1024);
         }
-        mma3_lo_last(acc, a_hi[u][0], al4, b4h, b4l);
-        mma3_lo_last(acc, a_hi[u][1], al5, b5h, b5l);
+#pragma unroll
+        for (int j = 0; j < kHS; ++j) mma3_lo_last(acc, a_hi[u][j], al[j], bh[j], bl[j]);
 #pragma unroll
         for (int g = 0; g < 3; ++g) *reinterpret_cast<f32x4 __attribute__((address_space(3)))*>(pbw + (ut * 3 + g) * 1024) = acc[g];
     }
@@ -313,13 +322,13 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) { hd_hi[sl] = glb_h8(wr + (20 + 2 * sl) * 1024); hd_lo[sl] = glb_h8(wr + (21 + 2 * sl) * 1024); }
     hd_r = glb_h8(wr + 26 * 1024);
-    h8 hp_hi[1][2][3];                                                  // helper: W_ih1 hi of k-slabs 4, 5 of unit tile 0
+    h8 hp_hi[1][kHS][3];                                                  // helper: W_ih1 hi of k-slabs 4, 5 of unit tile 0
 #pragma unroll
     for (int u = 0; u < 1; ++u)
 #pragma unroll
-        for (int sl = 0; sl < 2; ++sl)
+        for (int sl = 0; sl < kHS; ++sl)
 #pragma unroll
-            for (int g = 0; g < 3; ++g) hp_hi[u][sl][g] = glb_h8(c.wdir + (size_t)u * kUnitB + (21 + g * 7 + 4 + sl) * 1024 + lane * 16);
+            for (int g = 0; g < 3; ++g) hp_hi[u][sl][g] = glb_h8(c.wdir + (size_t)u * kUnitB + (21 + g * 7 + kMS + sl) * 1024 + lane * 16);
     const lds_cptr bias = c.lds + kLdsW + 6 * 256 + q * 16;             // init row: (r, z, b_hn, b_in) of unit 96 + q
     const lds_cptr hb = c.lds + kHB + lane * 16, ym = c.lds + kYM + lane * 16, yh = c.lds + kYH + lane * 16;
     const lds_ptr hw = (lds_ptr)(c.lds + kHB + 6144 + lane * 16);
@@ -329,15 +338,15 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
     // this wave's own tile: bias + k-slabs 4, 5 (at helper time, two steps ahead) ...
     auto own_part = [&](lds_cptr yhk) {
         f32x4 g = *reinterpret_cast<lds_f4c*>(bias);
-        mma1(g, ih_hi[4], ih_lo[4], lds_h8(yhk), lds_h8(yhk + 1024));
-        mma1(g, ih_hi[5], ih_lo[5], lds_h8(yhk + 2048), lds_h8(yhk + 3072));
+#pragma unroll
+        for (int j = 0; j < kHS; ++j) mma1(g, ih_hi[kMS + j], ih_lo[kMS + j], lds_h8(yhk + j * 2048), lds_h8(yhk + j * 2048 + 1024));
         return g;
     };
     // ... + k-slabs 0..3 and the remainder (one step ahead, like the unit waves)
     auto own_main = [&](f32x4& gi, lds_cptr y) {
 #pragma unroll
-        for (int sl = 0; sl < 4; ++sl) mma1(gi, ih_hi[sl], ih_lo[sl], lds_h8(y + sl * 2048), lds_h8(y + sl * 2048 + 1024));
-        mma1r(gi, ih_r, lds_h8(y + 8192), lds_h8(y + 9216));
+        for (int sl = 0; sl < kMS; ++sl) mma1(gi, ih_hi[sl], ih_lo[sl], lds_h8(y + sl * 2048), lds_h8(y + sl * 2048 + 1024));
+        mma1r(gi, ih_r, lds_h8(y + kMS * 2048), lds_h8(y + kMS * 2048 + 1024));
     };
     // head products of the state in h buffer `hc` -> hpart[(grp L + t) 16 + n][dir][8]
     auto head = [&](lds_cptr hc, const __amdgpu_buffer_rsrc_t& rs, int t) {
@@ -403,13 +412,13 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
 }
 
 // ---- staging wave: y0 rows -> B fragments in LDS; helper for unit tiles 1..5 ------------------------------------------------------
-struct YM { u32x4v v[8]; u32x2v rh, rl; };            // k-slabs 0..3 (hi, lo) + the K = 16 remainder of one step
-struct YH { u32x4v v[4]; };                           // k-slabs 4, 5 (hi, lo)
+struct YM { u32x4v v[2 * kMS]; u32x2v rh, rl; };            // k-slabs 0..3 (hi, lo) + the K = 16 remainder of one step
+struct YH { u32x4v v[2 * kHS]; };                           // k-slabs 4, 5 (hi, lo)
 
 // lane (n, kq) supplies k = 32 sl + 8 kq .. + 7 of block n: bytes plane * 400 + sl * 64 + kq * 16 of the block's 800-byte row
 __device__ __forceinline__ void ym_load(YM& r, __amdgpu_buffer_rsrc_t rs, uint32_t v0, uint32_t vr, uint32_t so) {
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
+    for (int sl = 0; sl < kMS; ++sl) {
         r.v[2 * sl] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + sl * 64, so, 0);
         r.v[2 * sl + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + 400 + sl * 64, so, 0);
     }
@@ -418,31 +427,31 @@ __device__ __forceinline__ void ym_load(YM& r, __amdgpu_buffer_rsrc_t rs, uint32
 }
 __device__ __forceinline__ void yh_load(YH& r, __amdgpu_buffer_rsrc_t rs, uint32_t v0, uint32_t so) {
 #pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-        r.v[2 * sl] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + (4 + sl) * 64, so, 0);
-        r.v[2 * sl + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + 400 + (4 + sl) * 64, so, 0);
+    for (int sl = 0; sl < kHS; ++sl) {
+        r.v[2 * sl] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + (kMS + sl) * 64, so, 0);
+        r.v[2 * sl + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + 400 + (kMS + sl) * 64, so, 0);
     }
 }
 __device__ __forceinline__ void ym_store(const YM& r, lds_ptr y) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<lds_w4*>(y + i * 1024) = r.v[i];
-    *reinterpret_cast<lds_w4*>(y + 8192) = u32x4v{r.rl.x, r.rl.y, r.rh.x, r.rh.y};        // b1 = [lo | hi]
-    *reinterpret_cast<lds_w4*>(y + 9216) = u32x4v{r.rh.x, r.rh.y, 0, 0};                  // b2 = [hi | 0]
+    for (int i = 0; i < 2 * kMS; ++i) *reinterpret_cast<lds_w4*>(y + i * 1024) = r.v[i];
+    *reinterpret_cast<lds_w4*>(y + kMS * 2048) = u32x4v{r.rl.x, r.rl.y, r.rh.x, r.rh.y};        // b1 = [lo | hi]
+    *reinterpret_cast<lds_w4*>(y + kMS * 2048 + 1024) = u32x4v{r.rh.x, r.rh.y, 0, 0};           // b2 = [hi | 0]
 }
 __device__ __forceinline__ void yh_store(const YH& r, lds_ptr y) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<lds_w4*>(y + i * 1024) = r.v[i];
+    for (int i = 0; i < 2 * kHS; ++i) *reinterpret_cast<lds_w4*>(y + i * 1024) = r.v[i];
 }
 
 __device__ __forceinline__ void stage_wave(const Ctx& c) {
     const int lane = c.lane, L = c.L, n = c.n, q = c.q, dir = c.dir;
-    h8 hp_hi[5][2][3];                                                  // helper: W_ih1 hi of k-slabs 4, 5 of unit tiles 1..5
+    h8 hp_hi[5][kHS][3];                                                  // helper: W_ih1 hi of k-slabs 4, 5 of unit tiles 1..5
 #pragma unroll
     for (int u = 0; u < 5; ++u)
 #pragma unroll
-        for (int sl = 0; sl < 2; ++sl)
+        for (int sl = 0; sl < kHS; ++sl)
 #pragma unroll
-            for (int g = 0; g < 3; ++g) hp_hi[u][sl][g] = glb_h8(c.wdir + (size_t)(1 + u) * kUnitB + (21 + g * 7 + 4 + sl) * 1024 + lane * 16);
+            for (int g = 0; g < 3; ++g) hp_hi[u][sl][g] = glb_h8(c.wdir + (size_t)(1 + u) * kUnitB + (21 + g * 7 + kMS + sl) * 1024 + lane * 16);
     const lds_cptr yh = c.lds + kYH + lane * 16;
     const lds_ptr ymw = (lds_ptr)(c.lds + kYM + lane * 16), yhw = (lds_ptr)(c.lds + kYH + lane * 16);
     const lds_ptr pbw = (lds_ptr)(c.lds + kPB + lane * 16);
