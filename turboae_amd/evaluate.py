@@ -45,9 +45,9 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
     """model: turboae_amd.Channel_AE_HIP.  Returns {'snrs', 'ber', 'bler', 'bit_errors', 'block_errors', 'enc_power'}.
     decode_group: batches decoded per decoder call (None: enough for about 24 576 blocks per rank; 1: one call per batch).
     hip_graph: capture every SNR point (all of its launches, the all-reduces included) into one hipGraph and launch that
-    (every channel: all noise generators are device kernels keyed by Philox counters).  The sweep is GPU-bound either way; the
-    option exists because the entry points are capturable (no allocation, no synchronisation) and a launch-bound caller
-    (tiny batches) can use it."""
+    (every channel: all noise generators are device kernels keyed by Philox counters).  The points are pipelined: the host captures
+    point i + 2 while the device runs point i and has point i + 1 queued (with the positional statistics of --print_pos_ber /
+    --print_pos_power, whose second pass needs the first one's ranking on the host, the points are captured one after another)."""
     import torch.distributed as dist
     rank, world = 0, 1
     if dist.is_available() and dist.is_initialized():
@@ -168,22 +168,9 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
 
     if hip_graph and nloc > 0:
         model.reserve(decode_group * nloc)           # no workspace growth (an allocation) inside a capture
-    for si, snr in enumerate(snrs):
-        # per-batch (bit errors, block errors) stay on the device; one host read per SNR point
-        per_batch = torch.zeros((max(num_test_batch, 1), 2), dtype=torch.int64, device=dev)
-        pos_err.zero_()
-        pos_pow.zero_()
-        if hip_graph:
-            torch.cuda.synchronize(dev)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                run_point(si, snr, per_batch)
-            graph.replay()
-            torch.cuda.synchronize(dev)
-            del graph
-        else:
-            run_point(si, snr, per_batch)
-        pb = per_batch.cpu().tolist()
+
+    def report_point(si, snr, pb):
+        """pb: the point's per-batch (bit errors, block errors) on the host.  Everything trainer.py:176-236 prints / collects for it."""
         # BER / BLER = mean over batches of the per-batch rates (trainer.py:176-177,215-216), accumulated in the same order
         test_ber, test_bler = 0.0, 0.0
         for c in pb[:num_test_batch]:
@@ -191,7 +178,6 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
             test_bler += c[1] / float(batch_size)                              # errors_bler, utils.py:49-66
         test_ber /= num_test_batch
         test_bler /= num_test_batch
-        tot = per_batch.sum(dim=0)
         # printed objects have the reference's types (numpy fp32 array / torch fp32 tensor), so the lines read the same
         if print_pos_power:
             pos_power_res.append((pos_pow / float(batch_size * num_test_batch)).cpu().tolist())
@@ -225,10 +211,71 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
         bler_punc_res.append(float(bler_p))
         ber_res.append(float(test_ber))
         bler_res.append(float(test_bler))
-        t = tot.cpu().tolist()
-        bit_res.append(int(t[0]))
-        blk_res.append(int(t[1]))
-        model.check_range()          # fp16-split kernels: fail loudly if an activation left the fp16 range
+        bit_res.append(int(sum(c[0] for c in pb)))
+        blk_res.append(int(sum(c[1] for c in pb)))
+
+    def new_counts():
+        # per-batch (bit errors, block errors) stay on the device; one host read per SNR point
+        return torch.zeros((max(num_test_batch, 1), 2), dtype=torch.int64, device=dev)
+
+    if hip_graph and not want_pos and snr_points > 0 and num_test_batch > 0:
+        # One hipGraph per SNR point, PIPELINED: while the device runs point i, the host captures and instantiates point i + 2 and has
+        # already queued point i + 1, so the stream never drains between points (captured serially, each point cost ~2 ms of idle
+        # device: capture + instantiate + two synchronisations).  The graphs share one memory pool - they are launched in capture
+        # order on one stream, never concurrently - and the counts of a finished point are fetched on a side stream behind an event.
+        main, side, fetch = torch.cuda.current_stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        pool = torch.cuda.graph_pool_handle()
+        graphs, counts, done = {}, {}, {}
+
+        def capture(si):
+            counts[si] = new_counts()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                g.capture_begin(pool=pool)
+                try:
+                    run_point(si, snrs[si], counts[si])
+                finally:
+                    g.capture_end()
+            graphs[si] = g
+
+        def launch(si):
+            graphs[si].replay()
+            done[si] = torch.cuda.Event()
+            done[si].record(main)
+
+        capture(0)
+        launch(0)
+        if snr_points > 1:
+            capture(1)
+        for si, snr in enumerate(snrs):
+            if si + 1 < snr_points:
+                launch(si + 1)
+            with torch.cuda.stream(fetch):
+                fetch.wait_event(done[si])
+                pb = counts[si].cpu().tolist()        # synchronises `fetch` only: point si + 1 keeps running
+            del graphs[si], counts[si], done[si]
+            report_point(si, snr, pb)
+            if si + 2 < snr_points:
+                capture(si + 2)
+        torch.cuda.synchronize(dev)
+        model.check_range()          # fp16-split kernels: fail loudly if an activation left the fp16 range (the flag is sticky)
+    else:
+        for si, snr in enumerate(snrs):
+            per_batch = new_counts()
+            pos_err.zero_()
+            pos_pow.zero_()
+            if hip_graph:
+                torch.cuda.synchronize(dev)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    run_point(si, snr, per_batch)
+                graph.replay()
+                torch.cuda.synchronize(dev)
+                del graph
+            else:
+                run_point(si, snr, per_batch)
+            report_point(si, snr, per_batch.cpu().tolist())
+            model.check_range()          # fp16-split kernels: fail loudly if an activation left the fp16 range
     say("final results on SNRs ", snrs)
     say("BER", ber_res)
     say("BLER", bler_res)
