@@ -76,6 +76,7 @@ PARITY_BLOCKS = 500               # BASELINE configs[0]: the reference's own CPU
 TRAINED = os.path.join(ROOT, "tests", "golden", "trained_enc2dec5_u100_fp32.npz")
 TRAINED_ENC5 = os.path.join(ROOT, "tests", "golden", "trained_enc5dec5_u100_fp32.npz")      # BASELINE configs[2]
 TRAINED_GRU = os.path.join(ROOT, "tests", "golden", "trained_cnn_gru_u100_fp32.npz")        # BASELINE configs[4]
+TRAINED_LSTM = os.path.join(ROOT, "tests", "golden", "trained_cnn_lstm_u100_fp32.npz")      # the same shape with -dec_rnn lstm
 
 
 def host_cpu_info():
@@ -352,16 +353,19 @@ def other_configs(dev, snr: float, sd_trained):
 
 
 def generic_configs(dev, snr: float):
-    """Other cells / widths the reference's parser accepts (random-init weights, no reference-trained fixture: timing only): the LSTM
-    decoder (`-dec_rnn lstm`) on its unit-split f16x2 kernels (r05) and, for comparison, on the generic fp32 MFMA kernels
-    (precision f32), and a 256-wide CNN pair (generic kernels)."""
+    """Other cells / widths the reference's parser accepts: the LSTM decoder (`-dec_rnn lstm`; reference-trained fixture when
+    tests/golden/ has it) on its unit-split f16x2 kernels (r05) and, for comparison, on the generic fp32 MFMA kernels
+    (precision f32), and a 256-wide CNN pair (generic kernels, random-init weights: timing only)."""
     from dataclasses import replace
     res = []
     cl = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="lstm")
-    sdl = W.generate_state_dict(cl, seed=SEED, gain=1.0)
-    res.append(time_other_config("-dec_rnn lstm (DEC_LargeRNN, LSTM cell), block_len=100, batch=16384", cl, sdl, 16384, dev, snr, "random-init", runs=3))
+    if os.path.isfile(TRAINED_LSTM):
+        sdl, wl = W.unpack_blob(cl, np.load(TRAINED_LSTM)["weights_fp32"]), "trained"
+    else:
+        sdl, wl = W.generate_state_dict(cl, seed=SEED, gain=1.0), "random-init"
+    res.append(time_other_config("-dec_rnn lstm (DEC_LargeRNN, LSTM cell), block_len=100, batch=16384", cl, sdl, 16384, dev, snr, wl, runs=3))
     res.append(time_other_config("-dec_rnn lstm on the generic fp32 kernels (precision f32), block_len=100, batch=16384", replace(cl, precision="f32"), sdl,
-                                 16384, dev, snr, "random-init", runs=3))
+                                 16384, dev, snr, wl, runs=3))
     cw = TurboAEConfig(enc_num_unit=256, dec_num_unit=256)
     res.append(time_other_config("-enc_num_unit 256 -dec_num_unit 256, block_len=100, batch=2048", cw,
                                  W.generate_state_dict(cw, seed=SEED, gain=1.0), 2048, dev, snr, "random-init", runs=3))
@@ -480,6 +484,8 @@ def flatten_scalars(out) -> None:
             key = "lstm_generic_f32" if "generic fp32" in name else ("lstm" if "lstm" in name else "wide256")
             out[f"{key}_bits_per_s"] = oc["bits_per_s"]
             out[f"{key}_frac"] = oc["decoder_frac"]
+            if key != "wide256":
+                out[f"{key}_ber"] = oc["ber"]
     rf["cfg0_b500_frac"], rf["cfg2_enc5_frac"] = out.get("cfg0_b500_frac"), out.get("cfg2_enc5_frac")
     rf["cfg3_l1000_frac"], rf["cfg4_gru_frac"] = out.get("cfg3_l1000_frac"), out.get("cfg4_gru_frac")
     if out.get("cfg1_head2_ms") and rf.get("kernel_ms"):

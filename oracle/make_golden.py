@@ -286,6 +286,11 @@ TRAINED_KINDS = {
                              "-batch_size 100 -num_block 2000 -num_train_enc 0 -num_train_dec 5 -dec_lr 1e-3, decoder at 1..2 dB): the "
                              "GRU decoder trained from torch's default init against the FIXED reference-trained enc2 encoder "
                              "(oracle/make_init_checkpoint.py encoder_only)"),
+    "trained_cnn_lstm_fp32": (dict(decoder="TurboAE_rate3_rnn", dec_rnn="lstm"), "cnn_lstm_u100",
+                              "-dec_rnn lstm (decoders.py:27-32). reference main.py (oracle/train_chain.sh: 3 stages x 4 epochs, -decoder "
+                              "TurboAE_rate3_rnn -dec_rnn lstm -batch_size 100 -num_block 2000 -num_train_enc 0 -num_train_dec 5 -dec_lr 1e-3, "
+                              "decoder at 1..2 dB): the LSTM decoder trained from torch's default init against the FIXED reference-trained "
+                              "enc2 encoder (the same oracle/make_init_checkpoint.py encoder_only start as the GRU fixture)"),
 }
 
 

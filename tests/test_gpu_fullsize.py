@@ -155,12 +155,14 @@ def test_configs3_per_gpu_shape_25000_blocks_of_1000(gpu_device):
     print("configs[3] 25 000 x 1000 @ 8 dB: BER", ber)
 
 
-def test_configs4_gru_decoder_16384_blocks(gpu_device):
+@pytest.mark.parametrize("cell", ["gru", "lstm"])
+def test_configs4_gru_decoder_16384_blocks(gpu_device, cell):
     """BASELINE configs[4] (DeepTurbo GRU decoder) at one full wave of recurrent workgroups: 16 384 blocks (256 CUs x 8 waves x
-    16 blocks / 2 directions), the GRU path's internal chunk size - so this also runs the chunk boundary when 16 400 are given."""
+    16 blocks / 2 directions), the GRU path's internal chunk size - so this also runs the chunk boundary when 16 400 are given.
+    cell = lstm: the same shape with -dec_rnn lstm (decoders.py:27-32) on the unit-split kernels of turboae_rnn_u.hip."""
     from turboae_amd import Channel_AE_HIP
-    cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn")
-    sd = _trained_sd(cfg, "trained_cnn_gru_u100_fp32.npz")           # reference-trained GRU decoder behind the trained enc2 encoder
+    cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn=cell)
+    sd = _trained_sd(cfg, f"trained_cnn_{cell}_u100_fp32.npz")       # reference-trained recurrent decoder behind the trained enc2 encoder
     B, L = 16400, cfg.block_len
     model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
     u, noise = model.generate_inputs(B, 2.0, seed=78)
@@ -176,15 +178,15 @@ def test_configs4_gru_decoder_16384_blocks(gpu_device):
     w = O.to_torch(sd)
     p = torch.from_numpy(O.rand_interleaver(L, 0))
     with torch.no_grad():
-        xd_o = O.decode_rnn(rx[torch.from_numpy(idx).to(gpu_device)].cpu(), w, p, cfg.dec_num_unit, cfg.num_iteration, cfg.num_iter_ft)
+        xd_o = O.decode_rnn(rx[torch.from_numpy(idx).to(gpu_device)].cpu(), w, p, cfg.dec_num_unit, cfg.num_iteration, cfg.num_iter_ft, cell=cell)
     d = float((x_dec[torch.from_numpy(idx).to(gpu_device)].cpu() - xd_o).abs().max())
     assert d <= 5e-5, d                                          # the GRU golden tests' tolerance (100 sequential steps x 12 stacks)
     counts = model.count_errors(x_dec, u).cpu().tolist()
     err = (x_dec > 0.5) != (u > 0.5)
     assert counts == [int(err.sum()), int(err.any(dim=1).sum())]
     # an operating point: 1.64e6 bits at 2 dB against the BER the reference measured for this network on 2e5 bits
-    ber, ref = counts[0] / (float(B) * L), _manifest("trained_cnn_gru_fp32")["ber"]["2dB"]
-    print("configs[4] 16 400 x 100 @ 2 dB: BER", ber, "reference", ref)
+    ber, ref = counts[0] / (float(B) * L), _manifest(f"trained_cnn_{cell}_fp32")["ber"]["2dB"]
+    print(f"configs[4] ({cell}) 16 400 x 100 @ 2 dB: BER", ber, "reference", ref)
     assert abs(ber - ref) <= 0.1 * ref, (ber, ref)
     model.check_range()
 

@@ -1,6 +1,7 @@
 """HIP path on reference-trained networks in FULL fp32 precision (oracle/make_golden.py::trained_fp32) - one fixture per trained
 BASELINE configuration: trained_enc2dec5_u100_fp32.npz (configs[0] / [1] / [3]), trained_enc5dec5_u100_fp32.npz (configs[2]) and
-trained_cnn_gru_u100_fp32.npz (configs[4]: CNN encoder + GRU decoder), all at a BER of about 6e-3 @ 2 dB (main.py:162-174 loads
+trained_cnn_gru_u100_fp32.npz (configs[4]: CNN encoder + GRU decoder), plus trained_cnn_lstm_u100_fp32.npz (-dec_rnn lstm: precision
+auto runs the unit-split f16x2 kernels of turboae_rnn_u.hip, f32 the generic kernels), all at a BER of about 6e-3 @ 2 dB (main.py:162-174 loads
 such a checkpoint before trainer.test).  Unlike trained_enc2dec5_u100.npz the weights are not rounded to fp16, so the
 fp16-split kernels' lo halves carry real bits for every weight and the per-layer power-of-two scales (pack_stack_h) see
 a trained network's dynamic range.  4 x 500 blocks per SNR point (200 000 bits: BER resolution 5e-6) at 2 / 4 / 6 dB -
@@ -22,14 +23,14 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 with open(os.path.join(GOLD, "MANIFEST.json")) as _fh:
     _MAN = json.load(_fh)
 KINDS = {"trained_fp32": "trained_enc2dec5_u100_fp32.npz", "trained_enc5dec5_fp32": "trained_enc5dec5_u100_fp32.npz",
-         "trained_cnn_gru_fp32": "trained_cnn_gru_u100_fp32.npz"}
-META = _MAN["trained_fp32"]            # batch geometry / seeds / SNR points are the same for all three
+         "trained_cnn_gru_fp32": "trained_cnn_gru_u100_fp32.npz", "trained_cnn_lstm_fp32": "trained_cnn_lstm_u100_fp32.npz"}
+META = _MAN["trained_fp32"]            # batch geometry / seeds / SNR points are the same for all of them
 
 ATOL_CODES = 1e-5
 ATOL_XDEC = 2e-5
 
 
-@pytest.fixture(scope="module", params=list(KINDS), ids=["enc2dec5", "enc5dec5", "cnn_gru"])
+@pytest.fixture(scope="module", params=list(KINDS), ids=["enc2dec5", "enc5dec5", "cnn_gru", "cnn_lstm"])
 def fixture_data(request):
     g = np.load(os.path.join(GOLD, KINDS[request.param]))
     meta = _MAN[request.param]
@@ -102,7 +103,7 @@ def test_stage_taps_on_trained_weights(gpu_device, fixture_data, precision):
     from turboae_amd import Channel_AE_HIP
     g, cfg, sd, meta = fixture_data
     if "dec_taps_first4" not in g.files:
-        pytest.skip("the GRU decoder has no tap export (tae_decode_taps is CNN only)")
+        pytest.skip("the recurrent decoders have no tap export (tae_decode_taps is CNN only)")
     _, noise = _inputs(0, META["snrs"][0])
     rx = torch.from_numpy(g["codes_batch0"][:4] + noise[:4]).to(gpu_device)
     model = Channel_AE_HIP(replace(cfg, precision=precision), sd, device=gpu_device, max_batch=4)

@@ -126,10 +126,11 @@ def test_oracle_matches_reference_on_trained_weights():
 
 @pytest.mark.parametrize("kind,fname", [("trained_fp32", "trained_enc2dec5_u100_fp32.npz"),
                                         ("trained_enc5dec5_fp32", "trained_enc5dec5_u100_fp32.npz"),
-                                        ("trained_cnn_gru_fp32", "trained_cnn_gru_u100_fp32.npz")])
+                                        ("trained_cnn_gru_fp32", "trained_cnn_gru_u100_fp32.npz"),
+                                        ("trained_cnn_lstm_fp32", "trained_cnn_lstm_u100_fp32.npz")])
 def test_oracle_matches_reference_on_full_precision_trained_weights(kind, fname):
     """Reference-trained fp32 checkpoints (weights NOT rounded to fp16; oracle/make_golden.py::trained_fp32) of BASELINE's three
-    trained shapes - enc2/dec5, enc5/dec5 (configs[2]), CNN encoder + GRU decoder (configs[4]): batch 0 at each SNR."""
+    trained shapes - enc2/dec5, enc5/dec5 (configs[2]), CNN encoder + GRU decoder (configs[4]) - and of the LSTM decoder: batch 0 at each SNR."""
     from turboae_amd import philox
     g = np.load(os.path.join(GOLD, fname))
     meta = MANIFEST[kind]
@@ -151,7 +152,7 @@ def test_oracle_matches_reference_on_full_precision_trained_weights(kind, fname)
         rx = codes[:n] + torch.from_numpy(noise[:n])
         with torch.no_grad():
             if rnn:
-                x = O.decode_rnn(rx, w, p, cfg.dec_num_unit, cfg.num_iteration, cfg.num_iter_ft, 1)
+                x = O.decode_rnn(rx, w, p, cfg.dec_num_unit, cfg.num_iteration, cfg.num_iter_ft, 1, cell=cfg.dec_rnn)
             else:
                 x = O.decode(rx, w, p, cfg.dec_num_layer, cfg.num_iteration, cfg.num_iter_ft, 1, taps)
         xr = g[f"x_dec_batch0_{key}"][:n]
