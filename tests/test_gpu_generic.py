@@ -75,12 +75,15 @@ def test_lstm_and_rnn_decoders_on_the_unit_split_f16x2_kernels(gpu_device, name)
     assert np.abs(xd - xd32).max() <= 5e-5 and np.abs(codes - codes32).max() <= 1e-5
 
 
-@pytest.mark.parametrize("cell,B,L", [("lstm", 37, 100), ("rnn", 70, 33), ("lstm", 5, 7)])
-def test_lstm_rnn_unit_split_kernels_batch_independence_and_oracle(gpu_device, cell, B, L):
-    """100-unit LSTM / RNN decoders (the width the kernels are built for; the goldens above run narrower cells embedded in it): against
-    the float64-free oracle, ragged batches (partial groups of 32 blocks), sub-batches bit for bit, determinism."""
+@pytest.mark.parametrize("cell,B,L,U,F", [("lstm", 37, 100, 100, 5), ("rnn", 70, 33, 100, 5), ("lstm", 5, 7, 100, 5),
+                                          ("lstm", 1, 1, 100, 5), ("lstm", 3, 321, 100, 5), ("rnn", 33, 1000, 100, 5),
+                                          ("lstm", 20, 50, 37, 3), ("rnn", 40, 64, 64, 6)])
+def test_lstm_rnn_unit_split_kernels_batch_independence_and_oracle(gpu_device, cell, B, L, U, F):
+    """LSTM / RNN decoders on the unit-split kernels at the width they are built for (100) and narrower cells embedded in it: against
+    the float64-free oracle, ragged batches (partial groups of 32 blocks), one block, one position, long blocks, other num_iter_ft,
+    sub-batches bit for bit, determinism."""
     from turboae_amd import Channel_AE_HIP
-    cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn=cell, block_len=L, num_iteration=2)
+    cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn=cell, block_len=L, num_iteration=2, dec_num_unit=U, num_iter_ft=F)
     assert not cfg.generic
     sd = W.generate_state_dict(cfg, seed=500 + L, gain=1.0)
     u = philox.random_bits(9, 0, B * L).reshape(B, L, 1)
@@ -95,7 +98,7 @@ def test_lstm_rnn_unit_split_kernels_batch_independence_and_oracle(gpu_device, c
     assert d <= 6e-5, d
     rx = codes + nd
     assert torch.equal(model.dec(rx), xd)                                  # run to run
-    for lo, hi in ((0, 1), (B // 2, B // 2 + 3), (B - 2, B)):
+    for lo, hi in ((0, 1), (B // 2, min(B, B // 2 + 3)), (max(0, B - 2), B)):
         assert torch.equal(model.dec(rx[lo:hi].contiguous()), xd[lo:hi]), (lo, hi)
 
 
