@@ -95,7 +95,7 @@ typedef struct tae_config {
 
 /* Configurations the fused MFMA kernels do not instantiate run on generic fp32 kernels (one launch per layer, fp32 operands on the
  * fp32 matrix cores, activations through HBM: 3..8 times slower than the kernels above, same results): channel widths 125..1024
- * (101..124 in TAE_PREC_F32), odd kernel sizes 11..63,
+ * (recurrent cells: 101..1024), odd kernel sizes 11..63,
  * num_iter_ft 7..64, LSTM / vanilla-RNN cells, ENC_interRNN with enc_num_layer != 2 or in front of a CNN decoder (which the
  * reference then builds from DenseSameShapeConv1d, decoders.py:173-176), and TAE_PREC_F32 for dense stacks / kernel sizes 7, 9. */
 #define TAE_RNN_GRU 0

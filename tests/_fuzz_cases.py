@@ -33,8 +33,8 @@ def draw_cases(n, seed):
 
 
 def draw_wide_cases(n, seed):
-    """Channel widths 101 .. 124 on at least one side (r04: the 124-wide instantiation of the fp16-split kernels; precision='f32' takes the
-    same networks to the generic kernels).  Its own generator: draw_cases' random stream is pinned by oracle/fuzz_vs_reference.py."""
+    """Channel widths 101 .. 124 on at least one side (the 124-wide instantiations of the MFMA kernels: fp16-split since r04, fp32 twins since late r05;
+    precision='f32' with kernel sizes 7 / 9 takes a network to the generic kernels).  Its own generator: draw_cases' random stream is pinned by oracle/fuzz_vs_reference.py."""
     rng = np.random.RandomState(seed)
     cases = []
     for i in range(n):

@@ -27,7 +27,8 @@ WIDE_CASES = draw_wide_cases(int(os.environ.get("TAE_FUZZ_CASES", "18")), int(os
 
 @pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: "U{enc_num_unit}x{dec_num_unit}_k{enc_kernel_size}{dec_kernel_size}_L{block_len}_B{B}_e{enc_num_layer}d{dec_num_layer}_F{num_iter_ft}_it{num_iteration}".format(**c))
 def test_random_wide_shape_matches_oracle(gpu_device, monkeypatch, case):
-    """Widths 101 .. 124: the 124-wide fp16-split kernels (whole-block and long-block paths) and, as precision='f32', the generic kernels."""
+    """Widths 101 .. 124: the 124-wide instantiations of the fp16-split and (late r05) fp32 MFMA kernels, whole-block and long-block paths
+    (precision='f32' with kernel sizes 7 / 9: the generic kernels)."""
     _check_shape_case(gpu_device, monkeypatch, case)
 
 

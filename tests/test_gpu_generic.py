@@ -127,10 +127,10 @@ def test_random_generic_configurations_match_oracle(gpu_device, case):
     case = dict(case)
     B, wseed, kind = case.pop("B"), case.pop("wseed"), case.pop("kind")
     cfg = TurboAEConfig(**case)
-    if not cfg.generic:            # a "wide" draw with both widths <= 124: since r04 that is MFMA territory; precision='f32' keeps it generic
-        from dataclasses import replace
+    if not cfg.generic:            # a "wide" draw with both widths <= 124 (MFMA territory in both arithmetics) or an LSTM / RNN decoder
+        from dataclasses import replace     # behind the CNN encoder (unit-split f16x2 kernels): precision='f32' keeps the recurrent ones generic
         cfg = replace(cfg, precision="f32")
-    assert cfg.generic
+    assert cfg.generic or kind == "wide"
     L = cfg.block_len
     sd = W.generate_state_dict(cfg, seed=wseed, gain=1.0)
     u = philox.random_bits(wseed, 0, B * L).reshape(B, L, 1)

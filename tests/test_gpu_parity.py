@@ -675,21 +675,24 @@ def test_handle_is_bound_to_its_device(gpu_device):
         assert rc == -4 and b"current device" in e.lib.tae_last_error()      # TAE_ESTATE
 
 
+@pytest.mark.parametrize("precision", ["auto", "f32"])
 @pytest.mark.parametrize("ue,ud,L,B", [(124, 124, 100, 5), (101, 124, 37, 9), (110, 104, 330, 2), (124, 64, 64, 4), (32, 117, 100, 7)])
-def test_widths_101_to_124_run_on_the_mfma_kernels(gpu_device, ue, ud, L, B):
+def test_widths_101_to_124_run_on_the_mfma_kernels(gpu_device, ue, ud, L, B, precision):
     """-enc_num_unit / -dec_num_unit 101 .. 124 (get_args.py:97-98) used to fall to the generic vector-ALU kernels
-    (a >100x cliff at width 104).  The fp16-split kernels are instantiated for 124 (8 full channel tiles; like 100 it is = 4 mod 8,
-    the widths whose unpadded LDS rows are bank-conflict-free), narrower stacks run embedded: same tolerances as every other width,
-    the fp16-split arithmetic reported, and - against the generic kernels on the same network - the speed of an MFMA path."""
+    (a >100x cliff at width 104).  The fused kernels of both arithmetics are instantiated for 124 (8 full channel tiles; like 100 it is
+    = 4 mod 8, the widths whose unpadded LDS rows are bank-conflict-free; the fp32 twins since late r05), narrower stacks run embedded:
+    same tolerances as every other width, the arithmetic asked for reported, and - against the generic kernels on the same network -
+    the speed of an MFMA path."""
     from turboae_amd import Channel_AE_HIP
-    cfg = TurboAEConfig(enc_num_unit=ue, dec_num_unit=ud, block_len=L, num_iteration=2, dec_num_layer=3)
+    cfg = TurboAEConfig(enc_num_unit=ue, dec_num_unit=ud, block_len=L, num_iteration=2, dec_num_layer=3, precision=precision)
     assert not cfg.generic
     sd = W.generate_state_dict(cfg, seed=100 + ue + ud, gain=1.0)
     u, noise = make_inputs(B, L, seed=71)
     xd, codes, xo, co, taps = run_both(cfg, sd, u, noise, gpu_device)
     assert np.abs(codes - co).max() <= ATOL_CODES and np.abs(xd - xo).max() <= ATOL_XDEC
     model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
-    assert model.range_status() == ("f16x2", False)
+    assert model.range_status() == ("f16x2" if precision == "auto" else "f32", False)
+    assert model.kernel_info()[1] > 0              # the fused / long-block kernels' LDS bytes (0: generic kernels)
 
 
 def test_width_104_is_no_longer_a_performance_cliff(gpu_device, monkeypatch):

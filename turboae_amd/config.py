@@ -71,8 +71,8 @@ class TurboAEConfig:
         (csrc/turboae_generic.hip; mirrors tae::generic_needed): one launch per layer, same results, far slower."""
         ks = (self.enc_kernel_size, self.dec_kernel_size)
         enc_rnn, dec_rnn = self.encoder == "TurboAE_rate3_rnn", self.decoder == "TurboAE_rate3_rnn"
-        # CNN stacks up to 124 wide on the fp16-split MFMA kernels (32 / 64 / 100 / 124 instantiated), fp32 MFMA and GRU kernels up to 100
-        cnn_max = 100 if self.precision == "f32" else 124
+        # CNN stacks up to 124 wide on the MFMA kernels of both arithmetics (32 / 64 / 100 / 124 instantiated), recurrent kernels up to 100
+        cnn_max = 124
         enc_max, dec_max = (100 if enc_rnn else cnn_max), (100 if dec_rnn else cnn_max)
         if max(ks) > 9 or self.enc_num_unit > enc_max or self.dec_num_unit > dec_max or self.num_iter_ft > 6:
             return True

@@ -1205,10 +1205,6 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         if (!strcmp(pe, "f32")) want_h2 = 0;
         else if (!strcmp(pe, "f16x2")) want_h2 = 1;
     }
-    if (!want_h2 && (h->U > 100 || h->Ud > 100)) {
-        delete h;
-        return fail(TAE_EINVAL, "channel widths 101..124 run on the fp16-split kernels only (TAE_PRECISION=f32 given): use tae_config.precision = TAE_PREC_F32 for the generic fp32 kernels");
-    }
     h->nb = choose_nb(h->U, cfg->block_len, &h->lds_bytes, want_h2 != 0, taps_e, 3 * cfg->enc_num_layer);
     h->nbd = choose_nb(h->Ud, cfg->block_len, &h->lds_bytes_d, want_h2 != 0, taps_d, 2 * cfg->num_iteration * cfg->dec_num_layer);
     // Testing knobs (documented in DESIGN.md): TAE_FORCE_SEGMENTED=1 selects the long-block path even
@@ -1297,9 +1293,9 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
                                          (uint32_t)(2 * it + half) * h->dec_stride_h);
             }
         if ((size_t)(s2 - weights) != n_weights) { delete h; return fail(TAE_EINVAL, "internal: dense weight walk mismatch"); }
-    } else if ((big_taps || h->U > 100 || h->Ud > 100) && !h2_ok) {
+    } else if (big_taps && !h2_ok) {
         delete h;
-        return fail(TAE_EINVAL, "kernel sizes 7 / 9 and channel widths above 100 need the fp16-split kernels (precision auto; TAE_PRECISION=f32 given, or the panels do not fit the LDS)");
+        return fail(TAE_EINVAL, "kernel sizes 7 / 9 need the fp16-split kernels (precision auto; TAE_PRECISION=f32 given, or the panels do not fit the LDS)");
     } else if (h2_ok) {
         h->prec = 1;
         const LayoutH lh(h->U, taps_e), lhd(h->Ud, taps_d);

@@ -1,5 +1,5 @@
 // Generic fp32 kernels: the reference's layer arithmetic one layer at a time, for every configuration the reference's argument
-// parser accepts on this path but the MFMA kernels do not instantiate - channel widths above 124 (100 in fp32 / GRU), kernel sizes above 9 (any odd
+// parser accepts on this path but the MFMA kernels do not instantiate - channel widths above 124 (100 for recurrent cells), kernel sizes above 9 (any odd
 // size), num_iter_ft above 6, LSTM / vanilla-RNN cells (decoders.py:27-32, encoders.py:242-253), ENC_interRNN with
 // enc_num_layer != 2, an RNN encoder in front of the (then dense, decoders.py:173-176) CNN decoder - and `precision = f32` for the
 // variants whose MFMA kernels exist in the fp16-split arithmetic only (DenseSameShapeConv1d, kernel sizes 7 / 9).
@@ -693,9 +693,9 @@ bool generic_needed(const tae_config* c) {
     if (const char* e = tae::debug_knob("TAE_FORCE_GENERIC")) if (e[0] == '1') return true;
     const bool big_k = c->enc_kernel_size > 9 || c->dec_kernel_size > 9;
     const bool mid_k = c->enc_kernel_size > 5 || c->dec_kernel_size > 5;
-    // channel widths: CNN stacks up to 124 on the fp16-split MFMA kernels (instantiated for 32 / 64 / 100 / 124 - the widths whose
-    // unpadded LDS rows are conflict-free, U = 4 mod 8; narrower ones run embedded), fp32 MFMA kernels and the GRU kernels up to 100
-    const int cnn_max = c->precision == TAE_PREC_F32 ? 100 : 124;
+    // channel widths: CNN stacks up to 124 on the MFMA kernels of both arithmetics (instantiated for 32 / 64 / 100 / 124 - the widths whose
+    // unpadded LDS rows are conflict-free, U = 4 mod 8; narrower ones run embedded), the recurrent kernels up to 100
+    const int cnn_max = 124;
     const int enc_max = c->enc_type == 1 ? 100 : cnn_max, dec_max = c->dec_type == 1 ? 100 : cnn_max;
     if (big_k || c->enc_num_unit > enc_max || c->dec_num_unit > dec_max || c->num_iter_ft > 6) return true;
     if (c->enc_type == 1 && c->enc_rnn != 0) return true;

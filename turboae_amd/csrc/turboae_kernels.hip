@@ -783,6 +783,7 @@ static hipError_t launch_fused_u(bool decoder, const FusedParams& P, int grid, h
 
 hipError_t launch_fused(int U, bool decoder, const FusedParams& P, int grid, hipStream_t st) {
     switch (U) {
+        case 124: return launch_fused_u<124>(decoder, P, grid, st);
         case 100: return launch_fused_u<100>(decoder, P, grid, st);
         case 64: return launch_fused_u<64>(decoder, P, grid, st);
         case 32: return launch_fused_u<32>(decoder, P, grid, st);
@@ -803,6 +804,7 @@ static hipError_t launch_seg_u(const SegParams& P, int grid, hipStream_t st) {
 
 hipError_t launch_seg(int U, const SegParams& P, int grid, hipStream_t st) {
     switch (U) {
+        case 124: return launch_seg_u<124>(P, grid, st);
         case 100: return launch_seg_u<100>(P, grid, st);
         case 64: return launch_seg_u<64>(P, grid, st);
         case 32: return launch_seg_u<32>(P, grid, st);
