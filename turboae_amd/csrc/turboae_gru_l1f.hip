@@ -31,7 +31,8 @@
 
 // timing experiments on this kernel (results wrong; -DTAE_EXPERIMENT builds only): 1 linear gates (no exp / rcp), 2 no step barrier,
 // 4 no projection MFMAs in the unit waves' step, 8 no recurrence MFMAs in the unit waves' step, 16 no y0 loads in the staging wave's step,
-// 32 no helper partials in the step loops, 64 no LDS stores of the staged rows
+// 32 no helper partials in the step loops, 64 no LDS stores of the staged rows, 128 cycle stamps (s_memtime at the phase boundaries of steps
+// 40..47 of workgroup (0, 0)'s first group, printed per wave at the end of the kernel; results stay correct)
 #if defined(TAE_EXPERIMENT) && defined(TAE_L1F_X)
 constexpr int kL1fX = TAE_L1F_X;
 #else
@@ -70,7 +71,9 @@ constexpr int kPB = kYH + 2 * kYHsz;                // helper partials = accumul
 constexpr int kPBsz = 18 * 1024;
 constexpr int kLds = kPB + 2 * kPBsz;
 constexpr int kUnitB = 42 * 1024, kRemB = 27 * 1024, kLo01B = 36 * 1024;
-static_assert(kLds <= 160 * 1024, "LDS budget");
+constexpr int kDbgSteps = 8, kDbgS0 = 40, kDbgStamps = 8;
+constexpr int kDbgB = (kL1fX & 128) ? 8 * kDbgSteps * kDbgStamps * 4 : 0;
+static_assert(kLds + kDbgB <= 160 * 1024, "LDS budget");
 static_assert(kUnitB == GruL1fLayout::kUnitB && kRemB == GruL1fLayout::kRemB && kLo01B == GruL1fLayout::kLo01B &&
               kLdsW + kBiasB == GruL1fLayout::kLdsImgB, "host packing");
 
@@ -162,7 +165,31 @@ struct Ctx {
     lds_cptr lds;
     int lane, n, q, dir, L;
     float inv, inv_head;
+    int wave;
 };
+
+// experiment 128: shader-clock stamp i of step s of this wave (first group of workgroup (0, 0) only)
+__device__ __forceinline__ void stamp(const Ctx& c, bool first, int s, int i) {
+    if constexpr ((kL1fX & 128) != 0) {
+        if (first && blockIdx.x == 0 && blockIdx.y == 0 && s >= kDbgS0 && s < kDbgS0 + kDbgSteps) {
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t t = (uint32_t)__builtin_readcyclecounter();
+            if (c.lane == 0) *reinterpret_cast<uint32_t __attribute__((address_space(3)))*>((lds_ptr)c.lds + kLds + ((c.wave * kDbgSteps + (s - kDbgS0)) * kDbgStamps + i) * 4) = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+__device__ __forceinline__ void stamp_print(const Ctx& c, int nst) {
+    if constexpr ((kL1fX & 128) != 0) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && c.lane == 0) {
+            for (int s = 0; s < kDbgSteps; ++s) {
+                const uint32_t __attribute__((address_space(3)))* r = reinterpret_cast<const uint32_t __attribute__((address_space(3)))*>((lds_ptr)c.lds + kLds + ((c.wave * kDbgSteps + s) * kDbgStamps) * 4);
+                const uint32_t t0 = r[0];
+                printf("l1f wave %d step %d: t0 %u  +%u +%u +%u +%u +%u +%u (%d stamps)\n", c.wave, kDbgS0 + s, t0, r[1] - t0, r[2] - t0, r[3] - t0, r[4] - t0, r[5] - t0, r[6] - t0, nst);
+            }
+        }
+    }
+}
 
 // Buffer parity: M[k & 1] / H[k & 1] hold the y0 fragments of step k, pb[k & 1] the partial tiles of step k, hb[k & 1] the B
 // fragments of h_{k-1}.  During step s
@@ -227,6 +254,7 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
             //   the owner's share of step s + 1's projection (off it): B fragments one slab ahead, the gate arithmetic of step s dealt
             //   out between its MFMAs (two vector-ALU instructions per MFMA): the matrix pipe never waits for the gates.
             const int p1 = (s + 1) & 1;
+            stamp(c, grp == (int)blockIdx.x, s, 0);
             const lds_cptr hc = hb + (s & 1) * kHBsz, y = ym + p1 * kYMsz, pbn = pb + p1 * kPBsz;
             f32x4 acc[3] = {gi[0], gi[1], *reinterpret_cast<lds_f4c*>(bias_nh)};
             const f32x4 gin = gi[2];
@@ -246,6 +274,7 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
             for (int g = 0; g < 3; ++g) gi[g] = *reinterpret_cast<lds_f4c*>(pbn + g * 1024);       // helpers' partial (bias + slabs 4, 5)
             if (kL1fX & 8) skip3(acc, hh_r, xh[1], xl[1]); else mma3r(acc, hh_r, xh[1], xl[1]);
             pin<5, 6, 0>();
+            stamp(c, grp == (int)blockIdx.x, s, 1);
             f32x4 hn;
             static_for<kMS>([&](auto SL) {
                 constexpr int sl = decltype(SL)::value, cur = sl & 1, nxt = cur ^ 1;
@@ -267,6 +296,7 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
                     pin<(sl < 2 ? 2 : 5), 9, 2>();
                 } else pin<5, 9, 0>();
             });
+            stamp(c, grp == (int)blockIdx.x, s, 2);
             h = hn;
             h4 nhi, nlo;
             split4(hn, nhi, nlo);
@@ -275,10 +305,12 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
             *reinterpret_cast<lds_w2*>(hn_w + 1024) = __builtin_bit_cast(u32x2v, nlo);
             if (kL1fX & 4) skip3(gi, ih_r, xh[kMS & 1], xl[kMS & 1]); else mma3r(gi, ih_r, xh[kMS & 1], xl[kMS & 1]);
             pin<0, 6, 1>();
+            stamp(c, grp == (int)blockIdx.x, s, 3);
             step_barrier();
         }
         step_barrier();                                   // the remainder wave's last head product has read the h buffer
     }
+    stamp_print(c, 4);
 }
 
 // Helper share of the projection: for NU unit tiles starting at u0, tile (ut, g) <- bias + W_ih1[rows, k-slabs 4, 5] * y0, written
@@ -378,6 +410,7 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
 #pragma unroll 1
         for (int s = 0; s < L; ++s) {
             const int p0 = s & 1, p1 = p0 ^ 1;
+            stamp(c, grp == (int)blockIdx.x, s, 0);
             const lds_cptr hc = hb + p0 * kHBsz;
             f32x4 acc = gi;
 #pragma unroll
@@ -389,11 +422,15 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
                 const h8 b1 = lds_h8(hc + 6144), b2 = lds_h8(hc + 7168);
                 mma1r(acc, hh_r, b1, b2);
             }
+            stamp(c, grp == (int)blockIdx.x, s, 1);
             gi = gp1;                                                                    // own tile, step s + 1
             own_main(gi, ym + p1 * kYMsz);
             gp1 = own_part(yh + p0 * kYHsz);                                             // own tile, step s + 2
+            stamp(c, grp == (int)blockIdx.x, s, 2);
             if (!(kL1fX & 32)) helper_partials<1>(hp_hi, c.lds, lane, 0, q, yh + p0 * kYHsz, pbw + p0 * kPBsz);   // unit tile 0, step s + 2
+            stamp(c, grp == (int)blockIdx.x, s, 3);
             if (s > 0) head(hc, rs, dir ? L - s : s - 1);          // Linear head on h_{s-1} (the state this step started from)
+            stamp(c, grp == (int)blockIdx.x, s, 4);
             const float r = sigm_f(acc[0] * inv);
             const float z = sigm_f(acc[1] * inv);
             const float nn = tanh_f(fmaf(r, acc[2] * inv, acc[3] * inv));
@@ -404,11 +441,13 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
             const lds_ptr hn_w = hw + p1 * kHBsz;
             *reinterpret_cast<lds_w4*>(hn_w) = __builtin_bit_cast(u32x4v, b1);
             *reinterpret_cast<lds_w4*>(hn_w + 1024) = __builtin_bit_cast(u32x4v, b2);
+            stamp(c, grp == (int)blockIdx.x, s, 5);
             step_barrier();
         }
         head(hb + (L & 1) * kHBsz, rs, dir ? 0 : L - 1);
         step_barrier();
     }
+    stamp_print(c, 6);
 }
 
 // ---- staging wave: y0 rows -> B fragments in LDS; helper for unit tiles 1..5 ------------------------------------------------------
@@ -484,13 +523,18 @@ __device__ __forceinline__ void stage_wave(const Ctx& c) {
         for (int s = 0; s < L; ++s) {
             const int p0 = s & 1, p1 = p0 ^ 1;
             // m0 / h1 hold M(s + 2) / H(s + 3), fetched a step ago
+            stamp(c, grp == (int)blockIdx.x, s, 0);
             if (!(kL1fX & 64)) { ym_store(m0, ymw + p0 * kYMsz); yh_store(h1, yhw + p1 * kYHsz); }
+            stamp(c, grp == (int)blockIdx.x, s, 1);
             if (!(kL1fX & 16)) { ym_load(m0, rs, v0, vr, so(s + 3)); yh_load(h1, rs, v0, so(s + 4)); }
+            stamp(c, grp == (int)blockIdx.x, s, 2);
             if (!(kL1fX & 32)) helper_partials<5>(hp_hi, c.lds, lane, 1, q, yh + p0 * kYHsz, pbw + p0 * kPBsz);   // unit tiles 1..5, step s + 2
+            stamp(c, grp == (int)blockIdx.x, s, 3);
             step_barrier();
         }
         step_barrier();
     }
+    stamp_print(c, 4);
 }
 
 __global__ __launch_bounds__(512) void gru_l1f_kernel(GruL1fParams P) {
@@ -506,7 +550,7 @@ __global__ __launch_bounds__(512) void gru_l1f_kernel(GruL1fParams P) {
     __syncthreads();
     const float inv = *reinterpret_cast<const float*>(smem + kLdsW + 6 * 256 + 64);
     const float inv_head = *reinterpret_cast<const float*>(smem + kLdsW + 6 * 256 + 68);
-    const Ctx c{P, wdir, (lds_cptr)smem, lane, lane & 15, lane >> 4, dir, P.L, inv, inv_head};
+    const Ctx c{P, wdir, (lds_cptr)smem, lane, lane & 15, lane >> 4, dir, P.L, inv, inv_head, wave};
     if (wave == 3) rem_wave(c);
     else if (wave == 7) stage_wave(c);
     else unit_wave(c, wave < 3 ? wave : wave - 1);
@@ -514,7 +558,7 @@ __global__ __launch_bounds__(512) void gru_l1f_kernel(GruL1fParams P) {
 
 }  // namespace
 
-int gru_l1f_lds_bytes() { return kLds; }
+int gru_l1f_lds_bytes() { return kLds + kDbgB; }
 
 hipError_t launch_gru_l1f(const GruL1fParams& P, hipStream_t st) {
     static int ncu = 0;
@@ -524,12 +568,12 @@ hipError_t launch_gru_l1f(const GruL1fParams& P, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
         ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_l1f_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_l1f_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds + kDbgB);
     if (e != hipSuccess) return e;
     // one workgroup per CU (157 KB of LDS), half of them per direction; each walks its share of the 16-block groups
     const int per_dir = std::max(1, ncu / 2);
     const dim3 grid((unsigned)std::min(P.ngroups, per_dir), 2);
-    hipLaunchKernelGGL(gru_l1f_kernel, grid, dim3(512), kLds, st, P);
+    hipLaunchKernelGGL(gru_l1f_kernel, grid, dim3(512), kLds + kDbgB, st, P);
     return hipGetLastError();
 }
 
