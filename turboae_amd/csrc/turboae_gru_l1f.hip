@@ -77,13 +77,15 @@ static_assert(kLds + kDbgB <= 160 * 1024, "LDS budget");
 static_assert(kUnitB == GruL1fLayout::kUnitB && kRemB == GruL1fLayout::kRemB && kLo01B == GruL1fLayout::kLo01B &&
               kLdsW + kBiasB == GruL1fLayout::kLdsImgB, "host packing");
 
-__device__ __forceinline__ float sigm_f(float x) {
-    if (kL1fX & 1) return fmaf(x, 0.25f, 0.5f);
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+// sigmoid / tanh of x 2^-S given cs = -log2(e) 2^-S, ct = 2 log2(e) 2^-S: the accumulators' power-of-two scale rides in the
+// exp2 argument's constant - bit for bit what scaling x first gives (a power of two commutes with every rounding here)
+__device__ __forceinline__ float sigm_s(float x, float cs) {
+    if (kL1fX & 1) return fmaf(x * cs, -0.17f, 0.5f);
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * cs));
 }
-__device__ __forceinline__ float tanh_f(float x) {
-    if (kL1fX & 1) return x * 0.5f;
-    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)), 1.0f);
+__device__ __forceinline__ float tanh_s(float x, float ct) {
+    if (kL1fX & 1) return x * ct * 0.17f;
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * ct)), 1.0f);
 }
 __device__ __forceinline__ h8 lds_h8(lds_cptr p) { return __builtin_bit_cast(h8, *reinterpret_cast<lds_q4*>(p)); }
 __device__ __forceinline__ h8 glb_h8(const char* p) { return __builtin_bit_cast(h8, *reinterpret_cast<const u32x4v*>(p)); }
@@ -223,7 +225,7 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
     const lds_cptr hb = c.lds + kHB + lane * 16, ym = c.lds + kYM + lane * 16;
     const lds_cptr pb = c.lds + kPB + ut * (3 * 1024) + lane * 16;
     const lds_ptr hw = (lds_ptr)(c.lds + kHB + (ut >> 1) * 2048 + lane * 16 + (ut & 1) * 8);
-    const float inv = c.inv;
+    const float cs = -1.44269504088896341f * c.inv, ct = 2.88539008177792681f * c.inv;
 
     for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
         // h_{-1} = 0: this wave's slots of buffer 0
@@ -289,9 +291,9 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
                 }
                 if constexpr (sl < 4) {
                     const int i = sl;
-                    const float r = sigm_f(acc[0][i] * inv);
-                    const float z = sigm_f(acc[1][i] * inv);
-                    const float nn = tanh_f(fmaf(r, acc[2][i] * inv, gin[i] * inv));
+                    const float r = sigm_s(acc[0][i], cs);
+                    const float z = sigm_s(acc[1][i], cs);
+                    const float nn = tanh_s(fmaf(r, acc[2][i], gin[i]), ct);
                     hn[i] = fmaf(z, h[i] - nn, nn);
                     pin<(sl < 2 ? 2 : 5), 9, 2>();
                 } else pin<5, 9, 0>();
@@ -365,7 +367,7 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
     const lds_cptr hb = c.lds + kHB + lane * 16, ym = c.lds + kYM + lane * 16, yh = c.lds + kYH + lane * 16;
     const lds_ptr hw = (lds_ptr)(c.lds + kHB + 6144 + lane * 16);
     const lds_ptr pbw = (lds_ptr)(c.lds + kPB + lane * 16);
-    const float inv = c.inv, inv_head = c.inv_head;
+    const float inv_head = c.inv_head, cs = -1.44269504088896341f * c.inv, ct = 2.88539008177792681f * c.inv;
 
     // this wave's own tile: bias + k-slabs 4, 5 (at helper time, two steps ahead) ...
     auto own_part = [&](lds_cptr yhk) {
@@ -431,9 +433,9 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
             stamp(c, grp == (int)blockIdx.x, s, 3);
             if (s > 0) head(hc, rs, dir ? L - s : s - 1);          // Linear head on h_{s-1} (the state this step started from)
             stamp(c, grp == (int)blockIdx.x, s, 4);
-            const float r = sigm_f(acc[0] * inv);
-            const float z = sigm_f(acc[1] * inv);
-            const float nn = tanh_f(fmaf(r, acc[2] * inv, acc[3] * inv));
+            const float r = sigm_s(acc[0], cs);
+            const float z = sigm_s(acc[1], cs);
+            const float nn = tanh_s(fmaf(r, acc[2], acc[3]), ct);
             hr = fmaf(z, hr - nn, nn);
             const _Float16 hi = (_Float16)hr;
             const _Float16 lo = (_Float16)(hr - (float)hi);
