@@ -31,7 +31,7 @@
 
 // timing experiments on this kernel (results wrong; -DTAE_EXPERIMENT builds only): 1 linear gates (no exp / rcp), 2 no step barrier,
 // 4 no projection MFMAs in the unit waves' step, 8 no recurrence MFMAs in the unit waves' step, 16 no y0 loads in the staging wave's step,
-// 32 no helper partials in the step loops, 64 no LDS stores of the staged rows, 128 cycle stamps (s_memtime at the phase boundaries of steps
+// 32 no helper partials in the step loops, 128 cycle stamps (s_memtime at the phase boundaries of steps
 // 40..47 of workgroup (0, 0)'s first group, printed per wave at the end of the kernel; results stay correct)
 #if defined(TAE_EXPERIMENT) && defined(TAE_L1F_X)
 constexpr int kL1fX = TAE_L1F_X;
@@ -453,36 +453,36 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
 }
 
 // ---- staging wave: y0 rows -> B fragments in LDS; helper for unit tiles 1..5 ------------------------------------------------------
-struct YM { u32x4v v[2 * kMS]; u32x2v rh, rl; };            // k-slabs 0..3 (hi, lo) + the K = 16 remainder of one step
-struct YH { u32x4v v[2 * kHS]; };                           // k-slabs 4, 5 (hi, lo)
-
-// lane (n, kq) supplies k = 32 sl + 8 kq .. + 7 of block n: bytes plane * 400 + sl * 64 + kq * 16 of the block's 800-byte row
-__device__ __forceinline__ void ym_load(YM& r, __amdgpu_buffer_rsrc_t rs, uint32_t v0, uint32_t vr, uint32_t so) {
+// LDS-DMA (buffer_load ... lds): every lane's 16 bytes land at the wave-uniform LDS address + lane * 16 - exactly a fragment tile.
+// The staged rows never touch a register and cost no ds_write; the staging wave's registers go to its helper share instead.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, lds_ptr dst, uint32_t v, uint32_t so) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, v, so, 0, 0);
+}
+__device__ __forceinline__ void ym_dma(__amdgpu_buffer_rsrc_t rs, lds_ptr y, uint32_t v0, uint32_t so) {       // y: tile base (no lane term)
 #pragma unroll
     for (int sl = 0; sl < kMS; ++sl) {
-        r.v[2 * sl] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + sl * 64, so, 0);
-        r.v[2 * sl + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + 400 + sl * 64, so, 0);
+        dma16(rs, y + (2 * sl) * 1024, v0 + sl * 64, so);
+        dma16(rs, y + (2 * sl + 1) * 1024, v0 + 400 + sl * 64, so);
     }
+}
+__device__ __forceinline__ void yh_dma(__amdgpu_buffer_rsrc_t rs, lds_ptr y, uint32_t v0, uint32_t so) {
+#pragma unroll
+    for (int sl = 0; sl < kHS; ++sl) {
+        dma16(rs, y + (2 * sl) * 1024, v0 + (kMS + sl) * 64, so);
+        dma16(rs, y + (2 * sl + 1) * 1024, v0 + 400 + (kMS + sl) * 64, so);
+    }
+}
+// the K = 16 remainder of a step goes through registers (its halves are re-paired into b1 = [lo | hi], b2 = [hi | 0])
+struct YR { u32x2v rh, rl; };
+__device__ __forceinline__ void yr_load(YR& r, __amdgpu_buffer_rsrc_t rs, uint32_t vr, uint32_t so) {
     r.rh = __builtin_amdgcn_raw_buffer_load_b64(rs, vr, so, 0);               // out-of-range lanes read zeros
     r.rl = __builtin_amdgcn_raw_buffer_load_b64(rs, vr + 400, so, 0);
 }
-__device__ __forceinline__ void yh_load(YH& r, __amdgpu_buffer_rsrc_t rs, uint32_t v0, uint32_t so) {
-#pragma unroll
-    for (int sl = 0; sl < kHS; ++sl) {
-        r.v[2 * sl] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + (kMS + sl) * 64, so, 0);
-        r.v[2 * sl + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + 400 + (kMS + sl) * 64, so, 0);
-    }
+__device__ __forceinline__ void yr_store(const YR& r, lds_ptr y) {            // y: this lane's slot of the M part
+    *reinterpret_cast<lds_w4*>(y + kMS * 2048) = u32x4v{r.rl.x, r.rl.y, r.rh.x, r.rh.y};
+    *reinterpret_cast<lds_w4*>(y + kMS * 2048 + 1024) = u32x4v{r.rh.x, r.rh.y, 0, 0};
 }
-__device__ __forceinline__ void ym_store(const YM& r, lds_ptr y) {
-#pragma unroll
-    for (int i = 0; i < 2 * kMS; ++i) *reinterpret_cast<lds_w4*>(y + i * 1024) = r.v[i];
-    *reinterpret_cast<lds_w4*>(y + kMS * 2048) = u32x4v{r.rl.x, r.rl.y, r.rh.x, r.rh.y};        // b1 = [lo | hi]
-    *reinterpret_cast<lds_w4*>(y + kMS * 2048 + 1024) = u32x4v{r.rh.x, r.rh.y, 0, 0};           // b2 = [hi | 0]
-}
-__device__ __forceinline__ void yh_store(const YH& r, lds_ptr y) {
-#pragma unroll
-    for (int i = 0; i < 2 * kHS; ++i) *reinterpret_cast<lds_w4*>(y + i * 1024) = r.v[i];
-}
+__device__ __forceinline__ void dma_landed() { __builtin_amdgcn_s_waitcnt(0x0F70); }       // vmcnt(0): an LDS-DMA is a pending LDS write on the VM counter
 
 __device__ __forceinline__ void stage_wave(const Ctx& c) {
     const int lane = c.lane, L = c.L, n = c.n, q = c.q, dir = c.dir;
@@ -494,7 +494,8 @@ __device__ __forceinline__ void stage_wave(const Ctx& c) {
 #pragma unroll
             for (int g = 0; g < 3; ++g) hp_hi[u][sl][g] = glb_h8(c.wdir + (size_t)(1 + u) * kUnitB + (21 + g * 7 + kMS + sl) * 1024 + lane * 16);
     const lds_cptr yh = c.lds + kYH + lane * 16;
-    const lds_ptr ymw = (lds_ptr)(c.lds + kYM + lane * 16), yhw = (lds_ptr)(c.lds + kYH + lane * 16);
+    const lds_ptr ymu = (lds_ptr)(c.lds + kYM), yhu = (lds_ptr)(c.lds + kYH);          // tile bases of the DMA
+    const lds_ptr ymw = (lds_ptr)(c.lds + kYM + lane * 16);
     const lds_ptr pbw = (lds_ptr)(c.lds + kPB + lane * 16);
     const uint32_t v0 = (uint32_t)(n * 800 + q * 16);
     const uint32_t vr = q < 2 ? (uint32_t)(n * 800 + 384 + q * 8) : 0x80000000u;        // remainder k = 192 + 4 kq .. + 3 (kq < 2)
@@ -502,35 +503,39 @@ __device__ __forceinline__ void stage_wave(const Ctx& c) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(c.P.y0) + (size_t)grp * L * (16 * 800), 0, L * 16 * 800, 0x00020000);
         // byte offset of step k's 16 rows (steps past the end: the last step again - fetched, never used)
         const auto so = [&](int k) { k = k < L ? k : L - 1; return (uint32_t)__builtin_amdgcn_readfirstlane(dir ? L - 1 - k : k) * (16 * 800u); };
-        YM m0;
-        YH h0, h1;
-        // one set of row registers, refilled in turn (register pressure: the helper's 120 weight registers stay live here)
-        ym_load(m0, rs, v0, vr, so(0)); yh_load(h0, rs, v0, so(0)); yh_load(h1, rs, v0, so(1));
-        ym_store(m0, ymw); yh_store(h0, yhw); yh_store(h1, yhw + kYHsz);
-        __builtin_amdgcn_sched_barrier(0);
-        ym_load(m0, rs, v0, vr, so(1)); yh_load(h0, rs, v0, so(2));
-        ym_store(m0, ymw + kYMsz);
-        __builtin_amdgcn_sched_barrier(0);
+        YR r0, r1;
+        ym_dma(rs, ymu, v0, so(0)); ym_dma(rs, ymu + kYMsz, v0, so(1));
+        yh_dma(rs, yhu, v0, so(0)); yh_dma(rs, yhu + kYHsz, v0, so(1));
+        yr_load(r0, rs, vr, so(0)); yr_load(r1, rs, vr, so(1));
+        yr_store(r0, ymw); yr_store(r1, ymw + kYMsz);
+        dma_landed();
         step_barrier();                                   // B0
         helper_partials<5>(hp_hi, c.lds, lane, 1, q, yh, pbw);                             // steps 0 and 1
         __builtin_amdgcn_sched_barrier(0);
         helper_partials<5>(hp_hi, c.lds, lane, 1, q, yh + kYHsz, pbw + kPBsz);
         __builtin_amdgcn_sched_barrier(0);
-        ym_load(m0, rs, v0, vr, so(2));
-        yh_load(h1, rs, v0, so(3));
         step_barrier();                                   // B1: every helper has read H[0]
-        yh_store(h0, yhw);                                // H[0] <- step 2
+        yh_dma(rs, yhu, v0, so(2));                       // H[0] <- step 2
+        dma_landed();
         step_barrier();                                   // B2
 #pragma unroll 1
         for (int s = 0; s < L; ++s) {
             const int p0 = s & 1, p1 = p0 ^ 1;
-            // m0 / h1 hold M(s + 2) / H(s + 3), fetched a step ago
             stamp(c, grp == (int)blockIdx.x, s, 0);
-            if (!(kL1fX & 64)) { ym_store(m0, ymw + p0 * kYMsz); yh_store(h1, yhw + p1 * kYHsz); }
+            // step s + 2 -> M[p0] (the owners read M[p1] now), step s + 3's helper slabs -> H[p1] (the helpers read H[p0] now):
+            // in flight behind this wave's helper share, landed before the barrier that hands the buffers over
+            if (!(kL1fX & 16)) {
+                ym_dma(rs, ymu + p0 * kYMsz, v0, so(s + 2));
+                yh_dma(rs, yhu + p1 * kYHsz, v0, so(s + 3));
+                yr_load(r0, rs, vr, so(s + 2));
+            }
             stamp(c, grp == (int)blockIdx.x, s, 1);
-            if (!(kL1fX & 16)) { ym_load(m0, rs, v0, vr, so(s + 3)); yh_load(h1, rs, v0, so(s + 4)); }
-            stamp(c, grp == (int)blockIdx.x, s, 2);
+            __builtin_amdgcn_sched_barrier(0);
             if (!(kL1fX & 32)) helper_partials<5>(hp_hi, c.lds, lane, 1, q, yh + p0 * kYHsz, pbw + p0 * kPBsz);   // unit tiles 1..5, step s + 2
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(c, grp == (int)blockIdx.x, s, 2);
+            yr_store(r0, ymw + p0 * kYMsz);
+            dma_landed();
             stamp(c, grp == (int)blockIdx.x, s, 3);
             step_barrier();
         }
