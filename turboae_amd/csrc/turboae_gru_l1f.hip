@@ -413,25 +413,48 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
         for (int s = 0; s < L; ++s) {
             const int p0 = s & 1, p1 = p0 ^ 1;
             stamp(c, grp == (int)blockIdx.x, s, 0);
-            const lds_cptr hc = hb + p0 * kHBsz;
-            f32x4 acc = gi;
+            const lds_cptr hc = hb + p0 * kHBsz, y = ym + p1 * kYMsz, yk = yh + p0 * kYHsz;
+            // Four single-accumulator chains - this tile's recurrence (acc), the head products of h_{s-1} (hd: the same B fragments),
+            // the own tile's projection of step s + 1 (gi: k-slabs 0..3 + remainder) and of step s + 2 (gp: the helper slabs) - issued
+            // product by product in turn: a chain's next MFMA is four issue slots behind the one it depends on, so none of them
+            // waits for its accumulator (issued one after the other, each dependent MFMA held the pipe - and the staging wave - for its latency)
+            f32x4 acc = gi, hd = {0.f, 0.f, 0.f, 0.f}, gp = *reinterpret_cast<lds_f4c*>(bias);
+            gi = gp1;
 #pragma unroll
-            for (int sl = 0; sl < 3; ++sl) {
-                const h8 bh = lds_h8(hc + sl * 2048), bl = lds_h8(hc + sl * 2048 + 1024);
-                mma1(acc, hh_hi[sl], hh_lo[sl], bh, bl);
+            for (int r = 0; r < 3; ++r) {
+                const h8 bh = lds_h8(hc + r * 2048), bl = lds_h8(hc + r * 2048 + 1024);
+                const h8 mh = lds_h8(y + r * 2048), ml = lds_h8(y + r * 2048 + 1024);
+                h8 kh = bh, kl = bl;
+                if (r < kHS) { kh = lds_h8(yk + r * 2048); kl = lds_h8(yk + r * 2048 + 1024); }
+                acc = mfma16x16x32h(hh_hi[r], bl, acc); hd = mfma16x16x32h(hd_hi[r], bl, hd); gi = mfma16x16x32h(ih_hi[r], ml, gi);
+                if (r < kHS) gp = mfma16x16x32h(ih_hi[kMS + r], kl, gp);
+                acc = mfma16x16x32h(hh_lo[r], bh, acc); hd = mfma16x16x32h(hd_lo[r], bh, hd); gi = mfma16x16x32h(ih_lo[r], mh, gi);
+                if (r < kHS) gp = mfma16x16x32h(ih_lo[kMS + r], kh, gp);
+                acc = mfma16x16x32h(hh_hi[r], bh, acc); hd = mfma16x16x32h(hd_hi[r], bh, hd); gi = mfma16x16x32h(ih_hi[r], mh, gi);
+                if (r < kHS) gp = mfma16x16x32h(ih_hi[kMS + r], kh, gp);
             }
             {
                 const h8 b1 = lds_h8(hc + 6144), b2 = lds_h8(hc + 7168);
-                mma1r(acc, hh_r, b1, b2);
+#pragma unroll
+                for (int r = 3; r < kMS; ++r) {                     // the projection's remaining slabs, the K = 16 remainders between its products
+                    const h8 mh = lds_h8(y + r * 2048), ml = lds_h8(y + r * 2048 + 1024);
+                    gi = mfma16x16x32h(ih_hi[r], ml, gi);
+                    if (r == 3) { acc = mfma16x16x32h(hh_r, b1, acc); hd = mfma16x16x32h(hd_r, b1, hd); }
+                    gi = mfma16x16x32h(ih_lo[r], mh, gi);
+                    if (r == 3) { acc = mfma16x16x32h(hh_r, b2, acc); hd = mfma16x16x32h(hd_r, b2, hd); }
+                    gi = mfma16x16x32h(ih_hi[r], mh, gi);
+                }
             }
             stamp(c, grp == (int)blockIdx.x, s, 1);
-            gi = gp1;                                                                    // own tile, step s + 1
-            own_main(gi, ym + p1 * kYMsz);
-            gp1 = own_part(yh + p0 * kYHsz);                                             // own tile, step s + 2
+            if (!(kL1fX & 32)) helper_partials<1>(hp_hi, c.lds, lane, 0, q, yk, pbw + p0 * kPBsz);   // unit tile 0, step s + 2
+            mma1r(gi, ih_r, lds_h8(y + kMS * 2048), lds_h8(y + kMS * 2048 + 1024));
+            gp1 = gp;
             stamp(c, grp == (int)blockIdx.x, s, 2);
-            if (!(kL1fX & 32)) helper_partials<1>(hp_hi, c.lds, lane, 0, q, yh + p0 * kYHsz, pbw + p0 * kPBsz);   // unit tile 0, step s + 2
+            if (s > 0) {                                            // Linear head on h_{s-1} (the state this step started from)
+                const uint32_t v = q < 2 ? (uint32_t)(n * 64 + dir * 32 + q * 16) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, hd * inv_head), rs, v, (uint32_t)(dir ? L - s : s - 1) * 1024u, 0);
+            }
             stamp(c, grp == (int)blockIdx.x, s, 3);
-            if (s > 0) head(hc, rs, dir ? L - s : s - 1);          // Linear head on h_{s-1} (the state this step started from)
             stamp(c, grp == (int)blockIdx.x, s, 4);
             const float r = sigm_s(acc[0], cs);
             const float z = sigm_s(acc[1], cs);
