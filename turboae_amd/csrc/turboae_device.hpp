@@ -7,6 +7,7 @@
 // Timing-experiment bitmasks (the results become WRONG by construction; tools/build_variant.sh).  They exist only in builds made
 // with -DTAE_EXPERIMENT; in every other build they are the constant 0 and the code they guard is compiled out.
 //   TAE_X      (CNN kernels)           1 no layer barriers, 2 no panel writes, 4 no ELU, 8 no weight loads in loop, 16 no LDS reads in loop
+//                                      1024 cycle stamps per layer phase of workgroup 0 (turboae_h2_impl.hpp stamp_h; results stay correct)
 //   TAE_REC_X  (gru_rec_h)             1 no exp / rcp in the gates, 2 no LDS fragment reads, 4 no GI loads / Y0 stores, 8 no MFMAs
 //   TAE_PROJ_X (gru_proj_h)            1 no GI stores, 2 no K loop, 4 no Y0 staging loads
 #ifdef TAE_EXPERIMENT

@@ -392,6 +392,20 @@ __device__ __forceinline__ const float* dense_tail(const float* wpack, uint32_t 
     return reinterpret_cast<const float*>(reinterpret_cast<const char*>(wpack) + off) + G::CP;
 }
 
+// Timing experiment TAE_X & 1024 (results stay correct): shader-clock stamps of workgroup 0 at the phase boundaries of every conv layer of
+// the stack that ran last (bias loaded | K loop issued | panel free | epilogue issued | panel written), printed per wave by dec_kernel_h.
+constexpr int kStampBase = 155 * 1024;             // 158 720: behind the U = 100 panels (158 240 B), inside the 160 KB the experiment launch asks for
+__device__ __forceinline__ void stamp_h(char* smem, int lane, int layer, int i) {
+    if constexpr ((TAE_X & 1024) != 0) {
+        if (blockIdx.x == 0 && layer < 5) {
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t t = (uint32_t)__builtin_readcyclecounter();
+            if (lane == 0) reinterpret_cast<uint32_t*>(smem + kStampBase)[((threadIdx.x >> 6) * 5 + layer) * 8 + i] = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // One SameShapeConv1d stack (cnn_utils.py:36-46) + Linear head; same contract as run_stack in
 // turboae_kernels.hip, except that `g` is the first position TILE of the wave's group (not the group index).  `rg`: range
 // bookkeeping of the layer panels (above; TRACK = 0 compiles it out, 1 = the panels, 2 = also the maximum of the last layer's ELU
@@ -418,6 +432,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
         // the layer's scales (tail: 2^-(S + A_in) | 2^A_out | low | high | ELU kind) are fetched HERE, a K loop ahead of the epilogue
         // that needs them: fetched after the loop (r04 first cut, to spare three scalar registers) every layer's epilogue began with
         // an exposed scalar-load latency - 60 of them per decoder workgroup, +2 % (tools/ab_abi.sh against the r03 library)
+        stamp_h(smem, lane, l, 0);
         inv_scale = bias[G::CP];
         const float out_scale_l = bias[G::CP + 1];
         const int kind_l = (int)bias[G::CP + 4];
@@ -441,6 +456,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
         }
         conv_accumulate_h<CTT, C0, NC, PT, 0>(acc, ws.a, ws.rsrc, ws.voff, lo, smem, bh, bl,
                                               first ? (l0_slabs > 0 ? l0_slabs : tg.nsl_l0) : tg.nsl_mid);
+        stamp_h(smem, lane, l, 1);
         lo += fragb + G::TAILB;
         {
             const uint32_t nxt = (l + 1 < n_layer) ? lo : snext;
@@ -448,6 +464,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
         }
         if (l + 1 < n_layer) {
             if (!first && !(TAE_X & 1)) __syncthreads();
+            stamp_h(smem, lane, l, 2);
             int wrow[PT];
 #pragma unroll
             for (int p = 0; p < PT; ++p) wrow[p] = tc.row(p);
@@ -487,7 +504,9 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
 #endif
             if (TAE_RANGE_BOOK == 1 && TRACK) range_note_layer(rg, l, vmax);      // !TRACK: vmax is dead, its arithmetic goes with it
             else if (TAE_RANGE_BOOK == 2) asm volatile("" :: "v"(vmax));      // A/B: the per-value maximum alone (as r03 carried it), no per-layer reduction
+            stamp_h(smem, lane, l, 3);
             if (!(TAE_X & 1)) __syncthreads();
+            stamp_h(smem, lane, l, 4);
         }
     }
     // ---- Linear head on the accumulators of the last conv layer, fp32 vector ALU (as in run_stack)
@@ -838,6 +857,16 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
     dispatch_tiles<PT>(gs.live, run);
     // every stack ends with a barrier: all rows are in place.  Row i = (stack i / n_layer, layer i % n_layer); the last layer of a stack has no panel
     if (TAE_RANGE_BOOK == 1) range_finish(pn.RNG, 2 * P.n_iter * P.n_layer, 1, [&](int i) { return plain_tail<U>(P.wpack, P.stack_stride, P.n_layer, P.taps, i); });
+    if constexpr ((TAE_X & 1024) != 0) {
+        __syncthreads();
+        if (blockIdx.x == 0 && lane == 0) {
+            const uint32_t* r = reinterpret_cast<const uint32_t*>(smem + kStampBase) + wave * 40;
+            const uint32_t t0 = reinterpret_cast<const uint32_t*>(smem + kStampBase)[0];
+            for (int l = 0; l < 5; ++l)
+                printf("dec wave %d (group %d half %d) layer %d: top +%u  k-loop +%u  panel-free +%u  epilogue +%u  written +%u\n", wave, g, h, l,
+                       r[l * 8] - t0, r[l * 8 + 1] - t0, r[l * 8 + 2] - t0, r[l * 8 + 3] - t0, r[l * 8 + 4] - t0);
+        }
+    }
 }
 
 // =============================================================================================
@@ -1126,11 +1155,12 @@ hipError_t launch_fused_h_u(bool decoder, const FusedParams& P, int grid, hipStr
     const bool h2 = P.head2 != 0;
     const void* fn = decoder ? (taps ? reinterpret_cast<const void*>(kt) : (h2 ? reinterpret_cast<const void*>(kd2) : reinterpret_cast<const void*>(kd)))
                              : (etrack ? reinterpret_cast<const void*>(ket) : (h2 ? reinterpret_cast<const void*>(ke2) : reinterpret_cast<const void*>(ke)));
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes);
+    const int lds_launch = (TAE_X & 1024) ? 160 * 1024 : P.lds_bytes;       // experiment 1024: room for the stamps behind the panels
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_launch);
     if (e != hipSuccess) return e;
-    if (taps) hipLaunchKernelGGL(kt, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
-    else if (decoder && h2) hipLaunchKernelGGL(kd2, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
-    else if (decoder) hipLaunchKernelGGL(kd, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
+    if (taps) hipLaunchKernelGGL(kt, dim3(grid), dim3(kThreads), lds_launch, st, P);
+    else if (decoder && h2) hipLaunchKernelGGL(kd2, dim3(grid), dim3(kThreads), lds_launch, st, P);
+    else if (decoder) hipLaunchKernelGGL(kd, dim3(grid), dim3(kThreads), lds_launch, st, P);
     else if (etrack) hipLaunchKernelGGL(ket, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
     else if (h2) hipLaunchKernelGGL(ke2, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
     else hipLaunchKernelGGL(ke, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
