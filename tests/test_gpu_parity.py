@@ -551,12 +551,12 @@ def test_plain_c_host_reproduces_the_eval_sweep(gpu_device, tmp_path):
         assert c == [res["bit_errors"][si], res["block_errors"][si]]
 
 
-@pytest.mark.parametrize("decoder", ["TurboAE_rate3_cnn", "TurboAE_rate3_rnn"])
-def test_forward_is_hip_graph_capturable(gpu_device, decoder):
+@pytest.mark.parametrize("decoder,cell", [("TurboAE_rate3_cnn", "gru"), ("TurboAE_rate3_rnn", "gru"), ("TurboAE_rate3_rnn", "lstm")])
+def test_forward_is_hip_graph_capturable(gpu_device, decoder, cell):
     """The compute entry points only enqueue work on the caller's stream (no allocation, no synchronisation), so a whole
     forward - and with it a whole SNR point - can be captured into one hipGraph and replayed on new inputs."""
     from turboae_amd import Channel_AE_HIP
-    cfg = TurboAEConfig(decoder=decoder, num_iteration=2)
+    cfg = TurboAEConfig(decoder=decoder, dec_rnn=cell, num_iteration=2)
     sd = W.generate_state_dict(cfg, seed=31, gain=1.0)
     B = 37
     model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
