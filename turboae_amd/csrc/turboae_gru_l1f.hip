@@ -11,8 +11,10 @@
 //     of slabs 0, 1; the lo fragments of slabs 2, 3 come from LDS.  Per step: 33 MFMAs of recurrence (the critical path) + 42 of
 //     projection for the NEXT step (off it: they fill the pipe while the gates are computed and the other waves arrive);
 //   * the remainder wave: units 96..99 as one mixed row tile (row 4 qq + i = r, z, n_h, n_i of unit 96 + qq; all in registers),
-//     plus the head tile: W_lin[:, dir H .. dir H + H) * h_t - 16 floats per position leave the kernel, as before;
-//   * the staging wave: y0 rows (16 x 800 bytes per step) from HBM into LDS in B-fragment order, fetched a step ahead.
+//     plus the head tile: W_lin[:, dir H .. dir H + H) * h_t - 16 floats per position leave the kernel, as before; its four
+//     single-accumulator chains are issued product by product in turn;
+//   * the staging wave: y0 rows (16 x 800 bytes per step) from HBM into LDS in B-fragment order by LDS-DMA (buffer_load ... lds: the
+//     fragment tiles are lane-linear), issued at the top of the step before the one that reads them and waited for at its barrier.
 // Waves w and w + 4 share a SIMD, so the two light waves are 3 and 7 and every other SIMD carries two unit waves.  To level the
 // SIMDs (r05 v1 had 2 x 93 MFMAs per step on three of them and 42 on the fourth, and ran at exactly the 81 % of the sustained
 // MFMA rate that split allows) the two light waves are also HELPERS: k-slabs 4 and 5 of the projection of EVERY unit tile
