@@ -494,6 +494,27 @@ def test_rnn_decoder_batch_independent_and_chunked(gpu_device):
     assert np.abs(xd.cpu().numpy() - xo.numpy()).max() <= ATOL_XDEC_RNN
 
 
+@pytest.mark.parametrize("B,L", [(1, 100), (5, 1), (16, 3), (17, 37), (100, 100), (500, 100), (33, 321)])
+def test_gru_layer0_kernels_are_bit_identical(gpu_device, monkeypatch, B, L):
+    """Layer 0 of the f16x2 GRU decoder stacks has two kernels - gru_rec_h_kernel<true> (one wave walks all gate tiles of 16 blocks: large
+    batches) and gru_rec0u_kernel (the same tiles dealt out to seven waves, h exchanged through LDS: small batches, 2.2x at 500 blocks) -
+    and the host picks by batch size.  Results may not depend on the batch, so the two must agree bit for bit."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", block_len=L, num_iteration=2)
+    sd = W.generate_state_dict(cfg, seed=77 + L, gain=1.0)
+    u, noise = make_inputs(B, L, seed=12)
+    out = {}
+    monkeypatch.setenv("TAE_DEBUG_KNOBS", "1")      # the library ignores its debug knobs without it
+    for mode in ("block", "unit"):
+        monkeypatch.setenv("TAE_GRU_L0", mode)
+        model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+        assert f"TAE_GRU_L0={mode}" in model.overrides()
+        out[mode] = [t.clone() for t in model(torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device))]
+    assert torch.equal(out["block"][0], out["unit"][0]) and torch.equal(out["block"][1], out["unit"][1])
+    xo, _ = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict())
+    assert np.abs(out["unit"][0].cpu().numpy() - xo.numpy()).max() <= ATOL_XDEC_RNN
+
+
 def test_variable_block_length(gpu_device):
     """--is_variable_block_len: the same weights on other block lengths (seed-0 permutation of that length)."""
     from turboae_amd import Channel_AE_HIP

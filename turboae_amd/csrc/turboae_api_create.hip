@@ -1195,6 +1195,7 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     (void)hipGetDevice(&h->device);
     if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || h->ncu < 1) h->ncu = 256;
     if (const char* e = tae::debug_knob("TAE_GRU_L1")) h->gru_l1_split = !strcmp(e, "split");     // r04 form of the f16x2 GRU layer 1
+    if (const char* e = tae::debug_knob("TAE_GRU_L0")) h->gru_l0_mode = !strcmp(e, "block") ? 1 : (!strcmp(e, "unit") ? 2 : 0);     // A/B of the two bit-identical layer-0 kernels
     const char* fixed_nb = tae::debug_knob("TAE_FIXED_NB");
     h->fixed_nb = fixed_nb && fixed_nb[0] == '1';
     const int taps_e = cfg->enc_kernel_size, taps_d = cfg->dec_kernel_size;      // 5, 7 or 9 here (1 and 3 were embedded)

@@ -330,6 +330,14 @@ int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_
 }
 
 // layer 1 of a GRU stack as one kernel (f16x2 path): `img` = the stack's two GruL1fLayout images
+// Layer 0 of an f16x2 GRU stack.  Two bit-identical kernels: one wave per 16 blocks (4.7 us per step whatever the batch - best when
+// every SIMD of the chip holds two of them) or seven waves per 16 blocks, two workgroups per CU (a short step: 2.2x at 500 blocks,
+// equal at a full 16 384-block chunk; tools/probes/gru_l0_ab.py).  Results do not depend on the choice (tests/test_gpu_parity.py).
+hipError_t launch_gru_l0(const tae_handle* h, const tae::GruRecParams& R0, hipStream_t st) {
+    const bool unit = h->gru_l0_mode == 2 || (h->gru_l0_mode == 0 && R0.B <= kGruL0UnitMaxB);
+    return unit ? tae::launch_gru_rec0u(R0, st) : tae::launch_gru_rec_h(true, R0, st);
+}
+
 tae::GruL1fParams l1f_params(const tae_handle* h, const char* img, int32_t Bc) {
     tae::GruL1fParams F;
     memset(&F, 0, sizeof(F));
@@ -377,7 +385,7 @@ int run_encoder_rnn(tae_handle* h, const float* u, float* xtx, double* stats, in
                 R1.w = reinterpret_cast<const float*>(w1 + kGHProjB); R1.w_dir_stride = (uint32_t)kGHRec1B;
                 wl = reinterpret_cast<const float*>(w1 + kGHProjB + 2 * kGHRec1B);
                 R1.hpart = h->d_gy1;          // per-direction head products (the layer-1 recurrence contracts Y1 away)
-                TAE_HIP(tae::launch_gru_rec_h(true, R0, st));
+                TAE_HIP(launch_gru_l0(h, R0, st));
                 if (h->gru_l1_split) {
                     TAE_HIP(tae::launch_gru_proj_h(PP, st));
                     TAE_HIP(tae::launch_gru_rec_h(false, R1, st));
@@ -426,7 +434,7 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
                 tae::GruRecParams R0;
                 memset(&R0, 0, sizeof(R0));
                 R0.w = reinterpret_cast<const float*>(wb); R0.w_dir_stride = (uint32_t)kGHRec0B; R0.x = xin; R0.B = Bc; R0.L = L; R0.y = h->d_gy0;
-                TAE_HIP(tae::launch_gru_rec_h(true, R0, st));
+                TAE_HIP(launch_gru_l0(h, R0, st));
                 const char* w1 = wb + 2 * kGHRec0B;
                 tae::GruProjParams PP;
             memset(&PP, 0, sizeof(PP));

@@ -328,6 +328,182 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
     }
 }
 
+// ---- layer 0, unit-split twin for small batches -------------------------------------------------------------------------------
+// gru_rec_h_kernel<true> walks all 19 gate-row tiles of its 16 blocks in ONE wave: 4.7 us per step whatever the batch, so a batch of
+// 500 blocks keeps 64 waves of the chip busy for 100 x 4.7 us per stack.  Here the same tiles of the same 16 blocks are dealt out
+// to seven waves of one workgroup (unit tile u to wave u, the remainder tile + the input x_t to wave 6), h_t is exchanged through
+// LDS once per step (the B-fragment layout gru_l1f_kernel uses), and every accumulator sees EXACTLY the products gru_rec_h_kernel
+// gives it, in the same order, from the same packed fragments (read from the image in global memory into registers, once): the
+// two kernels are bit-identical, so the host may pick by batch size without results depending on it (tests/test_gpu_parity.py).
+constexpr int kU0HB = 8192;                                   // one exchange buffer: 3 slabs x (hi | lo) + remainder (b1 | b2)
+
+__device__ __forceinline__ h8 u0_glb(const char* p) { return __builtin_bit_cast(h8, *reinterpret_cast<const u32x4v*>(p)); }
+__device__ __forceinline__ h8 u0_lds(lds_cptr p) { return __builtin_bit_cast(h8, *reinterpret_cast<lds_q4*>(p)); }
+__device__ __forceinline__ void u0_barrier() {               // LDS-only fence: the Y0 stores and x loads stay in flight across steps
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__global__ __launch_bounds__(448, 4) void gru_rec0u_kernel(GruRecParams P) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * kU0HB + 25 * 64];       // h exchange (two buffers) | accumulator-init rows
+    using lds_w4 = u32x4v __attribute__((address_space(3)));
+    using lds_w2 = u32x2v __attribute__((address_space(3)));
+    using lds_ptr = char __attribute__((address_space(3)))*;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y, L = P.L;
+    const char* img = reinterpret_cast<const char*>(P.w) + (size_t)dir * P.w_dir_stride;
+    const int b0 = blockIdx.x * 16;
+    const int nb = min(16, P.B - b0);
+    const bool valid = n < nb;
+    const int nc = valid ? n : nb - 1;
+    const float inv = *reinterpret_cast<const float*>(img + kRecFragB + kNiFragB + 25 * 64);
+    const lds_cptr biasl = (lds_cptr)smem + 2 * kU0HB + q * 16;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y + (size_t)b0 * L * 2 * kGH, 0, 16 * L * 2 * kGH * 4, 0x00020000);
+    for (int i = tid; i < kU0HB / 16; i += 448) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};       // h_{-1} = 0
+    if (tid < 25 * 4) reinterpret_cast<f32x4*>(smem + 2 * kU0HB)[tid] = reinterpret_cast<const f32x4*>(img + kRecFragB + kNiFragB)[tid];
+    __syncthreads();
+    const lds_cptr hb = (lds_cptr)smem + lane * 16;
+
+    if (wave < 6) {
+        // ---- unit tile u = wave: gate tiles 3u .. 3u + 2 and the n-gate input tile, as iteration u of gru_rec_h_kernel's loop
+        const int u = wave;
+        const char* fr = img + (size_t)(3 * u) * kRecTileB + lane * 16;
+        FragS<3> f0, f1, f2;
+        FragR<3> fq;
+        FragR<1> fn;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            f0.ah[g] = u0_glb(fr + g * kRecTileB);        f0.al[g] = u0_glb(fr + g * kRecTileB + 1024);
+            f1.ah[g] = u0_glb(fr + g * kRecTileB + 2048); f1.al[g] = u0_glb(fr + g * kRecTileB + 3072);
+            f2.ah[g] = u0_glb(fr + g * kRecTileB + 4096); f2.al[g] = u0_glb(fr + g * kRecTileB + 5120);
+            fq.a[g] = u0_glb(fr + g * kRecTileB + 6144);
+        }
+        fn.a[0] = u0_glb(img + kRecFragB + u * 1024 + lane * 16);
+        const uint32_t v_y = !valid ? 0x80000000u : (uint32_t)(n * 800 + (dir * kGH + 4 * q) * 2 + u * 32);
+        const lds_ptr hw = (lds_ptr)smem + (u >> 1) * 2048 + lane * 16 + (u & 1) * 8;
+        f32x4 h = {0.f, 0.f, 0.f, 0.f};
+        u0_barrier();                                         // B0: the remainder wave's b1 | b2 of step 0 are in buffer 0
+#pragma unroll 1
+        for (int s = 0; s < L; ++s) {
+            const int t = dir ? L - 1 - s : s;
+            const lds_cptr hc = hb + (s & 1) * kU0HB;
+            const h8 bh0 = u0_lds(hc), bl0 = u0_lds(hc + 1024), bh1 = u0_lds(hc + 2048), bl1 = u0_lds(hc + 3072);
+            const h8 bh2 = u0_lds(hc + 4096), bl2 = u0_lds(hc + 5120), rb1 = u0_lds(hc + 6144), rb2 = u0_lds(hc + 7168);
+            f32x4 a3[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) a3[g] = *reinterpret_cast<lds_f4c*>(biasl + (3 * u + g) * 64);
+            mma_slab<3>(a3, f0, bh0, bl0);
+            mma_slab<3>(a3, f1, bh1, bl1);
+            mma_slab<3>(a3, f2, bh2, bl2);
+            mma_rem<3>(a3, fq, rb1, rb2);
+            f32x4 a1[1] = {*reinterpret_cast<lds_f4c*>(biasl + (19 + u) * 64)};
+            mma_rem<1>(a1, fn, rb1, rb2);
+            const f32x4 ani = a1[0];
+            f32x4 hn;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float r = sigm_h(a3[0][i] * inv);
+                const float z = sigm_h(a3[1][i] * inv);
+                const float nn = tanh_h(fmaf(r, a3[2][i] * inv, ani[i] * inv));
+                hn[i] = fmaf(z, h[i] - nn, nn);
+            }
+            h = hn;
+            h4 nhi, nlo;
+            split4(hn, nhi, nlo);
+            const uint32_t yo = (uint32_t)t * (16 * 800u);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nhi), rs_y, v_y, yo, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nlo), rs_y, v_y + 400, yo, 0);
+            const lds_ptr hn_w = hw + ((s + 1) & 1) * kU0HB;
+            *reinterpret_cast<lds_w2*>(hn_w) = __builtin_bit_cast(u32x2v, nhi);
+            *reinterpret_cast<lds_w2*>(hn_w + 1024) = __builtin_bit_cast(u32x2v, nlo);
+            u0_barrier();
+        }
+    } else {
+        // ---- remainder tile 18 (rows 4 qq + i = r, z, n_h, n_i of unit 96 + qq) + x_t: builds the remainder slab's B operands
+        const char* fr = img + (size_t)18 * kRecTileB + lane * 16;
+        FragS<1> f0, f1, f2;
+        FragR<1> fq;
+        f0.ah[0] = u0_glb(fr);        f0.al[0] = u0_glb(fr + 1024);
+        f1.ah[0] = u0_glb(fr + 2048); f1.al[0] = u0_glb(fr + 3072);
+        f2.ah[0] = u0_glb(fr + 4096); f2.al[0] = u0_glb(fr + 5120);
+        fq.a[0] = u0_glb(fr + 6144);
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x + (size_t)b0 * L * kGXW), 0, nb * L * kGXW * 4, 0x00020000);
+        const uint32_t v_in = (uint32_t)(nc * L * kGXW * 4);
+        const uint32_t v_yr = !valid ? 0x80000000u : (uint32_t)(n * 800 + (dir * kGH + 96 + q) * 2);
+        h4 rh = {0, 0, 0, 0}, rl = {0, 0, 0, 0};           // k0 = h of unit 96 + q, k1..3 = this lane group's share of x_t
+        h8 rb1, rb2;
+        auto set_rb = [&]() {
+            rb1 = h8{rl[0], rl[1], rl[2], rl[3], rh[0], rh[1], rh[2], rh[3]};
+            rb2 = h8{rh[0], rh[1], rh[2], rh[3], 0, 0, 0, 0};
+        };
+        auto load_x = [&](int t, f32x4& xa, f32x4& xb) {
+            const uint32_t so = (uint32_t)t * kGXW * 4;
+            xa = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_in, so, 0));
+            xb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, v_in + 16, so, 0));
+        };
+        auto set_x = [&](const f32x4& xa, const f32x4& xb) {
+            const float x0 = q == 0 ? xa.x : (q == 1 ? xa.w : (q == 2 ? xb.z : 0.0f));
+            const float x1 = q == 0 ? xa.y : (q == 1 ? xb.x : (q == 2 ? xb.w : 0.0f));
+            const float x2 = q == 0 ? xa.z : (q == 1 ? xb.y : 0.0f);
+            const float xs[3] = {x0, x1, x2};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const _Float16 hi = (_Float16)xs[j];
+                rh[j + 1] = hi;
+                rl[j + 1] = (_Float16)(xs[j] - (float)hi);
+            }
+        };
+        const lds_ptr rw = (lds_ptr)smem + 6144 + lane * 16;
+        f32x4 xa, xb;
+        load_x(dir ? L - 1 : 0, xa, xb);
+        set_x(xa, xb);
+        set_rb();
+        *reinterpret_cast<lds_w4*>(rw) = __builtin_bit_cast(u32x4v, rb1);
+        *reinterpret_cast<lds_w4*>(rw + 1024) = __builtin_bit_cast(u32x4v, rb2);
+        float hr = 0.0f;
+        u0_barrier();                                         // B0
+#pragma unroll 1
+        for (int s = 0; s < L; ++s) {
+            const int t = dir ? L - 1 - s : s;
+            const int tn = dir ? (t > 0 ? t - 1 : 0) : (t + 1 < L ? t + 1 : t);
+            load_x(tn, xa, xb);
+            const lds_cptr hc = hb + (s & 1) * kU0HB;
+            const h8 bh0 = u0_lds(hc), bl0 = u0_lds(hc + 1024), bh1 = u0_lds(hc + 2048), bl1 = u0_lds(hc + 3072);
+            const h8 bh2 = u0_lds(hc + 4096), bl2 = u0_lds(hc + 5120);
+            f32x4 a1[1] = {*reinterpret_cast<lds_f4c*>(biasl + 18 * 64)};
+            mma_slab<1>(a1, f0, bh0, bl0);
+            mma_slab<1>(a1, f1, bh1, bl1);
+            mma_slab<1>(a1, f2, bh2, bl2);
+            mma_rem<1>(a1, fq, rb1, rb2);
+            const f32x4 a = a1[0];
+            const float r = sigm_h(a[0] * inv);
+            const float z = sigm_h(a[1] * inv);
+            const float nn = tanh_h(fmaf(r, a[2] * inv, a[3] * inv));
+            hr = fmaf(z, hr - nn, nn);
+            const _Float16 hi = (_Float16)hr;
+            const _Float16 lo = (_Float16)(hr - (float)hi);
+            rh[0] = hi;
+            rl[0] = lo;
+            const uint32_t yo = (uint32_t)t * (16 * 800u);
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, hi), rs_y, v_yr, yo, 0);
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, lo), rs_y, v_yr + 400, yo, 0);
+            set_x(xa, xb);
+            set_rb();
+            const lds_ptr rn = rw + ((s + 1) & 1) * kU0HB;
+            *reinterpret_cast<lds_w4*>(rn) = __builtin_bit_cast(u32x4v, rb1);
+            *reinterpret_cast<lds_w4*>(rn + 1024) = __builtin_bit_cast(u32x4v, rb2);
+            u0_barrier();
+        }
+    }
+}
+
+hipError_t launch_gru_rec0u(const GruRecParams& P, hipStream_t st) {
+    hipLaunchKernelGGL(gru_rec0u_kernel, dim3((unsigned)((P.B + 15) / 16), 2), dim3(448), 0, st, P);
+    return hipGetLastError();
+}
+
 // ---- layer-1 input projections, f16x2 GEMM ---------------------------------------------------------------
 // Workgroup = 8 waves, 160 positions staged in LDS (hi plane | lo plane, rows of 200 halves); wave (pg, rq):
 // position group pg (5 tiles), row quarter rq = (direction, half): gate tiles [0, 10) or [10, 19) of that

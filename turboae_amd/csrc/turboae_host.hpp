@@ -91,6 +91,7 @@ struct tae_handle {
     double* d_rnn_partials = nullptr;   // GRU encoder: per (chunk, stack, head workgroup) partial sums
     int32_t rnn_partial_slots = 0;
     bool gru_l1_split = false; // f16x2 GRU stacks: layer 1 as projection kernel + recurrence kernel (r04) instead of the fused kernel
+    int gru_l0_mode = 0;         // layer 0 of the f16x2 GRU decoder stacks: 0 by batch (unit-split twin up to kGruL0UnitMaxB blocks), 1 block-split, 2 unit-split (TAE_GRU_L0, debug knob)
     int32_t rnn_chunk = 0;   // blocks per internal chunk (bounds the workspace)
     float* d_gxa = nullptr;  // (chunk, L, 8) natural-order panel
     float* d_gxb = nullptr;  // (chunk, L, 8) interleaved-order panel
@@ -133,6 +134,7 @@ constexpr size_t kGProjF = 2 * 25 * (size_t)kGRT * 128, kGPB = 2 * (size_t)kGRT 
 constexpr size_t kGL0Dir = kGRecF + kGXF + kGB0, kGL1Dir = kGRecF + kGB1;
 constexpr size_t kGHTileB = 3 * 2048 + 1024, kGHFragB = 19 * kGHTileB, kGHNiB = 6 * 1024;
 constexpr size_t kGHRec0B = kGHFragB + kGHNiB + 25 * 64 + 16, kGHRec1B = kGHFragB + kGHTileB + 7 * 64 + 16;
+constexpr int32_t kGruL0UnitMaxB = 12288;    // blocks per chunk up to which layer 0 of the f16x2 GRU decoder runs on gru_rec0u_kernel (equal at 16 384, faster below: LABNOTES 11.11)
 constexpr size_t kGHProjDirB = 7 * 19 * 2048, kGHProjB = 2 * kGHProjDirB + 2 * 19 * 64 + 16;
 // gates of a recurrent cell (tae_config.enc_rnn / dec_rnn): GRU 3 (r, z, n), LSTM 4 (i, f, g, o), vanilla RNN 1
 inline int cell_gates(int rnn) { return rnn == 1 ? 4 : (rnn == 2 ? 1 : 3); }

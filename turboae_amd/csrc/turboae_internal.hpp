@@ -160,6 +160,7 @@ hipError_t launch_gru_prep(const float* rx, const int32_t* perm, float* XA, floa
 hipError_t launch_gru_rec(bool layer0, const GruRecParams& P, hipStream_t st);
 hipError_t launch_gru_proj(const GruProjParams& P, hipStream_t st);
 hipError_t launch_gru_rec_h(bool layer0, const GruRecParams& P, hipStream_t st);      // f16x2: w / w_dir_stride in BYTES, layer-0 y as halves
+hipError_t launch_gru_rec0u(const GruRecParams& P, hipStream_t st);                    // layer 0 again, one 16-block group per 7-wave workgroup (small batches); bit-identical to launch_gru_rec_h(true, ...)
 hipError_t launch_gru_proj_h(const GruProjParams& P, hipStream_t st);
 hipError_t launch_gru_head_part(const GruHeadParams& P, hipStream_t st);       // f16x2: bias + act + extrinsic + scatter on the fused head products
 hipError_t launch_gru_head(const GruHeadParams& P, hipStream_t st);
