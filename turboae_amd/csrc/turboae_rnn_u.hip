@@ -34,11 +34,11 @@ using lds_w4 = u32x4v __attribute__((address_space(3)));
 using lds_w2 = u32x2v __attribute__((address_space(3)));
 using lds_ptr = char __attribute__((address_space(3)))*;
 
-constexpr int kNT = 2;                              // N tiles (of 16 blocks) per workgroup
-constexpr int kHBsz = kNT * 8192;                   // h exchange of one step: per N tile 3 slabs x (hi | lo) + remainder (b1 | b2)
-constexpr int kXBsz = kNT * 2048;                   // layer 0: x_t as the K = 16 slab's (b1 | b2) per N tile
-
-template <int G> struct Geo {
+// NT = N tiles (of 16 blocks) per workgroup: 2 amortises the step's latencies over twice the MFMAs (large batches); 1 for batches that
+// would leave CUs idle (a shorter step on twice the workgroups).  Columns are independent: results do not depend on NT.
+template <int G, int NT = 2> struct Geo {
+    static constexpr int kHBsz = NT * 8192;                       // h exchange of one step: per N tile 3 slabs x (hi | lo) + remainder (b1 | b2)
+    static constexpr int kXBsz = NT * 2048;                       // layer 0: x_t as the K = 16 slab's (b1 | b2) per N tile
     static constexpr int kBiasB = 6 * G * 64 + 64 + 16;          // [ut][gate][16] + remainder-tile row + (2^-S, 2^-S_head, 0, 0)
     static constexpr int kHB = (kBiasB + 15) / 16 * 16;
     static constexpr int kXB = kHB + 2 * kHBsz;
@@ -47,7 +47,7 @@ template <int G> struct Geo {
     static constexpr int kFragR = 8 + 7;                          // remainder wave: mixed tile {7 + input slab} + head tile 7
     static constexpr int kDirB = (6 * kFragU + kFragR) * 1024 + kHB;
 };
-static_assert(Geo<4>::kDirB == RnnULayout::dir_bytes(4) && Geo<1>::kDirB == RnnULayout::dir_bytes(1), "host packing");
+static_assert(Geo<4>::kDirB == RnnULayout::dir_bytes(4) && Geo<1>::kDirB == RnnULayout::dir_bytes(1) && Geo<4, 1>::kDirB == Geo<4, 2>::kDirB, "host packing");
 
 __device__ __forceinline__ float sigm_f(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
@@ -113,9 +113,10 @@ struct Ctx {
 };
 
 // ---- unit wave: units 16 ut .. 16 ut + 15, G gate tiles -------------------------------------------------------------------------
-template <int G, bool LAYER0>
+template <int G, bool LAYER0, int NT>
 __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
-    using GE = Geo<G>;
+    using GE = Geo<G, NT>;
+    constexpr int kNT = NT, kHBsz = GE::kHBsz, kXBsz = GE::kXBsz;
     constexpr int CTT = 6 * G + 1;
     const int lane = c.lane, L = c.L, n = c.n, q = c.q, dir = c.dir;
     const char* wr = c.wdir + (size_t)ut * GE::kFragU * 1024 + lane * 16;
@@ -211,9 +212,10 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
 }
 
 // ---- remainder wave: units 96..99 as one mixed tile (row 4 qq + g = gate g of unit 96 + qq) + the head tile (layer 1) ---------------
-template <int G, bool LAYER0>
+template <int G, bool LAYER0, int NT>
 __device__ __forceinline__ void rem_wave(const Ctx& c) {
-    using GE = Geo<G>;
+    using GE = Geo<G, NT>;
+    constexpr int kNT = NT, kHBsz = GE::kHBsz, kXBsz = GE::kXBsz;
     constexpr int CTT = 6 * G + 1;
     const int lane = c.lane, L = c.L, n = c.n, q = c.q, dir = c.dir;
     const char* wr = c.wdir + (size_t)6 * GE::kFragU * 1024 + lane * 16;
@@ -312,9 +314,10 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
 }
 
 // ---- eighth wave: layer 0 stages x_t (B, L, 8) as the input slab's B fragments; layer 1 only keeps the barrier count ------------------
-template <int G, bool LAYER0>
+template <int G, bool LAYER0, int NT>
 __device__ __forceinline__ void stage_wave(const Ctx& c) {
-    using GE = Geo<G>;
+    using GE = Geo<G, NT>;
+    constexpr int kNT = NT, kXBsz = GE::kXBsz;
     const int lane = c.lane, L = c.L, n = c.n, q = c.q, dir = c.dir;
     const lds_ptr xw = (lds_ptr)(c.lds + GE::kXB + lane * 16);
     for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
@@ -344,9 +347,9 @@ __device__ __forceinline__ void stage_wave(const Ctx& c) {
     }
 }
 
-template <int G, bool LAYER0>
+template <int G, bool LAYER0, int NT>
 __global__ __launch_bounds__(512) void rnn_rec_u_kernel(RnnUParams P) {
-    using GE = Geo<G>;
+    using GE = Geo<G, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -360,9 +363,9 @@ __global__ __launch_bounds__(512) void rnn_rec_u_kernel(RnnUParams P) {
     const float inv = *reinterpret_cast<const float*>(smem + 6 * G * 64 + 64);
     const float inv_head = *reinterpret_cast<const float*>(smem + 6 * G * 64 + 68);
     const Ctx c{P, wdir, (lds_cptr)smem, lane, lane & 15, lane >> 4, dir, P.L, inv, inv_head};
-    if (wave == 3) rem_wave<G, LAYER0>(c);
-    else if (wave == 7) stage_wave<G, LAYER0>(c);
-    else unit_wave<G, LAYER0>(c, wave < 3 ? wave : wave - 1);
+    if (wave == 3) rem_wave<G, LAYER0, NT>(c);
+    else if (wave == 7) stage_wave<G, LAYER0, NT>(c);
+    else unit_wave<G, LAYER0, NT>(c, wave < 3 ? wave : wave - 1);
 }
 
 // ---- layer-1 input projections: GI = (W_ih1 * Y0 + b) * gi_mul as an f16x2 GEMM, CTT row tiles per direction -------------------------
@@ -439,6 +442,16 @@ __global__ __launch_bounds__(256, 2) void rnn_proj_u_kernel(RnnProjParams P) {
     }
 }
 
+template <int G, bool LAYER0, int NT>
+hipError_t launch_rec_nt(RnnUParams P, int ncu, hipStream_t st) {
+    constexpr int lds = Geo<G, NT>::kLds;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_rec_u_kernel<G, LAYER0, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    P.ngroups = (P.B + 16 * NT - 1) / (16 * NT);
+    const dim3 grid((unsigned)std::min(P.ngroups, std::max(1, ncu / 2)), 2);       // one workgroup per CU, half of them per direction
+    hipLaunchKernelGGL((rnn_rec_u_kernel<G, LAYER0, NT>), grid, dim3(512), lds, st, P);
+    return hipGetLastError();
+}
 template <int G, bool LAYER0>
 hipError_t launch_rec(const RnnUParams& P, hipStream_t st) {
     static int ncu = 0;
@@ -448,12 +461,9 @@ hipError_t launch_rec(const RnnUParams& P, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
         ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    constexpr int lds = Geo<G>::kLds;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_rec_u_kernel<G, LAYER0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    const dim3 grid((unsigned)std::min(P.ngroups, std::max(1, ncu / 2)), 2);       // one workgroup per CU, half of them per direction
-    hipLaunchKernelGGL((rnn_rec_u_kernel<G, LAYER0>), grid, dim3(512), lds, st, P);
-    return hipGetLastError();
+    // one 16-block tile per workgroup while that still fits one round of workgroups (two per pair of directions and CU)
+    const bool small = 2 * ((P.B + 15) / 16) <= ncu;
+    return small ? launch_rec_nt<G, LAYER0, 1>(P, ncu, st) : launch_rec_nt<G, LAYER0, 2>(P, ncu, st);
 }
 
 template <int CTT>
