@@ -349,6 +349,8 @@ def other_configs(dev, snr: float, sd_trained):
     c4 = TurboAEConfig(decoder="TurboAE_rate3_rnn")
     sd4, w4 = fixture(TRAINED_GRU, c4)
     res.append(time_other_config("configs[4]: TurboAE_rate3_rnn (GRU decoder), block_len=100, batch=16384", c4, sd4, 16384, dev, snr, w4))
+    # the same network at the reference README's batch: layer 0 of every stack on the bit-identical unit-split twin (gru_rec0u_kernel)
+    res.append(time_other_config("configs[4] at batch=500: TurboAE_rate3_rnn (GRU decoder), block_len=100", c4, sd4, 500, dev, snr, w4, runs=9))
     return res
 
 
@@ -465,8 +467,8 @@ def flatten_scalars(out) -> None:
     out["roofline_traffic_gb"] = rf.get("traffic")
     out["roofline_frac_of_sustained"] = rf.get("frac_of_sustained")
     out["sustained_probe_tflops"] = rf.get("sustained_probe_tflops")
-    names = {"configs[0]": "cfg0_b500", "configs[2]": "cfg2_enc5", "configs[3]": "cfg3_l1000", "configs[4]": "cfg4_gru",
-             "configs[1] shape, last conv layers": "cfg1_head2"}
+    names = {"configs[0]": "cfg0_b500", "configs[2]": "cfg2_enc5", "configs[3]": "cfg3_l1000", "configs[4] at batch=500": "cfg4_gru_b500",
+             "configs[4]": "cfg4_gru", "configs[1] shape, last conv layers": "cfg1_head2"}
     for oc in list(rf.get("other_configs", []) or []) + list(rf.get("generic_configs", []) or []):
         if "_variants" in oc:
             oc["kernel_variants_enc_dec"] = oc.pop("_variants")
