@@ -512,7 +512,7 @@ int run_decoder_rnn_u(tae_handle* h, const float* rx, float* xdec, int32_t B, hi
             tae::RnnUParams R;
             memset(&R, 0, sizeof(R));
             R.w = wb; R.w_dir_stride = (uint32_t)dirb; R.x = xin; R.y0 = reinterpret_cast<char*>(h->d_gy0);
-            R.B = Bc; R.L = L; R.ngroups = (Bc + 31) / 32;
+            R.B = Bc; R.L = L;
             TAE_HIP(tae::launch_rnn_rec_u(G, true, R, st));
             tae::RnnProjParams PP;
             memset(&PP, 0, sizeof(PP));

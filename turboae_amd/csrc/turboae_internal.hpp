@@ -142,7 +142,7 @@ struct RnnUParams {
     const float* gi;        // layer 1: projections [(g16 L + t) 2 + dir][6 G + 1][lane][4], already times the recurrence's 2^S
     char* y0;               // layer 0: outputs as halves [pos'][hi 200 | lo 200], pos' = ((b / 16) L + t) 16 + b % 16
     float* hpart;           // layer 1: [pos'][dir][8] this direction's share of the Linear head
-    int32_t B, L, ngroups;  // ngroups = ceil(B / 32)
+    int32_t B, L, ngroups;  // ngroups: set by the launcher (ceil(B / 16 NT), NT = N tiles per workgroup, picked by batch)
 };
 struct RnnProjParams {
     const float* yin;       // layer-0 outputs (halves)
