@@ -48,6 +48,16 @@ __device__ __forceinline__ float sigm_h(float x) {
     if (TAE_REC_X & 1) return fmaf(x, 0.25f, 0.5f);
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
 }
+// sigmoid / tanh of x 2^-S with the accumulators' power-of-two scale inside the exp2 constant (cs = -log2(e) 2^-S, ct = 2 log2(e) 2^-S):
+// bit for bit what scaling x first gives (a power of two commutes with every rounding involved), two to three instructions fewer per gate
+__device__ __forceinline__ float sigm_hs(float x, float cs) {
+    if (TAE_REC_X & 1) return fmaf(x * cs, -0.17f, 0.5f);
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * cs));
+}
+__device__ __forceinline__ float tanh_hs(float x, float ct) {
+    if (TAE_REC_X & 1) return x * ct * 0.17f;
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * ct)), 1.0f);
+}
 __device__ __forceinline__ float tanh_h(float x) {
     if (TAE_REC_X & 1) return x * 0.5f;
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)), 1.0f);
@@ -138,6 +148,7 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
     const lds_cptr lds3 = (lds_cptr)smem;
     const lds_cptr bias = lds3 + kRecFragB + (LAYER0 ? kNiFragB : kRecTileB) + q * 16;
     const float inv = *reinterpret_cast<const float*>(smem + kRecFragB + (LAYER0 ? kNiFragB + 25 * 64 : kRecTileB + 7 * 64));
+    const float cs = -1.44269504088896341f * inv, ct = 2.88539008177792681f * inv;
     const float inv_head = LAYER0 ? 0.0f : *reinterpret_cast<const float*>(smem + kRecFragB + kRecTileB + 7 * 64 + 4);
 
     const __amdgpu_buffer_rsrc_t rs_in = LAYER0
@@ -256,9 +267,9 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
             f32x4 hn;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float r = sigm_h(LAYER0 ? a3[0][i] * inv : fmaf(a3[0][i], inv, g[3 * u][i]));
-                const float z = sigm_h(LAYER0 ? a3[1][i] * inv : fmaf(a3[1][i], inv, g[3 * u + 1][i]));
-                const float nn = tanh_h(fmaf(r, a3[2][i] * inv, LAYER0 ? ani[i] * inv : g[3 * u + 2][i]));
+                const float r = LAYER0 ? sigm_hs(a3[0][i], cs) : sigm_h(fmaf(a3[0][i], inv, g[3 * u][i]));
+                const float z = LAYER0 ? sigm_hs(a3[1][i], cs) : sigm_h(fmaf(a3[1][i], inv, g[3 * u + 1][i]));
+                const float nn = LAYER0 ? tanh_hs(fmaf(r, a3[2][i], ani[i]), ct) : tanh_h(fmaf(r, a3[2][i] * inv, g[3 * u + 2][i]));
                 hn[i] = fmaf(z, h[u][i] - nn, nn);
             }
             h[u] = hn;
@@ -284,9 +295,9 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
             load_slab<3>(fa, lds3 + lane * 16);          // slab 0 of unit tile 0 for the next step
             mma_rem<1>(a1, fq, rb1, rb2);
             const f32x4 a = a1[0];
-            const float r = sigm_h(LAYER0 ? a[0] * inv : fmaf(a[0], inv, g[18][0]));
-            const float z = sigm_h(LAYER0 ? a[1] * inv : fmaf(a[1], inv, g[18][1]));
-            const float nn = tanh_h(fmaf(r, a[2] * inv, LAYER0 ? a[3] * inv : g[18][2]));
+            const float r = LAYER0 ? sigm_hs(a[0], cs) : sigm_h(fmaf(a[0], inv, g[18][0]));
+            const float z = LAYER0 ? sigm_hs(a[1], cs) : sigm_h(fmaf(a[1], inv, g[18][1]));
+            const float nn = LAYER0 ? tanh_hs(fmaf(r, a[2], a[3]), ct) : tanh_h(fmaf(r, a[2] * inv, g[18][2]));
             hr = fmaf(z, hr - nn, nn);
         }
         // next step's B operands
@@ -359,6 +370,7 @@ __global__ __launch_bounds__(448, 4) void gru_rec0u_kernel(GruRecParams P) {
     const bool valid = n < nb;
     const int nc = valid ? n : nb - 1;
     const float inv = *reinterpret_cast<const float*>(img + kRecFragB + kNiFragB + 25 * 64);
+    const float cs = -1.44269504088896341f * inv, ct = 2.88539008177792681f * inv;
     const lds_cptr biasl = (lds_cptr)smem + 2 * kU0HB + q * 16;
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y + (size_t)b0 * L * 2 * kGH, 0, 16 * L * 2 * kGH * 4, 0x00020000);
     for (int i = tid; i < kU0HB / 16; i += 448) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};       // h_{-1} = 0
@@ -404,9 +416,9 @@ __global__ __launch_bounds__(448, 4) void gru_rec0u_kernel(GruRecParams P) {
             f32x4 hn;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float r = sigm_h(a3[0][i] * inv);
-                const float z = sigm_h(a3[1][i] * inv);
-                const float nn = tanh_h(fmaf(r, a3[2][i] * inv, ani[i] * inv));
+                const float r = sigm_hs(a3[0][i], cs);
+                const float z = sigm_hs(a3[1][i], cs);
+                const float nn = tanh_hs(fmaf(r, a3[2][i], ani[i]), ct);
                 hn[i] = fmaf(z, h[i] - nn, nn);
             }
             h = hn;
@@ -478,9 +490,9 @@ __global__ __launch_bounds__(448, 4) void gru_rec0u_kernel(GruRecParams P) {
             mma_slab<1>(a1, f2, bh2, bl2);
             mma_rem<1>(a1, fq, rb1, rb2);
             const f32x4 a = a1[0];
-            const float r = sigm_h(a[0] * inv);
-            const float z = sigm_h(a[1] * inv);
-            const float nn = tanh_h(fmaf(r, a[2] * inv, a[3] * inv));
+            const float r = sigm_hs(a[0], cs);
+            const float z = sigm_hs(a[1], cs);
+            const float nn = tanh_hs(fmaf(r, a[2], a[3]), ct);
             hr = fmaf(z, hr - nn, nn);
             const _Float16 hi = (_Float16)hr;
             const _Float16 lo = (_Float16)(hr - (float)hi);
