@@ -635,11 +635,20 @@ __global__ __launch_bounds__(kHeadPartThreads) void gru_head_part_kernel(GruHead
             esum += (double)v;
             esq += (double)v * (double)v;
         } else if (!P.last) {
-            const float* xc = P.xcur + pos * kGXW + 2;
-            float* xn = P.xnext + (b * P.L + P.ptab[t]) * kGXW + 2;
+            // rows of the X panels are 32 bytes [x0, x1, f0 .. f5]: whole 16-byte pieces in and out (a lane's row is 3 200 bytes from its
+            // neighbour's, so every 4-byte access was one cache line per lane: 12 such instructions per position, now 5).  The target
+            // row's x0, x1 are constants of the call (gru_prep) and channels past F stay zero, so the row can be rewritten whole.
+            const f32x4* xc4 = reinterpret_cast<const f32x4*>(P.xcur + pos * kGXW);
+            f32x4* xn4 = reinterpret_cast<f32x4*>(P.xnext + (b * P.L + P.ptab[t]) * kGXW);
+            const f32x4 c0 = P.extrinsic ? xc4[0] : f32x4{0.f, 0.f, 0.f, 0.f}, c1 = P.extrinsic ? xc4[1] : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float xc[6] = {c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            float v[6];
 #pragma unroll
-            for (int f = 0; f < 6; ++f)
-                if (f < P.F) xn[f] = act_apply(o[f] + P.b[f], P.act) - (P.extrinsic ? xc[f] : 0.0f);      // dec_act, then extrinsic (decoders.py:103-106)
+            for (int f = 0; f < 6; ++f) v[f] = f < P.F ? act_apply(o[f] + P.b[f], P.act) - (P.extrinsic ? xc[f] : 0.0f) : 0.0f;      // dec_act, then extrinsic (decoders.py:103-106)
+            f32x4 n0 = xn4[0];
+            n0.z = v[0]; n0.w = v[1];
+            xn4[0] = n0;
+            xn4[1] = f32x4{v[2], v[3], v[4], v[5]};
         } else {
             const float v = act_apply(o[0] + P.b[0], P.act);
             P.xdec[b * P.L + P.ptab[t]] = 1.0f / (1.0f + expf(-v));      // sigmoid(deinterleave(dec_act(x_plr))), decoders.py:143-147
