@@ -259,7 +259,7 @@ def mfma_sustained_probe(min_ms: int = 150):
     return float(tf.value), float(ms.value)
 
 
-def time_other_config(name: str, cfg: TurboAEConfig, sd, B: int, dev, snr: float, weights: str, runs: int = 5):
+def time_other_config(name: str, cfg: TurboAEConfig, sd, B: int, dev, snr: float, weights: str, runs: int = 5, parity_blocks: int = 0):
     """One of the other BASELINE configs: `runs` forwards (after 2 warm-ups) of encoder -> power constraint + AWGN -> decoder ->
     error count on B resident blocks, HIP events around the forward and around the decoder; medians."""
     model = Channel_AE_HIP(cfg, sd, device=dev, max_batch=B)
@@ -315,6 +315,21 @@ def time_other_config(name: str, cfg: TurboAEConfig, sd, B: int, dev, snr: float
            "bits_per_s": B * L / (fwd_ms * 1e-3), "dominant_kernel": kern, "decoder_ms": dec_ms, "decoder_tflops": dec_tf,
            "decoder_frac": dec_tf / peak, "encoder_plus_norm_ms": enc_ms, "encoder_frac": enc_tf / peak, "peak": peak,
            "ber": int(counts[0].item()) / (float(B) * L * runs), "blocks_per_workgroup": nb, "_variants": variants}
+    if parity_blocks and cfg.decoder == "TurboAE_rate3_rnn":
+        # the recurrent decoder of THIS line against the CPU oracle (checker only) on the first blocks of the batch it was timed on:
+        # the received blocks come from the product path, the full batch is decoded (rows of the timed launch), the oracle decodes
+        # the same rows (decoders.py:84-149 is per block, so a subset of the rows is a valid input)
+        from oracle import turboae_oracle as O          # checker only
+        n = min(parity_blocks, B)
+        x_tx, stats = model.encode_prenorm(u)
+        _, rx = model.normalize(x_tx, stats, noise, want_codes=False)
+        xg = model.dec(rx)[:n].cpu()
+        with torch.no_grad():
+            xo = O.decode_rnn(rx[:n].cpu(), O.to_torch(sd), torch.from_numpy(O.rand_interleaver(L, 0)), cfg.dec_num_unit, cfg.num_iteration,
+                              cfg.num_iter_ft, cfg.extrinsic, None, cfg.dec_act, cfg.dec_rnn)
+        out["parity_blocks"] = n
+        out["parity_flips"] = int(((xg > 0.5) != (xo > 0.5)).sum())
+        out["parity_max_abs_x_dec"] = float((xg - xo).abs().max())
     del model
     torch.cuda.empty_cache()
     return out
@@ -348,7 +363,7 @@ def other_configs(dev, snr: float, sd_trained):
         res.append(r)
     c4 = TurboAEConfig(decoder="TurboAE_rate3_rnn")
     sd4, w4 = fixture(TRAINED_GRU, c4)
-    res.append(time_other_config("configs[4]: TurboAE_rate3_rnn (GRU decoder), block_len=100, batch=16384", c4, sd4, 16384, dev, snr, w4))
+    res.append(time_other_config("configs[4]: TurboAE_rate3_rnn (GRU decoder), block_len=100, batch=16384", c4, sd4, 16384, dev, snr, w4, parity_blocks=256))
     # the same network at the reference README's batch: layer 0 of every stack on the bit-identical unit-split twin (gru_rec0u_kernel)
     res.append(time_other_config("configs[4] at batch=500: TurboAE_rate3_rnn (GRU decoder), block_len=100", c4, sd4, 500, dev, snr, w4, runs=9))
     return res
@@ -365,7 +380,7 @@ def generic_configs(dev, snr: float):
         sdl, wl = W.unpack_blob(cl, np.load(TRAINED_LSTM)["weights_fp32"]), "trained"
     else:
         sdl, wl = W.generate_state_dict(cl, seed=SEED, gain=1.0), "random-init"
-    res.append(time_other_config("-dec_rnn lstm (DEC_LargeRNN, LSTM cell), block_len=100, batch=16384", cl, sdl, 16384, dev, snr, wl, runs=3))
+    res.append(time_other_config("-dec_rnn lstm (DEC_LargeRNN, LSTM cell), block_len=100, batch=16384", cl, sdl, 16384, dev, snr, wl, runs=3, parity_blocks=256))
     res.append(time_other_config("-dec_rnn lstm on the generic fp32 kernels (precision f32), block_len=100, batch=16384", replace(cl, precision="f32"), sdl,
                                  16384, dev, snr, wl, runs=3))
     cw = TurboAEConfig(enc_num_unit=256, dec_num_unit=256)
@@ -480,6 +495,8 @@ def flatten_scalars(out) -> None:
             out[f"{key}_bits_per_s"] = oc["bits_per_s"]
             out[f"{key}_ms"] = oc["ms_per_forward"]
             out[f"{key}_ber"] = oc["ber"]
+            if "parity_flips" in oc:
+                out[f"{key}_parity_flips"], out[f"{key}_parity_max_abs_x_dec"] = oc["parity_flips"], oc["parity_max_abs_x_dec"]
     for oc in rf.get("generic_configs", []) or []:
         if "error" not in oc:
             name = str(oc.get("config", ""))
@@ -488,6 +505,8 @@ def flatten_scalars(out) -> None:
             out[f"{key}_frac"] = oc["decoder_frac"]
             if key != "wide256":
                 out[f"{key}_ber"] = oc["ber"]
+            if "parity_flips" in oc:
+                out[f"{key}_parity_flips"], out[f"{key}_parity_max_abs_x_dec"] = oc["parity_flips"], oc["parity_max_abs_x_dec"]
     rf["cfg0_b500_frac"], rf["cfg2_enc5_frac"] = out.get("cfg0_b500_frac"), out.get("cfg2_enc5_frac")
     rf["cfg3_l1000_frac"], rf["cfg4_gru_frac"] = out.get("cfg3_l1000_frac"), out.get("cfg4_gru_frac")
     if out.get("cfg1_head2_ms") and rf.get("kernel_ms"):
@@ -520,6 +539,42 @@ def flatten_scalars(out) -> None:
         out["cpu_baseline_B2000_as_4x500_bits_per_s"] = cpu.get("value_B2000_as_4x500")
         out["cpu_baseline_b2000_as_4x500_over_b500"] = cpu.get("b2000_as_4x500_over_b500")
     out["overrides"] = tae_overrides()
+
+
+# The driver keeps the parsed contract keys, the NAMES of the other keys, and the last 2 000 characters of stdout + stderr.  The flat
+# scalars a reader needs therefore close the line, in this order, compacted to 5 significant digits, within TAIL_BUDGET bytes by
+# construction (tests/test_bench_tail.py holds a canned line to it).
+TAIL_BUDGET = 1800
+TAIL_KEYS = (
+    "f32_bits_per_s", "f32_frac", "f32_ms_per_step",
+    "cfg4_gru_bits_per_s", "cfg4_gru_frac", "cfg4_gru_ms", "cfg4_gru_ber", "cfg4_gru_parity_flips", "cfg4_gru_parity_max_abs_x_dec",
+    "cfg4_gru_b500_bits_per_s", "cfg4_gru_b500_frac",
+    "lstm_bits_per_s", "lstm_frac", "lstm_ber", "lstm_parity_flips", "lstm_parity_max_abs_x_dec", "lstm_generic_f32_bits_per_s",
+    "cfg0_b500_frac", "cfg0_b500_enc_frac", "cfg0_b500_bits_per_s", "cfg2_enc5_frac", "cfg2_enc5_bits_per_s", "cfg3_l1000_frac",
+    "cfg3_l1000_enc_frac", "cfg3_l1000_bits_per_s", "cfg1_head2_decoder_over_plain", "wide256_frac",
+    "graph_replay_ms", "sweep_cfg1_s", "sweep_cfg1_bits_per_s", "sweep_cfg1_ber_2dB",
+    "roofline_frac", "roofline_kernel_ms", "roofline_traffic_gb", "roofline_frac_of_sustained", "sustained_probe_tflops",
+    "parity_decision_flips", "parity_max_abs_x_dec", "parity_max_abs_codes", "parity_ber_abs_diff", "parity_decision_flips_f16x2_vs_f32",
+    "cpu_baseline_bits_per_s", "cpu_baseline_cores", "cpu_baseline_b2000_over_b500", "cpu_baseline_b2000_as_4x500_over_b500",
+    "overrides",
+)
+
+
+def _compact(v):
+    if isinstance(v, float) and v == v and abs(v) != float("inf"):
+        return float(f"{v:.5g}")
+    return v
+
+
+def ordered_for_tail(out: dict) -> dict:
+    """The same keys with TAIL_KEYS moved to the end (compacted); if they do not fit TAIL_BUDGET the first of them stay in the body."""
+    keys = [k for k in TAIL_KEYS if k in out and not isinstance(out[k], (dict, list))]
+    tail = {k: _compact(out[k]) for k in keys}
+    while keys and len(json.dumps({k: tail[k] for k in keys})) > TAIL_BUDGET:
+        keys.pop(0)
+    body = {k: v for k, v in out.items() if k not in keys}
+    body.update({k: tail[k] for k in keys})
+    return body
 
 
 def tae_overrides() -> str:
@@ -1133,7 +1188,7 @@ def main():
             while True:
                 time.sleep(1.0)
         guard.finished = True
-        print(json.dumps(out), flush=True)
+        print(json.dumps(ordered_for_tail(out)), flush=True)
     guard.done()
     if dist is not None:
         dist.destroy_process_group()

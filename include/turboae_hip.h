@@ -186,7 +186,9 @@ TAE_API int tae_decode(tae_handle* h, const float* received, float* x_dec, int32
  * floats) receives, for stack s = 2*it (dec1) the extrinsic output x_plr = dec1_outputs[it](...) - prior in natural order, and for
  * s = 2*it + 1 (dec2, it < num_iteration - 1) x_plr = dec2_outputs[it](...) - x_plr_int in INTERLEAVED order (prior = its
  * deinterleave), as [s][b][position][f].  Same results in x_dec as tae_decode; runs a separate instantiation of the decoder kernel
- * (the production kernel carries no tap code).  Used by tests/ to localise a regression to one stack.  CNN decoder only. */
+ * (the production kernel carries no tap code).  Used by tests/ to localise a regression to one stack.  DEC_LargeRNN handles (GRU / LSTM /
+ * vanilla RNN on the tuned kernels, either arithmetic) export the same values from their head epilogue: dec{1,2}_outputs[it] of
+ * decoders.py:84-149 after the extrinsic subtraction.  Not on the generic fp32 kernels, not for DenseSameShapeConv1d stacks. */
 TAE_API int tae_decode_taps(tae_handle* h, const float* received, float* x_dec, float* taps, int32_t B, void* stream);
 
 /* Replaces errors_ber / errors_bler (utils.py:6-18,49-66) as integer counts ACCUMULATED into

@@ -112,13 +112,19 @@ CASES = [
     ("var_small_last_all", dict(num_iteration=3), 4, 51, 1.0, 2.0),
     ("var_small_last_one_stack", dict(num_iteration=3), 3, 52, 1.0, 1.0),
     ("var_small_last_L1000", dict(block_len=1000, num_iteration=2), 2, 53, 1.0, 2.0),
+    # r06: LSTM / vanilla-RNN decoders at the reference's default width, so the unit-split f16x2 kernels (turboae_rnn_u.hip) have
+    # reference goldens of their own WITH per-stage taps (gen_dec_lstm / gen_dec_rnn_tanh run embedded from widths 24 / 40)
+    ("fwd_lstm_u100_L100_b3_it3", dict(decoder="TurboAE_rate3_rnn", dec_rnn="lstm", num_iteration=3), 3, 63, 1.0, 2.0),
+    ("fwd_rnntanh_u100_L64_b3_it2", dict(decoder="TurboAE_rate3_rnn", dec_rnn="rnn", num_iteration=2, block_len=64), 3, 64, 1.0, 1.0),
 ]
 
 FADING_SEED = 20190020
 
 # cases whose fixture also carries what every decoder half-iteration hands to the next one (`prior` after each
 # iteration), captured from the REAL reference with forward hooks on its dec1_outputs / dec2_outputs Linear modules
-TAP_CASES = ("fwd_enc2dec5_u100_L100_b4", "fwd_u32_L100_b8", "fwd_u32_L64_b6_ft3_noext", "fwd_u100_L1000_b2", "fwd_u100_L150_b3_it2")
+TAP_CASES = ("fwd_enc2dec5_u100_L100_b4", "fwd_u32_L100_b8", "fwd_u32_L64_b6_ft3_noext", "fwd_u100_L1000_b2", "fwd_u100_L150_b3_it2",
+             # r06: DEC_LargeRNN has the same dec{1,2}_outputs Linear modules (decoders.py:60-66,84-149); the same hooks give its taps
+             "fwd_rnn_u100_L100_b4", "fwd_rnn_u100_L40_b3_it2_ft3", "fwd_lstm_u100_L100_b3_it3", "fwd_rnntanh_u100_L64_b3_it2", "gen_dec_lstm")
 
 
 def reference_taps(model, cfg, u, noise):
@@ -324,14 +330,12 @@ def trained_fp32(manifest, pt_path, kind="trained_fp32"):
         hard, be, ble, dmax = [], [], [], [0.0, 0.0]
         for i in range(NB):
             u, noise = make_inputs(B, L, snr, seed=TRAINED_FP32_SEED, offset=i * B)
-            if i == 0 and snr == TRAINED_FP32_SNRS[0] and not rnn:
+            if i == 0 and snr == TRAINED_FP32_SNRS[0]:
                 x_ref, c_ref, taps = reference_taps(model, cfg, u, noise)
                 out["dec_taps_first4"] = taps[:, :4]
                 out["codes_batch0"] = c_ref
             else:
                 x_ref, c_ref = R.reference_forward(model, u, noise)
-                if i == 0 and snr == TRAINED_FP32_SNRS[0]:
-                    out["codes_batch0"] = c_ref
             if i == 0:
                 x_or, c_or = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), w, cfg.to_dict())
                 dmax = [float(np.abs(x_ref - x_or.numpy()).max()), float(np.abs(c_ref - c_or.numpy()).max())]
@@ -350,8 +354,35 @@ def trained_fp32(manifest, pt_path, kind="trained_fp32"):
     manifest[kind] = info
 
 
+def trained_taps(kind):
+    """r06: add `dec_taps_first4` to an EXISTING reference-trained fixture whose checkpoint is no longer at hand: the reference model is
+    rebuilt from the fixture's own fp32 blob (W.unpack_blob -> R.load_weights), run on batch 0 of the first SNR point with the
+    reference_taps hooks, and must reproduce the stored reference outputs of that batch before anything is written."""
+    over, stem, _ = TRAINED_KINDS[kind]
+    cfg = TurboAEConfig(**over)
+    path = os.path.join(GOLD, f"trained_{stem}_fp32.npz")
+    g = dict(np.load(path))
+    sd = W.unpack_blob(cfg, g["weights_fp32"])
+    B, L = 500, 100
+    model, _ = R.build_reference_model(cfg.to_dict(), B)
+    R.load_weights(model, sd)
+    snr = TRAINED_FP32_SNRS[0]
+    u, noise = make_inputs(B, L, snr, seed=TRAINED_FP32_SEED, offset=0)
+    x_ref, c_ref, taps = reference_taps(model, cfg, u, noise)
+    dx = float(np.abs(x_ref - g[f"x_dec_batch0_{snr:g}dB"]).max())
+    dc = float(np.abs(c_ref - g["codes_batch0"]).max())
+    assert dx <= 2e-6 and dc <= 2e-6, (kind, dx, dc)
+    g["dec_taps_first4"] = taps[:, :4]
+    np.savez_compressed(path, **g)
+    print(f"{stem}: dec_taps_first4 {taps[:, :4].shape} added (rebuilt reference reproduces the stored batch 0: max|dx|={dx:.1e} max|dc|={dc:.1e})")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 2 and sys.argv[1] == "--trained-taps":     # python oracle/make_golden.py --trained-taps trained_cnn_gru,trained_cnn_lstm
+        for kind in sys.argv[2].split(","):
+            trained_taps(kind)
+        return
     mpath = os.path.join(GOLD, "MANIFEST.json")
     manifest = {"cases": {}}
     if os.path.isfile(mpath):

@@ -16,6 +16,7 @@ import torch
 
 from turboae_amd import TurboAEConfig, weights as W
 from oracle import turboae_oracle as O
+from _tol import ATOL_XDEC_RNN, note
 
 pytestmark = pytest.mark.gpu
 
@@ -84,7 +85,7 @@ def test_configs1_small_last_layers_run_the_both_branch_twin_at_full_size(gpu_de
     every launch of such a network ran the calibration instantiation (dec_kernel_h<..., true>: 200 bytes of scratch, 108 spilled
     registers); since r05 it has a production twin (dec_kernel_h<100, 5, false, true> / enc_kernel_h<100, 5, 0, true>: 252 / 221 VGPRs,
     no scratch).  The trained network with every last layer scaled by 2^-5 (Linear heads by 2^5): the handle reports the twin on
-    both sides, 50 000 blocks pass the full-size checks against the oracle, and a decoder launch costs what the plain one costs."""
+    both sides and 50 000 blocks pass the full-size checks against the oracle (what a launch costs: bench.py)."""
     from turboae_amd import Channel_AE_HIP
     cfg = TurboAEConfig()
     sd = W.scale_last_layers(_trained_sd(), cfg, 2.0 ** -5)
@@ -94,23 +95,8 @@ def test_configs1_small_last_layers_run_the_both_branch_twin_at_full_size(gpu_de
     small = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
     plain = Channel_AE_HIP(cfg, _trained_sd(), device=gpu_device, max_batch=B)
     assert small.kernel_variants() == (True, True) and plain.kernel_variants() == (False, False)
-    u, noise = plain.generate_inputs(B, 2.0, seed=20190001)
-
-    def dec_ms(model):
-        rx = model.enc(u) + noise
-        for _ in range(2):
-            model.dec(rx)
-        ts = []
-        for _ in range(5):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); model.dec(rx); b.record(); torch.cuda.synchronize()
-            ts.append(a.elapsed_time(b))
-        model.check_range()
-        return float(np.median(ts))
-    t_plain, t_small = dec_ms(plain), dec_ms(small)
-    t_plain = min(t_plain, dec_ms(plain))
-    print(f"decoder launch: plain {t_plain:.2f} ms, both-branch twin {t_small:.2f} ms ({t_small / t_plain:.3f}x)")
-    assert t_small <= 1.05 * t_plain, (t_small, t_plain)       # VERDICT's mark is 3 % (bench.py reports the exact ratio); DVFS spread on top
+    # timing of the twin against the plain kernel is bench.py's business (`cfg1_head2_decoder_over_plain`): no wall-clock assertion
+    # lives under tests/ (VERDICT r05 item 4); _check_full_size above ran the twin against the oracle subsample
 
 
 def test_configs1_operating_point_2dB(gpu_device):
@@ -180,7 +166,7 @@ def test_configs4_gru_decoder_16384_blocks(gpu_device, cell):
     with torch.no_grad():
         xd_o = O.decode_rnn(rx[torch.from_numpy(idx).to(gpu_device)].cpu(), w, p, cfg.dec_num_unit, cfg.num_iteration, cfg.num_iter_ft, cell=cell)
     d = float((x_dec[torch.from_numpy(idx).to(gpu_device)].cpu() - xd_o).abs().max())
-    assert d <= 5e-5, d                                          # the GRU golden tests' tolerance (100 sequential steps x 12 stacks)
+    assert note(f"fullsize:{cell}:16400", d) <= ATOL_XDEC_RNN, d          # the recurrent golden tests' tolerance (tests/_tol.py)
     counts = model.count_errors(x_dec, u).cpu().tolist()
     err = (x_dec > 0.5) != (u > 0.5)
     assert counts == [int(err.sum()), int(err.any(dim=1).sum())]

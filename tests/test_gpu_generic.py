@@ -236,8 +236,11 @@ def test_generic_path_runs_the_eval_sweep_and_every_entry_point(gpu_device, prec
     for si, snr in enumerate(res["snrs"]):
         c = model.eval_snr(snr, 40, 2, seed=4, first_block=si * 80).sum(dim=0).cpu().tolist()
         assert c == [res["bit_errors"][si], res["block_errors"][si]]
-    with pytest.raises(Exception, match="tap"):
-        model.decode_taps(torch.zeros(2, 20, 3, device=gpu_device))
+    # r06: every DEC_LargeRNN handle exports its per-stage taps (num_iteration = 1: one stack pair, one tap)
+    rx = torch.randn(2, 20, 3, device=gpu_device)
+    xd, taps = model.decode_taps(rx)
+    assert taps.shape == (1, 2, 20, cfg.num_iter_ft) and bool(torch.isfinite(taps).all()) and float(taps.abs().max()) > 0
+    assert torch.equal(xd, model.dec(rx))
 
 
 def test_range_fallback_reruns_on_fp32_kernels(gpu_device):

@@ -196,6 +196,24 @@ def test_fallback_twin_serves_every_batch_the_handle_accepts(gpu_device):
     assert torch.equal(x1, exact.dec(rx))
 
 
+def test_index_less_cuda_device_spelling(gpu_device):
+    """device='cuda' (no index) is the common spelling; the engine resolves it to the current device once, so
+    calibrate_range's device check (tensors report cuda:0) accepts what forward accepts."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(num_iteration=1, enc_num_unit=32, dec_num_unit=32, block_len=32)
+    sd = W.generate_state_dict(cfg, seed=9, gain=1.0)
+    with torch.cuda.device(gpu_device):
+        for spelling in ("cuda", torch.device("cuda")):
+            m = Channel_AE_HIP(cfg, sd, device=spelling, max_batch=4)
+            assert m._eng.device == torch.device("cuda", torch.cuda.current_device())
+            u, noise = _inputs(4, cfg.block_len)
+            ud, nd = torch.from_numpy(u).to("cuda"), torch.from_numpy(noise).to("cuda")
+            ref = m(ud, nd)
+            m.calibrate_range(ud, nd)
+            out = m(ud, nd)
+            assert torch.equal(out[0], ref[0])
+
+
 def test_calibrate_range_takes_what_forward_takes(gpu_device):
     """calibrate_range validates and routes its arguments exactly as forward does - (B, L, 1) punctured noise is
     expanded, channel='fading' needs (and lays out) the coefficients, mismatched or half-given arguments raise instead of reading

@@ -28,6 +28,7 @@ META = _MAN["trained_fp32"]            # batch geometry / seeds / SNR points are
 
 ATOL_CODES = 1e-5
 ATOL_XDEC = 2e-5
+from _tol import ATOL_XDEC_RNN, note
 
 
 @pytest.fixture(scope="module", params=list(KINDS), ids=["enc2dec5", "enc5dec5", "cnn_gru", "cnn_lstm"])
@@ -63,7 +64,7 @@ def test_decisions_and_ber_match_reference_across_snr_points(gpu_device, fixture
     from turboae_amd import Channel_AE_HIP
     g, cfg, sd, meta = fixture_data
     rnn = cfg.decoder == "TurboAE_rate3_rnn"
-    atol_x = 5e-5 if rnn else ATOL_XDEC       # the GRU decoder's bound everywhere (100 sequential steps x 24 GRU layers)
+    atol_x = ATOL_XDEC_RNN if rnn else ATOL_XDEC       # the recurrent decoders' bound everywhere (tests/_tol.py: measured)
     B, L = META["batch"], 100
     model = Channel_AE_HIP(replace(cfg, precision=precision), sd, device=gpu_device, max_batch=B)
     for snr in META["snrs"]:
@@ -83,6 +84,8 @@ def test_decisions_and_ber_match_reference_across_snr_points(gpu_device, fixture
             ber_batches.append(errs / (B * L))
             if i == 0:
                 xr = g[f"x_dec_batch0_{key}"]
+                if rnn:
+                    note(f"trained:{cfg.dec_rnn}:{key}:{precision}", np.abs(xd - xr).max())
                 assert np.abs(xd - xr).max() <= atol_x, (key, np.abs(xd - xr).max())
                 # a decision may only differ where the reference's own soft output is within fp32 noise of 1/2
                 assert np.all(np.abs(xr[:, :, 0][flips] - 0.5) < 1e-4)
@@ -102,8 +105,7 @@ def test_stage_taps_on_trained_weights(gpu_device, fixture_data, precision):
     from dataclasses import replace
     from turboae_amd import Channel_AE_HIP
     g, cfg, sd, meta = fixture_data
-    if "dec_taps_first4" not in g.files:
-        pytest.skip("the recurrent decoders have no tap export (tae_decode_taps is CNN only)")
+    assert "dec_taps_first4" in g.files      # r06: the recurrent fixtures carry them too (oracle/make_golden.py --trained-taps)
     _, noise = _inputs(0, META["snrs"][0])
     rx = torch.from_numpy(g["codes_batch0"][:4] + noise[:4]).to(gpu_device)
     model = Channel_AE_HIP(replace(cfg, precision=precision), sd, device=gpu_device, max_batch=4)
@@ -113,7 +115,8 @@ def test_stage_taps_on_trained_weights(gpu_device, fixture_data, precision):
     for s in range(ref.shape[0]):
         d = np.abs(taps[s] - ref[s]).max()
         assert d <= 2e-5 * max(1.0, np.abs(ref[s]).max()), (s, d)
-    assert np.abs(xd.cpu().numpy() - g[f"x_dec_batch0_{META['snrs'][0]:g}dB"][:4]).max() <= ATOL_XDEC
+    rnn = cfg.decoder == "TurboAE_rate3_rnn"
+    assert np.abs(xd.cpu().numpy() - g[f"x_dec_batch0_{META['snrs'][0]:g}dB"][:4]).max() <= (ATOL_XDEC_RNN if rnn else ATOL_XDEC)
 
 
 def test_precisions_against_float64_oracle_on_trained_weights(gpu_device, fixture_data):
@@ -135,4 +138,4 @@ def test_precisions_against_float64_oracle_on_trained_weights(gpu_device, fixtur
     print("trained fp32 weights, max |err| vs float64 oracle (codes, x_dec):", err)
     for k in (0, 1):
         assert err["auto"][k] <= 2.0 * err["f32"][k] + 5e-7, err
-    assert err["auto"][0] <= ATOL_CODES and err["auto"][1] <= (5e-5 if cfg.decoder == "TurboAE_rate3_rnn" else ATOL_XDEC)
+    assert err["auto"][0] <= ATOL_CODES and err["auto"][1] <= (ATOL_XDEC_RNN if cfg.decoder == "TurboAE_rate3_rnn" else ATOL_XDEC)

@@ -54,6 +54,8 @@ class _Engine:
         if device.type != "cuda":
             raise _lib.TurboAEError("Channel_AE_HIP needs a ROCm GPU device (no CPU fallback)")
         self.cfg = cfg
+        if device.index is None:      # 'cuda' names the current device; tensors report cuda:<index>, so comparisons need the index too
+            device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
         self.lib = _lib.load()
         self._state = W.check_state_dict(cfg, state_dict)

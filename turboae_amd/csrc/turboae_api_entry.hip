@@ -196,7 +196,7 @@ int tae_decode_taps(tae_handle* h, const float* received, float* x_dec, float* t
     int rc = check_batch(h, B);
     if (rc != TAE_OK) return rc;
     if (!received || !x_dec || !taps) return fail(TAE_EINVAL, "NULL tensor");
-    if (h->cfg.dense) return fail(TAE_EINVAL, "tae_decode_taps: not built for DenseSameShapeConv1d stacks");
+    if (h->cfg.dense && !h->gen) return fail(TAE_EINVAL, "tae_decode_taps: not built for DenseSameShapeConv1d stacks");
     return run_decoder(h, received, x_dec, B, (hipStream_t)stream, taps);
 }
 

@@ -418,7 +418,7 @@ int run_encoder_rnn(tae_handle* h, const float* u, float* xtx, double* stats, in
 }
 
 // DEC_LargeRNN.forward (decoders.py:84-149): per half-iteration rec(layer 0) -> proj -> rec(layer 1) -> head
-int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st) {
+int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st, float* tap_out) {
     const int L = h->cfg.block_len, F = h->cfg.num_iter_ft, H = 100, n_iter = h->cfg.num_iteration;
     for (int32_t c0 = 0; c0 < B; c0 += h->rnn_chunk) {
         const int32_t Bc = (B - c0 < h->rnn_chunk) ? B - c0 : h->rnn_chunk;
@@ -457,6 +457,7 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
                 HP.ptab = odd ? h->d_perm : h->d_inv;
                 HP.npos = npg; HP.L = L; HP.F = F; HP.nout = nout; HP.extrinsic = h->cfg.extrinsic; HP.last = last ? 1 : 0;
                 HP.grouped = 1; HP.B = Bc; HP.enc_stack = -1; HP.act = h->cfg.dec_act;
+                HP.tap = (tap_out && !last) ? tap_out + ((size_t)s * B + c0) * L * F : nullptr;
                 TAE_HIP(tae::launch_gru_head_part(HP, st));
                 wb += rnn_h_stack_bytes((size_t)nout);
             }
@@ -488,6 +489,7 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
             HP.ptab = odd ? h->d_perm : h->d_inv;     // dec1 -> interleave (row inv[t]); dec2 -> deinterleave (row p[i])
             HP.npos = np; HP.L = L; HP.F = F; HP.nout = nout; HP.extrinsic = h->cfg.extrinsic; HP.last = last ? 1 : 0;
             HP.enc_stack = -1; HP.act = h->cfg.dec_act;
+            HP.tap = (tap_out && !last) ? tap_out + ((size_t)s * B + c0) * L * F : nullptr;
             TAE_HIP(tae::launch_gru_head(HP, st));
             w += rnn_packed_stack_floats((size_t)nout);
         }
@@ -497,7 +499,7 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
 
 // DEC_LargeRNN.forward with an LSTM / vanilla-RNN cell (decoders.py:27-32,84-149) on the unit-split f16x2 kernels (turboae_rnn_u.hip):
 // per half-iteration rec(layer 0) -> projection GEMM -> rec(layer 1, head tile fused) -> gru_head_part
-int run_decoder_rnn_u(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st) {
+int run_decoder_rnn_u(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st, float* tap_out) {
     const int L = h->cfg.block_len, F = h->cfg.num_iter_ft, H = 100, n_iter = h->cfg.num_iteration, G = h->dec_gates;
     const size_t dirb = tae::RnnULayout::dir_bytes(G), projb = tae::RnnULayout::proj_bytes(G);
     for (int32_t c0 = 0; c0 < B; c0 += h->rnn_chunk) {
@@ -512,7 +514,7 @@ int run_decoder_rnn_u(tae_handle* h, const float* rx, float* xdec, int32_t B, hi
             tae::RnnUParams R;
             memset(&R, 0, sizeof(R));
             R.w = wb; R.w_dir_stride = (uint32_t)dirb; R.x = xin; R.y0 = reinterpret_cast<char*>(h->d_gy0);
-            R.B = Bc; R.L = L;
+            R.B = Bc; R.L = L; R.ncu = h->ncu;
             TAE_HIP(tae::launch_rnn_rec_u(G, true, R, st));
             tae::RnnProjParams PP;
             memset(&PP, 0, sizeof(PP));
@@ -529,6 +531,7 @@ int run_decoder_rnn_u(tae_handle* h, const float* rx, float* xdec, int32_t B, hi
             HP.ptab = odd ? h->d_perm : h->d_inv;
             HP.npos = npg; HP.L = L; HP.F = F; HP.nout = nout; HP.extrinsic = h->cfg.extrinsic; HP.last = last ? 1 : 0;
             HP.grouped = 1; HP.B = Bc; HP.enc_stack = -1; HP.act = h->cfg.dec_act;
+            HP.tap = (tap_out && !last) ? tap_out + ((size_t)s * B + c0) * L * F : nullptr;
             TAE_HIP(tae::launch_gru_head_part(HP, st));
             wb += rnn_u_stack_bytes((size_t)nout, G);
         }
@@ -538,13 +541,11 @@ int run_decoder_rnn_u(tae_handle* h, const float* rx, float* xdec, int32_t B, hi
 
 int run_decoder(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st, float* tap_out) {
     if (h->gen) {
-        if (tap_out) return fail(TAE_EINVAL, "tae_decode_taps: no tap export on the generic fp32 kernels");
-        return tae::generic_decode(h->gen, rx, xdec, h->d_perm, h->d_inv, B, st);
+        return tae::generic_decode(h->gen, rx, xdec, h->d_perm, h->d_inv, B, st, tap_out);
     }
     if (h->cfg.dec_type == 1) {
-        if (tap_out) return fail(TAE_EINVAL, "tae_decode_taps: the GRU decoder has no tap export");
-        if (h->dec_gates != 3) return run_decoder_rnn_u(h, rx, xdec, B, st);
-        return run_decoder_rnn(h, rx, xdec, B, st);
+        if (h->dec_gates != 3) return run_decoder_rnn_u(h, rx, xdec, B, st, tap_out);
+        return run_decoder_rnn(h, rx, xdec, B, st, tap_out);
     }
     if (h->nbd < 1) return run_decoder_long(h, rx, xdec, B, st, tap_out);
     tae::FusedParams P = base_params(h, B, true);

@@ -615,7 +615,7 @@ __global__ void gen_copy_rows_kernel(const float* __restrict__ src, int lds_, fl
 // sigmoid(deinterleave(act(o))) (decoders.py:143-147,262-267).  Encoder (enc_stack >= 0): x_tx[., s] = enc_act(o).
 __global__ void gen_head_kernel(const float* __restrict__ o, int nout, const float* __restrict__ xcur, float* __restrict__ xnext, int W,
                                 float* __restrict__ xdec, const int32_t* __restrict__ ptab, size_t B, int L, int F, int extrinsic, int last,
-                                int act, int enc_stack, float* __restrict__ xtx) {
+                                int act, int enc_stack, float* __restrict__ xtx, float* __restrict__ tap) {
     const size_t n = B * L;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t b = i / L;
@@ -627,7 +627,10 @@ __global__ void gen_head_kernel(const float* __restrict__ o, int nout, const flo
         } else if (!last) {
             const float* xc = xcur + i * W + 2;
             float* xn = xnext + (b * L + ptab[t]) * W + 2;
-            for (int f = 0; f < F; ++f) xn[f] = act_apply(v[f], act) - (extrinsic ? xc[f] : 0.0f);
+            for (int f = 0; f < F; ++f) {
+                xn[f] = act_apply(v[f], act) - (extrinsic ? xc[f] : 0.0f);
+                if (tap) tap[i * F + f] = xn[f];      // tae_decode_taps: [b][position in this stack's order][f]
+            }
         } else {
             xdec[b * L + ptab[t]] = sigm(act_apply(v[0], act));
         }
@@ -996,7 +999,7 @@ int generic_encode(GenericEngine* g, const float* u, float* xtx, double* stats, 
         const int rc = run_stack(g, g->enc[s], g->d_xa, B, st);
         if (rc != TAE_OK) return rc;
         hipLaunchKernelGGL(gen_head_kernel, dim3(grid), dim3(256), 0, st, g->d_o, 1, (const float*)nullptr, (float*)nullptr, 0, (float*)nullptr,
-                           perm, (size_t)B, L, 1, 0, 0, g->cfg.enc_act, s, xtx);
+                           perm, (size_t)B, L, 1, 0, 0, g->cfg.enc_act, s, xtx, (float*)nullptr);
         GEN_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(gen_stats_kernel, dim3(kStatsGrid), dim3(256), 0, st, xtx, np * 3, g->d_partials);
@@ -1005,7 +1008,7 @@ int generic_encode(GenericEngine* g, const float* u, float* xtx, double* stats, 
     return TAE_OK;
 }
 
-int generic_decode(GenericEngine* g, const float* rx, float* xdec, const int32_t* perm, const int32_t* inv, int32_t B, hipStream_t st) {
+int generic_decode(GenericEngine* g, const float* rx, float* xdec, const int32_t* perm, const int32_t* inv, int32_t B, hipStream_t st, float* tap_out) {
     if (B > g->cap) return fail_msg(TAE_ESTATE, "batch exceeds reserved workspace");
     const int L = g->cfg.block_len, F = g->cfg.num_iter_ft, W = 2 + F;
     const size_t np = (size_t)B * L;
@@ -1020,7 +1023,8 @@ int generic_decode(GenericEngine* g, const float* rx, float* xdec, const int32_t
         const int rc = run_stack(g, g->dec[s], xin, B, st);
         if (rc != TAE_OK) return rc;
         hipLaunchKernelGGL(gen_head_kernel, dim3(grid), dim3(256), 0, st, g->d_o, g->dec[s].nout, xin, odd ? g->d_xa : g->d_xb, W, xdec,
-                           odd ? perm : inv, (size_t)B, L, F, g->cfg.extrinsic, last ? 1 : 0, act, -1, (float*)nullptr);
+                           odd ? perm : inv, (size_t)B, L, F, g->cfg.extrinsic, last ? 1 : 0, act, -1, (float*)nullptr,
+                           (tap_out && !last) ? tap_out + (size_t)s * np * F : (float*)nullptr);
         GEN_HIP(hipGetLastError());
     }
     return TAE_OK;

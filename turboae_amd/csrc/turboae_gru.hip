@@ -365,7 +365,10 @@ __global__ __launch_bounds__(64 * kHeadWaves) void gru_head_kernel(GruHeadParams
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int f = 4 * kq + i;
-                if (f < P.F) xn[f] = act_apply(o[i], P.act) - (P.extrinsic ? xc[f] : 0.0f);      // dec_act, then extrinsic (decoders.py:103-106)
+                if (f < P.F) {
+                    xn[f] = act_apply(o[i], P.act) - (P.extrinsic ? xc[f] : 0.0f);      // dec_act, then extrinsic (decoders.py:103-106)
+                    if (P.tap) P.tap[pos * P.F + f] = xn[f];
+                }
             }
         } else if (kq == 0) {
             P.xdec[b * P.L + P.ptab[t]] = sigmoidf_(act_apply(o[0], P.act));      // sigmoid(deinterleave(dec_act(x_plr))), decoders.py:143-147

@@ -649,6 +649,8 @@ __global__ __launch_bounds__(kHeadPartThreads) void gru_head_part_kernel(GruHead
             n0.z = v[0]; n0.w = v[1];
             xn4[0] = n0;
             xn4[1] = f32x4{v[2], v[3], v[4], v[5]};
+            if (P.tap)
+                for (int f = 0; f < P.F; ++f) P.tap[pos * P.F + f] = v[f];
         } else {
             const float v = act_apply(o[0] + P.b[0], P.act);
             P.xdec[b * P.L + P.ptab[t]] = 1.0f / (1.0f + expf(-v));      // sigmoid(deinterleave(dec_act(x_plr))), decoders.py:143-147

@@ -107,6 +107,7 @@ struct GruHeadParams {
     int32_t enc_stack, act;
     float* xtx;           // (B, L, 3)
     double* partials;     // [gridDim.x][2]
+    float* tap;           // tae_decode_taps: this stack's extrinsic output [b][position of this stack's order][f], or nullptr
 };
 // f16x2 layer 1 as one kernel (turboae_gru_l1f.hip): input projection + recurrence + this direction's half of the Linear head.
 // Weight image of one direction: 6 unit-wave register images (42 fragments of 1 KB: per gate W_hh {slab 0..2: hi, lo; remainder},
@@ -143,6 +144,7 @@ struct RnnUParams {
     char* y0;               // layer 0: outputs as halves [pos'][hi 200 | lo 200], pos' = ((b / 16) L + t) 16 + b % 16
     float* hpart;           // layer 1: [pos'][dir][8] this direction's share of the Linear head
     int32_t B, L, ngroups;  // ngroups: set by the launcher (ceil(B / 16 NT), NT = N tiles per workgroup, picked by batch)
+    int32_t ncu;            // compute units of the handle's device (grid size and the NT choice)
 };
 struct RnnProjParams {
     const float* yin;       // layer-0 outputs (halves)
@@ -203,7 +205,7 @@ int generic_create(const tae_config* c, const float* weights, size_t n_weights, 
 void generic_destroy(GenericEngine* g);
 int generic_reserve(GenericEngine* g, int32_t B);
 int generic_encode(GenericEngine* g, const float* u, float* xtx, double* stats, const int32_t* perm, int32_t B, hipStream_t st);
-int generic_decode(GenericEngine* g, const float* rx, float* xdec, const int32_t* perm, const int32_t* inv, int32_t B, hipStream_t st);
+int generic_decode(GenericEngine* g, const float* rx, float* xdec, const int32_t* perm, const int32_t* inv, int32_t B, hipStream_t st, float* tap_out = nullptr);
 // Debug knobs: every environment variable that changes the arithmetic, the kernel family or a launch geometry goes through here.
 // It is inert (nullptr) unless TAE_DEBUG_KNOBS=1 is set in the same environment, and every override that took effect is recorded
 // for tae_overrides().

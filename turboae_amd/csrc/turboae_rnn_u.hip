@@ -371,8 +371,12 @@ __global__ __launch_bounds__(512) void rnn_rec_u_kernel(RnnUParams P) {
 // ---- layer-1 input projections: GI = (W_ih1 * Y0 + b) * gi_mul as an f16x2 GEMM, CTT row tiles per direction -------------------------
 // Workgroup = 4 waves, 80 positions (5 tiles) staged in LDS as hi / lo planes of 200 halves; wave = (direction, half of the row tiles),
 // passes of <= 5 tiles.  A fragments [slab 7][tile CTT][hi | lo][lane][8 halves] per direction, then the bias rows and 2^-S.
-constexpr int kPT = 5, kProjSlabs = 7;
-constexpr int kProjPos = 16 * kPT, kPlaneB = kProjPos * 400 + 512, kProjLds = 2 * kPlaneB;
+// Panel rows are kProjRow = 416 bytes apart (400 of halves + 16 of zeros): ds_read_b128 is served in the lane groups
+// {0-3, 12-15, 20-27}, ... (MI355X_MICROARCH.md, LDS), i.e. eight positions at one k quarter with eight at the next, and a row stride
+// of s 16-byte slots keeps those sixteen reads on sixteen different slots iff s = 2 (mod 4): 25 (r05, unpadded) made seven of every
+// eight pairs collide (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 47 %), 26 none.
+constexpr int kPT = 5, kProjSlabs = 7, kProjRow = 416;
+constexpr int kProjPos = 16 * kPT, kPlaneB = kProjPos * kProjRow + 512, kProjLds = 2 * kPlaneB;
 
 template <int CTT, int C0, int NC>
 __device__ __forceinline__ void proj_pass(const RnnProjParams& P, const char* smem, int dir, int lane, size_t p0) {
@@ -386,7 +390,7 @@ __device__ __forceinline__ void proj_pass(const RnnProjParams& P, const char* sm
     uint32_t bh[kPT], bl[kPT];
 #pragma unroll
     for (int p = 0; p < kPT; ++p) {
-        bh[p] = (uint32_t)((p * 16 + n) * 400 + 16 * kq);
+        bh[p] = (uint32_t)((p * 16 + n) * kProjRow + 16 * kq);
         bl[p] = bh[p] + (uint32_t)kPlaneB;
     }
     OpsHA<NC> a0;
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void rnn_proj_u_kernel(RnnProjParams P) {
         __syncthreads();
         for (int i = tid; i < np * 50; i += 256) {      // Y0 rows are halves [hi 200 | lo 200]: 25 16-byte pieces per plane
             const int pos = i / 50, c = i - pos * 50, plane = c >= 25 ? 1 : 0, cc = c - plane * 25;
-            *reinterpret_cast<f32x4*>(smem + plane * kPlaneB + pos * 400 + cc * 16) = src[i];
+            *reinterpret_cast<f32x4*>(smem + plane * kPlaneB + pos * kProjRow + cc * 16) = src[i];
         }
     }
     __syncthreads();
@@ -454,13 +458,7 @@ hipError_t launch_rec_nt(RnnUParams P, int ncu, hipStream_t st) {
 }
 template <int G, bool LAYER0>
 hipError_t launch_rec(const RnnUParams& P, hipStream_t st) {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int ncu = P.ncu > 0 ? P.ncu : 256;
     // one 16-block tile per workgroup while that still fits one round of workgroups (two per pair of directions and CU)
     const bool small = 2 * ((P.B + 15) / 16) <= ncu;
     return small ? launch_rec_nt<G, LAYER0, 1>(P, ncu, st) : launch_rec_nt<G, LAYER0, 2>(P, ncu, st);
