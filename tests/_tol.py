@@ -6,7 +6,7 @@ about twice its worst entry."""
 import json
 import os
 
-ATOL_XDEC_RNN = 5e-5
+ATOL_XDEC_RNN = 5e-6      # worst of 46 x_dec entries in profiles/r06_rnn_deviations.txt: 1.55e-6 (trained LSTM, 2 dB, f32 kernels)
 
 
 def note(tag: str, d: float) -> float:

@@ -152,7 +152,8 @@ def test_decoder_taps_rejected_for_dense_stacks(gpu_device):
     layer outputs; the generic kernels and every recurrent decoder export taps since r06)"""
     from turboae_amd import Channel_AE_HIP
     from turboae_amd._lib import TurboAEError
-    cfg = TurboAEConfig(decoder="TurboAE_rate3_cnn_dense", dec_num_unit=32, num_iteration=1, block_len=16, dec_num_layer=2)
+    cfg = TurboAEConfig(encoder="TurboAE_rate3_cnn_dense", decoder="TurboAE_rate3_cnn_dense", enc_num_unit=32, dec_num_unit=32, num_iteration=1,
+                        block_len=16, dec_num_layer=2)
     model = Channel_AE_HIP(cfg, W.generate_state_dict(cfg, seed=1, gain=1.0), device=gpu_device, max_batch=2)
     with pytest.raises(TurboAEError, match="DenseSameShapeConv1d"):
         model.decode_taps(torch.zeros((2, 16, 3), device=gpu_device))

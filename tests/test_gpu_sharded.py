@@ -327,4 +327,6 @@ def test_bench_also_configs3_in_the_same_launch(gpu_device):
     for tag in ("weak", "strong"):
         assert c3[tag]["rccl_ranks_seen"] == 2 and 1e-4 < c3[tag]["ber"] < 0.03 and c3[tag]["value"] > 0
         assert res[f"cfg3_{tag}_bits_per_s"] == c3[tag]["value"] and 0.05 < res[f"cfg3_{tag}_decoder_frac"] < 1.0
-    assert res["roofline_frac"] == res["roofline"]["frac"] and res["overrides"] == ""
+    # the flat block that closes the line carries 5 significant digits (bench.ordered_for_tail)
+    assert res["roofline_frac"] == pytest.approx(res["roofline"]["frac"], rel=1e-4) and res["overrides"] == ""
+    assert list(res)[-1] == "overrides"

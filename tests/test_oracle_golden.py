@@ -156,7 +156,7 @@ def test_oracle_matches_reference_on_full_precision_trained_weights(kind, fname)
             else:
                 x = O.decode(rx, w, p, cfg.dec_num_layer, cfg.num_iteration, cfg.num_iter_ft, 1, taps)
         xr = g[f"x_dec_batch0_{key}"][:n]
-        assert np.abs(x.numpy() - xr).max() <= (5e-5 if rnn else 5e-6)
+        assert np.abs(x.numpy() - xr).max() <= 5e-6        # r06: the recurrent oracle too (measured <= 4e-7 against the reference)
         hard_ref = np.unpackbits(g[f"hard_bits_{key}"])[: n * L].reshape(n, L)
         flips = (x.numpy()[:, :, 0] > 0.5).astype(np.uint8) != hard_ref
         assert np.all(np.abs(xr[:, :, 0][flips] - 0.5) < 1e-4) and flips.sum() <= (1 if rnn else 0)

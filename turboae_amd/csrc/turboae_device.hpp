@@ -484,10 +484,18 @@ struct OpsHB {
 };
 
 // B fragments of one position tile: 8 consecutive halves of the im2col row from each plane (8-byte aligned)
-template <int OFF>
+// B128: the rows are 16-byte aligned (the projection GEMMs' panels), one ds_read_b128 per plane - 4 LDS cycles per wave-instruction
+// against 8 for the ds_read2_b64 the 8-byte form compiles to, and banked mod 64 instead of mod 32
+template <int OFF, bool B128 = false>
 __device__ __forceinline__ void load_xh(OpsHB& o, lds_cptr ph, lds_cptr pl) {
     using lds_u2 = const u32x2v __attribute__((address_space(3)));
     if (TAE_X & 16) return;
+    if constexpr (B128) {
+        using lds_u4 = const u32x4w __attribute__((address_space(3)));
+        o.hi = __builtin_bit_cast(h8, *reinterpret_cast<lds_u4*>(ph + OFF));
+        o.lo = __builtin_bit_cast(h8, *reinterpret_cast<lds_u4*>(pl + OFF));
+        return;
+    }
     const u32x2v a0 = *reinterpret_cast<lds_u2*>(ph + OFF), a1 = *reinterpret_cast<lds_u2*>(ph + OFF + 8);
     const u32x2v b0 = *reinterpret_cast<lds_u2*>(pl + OFF), b1 = *reinterpret_cast<lds_u2*>(pl + OFF + 8);
     o.hi = __builtin_bit_cast(h8, u32x4w{a0.x, a0.y, a1.x, a1.y});
@@ -540,7 +548,7 @@ __device__ __forceinline__ void mma_tile_h(f32x4 (&acc)[NC], const OpsHA<NC>& a,
 // soff  : wave-uniform byte offset of this layer's A fragments
 // bh/bl : per position tile, LDS byte address of (row-2)*stride + 16*kq in the hi / lo plane
 // NSLAB = 0: the slab count is the (wave-uniform) run-time argument `nslab_rt` (conv stacks: it follows the kernel size).
-template <int CTT, int C0, int NC, int PT, int NSLAB>
+template <int CTT, int C0, int NC, int PT, int NSLAB, bool B128 = false>
 __device__ __forceinline__ void conv_accumulate_h(f32x4 (&acc)[PT][NC], OpsHA<NC>& a0, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff,
                                                   uint32_t soff, const char* lds, const uint32_t (&bh)[PT], const uint32_t (&bl)[PT],
                                                   int nslab_rt = 0) {
@@ -552,7 +560,7 @@ __device__ __forceinline__ void conv_accumulate_h(f32x4 (&acc)[PT][NC], OpsHA<NC
     for (int p = 0; p < PT; ++p) { ch[p] = lds3 + bh[p]; cl[p] = lds3 + bl[p]; }
     OpsHA<NC> a1;
     OpsHB b[2];                                // ring: tile j of the running (slab, tile) sequence sits in b[j % 2]
-    load_xh<0>(b[0], ch[0], cl[0]);
+    load_xh<0, B128>(b[0], ch[0], cl[0]);
     // One slab.  Tile p uses ring slot (RB + p) % 2 and prefetches the next tile (of this slab at OFF, or tile 0 of
     // the next slab at OFF + 64): one tile = 3 * NC MFMAs (>= 150 cycles) of cover for the LDS latency.  The issue
     // order is pinned with sched_group_barriers - left alone, the scheduler sinks every load to just before its
@@ -563,8 +571,8 @@ __device__ __forceinline__ void conv_accumulate_h(f32x4 (&acc)[PT][NC], OpsHA<NC
     constexpr int NVT = (2 * NC + NVS - 1) / NVS;      // weight loads threaded through one of those tiles' MFMAs
 #define TAE_H_SLAB(ACUR, OFF, RB)                                                                          \
     _Pragma("unroll") for (int p = 0; p < PT; ++p) {                                                       \
-        if (p + 1 < PT) load_xh<(OFF)>(b[((RB) + p + 1) % 2], ch[p + 1 < PT ? p + 1 : 0], cl[p + 1 < PT ? p + 1 : 0]);   \
-        else load_xh<(OFF) + 64>(b[((RB) + p + 1) % 2], ch[0], cl[0]);                                     \
+        if (p + 1 < PT) load_xh<(OFF), B128>(b[((RB) + p + 1) % 2], ch[p + 1 < PT ? p + 1 : 0], cl[p + 1 < PT ? p + 1 : 0]);   \
+        else load_xh<(OFF) + 64, B128>(b[((RB) + p + 1) % 2], ch[0], cl[0]);                                     \
         mma_tile_h<NC>(acc[p], ACUR, b[((RB) + p) % 2]);                                                   \
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                 \
         if (p < NVS) {                                                                                     \

@@ -402,7 +402,7 @@ __device__ __forceinline__ void proj_pass(const RnnProjParams& P, const char* sm
 #pragma unroll
         for (int p = 0; p < kPT; ++p) acc[p][ct] = bv;
     }
-    conv_accumulate_h<CTT, C0, NC, kPT, kProjSlabs>(acc, a0, rsrc, voff, soff, smem, bh, bl);
+    conv_accumulate_h<CTT, C0, NC, kPT, kProjSlabs, true>(acc, a0, rsrc, voff, soff, smem, bh, bl);
 #pragma unroll
     for (int p = 0; p < kPT; ++p) {
         const size_t pos = p0 + p * 16 + n;
