@@ -101,12 +101,14 @@ def test_config_validation():
     # outside the MFMA kernels' envelope: the generic fp32 kernels (r03) - still validated, with their own (wider) limits
     for over in (dict(enc_kernel_size=7, precision="f32"), dict(enc_num_unit=128, dec_num_unit=128), dict(num_iter_ft=9), dict(dec_kernel_size=21),
                  dict(decoder="TurboAE_rate3_rnn", dec_rnn="lstm", precision="f32"), dict(decoder="TurboAE_rate3_rnn", dec_rnn="rnn", dec_num_unit=101),
-                 dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", dec_rnn="lstm"),
+                 dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", dec_rnn="lstm", precision="f32"),
                  dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_num_layer=3),
                  dict(encoder="TurboAE_rate3_rnn"), dict(encoder="TurboAE_rate3_cnn_dense", precision="f32")):
         cfg = TurboAEConfig(**over)
         cfg.validate()
         assert cfg.generic, over
+    # r06: the 2-layer GRU encoder in front of an LSTM / vanilla-RNN decoder runs on the tuned kernels (GRU kernels + turboae_rnn_u.hip)
+    assert not TurboAEConfig(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", dec_rnn="lstm").generic
     # r05: LSTM / vanilla-RNN decoders behind the CNN encoder have unit-split f16x2 kernels (turboae_rnn_u.hip)
     for over in (dict(decoder="TurboAE_rate3_rnn", dec_rnn="lstm"), dict(decoder="TurboAE_rate3_rnn", dec_rnn="rnn", dec_num_unit=40)):
         cfg = TurboAEConfig(**over)

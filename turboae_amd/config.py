@@ -78,8 +78,8 @@ class TurboAEConfig:
             return True
         if enc_rnn and self.enc_rnn != "gru":
             return True
-        # LSTM / vanilla-RNN decoder: unit-split f16x2 kernels (csrc/turboae_rnn_u.hip) behind the CNN encoder; fp32 and RNN-encoder pairings stay generic
-        if dec_rnn and self.dec_rnn != "gru" and (self.precision == "f32" or enc_rnn):
+        # LSTM / vanilla-RNN decoder: unit-split f16x2 kernels (csrc/turboae_rnn_u.hip) behind the CNN or the 2-layer GRU encoder; fp32 stays generic
+        if dec_rnn and self.dec_rnn != "gru" and self.precision == "f32":
             return True
         if enc_rnn and (self.enc_num_layer != 2 or not dec_rnn):
             return True

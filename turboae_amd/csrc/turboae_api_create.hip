@@ -1345,6 +1345,22 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     TAE_HIP_H(hipMemcpy(h->d_wenc, penc.data(), penc.size() * sizeof(float), hipMemcpyHostToDevice));
     TAE_HIP_H(hipMemcpy(h->d_wdec, pdec.data(), pdec.size() * sizeof(float), hipMemcpyHostToDevice));
     h->dec_gates = cfg->dec_type == 1 ? cell_gates(cfg->dec_rnn) : 3;
+    // ENC_interRNN (GRU cells, 2 layers) on the GRU kernels, whatever cell the decoder uses (r06: also in front of an LSTM / vanilla-RNN
+    // decoder; the encoder shares the decoder's chunk workspace, not its kernels)
+    auto pack_rnn_encoder = [&]() -> int {
+        const std::vector<size_t> en(3, 1);
+        std::vector<float> pe(rnn_packed_floats(en), 0.0f);
+        repack_rnn(weights, pe.data(), 100, 1, en);
+        TAE_HIP_H(hipMalloc(&h->d_wernn, pe.size() * sizeof(float)));
+        TAE_HIP_H(hipMemcpy(h->d_wernn, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (h->prec == 1) {
+            std::vector<char> peh(rnn_h_packed_bytes(en), 0);
+            repack_rnn_h(weights, peh.data(), 1, en);
+            TAE_HIP_H(hipMalloc(&h->d_wernn_h, peh.size()));
+            TAE_HIP_H(hipMemcpy(h->d_wernn_h, peh.data(), peh.size(), hipMemcpyHostToDevice));
+        }
+        return TAE_OK;
+    };
     if (cfg->dec_type == 1 && h->dec_gates != 3) {
         // LSTM / vanilla-RNN decoder (generic_needed left it here: CNN encoder, precision auto): unit-split f16x2 kernels only
         if (h->prec != 1) { tae_destroy(h); return fail(TAE_EINVAL, "internal: the LSTM / RNN decoder kernels exist in the fp16-split arithmetic only"); }
@@ -1355,6 +1371,7 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         repack_rnn_u(dec_src, pu.data(), 2 + (size_t)F, nouts, h->dec_gates, h->rnn_u_gimul);
         TAE_HIP_H(hipMalloc(&h->d_wrnn_u, pu.size()));
         TAE_HIP_H(hipMemcpy(h->d_wrnn_u, pu.data(), pu.size(), hipMemcpyHostToDevice));
+        if (cfg->enc_type == 1) { rc = pack_rnn_encoder(); if (rc != TAE_OK) return rc; }
     } else if (cfg->dec_type == 1) {
         const size_t nrnn = (size_t)(weights + n_weights - dec_src);
         (void)nrnn;
@@ -1369,19 +1386,7 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
             TAE_HIP_H(hipMalloc(&h->d_wrnn_h, prnn_h.size()));
             TAE_HIP_H(hipMemcpy(h->d_wrnn_h, prnn_h.data(), prnn_h.size(), hipMemcpyHostToDevice));
         }
-        if (cfg->enc_type == 1) {
-            const std::vector<size_t> en(3, 1);
-            std::vector<float> pe(rnn_packed_floats(en), 0.0f);
-            repack_rnn(weights, pe.data(), 100, 1, en);
-            TAE_HIP_H(hipMalloc(&h->d_wernn, pe.size() * sizeof(float)));
-            TAE_HIP_H(hipMemcpy(h->d_wernn, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
-            if (h->prec == 1) {
-                std::vector<char> peh(rnn_h_packed_bytes(en), 0);
-                repack_rnn_h(weights, peh.data(), 1, en);
-                TAE_HIP_H(hipMalloc(&h->d_wernn_h, peh.size()));
-                TAE_HIP_H(hipMemcpy(h->d_wernn_h, peh.data(), peh.size(), hipMemcpyHostToDevice));
-            }
-        }
+        if (cfg->enc_type == 1) { rc = pack_rnn_encoder(); if (rc != TAE_OK) return rc; }
     }
     TAE_HIP_H(hipMemcpy(h->d_perm, ident.data(), L * sizeof(int32_t), hipMemcpyHostToDevice));
     TAE_HIP_H(hipMemcpy(h->d_inv, ident.data(), L * sizeof(int32_t), hipMemcpyHostToDevice));

@@ -258,7 +258,15 @@ def test(model, snr_test_start: float = -1.5, snr_test_end: float = 4.0, snr_poi
             if si + 2 < snr_points:
                 capture(si + 2)
         torch.cuda.synchronize(dev)
-        model.check_range()          # fp16-split kernels: fail loudly if an activation left the fp16 range (the flag is sticky)
+        # fp16-split kernels: fail loudly if an activation left the fp16 range.  The flag is sticky and reading it synchronises the
+        # device, so the pipelined sweep reads it ONCE, here: a failure cannot name the point, and the lines already printed for this
+        # sweep are then invalid - the error says so (the serial path checks after every point)
+        try:
+            model.check_range()
+        except Exception as e:
+            raise type(e)(f"{e} [pipelined hip_graph sweep: the sticky range flag was read after all {snr_points} SNR points "
+                          f"({snrs[0]:g} .. {snrs[-1]:g} dB); every BER / BLER line printed for this sweep is invalid - rerun with "
+                          "hip_graph=False to find the first point that overflows]") from e
     else:
         for si, snr in enumerate(snrs):
             per_batch = new_counts()
