@@ -369,6 +369,61 @@ def other_configs(dev, snr: float, sd_trained):
     return res
 
 
+def f16x1_line(cfg: TurboAEConfig, sd, B: int, dev, snr: float, runs: int = 5):
+    """OPTIONAL, SEPARATELY LABELLED reduced-precision line: the same workload with the decoder
+    on ONE fp16 product per slab (precision='f16x1': the hi halves of the f16x2 representation only, fp32 accumulation).  It is NOT
+    fp32-grade, never the headline and never what 'auto' selects, and no parity claim is attached: the line says what the north star's
+    fp32 tolerance costs - its rate, its hard-decision flips against the fp32-MFMA pass and its BER on the SAME blocks."""
+    from dataclasses import replace
+    L = cfg.block_len
+    models = {p: Channel_AE_HIP(replace(cfg, precision=p), sd, device=dev, max_batch=B) for p in ("f16x1", "f32", "auto")}
+    u, noise = models["auto"].generate_inputs(B, snr, seed=SEED)
+    xd, ber = {}, {}
+    for p, m in models.items():
+        x_tx, stats = m.encode_prenorm(u)
+        _, rx = m.normalize(x_tx, stats, noise, want_codes=False)
+        xd[p] = m.dec(rx).clone()
+        ber[p] = float(((xd[p] > 0.5) != (u > 0.5)).sum().item()) / (float(B) * L)
+    torch.cuda.synchronize()
+    m = models["f16x1"]
+    mode, overflow = m.range_status()
+    counts = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def fwd(ev=None):
+        if ev:
+            ev[0].record()
+        x_tx, stats = m.encode_prenorm(u)
+        _, rx = m.normalize(x_tx, stats, noise, want_codes=False)
+        if ev:
+            ev[1].record()
+        x_dec = m.dec(rx)
+        if ev:
+            ev[2].record()
+        m.count_errors(x_dec, u, counts)
+        if ev:
+            ev[3].record()
+    for _ in range(2):
+        fwd()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(runs)]
+    for e in evs:
+        fwd(e)
+    torch.cuda.synchronize()
+    fwd_ms = float(np.median([e[0].elapsed_time(e[3]) for e in evs]))
+    dec_ms = float(np.median([e[1].elapsed_time(e[2]) for e in evs]))
+    hard = {p: xd[p] > 0.5 for p in xd}
+    dec_tf = 2.0 * cfg.macs_per_bit()["dec"] * B * L / (dec_ms * 1e-3) / 1e12
+    return {"label": "OPTIONAL reduced-precision line, NOT fp32-grade, never the headline, no parity claim: decoder on one fp16 product per "
+                     "slab (precision='f16x1'); encoder, power constraint, channel and error count as in the headline",
+            "arithmetic": mode, "range_flags": int(overflow), "blocks": B, "block_len": L, "ms_per_forward": fwd_ms, "decoder_ms": dec_ms,
+            "bits_per_s": B * L / (fwd_ms * 1e-3), "decoder_frac_of_f16_peak": dec_tf / PEAK_F16_MFMA_TFLOPS,
+            "ber": ber["f16x1"], "ber_f32": ber["f32"], "ber_f16x2": ber["auto"],
+            "decision_flips_vs_f32": int((hard["f16x1"] != hard["f32"]).sum().item()),
+            "decision_flips_vs_f16x2": int((hard["f16x1"] != hard["auto"]).sum().item()),
+            "decision_flips_f16x2_vs_f32": int((hard["auto"] != hard["f32"]).sum().item()),
+            "max_abs_x_dec_vs_f32": float((xd["f16x1"] - xd["f32"]).abs().max().item()),
+            "max_abs_x_dec_f16x2_vs_f32": float((xd["auto"] - xd["f32"]).abs().max().item()), "bits_compared": B * L}
+
+
 def generic_configs(dev, snr: float):
     """Other cells / widths the reference's parser accepts: the LSTM decoder (`-dec_rnn lstm`; reference-trained fixture when
     tests/golden/ has it) on its unit-split f16x2 kernels (r05) and, for comparison, on the generic fp32 MFMA kernels
@@ -519,6 +574,10 @@ def flatten_scalars(out) -> None:
     gr = out.get("graph_replay")
     if gr:
         out["graph_replay_ms"], out["graph_replay_bits_per_s"] = gr["ms_per_step"], gr["bits_per_s"]
+    x1 = out.get("f16x1")
+    if x1 and "error" not in x1:
+        out["f16x1_bits_per_s"], out["f16x1_decoder_ms"], out["f16x1_ber"] = x1["bits_per_s"], x1["decoder_ms"], x1["ber"]
+        out["f16x1_flips_vs_f32"], out["f16x1_ber_f32"], out["f16x1_max_abs_x_dec_vs_f32"] = x1["decision_flips_vs_f32"], x1["ber_f32"], x1["max_abs_x_dec_vs_f32"]
     sw = out.get("sweep_cfg1")
     if sw and "error" not in sw:
         out["sweep_cfg1_s"], out["sweep_cfg1_bits_per_s"] = sw["seconds"], sw["bits_per_s"]
@@ -552,6 +611,7 @@ TAIL_KEYS = (
     "lstm_bits_per_s", "lstm_frac", "lstm_ber", "lstm_parity_flips", "lstm_parity_max_abs_x_dec", "lstm_generic_f32_bits_per_s",
     "cfg0_b500_frac", "cfg0_b500_enc_frac", "cfg0_b500_bits_per_s", "cfg2_enc5_frac", "cfg2_enc5_bits_per_s", "cfg3_l1000_frac",
     "cfg3_l1000_enc_frac", "cfg3_l1000_bits_per_s", "cfg1_head2_decoder_over_plain", "wide256_frac",
+    "f16x1_bits_per_s", "f16x1_decoder_ms", "f16x1_ber", "f16x1_ber_f32", "f16x1_flips_vs_f32", "f16x1_max_abs_x_dec_vs_f32",
     "graph_replay_ms", "sweep_cfg1_s", "sweep_cfg1_bits_per_s", "sweep_cfg1_ber_2dB",
     "roofline_frac", "roofline_kernel_ms", "roofline_traffic_gb", "roofline_frac_of_sustained", "sustained_probe_tflops",
     "parity_decision_flips", "parity_max_abs_x_dec", "parity_max_abs_codes", "parity_ber_abs_diff", "parity_decision_flips_f16x2_vs_f32",
@@ -777,6 +837,7 @@ def main():
     ap.add_argument("--random-weights", action="store_true", help="portable random-init weights instead of the trained fixture")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (cpu_baseline and the CPU side of parity)")
     ap.add_argument("--no-f32-pass", action="store_true", help="skip the second timed pass in precision='f32'")
+    ap.add_argument("--no-f16x1", action="store_true", help="skip the optional, separately labelled one-product decoder line (precision='f16x1', not fp32-grade)")
     ap.add_argument("--no-parity", action="store_true", help="skip the 500-block BER-match sample (profiling runs: only full-size launches)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the timings of BASELINE configs[0], [2], [3], [4] (roofline.other_configs)")
     ap.add_argument("--no-probe", action="store_true", help="skip the sustained-MFMA probe (roofline.sustained_probe_tflops)")
@@ -1098,6 +1159,12 @@ def main():
                 out["roofline"]["generic_configs"] = generic_configs(dev, args.snr)
             except Exception as e:
                 out["roofline"]["generic_configs"] = [{"error": f"{type(e).__name__}: {e}"}]
+        if world == 1 and not args.no_f16x1 and args.precision == "auto" and L <= 320 and cfg.decoder == "TurboAE_rate3_cnn" and not cfg.dense \
+                and 65 <= cfg.dec_num_unit <= 100 and cfg.dec_kernel_size <= 5:
+            try:
+                out["f16x1"] = f16x1_line(cfg, sd, B, dev, args.snr)
+            except Exception as e:       # a side measurement: never takes the headline line down
+                out["f16x1"] = {"error": f"{type(e).__name__}: {e}"}
         if main_res.get("graph") is not None:
             gr = dict(main_res["graph"])
             gr["eager_ms_per_step"] = elapsed / steps * 1e3

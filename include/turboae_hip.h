@@ -72,7 +72,11 @@ typedef struct tae_config {
     int32_t precision;        /* arithmetic of the conv contractions (no reference counterpart; the reference is fp32 on CPU/CUDA):
                                  TAE_PREC_AUTO = 0: fp32 operands carried as two fp16 halves, three v_mfma_f32_16x16x32_f16 products,
                                  fp32 accumulation - fp32-grade results - where the whole-block kernels apply,
-                                 TAE_PREC_F32 otherwise; TAE_PREC_F32 = 1: v_mfma_f32_16x16x4_f32 on the fp32 operands everywhere */
+                                 TAE_PREC_F32 otherwise; TAE_PREC_F32 = 1: v_mfma_f32_16x16x4_f32 on the fp32 operands everywhere;
+                                 TAE_PREC_F16X1 = 2 (r06): NOT fp32-grade and never chosen by the library - the TAE_PREC_AUTO handle with its
+                                 whole-block CNN decoder (dec_type = 0, 65 <= dec_num_unit <= 100, block_len <= 320) on the hi halves only
+                                 (one fp16 product per 32 k instead of three): soft outputs differ from the reference's at the 1e-3
+                                 level; exists to price the fp32-tolerance requirement (bench.py `f16x1_*`), carries no parity claim */
     int32_t dec_act;          /* -dec_act (get_args.py:101, decoders.py:59-73): TAE_ACT_* on the GRU decoder's Linear outputs (DEC_LargeCNN
                                  has no dec_act; ignored for dec_type = 0).  The reference default is TAE_ACT_LINEAR (= 1, NOT 0) */
     int32_t enc_rnn;          /* -enc_rnn (get_args.py:79, encoders.py:242-247): TAE_RNN_GRU / LSTM / RNN cell of ENC_interRNN (enc_type = 1) */
@@ -111,6 +115,7 @@ typedef struct tae_config {
 
 #define TAE_PREC_AUTO 0
 #define TAE_PREC_F32 1
+#define TAE_PREC_F16X1 2
 
 /* Encoder-output / channel variants of the same kernels (reference flags in parentheses).  Defaults
  * (all zero except the limits) are the reference defaults: batch power normalisation, AWGN add. */

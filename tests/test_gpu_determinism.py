@@ -1,6 +1,6 @@
 """Run-to-run determinism: the same inputs through each kernel family several times, outputs bit for bit.  (r03: the GRU recurrence once
 mixed two MFMA shapes in one dependent chain and read stale accumulators whenever two waves shared a SIMD - results changed from run to
-run at 1e-3 while every single-wave test stayed green; DESIGN.md 3.5, tools/probes/mfma_mixed_shape_hazard.hip.  tools/determinism_soak.py
+run at 1e-3 while every single-wave test stayed green; DESIGN.md 3.5, tools/lab/probes/mfma_mixed_shape_hazard.hip.  tools/determinism_soak.py
 is the long version.)"""
 import pytest
 import torch

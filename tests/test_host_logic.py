@@ -107,6 +107,12 @@ def test_config_validation():
         cfg = TurboAEConfig(**over)
         cfg.validate()
         assert cfg.generic, over
+    # r06: the optional one-product decoder precision exists for the 100-wide whole-block CNN decoder only, and is never generic
+    TurboAEConfig(precision="f16x1").validate()
+    assert not TurboAEConfig(precision="f16x1").generic
+    for over in (dict(decoder="TurboAE_rate3_rnn"), dict(dec_num_unit=32), dict(block_len=321), dict(dec_num_unit=128, enc_num_unit=128)):
+        with pytest.raises(ValueError):
+            TurboAEConfig(precision="f16x1", **over).validate()
     # r06: the 2-layer GRU encoder in front of an LSTM / vanilla-RNN decoder runs on the tuned kernels (GRU kernels + turboae_rnn_u.hip)
     assert not TurboAEConfig(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", dec_rnn="lstm").generic
     # r05: LSTM / vanilla-RNN decoders behind the CNN encoder have unit-split f16x2 kernels (turboae_rnn_u.hip)
@@ -173,14 +179,15 @@ def test_isa_audit_is_clean_on_the_built_library():
     names = list(res["kernels"])
     for prefix in A.BENCH_KERNELS:                       # every bench kernel was actually found (a renamed kernel must not drop out of rule ii)
         assert any(n.startswith(prefix) for n in names), prefix
-    for inst in ("tae::dec_kernel_h<100, 5, false, false>", "tae::dec_kernel_h<100, 5, false, true>", "tae::(anonymous namespace)::gru_l1f_kernel"):
-        k = res["kernels"][[n for n in names if n.startswith(inst)][0]]       # plain decoder, its both-branch-head twin, the fused GRU layer 1
+    for inst in ("tae::dec_kernel_h<100, 5, false, false, 3>", "tae::dec_kernel_h<100, 5, false, true, 3>", "tae::dec_kernel_h<100, 5, false, false, 1>",
+                 "tae::(anonymous namespace)::gru_l1f_kernel"):
+        k = res["kernels"][[n for n in names if n.startswith(inst)][0]]       # plain decoder, its both-branch-head twin, the one-product (f16x1) decoder, the fused GRU layer 1
         assert list(k["mfma"]) == ["v_mfma_f32_16x16x32_f16"] and k["scratch"] == 0 and k["vgpr_spill"] == 0 and k["vgpr"] <= 256, inst
     assert len(names) >= 88
 
 
 def test_isa_audit_flags_a_mixed_shape_kernel_and_inline_asm_loads(tmp_path):
-    """Red cases: the isolated gfx950 hazard (tools/probes/mfma_mixed_shape_hazard.hip mixes 16x16x32 and 16x16x16 f16 MFMAs on
+    """Red cases: the isolated gfx950 hazard (tools/lab/probes/mfma_mixed_shape_hazard.hip mixes 16x16x32 and 16x16x16 f16 MFMAs on
     purpose) must be reported by rule (i); a source with a hand-issued global_load by rule (iii)."""
     import shutil
     import subprocess
@@ -189,7 +196,7 @@ def test_isa_audit_flags_a_mixed_shape_kernel_and_inline_asm_loads(tmp_path):
     if not A.tools_available() or not os.path.isfile(hipcc):
         pytest.skip("needs hipcc and the ROCm llvm tools")
     obj = str(tmp_path / "mixed.o")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-c", os.path.join(ROOT, "tools", "probes", "mfma_mixed_shape_hazard.hip"), "-o", obj])
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-c", os.path.join(ROOT, "tools", "lab", "probes", "mfma_mixed_shape_hazard.hip"), "-o", obj])
     res = A.audit_binary(obj)
     assert any(v.startswith("(i) mixed MFMA shapes") for v in res["violations"]), res
     src = tmp_path / "csrc"

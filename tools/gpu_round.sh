@@ -32,10 +32,10 @@ python $R/tools/trace_summary.py $OUT/prof_$TAG $OUT/prof_${TAG}_by_grid.txt
 f=$(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -14 "$f"
 if [ "${PROF_CFG:-0}" = "1" ]; then     # kernel traces of the long-block (cfg 4 shape) and GRU (cfg 5) configurations
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_cfg4 -o cfg4 -- python $R/tools/quick_bench_cfg.py 1000 25000 2 > $OUT/prof_${TAG}_cfg4.log 2>&1
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_cfg5 -o cfg5 -- python $R/tools/quick_bench_cfg.py 100 16384 2 TurboAE_rate3_rnn > $OUT/prof_${TAG}_cfg5.log 2>&1
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_cfg2 -o cfg2 -- python $R/tools/quick_bench_cfg.py 100 100000 5 > $OUT/prof_${TAG}_cfg2.log 2>&1
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_cfg0 -o cfg0 -- python $R/tools/quick_bench_cfg.py 100 500 2 > $OUT/prof_${TAG}_cfg0.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_cfg4 -o cfg4 -- python $R/tools/lab/quick_bench_cfg.py 1000 25000 2 > $OUT/prof_${TAG}_cfg4.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_cfg5 -o cfg5 -- python $R/tools/lab/quick_bench_cfg.py 100 16384 2 TurboAE_rate3_rnn > $OUT/prof_${TAG}_cfg5.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_cfg2 -o cfg2 -- python $R/tools/lab/quick_bench_cfg.py 100 100000 5 > $OUT/prof_${TAG}_cfg2.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_cfg0 -o cfg0 -- python $R/tools/lab/quick_bench_cfg.py 100 500 2 > $OUT/prof_${TAG}_cfg0.log 2>&1
   for c in cfg4 cfg5 cfg2 cfg0; do f=$(find $OUT/prof_${TAG}_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { echo "== $c"; head -6 "$f"; }; python $R/tools/trace_summary.py $OUT/prof_${TAG}_$c $OUT/prof_${TAG}_${c}_by_grid.txt > /dev/null; done
 fi
 if [ "${PMC:-0}" = "1" ]; then cd $R; bash tools/gpu_pmc.sh $TAG; fi

@@ -7,7 +7,7 @@ turboae_amd/lib/libturboae_hip.so (or any hipcc object / library given on the co
 Rules, each from a defect this library has actually met on gfx950 with the ROCm 7.2 hipcc:
   (i)   ONE MFMA shape per kernel.  A v_mfma_f32_16x16x16_f16 that takes the result of a v_mfma_f32_16x16x32_f16 issued just before it
         as srcC reads a stale accumulator - the compiler inserts no wait states for that pair (DESIGN.md 3.5,
-        tools/probes/mfma_mixed_shape_hazard.hip, profiles/r03_mfma_mixed_shape_hazard.txt).  The set of v_mfma_* mnemonics of every
+        tools/lab/probes/mfma_mixed_shape_hazard.hip, profiles/r03_mfma_mixed_shape_hazard.txt).  The set of v_mfma_* mnemonics of every
         kernel must have at most one element.
   (ii)  No scratch on the kernels the bench times (BENCH_KERNELS): private_segment_fixed_size = 0 and no spilled vector registers, read
         from the code object's own metadata (r02: 272 bytes of scratch per lane cost the decoder 1.2 %; r04: three spilled registers

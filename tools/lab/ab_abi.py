@@ -1,8 +1,8 @@
 """Decoder / encoder kernel time of ANY build of the library on the bench workload (trained enc2/dec5, 50 000 blocks), talking to it
 through ctypes with the tae_config of ITS ABI version - so that an older round's library (e.g. r03 = ABI 9, built from its commit into
-tools/probes/libs/) can be timed on the same box as the current one:   python tools/ab_abi.py <lib.so> [B]"""
+tools/lab/probes/libs/) can be timed on the same box as the current one:   python tools/lab/ab_abi.py <lib.so> [B]"""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from turboae_amd import TurboAEConfig, weights as W, philox

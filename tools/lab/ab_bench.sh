@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of library builds on ONE box with the contract bench's own workload (trained weights, 50 000 blocks): decoder kernel time,
-# step time and the sustained-MFMA probe of each, alternating.  usage: bash tools/ab_bench.sh <lib1.so|in-tree> <lib2.so> ...
+# step time and the sustained-MFMA probe of each, alternating.  usage: bash tools/lab/ab_bench.sh <lib1.so|in-tree> <lib2.so> ...
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 for rep in 1 2 3; do
 for lib in "$@"; do

@@ -1,8 +1,8 @@
 """Index-width check at BASELINE configs[3] scale on ONE GPU: block_len 1000, 200 000 blocks (2e8 positions, 6e8 floats per
 code tensor, 1.6e9-float exchange buffers) and block_len 100, 2 000 000 blocks.  Decoder sub-batches must reproduce the
-big call bit for bit (any 32-bit index overflow would break the tail):  python tools/big_batch_check.py"""
+big call bit for bit (any 32-bit index overflow would break the tail):  python tools/lab/big_batch_check.py"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from turboae_amd import TurboAEConfig, Channel_AE_HIP, weights as W
 dev = torch.device("cuda", 0)

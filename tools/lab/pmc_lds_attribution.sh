@@ -1,6 +1,6 @@
 # LDS conflict attribution (profiles/r02_pmc_f16x2/lds_attribution.txt).  Build the timing variant first (here, no GPU needed):
 #   make -C turboae_amd/csrc OUT=../lib/variants/libtae_x16.so OBJD=../lib/obj_x16 EXTRA="-DTAE_EXPERIMENT -DTAE_X=16"
-# then on the GPU box:  gpurun -- 'bash tools/pmc_lds_attribution.sh'
+# then on the GPU box:  gpurun -- 'bash tools/lab/pmc_lds_attribution.sh'
 cd $GRAFT_REPO_ROOT
 bash tools/gpu_pmc.sh r02e 2>&1 | grep -E "dec_kernel_h" 
 echo "=== x16 (no LDS operand reads in the K loop; results wrong, counters only)"

@@ -1,7 +1,7 @@
 """One-off fuzz of the recurrent decoders on the tuned kernels (GRU: gru_rec_h + gru_l1f; LSTM / RNN: rnn_rec_u + rnn_proj_u) against the
-oracle: random cell, batch, block length, width, num_iter_ft, iterations, extrinsic, dec_act.  python tools/probes/fuzz_rnn_u.py [n] [seed]"""
+oracle: random cell, batch, block length, width, num_iter_ft, iterations, extrinsic, dec_act.  python tools/lab/probes/fuzz_rnn_u.py [n] [seed]"""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 import numpy as np, torch
 torch.set_num_threads(16)
 from turboae_amd import TurboAEConfig, philox, weights as W, Channel_AE_HIP

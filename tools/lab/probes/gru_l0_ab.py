@@ -1,7 +1,7 @@
 """Layer 0 of the f16x2 GRU decoder stacks: gru_rec_h_kernel<true> (one wave per 16 blocks) against gru_rec0u_kernel (seven waves per 16
-blocks) - bit-identity of x_dec and forward time per batch size.  python tools/probes/gru_l0_ab.py [B ...]"""
+blocks) - bit-identity of x_dec and forward time per batch size.  python tools/lab/probes/gru_l0_ab.py [B ...]"""
 import os, sys, subprocess, hashlib
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import numpy as np, torch
     from turboae_amd import TurboAEConfig, Channel_AE_HIP, weights as W

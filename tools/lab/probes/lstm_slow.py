@@ -1,10 +1,10 @@
 import sys, time, json, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 import numpy as np, torch
 from dataclasses import replace
 from turboae_amd import TurboAEConfig, philox, weights as W, Channel_AE_HIP
 from oracle import turboae_oracle as O
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests", "golden")
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "..", "tests", "golden")
 man = json.load(open(GOLD + '/MANIFEST.json'))
 dev = torch.device("cuda", 0)
 if len(sys.argv) > 1:

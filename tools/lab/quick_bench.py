@@ -1,6 +1,6 @@
-"""Quick decoder/forward timing on the GPU box (not the contract bench): python tools/quick_bench.py [B]"""
+"""Quick decoder/forward timing on the GPU box (not the contract bench): python tools/lab/quick_bench.py [B]"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from turboae_amd import TurboAEConfig, Channel_AE_HIP, weights as W
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 12288

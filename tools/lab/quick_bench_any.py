@@ -1,7 +1,7 @@
-"""Timing of any configuration on the GPU box: python tools/quick_bench_any.py B key=value ...   (TurboAEConfig fields; ints parsed)
-e.g. python tools/quick_bench_any.py 16384 decoder=TurboAE_rate3_rnn dec_rnn=lstm ; python tools/quick_bench_any.py 2048 dec_num_unit=136 enc_num_unit=136"""
+"""Timing of any configuration on the GPU box: python tools/lab/quick_bench_any.py B key=value ...   (TurboAEConfig fields; ints parsed)
+e.g. python tools/lab/quick_bench_any.py 16384 decoder=TurboAE_rate3_rnn dec_rnn=lstm ; python tools/lab/quick_bench_any.py 2048 dec_num_unit=136 enc_num_unit=136"""
 import sys, os, hashlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from turboae_amd import TurboAEConfig, Channel_AE_HIP, weights as W
 B = int(sys.argv[1])

@@ -1,6 +1,6 @@
-"""Timing of other BASELINE configs on the GPU box: python tools/quick_bench_cfg.py <block_len> <B> [enc_layers]"""
+"""Timing of other BASELINE configs on the GPU box: python tools/lab/quick_bench_cfg.py <block_len> <B> [enc_layers]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from turboae_amd import TurboAEConfig, Channel_AE_HIP, weights as W
 L = int(sys.argv[1]); B = int(sys.argv[2]); encl = int(sys.argv[3]) if len(sys.argv) > 3 else 2

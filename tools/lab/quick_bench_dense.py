@@ -1,6 +1,6 @@
-"""Timing of the DenseSameShapeConv1d variant (encoder = decoder = TurboAE_rate3_cnn_dense): python tools/quick_bench_dense.py [B]"""
+"""Timing of the DenseSameShapeConv1d variant (encoder = decoder = TurboAE_rate3_cnn_dense): python tools/lab/quick_bench_dense.py [B]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from turboae_amd import TurboAEConfig, Channel_AE_HIP, weights as W
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

@@ -1,7 +1,7 @@
-"""Timing of the generic RNN kernels on the GPU box: python tools/quick_bench_rnn.py <cell> <B> [block_len]
+"""Timing of the generic RNN kernels on the GPU box: python tools/lab/quick_bench_rnn.py <cell> <B> [block_len]
 (decoder = DEC_LargeRNN with -dec_rnn <cell>; 'lstm' and 'rnn' run on turboae_generic.hip, 'gru' on the MFMA kernels)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from turboae_amd import TurboAEConfig, Channel_AE_HIP, weights as W
 cell = sys.argv[1]; B = int(sys.argv[2]); L = int(sys.argv[3]) if len(sys.argv) > 3 else 100

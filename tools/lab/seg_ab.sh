@@ -3,5 +3,5 @@ cd $GRAFT_REPO_ROOT
 export TAE_DEBUG_KNOBS=1      # the library ignores its debug knobs without it
 for T in 125 143 167 200 250 ""; do
   echo "== TAE_SEG_T=$T"
-  TAE_SEG_T=$T python tools/quick_bench_cfg.py 1000 25000 2 2>&1 | grep -v amdgpu.ids
+  TAE_SEG_T=$T python tools/lab/quick_bench_cfg.py 1000 25000 2 2>&1 | grep -v amdgpu.ids
 done

@@ -1,9 +1,9 @@
 """Times the 12-point sweep of BASELINE configs[1] (bench.py::sweep_cfg1's workload) eagerly and with one hipGraph per SNR point:
-    python tools/sweep_time.py [points = 12] [blocks = 50000]"""
+    python tools/lab/sweep_time.py [points = 12] [blocks = 50000]"""
 import os, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import bench
 from turboae_amd import evaluate, weights as W
 from turboae_amd.channel_ae import Channel_AE_HIP

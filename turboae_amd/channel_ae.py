@@ -64,7 +64,7 @@ class _Engine:
                            cfg.enc_kernel_size, cfg.dec_num_layer, cfg.dec_num_unit, cfg.dec_kernel_size,
                            cfg.num_iteration, cfg.num_iter_ft, cfg.extrinsic, _ACT[cfg.enc_act], max_batch,
                            1 if cfg.decoder == "TurboAE_rate3_rnn" else 0, 1 if cfg.encoder == "TurboAE_rate3_rnn" else 0,
-                           1 if cfg.dense else 0, 1 if cfg.precision == "f32" else 0, _ACT[cfg.dec_act],
+                           1 if cfg.dense else 0, {"auto": 0, "f32": 1, "f16x1": 2}[cfg.precision], _ACT[cfg.dec_act],
                            _RNN[cfg.enc_rnn], _RNN[cfg.dec_rnn], 0 if cfg.range_calibration else 1, 1 if cfg.range_fallback else 0)
         n = self.lib.tae_num_weights(C.byref(c))
         if n != blob.size:
@@ -171,7 +171,7 @@ class _Engine:
         prec, ovf = C.c_int32(), C.c_int32()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.tae_range_status(self.h, C.byref(prec), C.byref(ovf)))
-        return ("f16x2" if prec.value == 1 else "f32"), int(ovf.value)
+        return {0: "f32", 1: "f16x2", 2: "f16x1"}[prec.value], int(ovf.value)
 
     def range_status(self) -> Tuple[str, bool]:
         """('f16x2' | 'f32', out_of_window): True when a launch since the last call left the window of the fp16-split

@@ -98,10 +98,14 @@ class TurboAEConfig:
         ks = (self.enc_kernel_size, self.dec_kernel_size)
         if any(k not in (1, 3, 5, 7, 9) for k in ks):
             raise ValueError("kernel sizes must be 1, 3, 5, 7 or 9 (odd: SameShapeConv1d pads with kernel_size // 2)")
-        if max(ks) > 5 and (self.precision != "auto" or self.dense):
+        if max(ks) > 5 and (self.precision not in ("auto", "f16x1") or self.dense):
             raise ValueError("kernel sizes 7 and 9 are built in the fp16-split kernels only (precision='auto', no dense stacks)")
-        if self.precision not in ("auto", "f32"):
-            raise ValueError("precision must be 'auto' or 'f32'")
+        if self.precision not in ("auto", "f32", "f16x1"):
+            raise ValueError("precision must be 'auto', 'f32' or 'f16x1'")
+        if self.precision == "f16x1" and (self.decoder != "TurboAE_rate3_cnn" or self.dense or self.dec_kernel_size > 5
+                                          or not 65 <= self.dec_num_unit <= 100 or self.block_len > 320):
+            raise ValueError("precision='f16x1' (one fp16 product per slab: NOT fp32-grade, no parity claim) exists for the 100-wide whole-block "
+                             "CNN decoder only: decoder='TurboAE_rate3_cnn', 65 <= dec_num_unit <= 100, dec_kernel_size <= 5, block_len <= 320")
         acts = ("tanh", "selu", "relu", "elu", "sigmoid", "linear")
         if self.enc_act not in acts or self.dec_act not in acts:
             raise ValueError("enc_act / dec_act must be one of tanh, selu, relu, elu, sigmoid, linear (get_args.py:100-101)")

@@ -221,12 +221,13 @@ int check_cfg(const tae_config* c) {
         if (c->block_len < 1) return fail(TAE_EINVAL, "block_len must be >= 1");
         if (c->enc_act < 0 || c->enc_act > 5 || c->dec_act < 0 || c->dec_act > 5) return fail(TAE_EINVAL, "enc_act / dec_act must be a TAE_ACT_* code");
         if ((c->dec_type | 1) != 1 || (c->enc_type | 1) != 1 || (c->dense | 1) != 1) return fail(TAE_EINVAL, "dec_type / enc_type / dense must be 0 or 1");
-        if (c->precision != TAE_PREC_AUTO && c->precision != TAE_PREC_F32) return fail(TAE_EINVAL, "precision must be TAE_PREC_AUTO (0) or TAE_PREC_F32 (1)");
+        if (c->precision != TAE_PREC_AUTO && c->precision != TAE_PREC_F32)
+            return fail(TAE_EINVAL, "precision must be TAE_PREC_AUTO (0) or TAE_PREC_F32 (1) (TAE_PREC_F16X1 exists for the 100-wide whole-block CNN decoder only)");
         return TAE_OK;
     }
     for (int ks : {c->enc_kernel_size, c->dec_kernel_size}) {
         if (ks != 1 && ks != 3 && ks != 5 && ks != 7 && ks != 9) return fail(TAE_EINVAL, "kernel_size must be 1, 3, 5, 7 or 9");
-        if (ks > 5 && (c->precision != TAE_PREC_AUTO || c->dense))
+        if (ks > 5 && ((c->precision != TAE_PREC_AUTO && c->precision != TAE_PREC_F16X1) || c->dense))
             return fail(TAE_EINVAL, "kernel sizes 7 and 9 are built in the fp16-split kernels only (precision = TAE_PREC_AUTO, no dense stacks)");
     }
     if (c->enc_num_unit < 1 || c->enc_num_unit > 124 || c->dec_num_unit < 1 || c->dec_num_unit > 124)
@@ -239,7 +240,11 @@ int check_cfg(const tae_config* c) {
     if (c->enc_act < 0 || c->enc_act > 5) return fail(TAE_EINVAL, "enc_act must be 0 (elu), 1 (linear), 2 (tanh), 3 (relu), 4 (selu) or 5 (sigmoid)");
     if (c->dec_act < 0 || c->dec_act > 5) return fail(TAE_EINVAL, "dec_act must be 0 (elu), 1 (linear), 2 (tanh), 3 (relu), 4 (selu) or 5 (sigmoid)");
     if (c->dec_type != 0 && c->dec_type != 1) return fail(TAE_EINVAL, "dec_type must be 0 (cnn) or 1 (rnn/gru)");
-    if (c->precision != TAE_PREC_AUTO && c->precision != TAE_PREC_F32) return fail(TAE_EINVAL, "precision must be TAE_PREC_AUTO (0) or TAE_PREC_F32 (1)");
+    if (c->precision != TAE_PREC_AUTO && c->precision != TAE_PREC_F32 && c->precision != TAE_PREC_F16X1)
+        return fail(TAE_EINVAL, "precision must be TAE_PREC_AUTO (0), TAE_PREC_F32 (1) or TAE_PREC_F16X1 (2)");
+    if (c->precision == TAE_PREC_F16X1 && (c->dec_type != 0 || c->dense || c->dec_kernel_size > 5 || c->dec_num_unit < 65 || c->dec_num_unit > 100))
+        return fail(TAE_EINVAL, "TAE_PREC_F16X1 (one fp16 product, NOT fp32-grade) is instantiated for the 100-wide whole-block CNN decoder only: "
+                                "dec_type = 0, no dense stacks, dec_kernel_size <= 5, 65 <= dec_num_unit <= 100");
     if (c->enc_type != 0 && c->enc_type != 1) return fail(TAE_EINVAL, "enc_type must be 0 (cnn) or 1 (rnn/gru)");
     if (c->dense != 0 && c->dense != 1) return fail(TAE_EINVAL, "dense must be 0 or 1");
     if (c->dense && (c->enc_type != 0 || c->dec_type != 0 || c->precision != TAE_PREC_AUTO))
@@ -1299,6 +1304,12 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
         return fail(TAE_EINVAL, "kernel sizes 7 / 9 need the fp16-split kernels (precision auto; TAE_PRECISION=f32 given, or the panels do not fit the LDS)");
     } else if (h2_ok) {
         h->prec = 1;
+        if (cfg->precision == TAE_PREC_F16X1) {
+            // the separately labelled reduced-precision decoder: the f16x2 handle as it is, decoder launches on the
+            // one-product instantiation of the 100-wide whole-block kernel
+            if (h->Ud != 100 || h->nbd < 1) { delete h; return fail(TAE_EINVAL, "TAE_PREC_F16X1 needs the 100-wide whole-block decoder kernel (block_len <= 320)"); }
+            h->x1 = true;
+        }
         const LayoutH lh(h->U, taps_e), lhd(h->Ud, taps_d);
         h->enc_stride_h = (uint32_t)lh.stack_bytes(cfg->enc_num_layer);
         h->dec_stride_h = (uint32_t)lhd.stack_bytes(cfg->dec_num_layer);

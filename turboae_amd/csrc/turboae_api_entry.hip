@@ -344,7 +344,7 @@ int tae_debug_split_f16(const float* x, size_t n, float scale, uint16_t* hi, uin
 
 int tae_range_status(tae_handle* h, int32_t* precision, int32_t* overflow) {
     { const int rc_h = check_handle(h); if (rc_h != TAE_OK) return rc_h; }
-    if (precision) *precision = h->prec;
+    if (precision) *precision = h->x1 ? TAE_PREC_F16X1 : h->prec;
     if (overflow) {
         uint32_t f = 0;
         // the launches whose flag is read may sit on any stream (torch side streams are non-blocking: the null-stream copy

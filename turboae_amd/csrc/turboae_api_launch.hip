@@ -205,6 +205,7 @@ tae::FusedParams base_params(const tae_handle* h, int32_t B, bool decoder) {
         for (size_t i = 0; i < K.size(); ++i) both = both || ((int)(i % nl) == nl - 1 && K[i] == 2);
         P.track = h->calibrating ? 2 : (decoder ? 1 : (h->calibrated ? 0 : 2));
         P.head2 = both ? 1 : 0;          // production launch with both-branch heads: its own (spill-free) instantiation, not the full one
+        P.prod = (decoder && h->x1) ? 1 : 3;
     }
     return P;
 }

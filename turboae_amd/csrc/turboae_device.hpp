@@ -507,8 +507,15 @@ __device__ __forceinline__ void load_xh(OpsHB& o, lds_cptr ph, lds_cptr pl) {
     }
 }
 
-template <int NC>
+// PROD = 3: the fp32-grade scheme (hi*lo + lo*hi + hi*hi).  PROD = 1: the hi halves only - a plain fp16 contraction with fp32
+// accumulation, NOT fp32-grade; instantiated for the separately labelled `precision = f16x1` decoder line only.
+template <int NC, int PROD = 3>
 __device__ __forceinline__ void mma_tile_h(f32x4 (&acc)[NC], const OpsHA<NC>& a, const OpsHB& b) {
+    if constexpr (PROD == 1) {
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma16x16x32h(a.hi[ct], b.hi, acc[ct]);
+        return;
+    }
 #if TAE_MMA_ORDER == 2
     // experiment: as order 1, odd tiles reversed, so EVERY consecutive pair of MFMAs shares one operand register set
 #pragma unroll
@@ -548,7 +555,7 @@ __device__ __forceinline__ void mma_tile_h(f32x4 (&acc)[NC], const OpsHA<NC>& a,
 // soff  : wave-uniform byte offset of this layer's A fragments
 // bh/bl : per position tile, LDS byte address of (row-2)*stride + 16*kq in the hi / lo plane
 // NSLAB = 0: the slab count is the (wave-uniform) run-time argument `nslab_rt` (conv stacks: it follows the kernel size).
-template <int CTT, int C0, int NC, int PT, int NSLAB, bool B128 = false>
+template <int CTT, int C0, int NC, int PT, int NSLAB, bool B128 = false, int PROD = 3>
 __device__ __forceinline__ void conv_accumulate_h(f32x4 (&acc)[PT][NC], OpsHA<NC>& a0, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff,
                                                   uint32_t soff, const char* lds, const uint32_t (&bh)[PT], const uint32_t (&bl)[PT],
                                                   int nslab_rt = 0) {
@@ -573,16 +580,16 @@ __device__ __forceinline__ void conv_accumulate_h(f32x4 (&acc)[PT][NC], OpsHA<NC
     _Pragma("unroll") for (int p = 0; p < PT; ++p) {                                                       \
         if (p + 1 < PT) load_xh<(OFF), B128>(b[((RB) + p + 1) % 2], ch[p + 1 < PT ? p + 1 : 0], cl[p + 1 < PT ? p + 1 : 0]);   \
         else load_xh<(OFF) + 64, B128>(b[((RB) + p + 1) % 2], ch[0], cl[0]);                                     \
-        mma_tile_h<NC>(acc[p], ACUR, b[((RB) + p) % 2]);                                                   \
+        mma_tile_h<NC, PROD>(acc[p], ACUR, b[((RB) + p) % 2]);                                                   \
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                 \
         if (p < NVS) {                                                                                     \
             _Pragma("unroll") for (int v = 0; v < NVT; ++v) {                                              \
-                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NC / NVT, 0);                              \
+                __builtin_amdgcn_sched_group_barrier(0x008, PROD * NC / NVT, 0);                              \
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                         \
             }                                                                                              \
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NC - NVT * (3 * NC / NVT), 0);                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NC - NVT * (PROD * NC / NVT), 0);                 \
         } else {                                                                                           \
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NC, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, PROD * NC, 0);                                        \
         }                                                                                                  \
     }
     int s = 0;

@@ -413,7 +413,7 @@ __device__ __forceinline__ void stamp_h(char* smem, int lane, int layer, int i) 
 // (the first layer's packed 2^-(S + A_x) undoes it).
 // `l0_slabs` > 0: the first layer walks that many K slabs instead of the tap_geo count (encoder stacks: C_in = 1 folds all taps
 // into ONE slab, see fold_enc_input).
-template <int U, int PT, int C0, int NC, int TRACK = 1, bool HEAD2 = (TRACK == 2), class Epi>
+template <int U, int PT, int C0, int NC, int TRACK = 1, bool HEAD2 = (TRACK == 2), int PROD = 3, class Epi>
 __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint32_t soff, uint32_t snext, int n_layer, char* smem,
                                             const PanelsH& pn, const XPlane& xin, const TileH<PT>& tc, int g, int lane,
                                             WeightStreamH<U, C0, NC>& ws, const RangeH& rg, Epi epi, int l0_slabs = 0) {
@@ -454,7 +454,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
             bh[p] = ph + o;
             bl[p] = pl + o;
         }
-        conv_accumulate_h<CTT, C0, NC, PT, 0>(acc, ws.a, ws.rsrc, ws.voff, lo, smem, bh, bl,
+        conv_accumulate_h<CTT, C0, NC, PT, 0, false, PROD>(acc, ws.a, ws.rsrc, ws.voff, lo, smem, bh, bl,
                                               first ? (l0_slabs > 0 ? l0_slabs : tg.nsl_l0) : tg.nsl_mid);
         stamp_h(smem, lane, l, 1);
         lo += fragb + G::TAILB;
@@ -757,7 +757,7 @@ __device__ __forceinline__ void range_check_inputs(uint32_t* slot, float low, ui
 
 // =============================================================================================
 // Decoder: DEC_LargeCNN.forward (decoders.py:206-269)
-template <int U, int PT, int C0, int NC, bool TAPS, bool HEAD2>
+template <int U, int PT, int C0, int NC, bool TAPS, bool HEAD2, int PROD = 3>
 __device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, const PanelsH& pn, const TileH<PT>& tc, int g, int lane, int blk0) {
     const int L = P.L;
     const int n_stack = 2 * P.n_iter;
@@ -777,7 +777,7 @@ __device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, con
         const int* ptab = (s & 1) ? pn.PERM : pn.INV;
         const RangeH rg{range_rows(pn.RNG) + s * P.n_layer * 8};
         if (s + 1 < n_stack) {
-            run_stack_h<U, PT, C0, NC, TAPS ? 2 : 1, HEAD2>(wpack, s * sstride, (s + 1) * sstride, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
+            run_stack_h<U, PT, C0, NC, TAPS ? 2 : 1, HEAD2, PROD>(wpack, s * sstride, (s + 1) * sstride, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
                                        [&](int p, int f, float v) {
                 if (f < F) {
                     if (extrinsic) v -= Xin.read(tc.row(p), 2 + f) * xinv;     // decoders.py:235-236,246-247
@@ -788,7 +788,7 @@ __device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, con
                 }
             });
         } else {
-            run_stack_h<U, PT, C0, NC, TAPS ? 2 : 1, HEAD2>(wpack, s * sstride, 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
+            run_stack_h<U, PT, C0, NC, TAPS ? 2 : 1, HEAD2, PROD>(wpack, s * sstride, 0xffffffffu, P.n_layer, smem, pn, Xin, tc, g, lane, ws, rg,
                                        [&](int p, int f, float v) {
                 if (f == 0) xdec[tc.blk(p) * L + ptab[tc.t(p)]] = 1.0f / (1.0f + expf(-v));   // decoders.py:262-267
             });
@@ -797,7 +797,7 @@ __device__ __forceinline__ void dec_body_h(const FusedParams& P, char* smem, con
     report_range_x(xmax, xinv, range_flags(pn.RNG), range_cal(pn.RNG));
 }
 
-template <int U, int PT, bool TAPS = false, bool HEAD2 = TAPS>
+template <int U, int PT, bool TAPS = false, bool HEAD2 = TAPS, int PROD = 3>
 __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -851,8 +851,8 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
         TileH<T> tc;
         make_tiles_h<T>(tc, pn.ROWT, gs.gt0, lane, L, npos, pad);
         __syncthreads();
-        if (!upper) dec_body_h<U, T, 0, Split<U>::CTA, TAPS, HEAD2>(P, smem, pn, tc, gs.gt0, lane, blk0);
-        else dec_body_h<U, T, Split<U>::CTA, Split<U>::CTB, TAPS, HEAD2>(P, smem, pn, tc, gs.gt0, lane, blk0);
+        if (!upper) dec_body_h<U, T, 0, Split<U>::CTA, TAPS, HEAD2, PROD>(P, smem, pn, tc, gs.gt0, lane, blk0);
+        else dec_body_h<U, T, Split<U>::CTA, Split<U>::CTB, TAPS, HEAD2, PROD>(P, smem, pn, tc, gs.gt0, lane, blk0);
     };
     dispatch_tiles<PT>(gs.live, run);
     // every stack ends with a barrier: all rows are in place.  Row i = (stack i / n_layer, layer i % n_layer); the last layer of a stack has no panel
@@ -1153,6 +1153,18 @@ hipError_t launch_fused_h_u(bool decoder, const FusedParams& P, int grid, hipStr
     const bool taps = decoder && (P.tap_out != nullptr || P.cal != nullptr || P.track == 2);
     const bool etrack = !decoder && (P.track != 0 || P.cal != nullptr);
     const bool h2 = P.head2 != 0;
+    if constexpr (U == 100) {
+        // precision = f16x1 (hi halves only, NOT fp32-grade): production decoder launches of the 100-wide kernel only
+        if (decoder && !taps && P.prod == 1) {
+            auto kx = dec_kernel_h<U, PT, false, false, 1>;
+            hipError_t ex = hipFuncSetAttribute(reinterpret_cast<const void*>(kx), hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes);
+            if (ex != hipSuccess) return ex;
+            hipLaunchKernelGGL(kx, dim3(grid), dim3(kThreads), P.lds_bytes, st, P);
+            return hipGetLastError();
+        }
+    } else if (P.prod == 1) {
+        return hipErrorInvalidValue;
+    }
     const void* fn = decoder ? (taps ? reinterpret_cast<const void*>(kt) : (h2 ? reinterpret_cast<const void*>(kd2) : reinterpret_cast<const void*>(kd)))
                              : (etrack ? reinterpret_cast<const void*>(ket) : (h2 ? reinterpret_cast<const void*>(ke2) : reinterpret_cast<const void*>(ke)));
     const int lds_launch = (TAE_X & 1024) ? 160 * 1024 : P.lds_bytes;       // experiment 1024: room for the stamps behind the panels

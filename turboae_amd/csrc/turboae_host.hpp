@@ -90,6 +90,7 @@ struct tae_handle {
     bool eval_noise_x2 = false;      // d_eval_noise holds fading coefficients + noise
     double* d_rnn_partials = nullptr;   // GRU encoder: per (chunk, stack, head workgroup) partial sums
     int32_t rnn_partial_slots = 0;
+    bool x1 = false;           // precision = TAE_PREC_F16X1: decoder launches take the one-product instantiation (hi halves only; not fp32-grade)
     bool gru_l1_split = false; // f16x2 GRU stacks: layer 1 as projection kernel + recurrence kernel (r04) instead of the fused kernel
     int gru_l0_mode = 0;         // layer 0 of the f16x2 GRU decoder stacks: 0 by batch (unit-split twin up to kGruL0UnitMaxB blocks), 1 block-split, 2 unit-split (TAE_GRU_L0, debug knob)
     int32_t rnn_chunk = 0;   // blocks per internal chunk (bounds the workspace)

@@ -43,6 +43,8 @@ struct FusedParams {
                             // launches, uncalibrated encoders)
     int32_t head2;          // f16x2 whole-block kernels, track < 2: 1 = the instantiation whose Linear heads evaluate both expm1 branches (one of
                             // this side's last conv layers stays below 1/4: exp2 - 1 alone is not relatively accurate there)
+    int32_t prod;           // f16x2 whole-block DECODER: 1 = the one-product instantiation (precision = TAE_PREC_F16X1: hi halves only, not
+                            // fp32-grade); anything else = the three products of the f16x2 scheme
 };
 
 // Arguments of the per-stack segmented kernel used when a block does not fit one workgroup.
