@@ -151,7 +151,10 @@ TAE_API int tae_create(const tae_config* cfg, const float* weights, size_t n_wei
 TAE_API int tae_destroy(tae_handle* h);
 
 /* Grow the internal workspace to `max_batch` blocks (allocates; not stream-ordered; call outside
- * timed / captured regions). */
+ * timed / captured regions).  Footprint per handle: CNN paths ~100 B per position; recurrent decoders work in chunks of at most 16 384
+ * blocks x 100 positions and hold, per position of min(max_batch, chunk): 1.7 KB (GRU on the fused layer-1 kernel: 2.7 GB per full chunk)
+ * or 1.7 KB + the layer-1 projections GI (LSTM: 3.2 KB -> 7.9 GB per full chunk; vanilla RNN 0.9 KB; fp32 GRU path 2.4 KB).  Every
+ * variable-block-length engine and every range_fallback twin is a handle of its own and owns its own copy. */
 TAE_API int tae_reserve(tae_handle* h, int32_t max_batch);
 
 /* Replaces enc.set_interleaver + dec.set_interleaver (channel_ae.py:35-36, encoders.py:340-341,
@@ -257,7 +260,11 @@ TAE_API int tae_kernel_info(tae_handle* h, int32_t* blocks_per_workgroup, int32_
 /* Which instantiation of the fp16-split whole-block kernels this handle's production launches use (no reference counterpart): 1 when
  * one of that side's last conv layers stayed below 1/4 in calibration, so its Linear heads evaluate both expm1 branches per value
  * (a twin of the plain kernel with the same registers and no scratch - not the calibration instantiation); 0 otherwise, and always 0
- * for fp32 / generic / long-block / GRU handles.  Either pointer may be NULL. */
+ * for fp32 / generic / long-block / GRU handles.  Known limit: the long-block, segmented and dense f16x2 kernels have no such
+ * twin and do not track their last layers' maxima - their heads always evaluate exp2 - 1 (3e-8 ABSOLUTE on an ELU output, i.e. a large
+ * relative error only for last-layer activations far below 1/4; `var_small_last_L1000` holds such a network to the golden tolerance),
+ * so a network with tiny last-layer activations is most accurate on the whole-block path (block_len <= 320) or with TAE_PREC_F32.
+ * Either pointer may be NULL. */
 TAE_API int tae_kernel_variants(tae_handle* h, int32_t* enc_both_branch_heads, int32_t* dec_both_branch_heads);
 
 /* Debug overrides in effect (no reference counterpart).  Environment variables that change the arithmetic, the kernel family or a
