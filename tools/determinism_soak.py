@@ -18,6 +18,8 @@ cases = [("cnn f16x2 50000x100", TurboAEConfig(), 50000), ("cnn f32 20000x100", 
          ("lstm H=100 16400 (unit-split f16x2)", TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="lstm", num_iteration=2), 16400),
          ("rnn H=100 8192 (unit-split f16x2)", TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="rnn", num_iteration=2), 8192),
          ("generic widths 256 1024 (fp32 MFMA)", TurboAEConfig(enc_num_unit=256, dec_num_unit=256, num_iteration=2), 1024),
+         ("f16x1 one-product decoder 20000x100 (r06)", TurboAEConfig(precision="f16x1"), 20000),
+         ("gru enc + lstm dec f16x2 4096 (r06 pairing)", TurboAEConfig(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", dec_rnn="lstm", num_iteration=2), 4096),
          ("generic rnn H=130 2048 (vector ALU)", TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="rnn", dec_num_unit=130, num_iteration=2), 2048)]
 bad = 0
 for name, cfg, B in cases:

@@ -11,7 +11,7 @@ cd /tmp
 B=${PMC_BATCH:-50000}
 run() {  # name, counters...
   name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_${TAG}_$name -o pmc -- python $R/bench.py --steps 2 --warmup 1 --batch $B --no-cpu-baseline --no-f32-pass --no-parity --no-other-configs --no-probe --no-graph --no-sweep --no-pmc > $OUT/pmc_${TAG}_$name.log 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_${TAG}_$name -o pmc -- python $R/bench.py --steps 2 --warmup 1 --batch $B --no-cpu-baseline --no-f32-pass --no-parity --no-other-configs --no-probe --no-graph --no-sweep --no-pmc --no-f16x1 > $OUT/pmc_${TAG}_$name.log 2>&1
   f=$(find $OUT/pmc_${TAG}_$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" $OUT/pmc_${TAG}_$name.txt $B <<'PY'
 import csv, sys, collections
@@ -25,7 +25,7 @@ for r in rows:
     if int(r.get("Grid_Size", 0) or 0) != gmax[k]: continue
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
 with open(sys.argv[2], "w") as fh:
-    fh.write(f"# rocprofv3 --pmc pass over `python bench.py --steps 2 --warmup 1 --batch {sys.argv[3]} --no-cpu-baseline --no-f32-pass --no-parity --no-other-configs --no-probe --no-graph --no-sweep --no-pmc`; mean counter value per FULL-SIZE dispatch (largest grid of each kernel)\n")
+    fh.write(f"# rocprofv3 --pmc pass over `python bench.py --steps 2 --warmup 1 --batch {sys.argv[3]} --no-cpu-baseline --no-f32-pass --no-parity --no-other-configs --no-probe --no-graph --no-sweep --no-pmc --no-f16x1`; mean counter value per FULL-SIZE dispatch (largest grid of each kernel)\n")
     for k in sorted(agg):
         for c in sorted(agg[k]):
             line = f"{k}\t{c}\t{agg[k][c]/n[(k,c)]:.6g}\t(dispatches={n[(k,c)]})"

@@ -27,7 +27,7 @@ print("parity:", p)
 PY
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity --no-other-configs --no-probe --no-graph --no-sweep --no-pmc > $OUT/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity --no-other-configs --no-probe --no-graph --no-sweep --no-pmc --no-f16x1 > $OUT/prof_$TAG.log 2>&1
 python $R/tools/trace_summary.py $OUT/prof_$TAG $OUT/prof_${TAG}_by_grid.txt
 f=$(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -14 "$f"

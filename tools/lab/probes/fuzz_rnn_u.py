@@ -18,7 +18,9 @@ for i in range(n):
     U = int(rng.choice([100, 100, int(rng.randint(1, 101))]))
     cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn=cell, block_len=L, dec_num_unit=U, num_iter_ft=int(rng.randint(1, 7)),
                         num_iteration=int(rng.randint(1, 4)), extrinsic=int(rng.randint(0, 2)),
-                        dec_act=str(rng.choice(["linear", "elu", "tanh", "relu", "selu", "sigmoid"])), enc_num_unit=int(rng.choice([32, 64, 100])))
+                        dec_act=str(rng.choice(["linear", "elu", "tanh", "relu", "selu", "sigmoid"])), enc_num_unit=int(rng.choice([32, 64, 100])),
+                        # r06: every fourth case puts the 2-layer GRU encoder (ENC_interRNN) in front - also of the LSTM / RNN decoders
+                        encoder="TurboAE_rate3_rnn" if i % 4 == 3 else "TurboAE_rate3_cnn")
     assert not cfg.generic, cfg
     sd = W.generate_state_dict(cfg, seed=int(rng.randint(1, 1 << 30)), gain=1.0)
     u = philox.random_bits(100 + i, 0, B * L).reshape(B, L, 1)
@@ -31,6 +33,6 @@ for i in range(n):
     k = B // 2
     sub = torch.equal(model.dec((codes + torch.from_numpy(noise).to(dev))[k:k + 1].contiguous()), xd[k:k + 1])
     worst = max(worst, dx)
-    flag = "" if (dc <= 1e-5 and dx <= 6e-5 and sub and mode == ("f16x2", False)) else "   <-- FAIL"
+    flag = "" if (dc <= 1e-5 and dx <= 1e-5 and sub and mode == ("f16x2", False)) else "   <-- FAIL"
     print(f"{i:3d} {cell:4s} B={B:3d} L={L:3d} U={U:3d} F={cfg.num_iter_ft} it={cfg.num_iteration} ex={cfg.extrinsic} act={cfg.dec_act:7s} dc={dc:.1e} dx={dx:.1e} sub={sub} {mode}{flag}", flush=True)
 print("worst dx", worst)
