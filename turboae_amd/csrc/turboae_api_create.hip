@@ -1200,6 +1200,7 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     (void)hipGetDevice(&h->device);
     if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || h->ncu < 1) h->ncu = 256;
     if (const char* e = tae::debug_knob("TAE_GRU_L1")) h->gru_l1_split = !strcmp(e, "split");     // r04 form of the f16x2 GRU layer 1
+    if (const char* e = tae::debug_knob("TAE_RNN_L1")) { h->rnn_l1_mode = !strcmp(e, "split") ? 1 : (!strcmp(e, "fused") ? 2 : 0); h->rnn_l1_check = !strcmp(e, "check"); }     // r05 form of the LSTM / RNN layer 1 (A/B, bit-identity test)
     if (const char* e = tae::debug_knob("TAE_GRU_L0")) h->gru_l0_mode = !strcmp(e, "block") ? 1 : (!strcmp(e, "unit") ? 2 : 0);     // A/B of the two bit-identical layer-0 kernels
     const char* fixed_nb = tae::debug_knob("TAE_FIXED_NB");
     h->fixed_nb = fixed_nb && fixed_nb[0] == '1';
@@ -1485,16 +1486,24 @@ int tae_reserve(tae_handle* h, int32_t max_batch) {
         TAE_HIP(hipMalloc(&h->d_gy1, np * 200 * sizeof(float)));
         // GI (layer-1 input projections, 2.4 KB per position = 4 GB per 16 384-block chunk) exists only on the fp32 path and in the
         // r04 split form of the f16x2 path: the fused layer-1 kernel (turboae_gru_l1f.hip) never writes it
-        const bool need_gi = h->prec != 1 || h->gru_l1_split || h->dec_gates != 3;
+        // LSTM / RNN (r06): GI only where the split form of layer 1 runs - calls below rnn_l1_split_below(h) blocks (or every call with the
+        // debug knob TAE_RNN_L1=split); the fused kernel never writes it
+        const bool rnn_u = h->dec_gates != 3;
+        const bool need_gi = rnn_u ? (h->rnn_l1_mode != 2 || h->rnn_l1_check) : (h->prec != 1 || h->gru_l1_split);
         const size_t gi_row = (size_t)2 * (6 * h->dec_gates + 1) * 16;          // floats per position: 2 directions x row tiles x 16 rows (GRU: 608)
-        if (need_gi) TAE_HIP(hipMalloc(&h->d_ggi, np * gi_row * sizeof(float)));
+        size_t np_gi = np;
+        if (rnn_u && h->rnn_l1_mode == 0 && !h->rnn_l1_check) {
+            const size_t cap = (size_t)((rnn_l1_split_below(h) + 31) / 32 * 32) * h->cfg.block_len;
+            if (cap < np_gi) np_gi = cap;
+        }
+        if (need_gi) TAE_HIP(hipMalloc(&h->d_ggi, np_gi * gi_row * sizeof(float)));
         TAE_HIP(hipMemset(h->d_gxa, 0, np * 8 * sizeof(float)));
         TAE_HIP(hipMemset(h->d_gxb, 0, np * 8 * sizeof(float)));
         // rows of padding blocks (last block group) are never written; they are read next to valid rows by the K-padding
         // over-read of the projection GEMM (x zero weights), so they must hold finite values
         TAE_HIP(hipMemset(h->d_gy0, 0, np * 200 * sizeof(float)));
         TAE_HIP(hipMemset(h->d_gy1, 0, np * 200 * sizeof(float)));
-        if (need_gi) TAE_HIP(hipMemset(h->d_ggi, 0, np * gi_row * sizeof(float)));
+        if (need_gi) TAE_HIP(hipMemset(h->d_ggi, 0, np_gi * gi_row * sizeof(float)));
         if (h->cfg.enc_type == 1) {
             (void)hipFree(h->d_rnn_partials);
             h->d_rnn_partials = nullptr;

@@ -498,8 +498,10 @@ int run_decoder_rnn(tae_handle* h, const float* rx, float* xdec, int32_t B, hipS
     return TAE_OK;
 }
 
+int rnn_l1_split_below(const tae_handle* h) { return 6 * h->ncu; }      // 2 * ceil(B / 16) workgroups < 3/4 of the CUs
+
 // DEC_LargeRNN.forward with an LSTM / vanilla-RNN cell (decoders.py:27-32,84-149) on the unit-split f16x2 kernels (turboae_rnn_u.hip):
-// per half-iteration rec(layer 0) -> projection GEMM -> rec(layer 1, head tile fused) -> gru_head_part
+// per half-iteration rec(layer 0) -> layer 1 (projection + recurrence + head tile in one kernel since r06; TAE_RNN_L1=split: the r05 pair) -> gru_head_part
 int run_decoder_rnn_u(tae_handle* h, const float* rx, float* xdec, int32_t B, hipStream_t st, float* tap_out) {
     const int L = h->cfg.block_len, F = h->cfg.num_iter_ft, H = 100, n_iter = h->cfg.num_iteration, G = h->dec_gates;
     const size_t dirb = tae::RnnULayout::dir_bytes(G), projb = tae::RnnULayout::proj_bytes(G);
@@ -517,13 +519,27 @@ int run_decoder_rnn_u(tae_handle* h, const float* rx, float* xdec, int32_t B, hi
             R.w = wb; R.w_dir_stride = (uint32_t)dirb; R.x = xin; R.y0 = reinterpret_cast<char*>(h->d_gy0);
             R.B = Bc; R.L = L; R.ncu = h->ncu;
             TAE_HIP(tae::launch_rnn_rec_u(G, true, R, st));
-            tae::RnnProjParams PP;
-            memset(&PP, 0, sizeof(PP));
-            PP.yin = h->d_gy0; PP.w = reinterpret_cast<const float*>(wb + 2 * dirb); PP.gi = h->d_ggi; PP.npos = npg;
-            PP.gi_mul[0] = h->rnn_u_gimul[2 * s]; PP.gi_mul[1] = h->rnn_u_gimul[2 * s + 1];
-            TAE_HIP(tae::launch_rnn_proj_u(G, PP, st));
-            R.w = wb + 2 * dirb + projb; R.x = nullptr; R.gi = h->d_ggi; R.y0 = nullptr; R.hpart = h->d_gy1;
-            TAE_HIP(tae::launch_rnn_rec_u(G, false, R, st));
+            if (h->rnn_l1_mode == 1 || (h->rnn_l1_mode == 0 && Bc < rnn_l1_split_below(h))) {        // r05 form: projection GEMM to HBM (GI), then the recurrence
+                tae::RnnProjParams PP;
+                memset(&PP, 0, sizeof(PP));
+                PP.yin = h->d_gy0; PP.w = reinterpret_cast<const float*>(wb + 2 * dirb); PP.gi = h->d_ggi; PP.npos = npg;
+                PP.gi_mul[0] = h->rnn_u_gimul[2 * s]; PP.gi_mul[1] = h->rnn_u_gimul[2 * s + 1];
+                TAE_HIP(tae::launch_rnn_proj_u(G, PP, st));
+                R.w = wb + 2 * dirb + projb; R.x = nullptr; R.gi = h->d_ggi; R.y0 = nullptr; R.hpart = h->d_gy1;
+                TAE_HIP(tae::launch_rnn_rec_u(G, false, R, st));
+            } else {                      // r06: the projection inside the recurrence (rnn_l1f_u_kernel), bit-identical, GI never exists
+                R.w = wb + 2 * dirb + projb; R.x = nullptr; R.gi = nullptr; R.hpart = h->d_gy1;
+                if (h->rnn_l1_check) {   // debug (TAE_RNN_L1=check, -DTAE_L1F_DBG_GI builds): GI from the projection kernel beside the fused kernel
+                    tae::RnnProjParams PP;
+                    memset(&PP, 0, sizeof(PP));
+                    PP.yin = h->d_gy0; PP.w = reinterpret_cast<const float*>(wb + 2 * dirb); PP.gi = h->d_ggi; PP.npos = npg;
+                    PP.gi_mul[0] = h->rnn_u_gimul[2 * s]; PP.gi_mul[1] = h->rnn_u_gimul[2 * s + 1];
+                    TAE_HIP(tae::launch_rnn_proj_u(G, PP, st));
+                    R.gi = h->d_ggi;
+                }
+                R.wproj = wb + 2 * dirb; R.gi_mul[0] = h->rnn_u_gimul[2 * s]; R.gi_mul[1] = h->rnn_u_gimul[2 * s + 1];
+                TAE_HIP(tae::launch_rnn_l1f_u(G, R, st));
+            }
             const float* wl = reinterpret_cast<const float*>(wb + 4 * dirb + projb);
             tae::GruHeadParams HP;
             memset(&HP, 0, sizeof(HP));

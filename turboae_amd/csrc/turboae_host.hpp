@@ -20,6 +20,11 @@
 
 namespace tae {
 namespace host {
+// LSTM / RNN decoder stacks: calls below this many blocks run layer 1 as projection kernel + recurrence (the projection GEMM spreads over
+// the whole chip whatever the batch), calls at or above it the fused kernel (one workgroup per 16 blocks and direction: measured r06, LSTM,
+// 256 CUs: 1 000 blocks 4.8 vs 5.1 ms, 2 048 blocks 6.8 vs 5.9 ms, 16 384 blocks 53.3 vs 43.3 ms).  The forms are bit-identical.
+int rnn_l1_split_below(const tae_handle* h);
+
 
 int fail(int code, const std::string& msg);       // sets the calling thread's tae_last_error string, returns `code`
 const char* last_error();
@@ -91,6 +96,9 @@ struct tae_handle {
     double* d_rnn_partials = nullptr;   // GRU encoder: per (chunk, stack, head workgroup) partial sums
     int32_t rnn_partial_slots = 0;
     bool x1 = false;           // precision = TAE_PREC_F16X1: decoder launches take the one-product instantiation (hi halves only; not fp32-grade)
+    bool rnn_l1_check = false; // debug: run rnn_proj_u beside the fused layer-1 kernel (its GI is what a -DTAE_L1F_DBG_GI build compares against)
+    int rnn_l1_mode = 0;       // LSTM / RNN stacks, layer 1: 0 = by batch (below), 1 = always rnn_proj_u + rnn_rec_u (r05 pair), 2 = always rnn_l1f_u_kernel
+                               // (the two forms are bit-identical: results never depend on the choice; debug knob TAE_RNN_L1=split|fused)
     bool gru_l1_split = false; // f16x2 GRU stacks: layer 1 as projection kernel + recurrence kernel (r04) instead of the fused kernel
     int gru_l0_mode = 0;         // layer 0 of the f16x2 GRU decoder stacks: 0 by batch (unit-split twin up to kGruL0UnitMaxB blocks), 1 block-split, 2 unit-split (TAE_GRU_L0, debug knob)
     int32_t rnn_chunk = 0;   // blocks per internal chunk (bounds the workspace)

@@ -147,6 +147,9 @@ struct RnnUParams {
     float* hpart;           // layer 1: [pos'][dir][8] this direction's share of the Linear head
     int32_t B, L, ngroups;  // ngroups: set by the launcher (ceil(B / 16 NT), NT = N tiles per workgroup, picked by batch)
     int32_t ncu;            // compute units of the handle's device (grid size and the NT choice)
+    // layer 1, fused form (r06, launch_rnn_l1f_u): the projection GEMM runs inside the recurrence, two steps at a time, GI never exists
+    const char* wproj;      // rnn_proj_u's image: A fragments [dir][slab 7][tile][hi | lo][lane][8 halves] | bias rows [dir][tile][16] | 2^-S
+    float gi_mul[2];        // per direction: the layer-1 recurrence's own power-of-two scale (RnnProjParams::gi_mul)
 };
 struct RnnProjParams {
     const float* yin;       // layer-0 outputs (halves)
@@ -157,6 +160,7 @@ struct RnnProjParams {
 };
 hipError_t launch_rnn_rec_u(int gates, bool layer0, const RnnUParams& P, hipStream_t st);
 hipError_t launch_rnn_proj_u(int gates, const RnnProjParams& P, hipStream_t st);
+hipError_t launch_rnn_l1f_u(int gates, const RnnUParams& P, hipStream_t st);          // layer 1 with the projection inside (y0 = layer-0 outputs, wproj, gi_mul)
 int gru_l1f_lds_bytes();
 hipError_t launch_gru_prep_enc(const float* u, const int32_t* perm, float* X, int B, int L, int interleaved, hipStream_t st);
 int gru_head_grid(size_t npos);

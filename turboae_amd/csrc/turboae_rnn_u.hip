@@ -36,6 +36,8 @@ using lds_ptr = char __attribute__((address_space(3)))*;
 
 // NT = N tiles (of 16 blocks) per workgroup: 2 amortises the step's latencies over twice the MFMAs (large batches); 1 for batches that
 // would leave CUs idle (a shorter step on twice the workgroups).  Columns are independent: results do not depend on NT.
+constexpr int kProjSlabs = 7;          // k-slabs of the layer-1 input projection (K = 200)
+
 template <int G, int NT = 2> struct Geo {
     static constexpr int kHBsz = NT * 8192;                       // h exchange of one step: per N tile 3 slabs x (hi | lo) + remainder (b1 | b2)
     static constexpr int kXBsz = NT * 2048;                       // layer 0: x_t as the K = 16 slab's (b1 | b2) per N tile
@@ -60,9 +62,24 @@ __device__ __forceinline__ h8 glb_h8(const char* p) { return __builtin_bit_cast(
 
 // LDS writes of this wave are done and visible, then the workgroup barrier (LDS-only fence: global loads / stores stay in flight)
 __device__ __forceinline__ void step_barrier() {
+#ifdef TAE_L1F_DBG_SYNC
+    __syncthreads();
+    return;
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// gfx950 hazard guard (r06, found with rnn_l1f_u_kernel<4, 2>): a vector-ALU write to a register that an MFMA issued a few cycles earlier
+// still reads as srcB corrupts that MFMA's LAST columns (blocks 12..15 of the tile) - the compiler reuses dead operand registers for
+// gate temporaries without wait states.  mfma_drain() keeps the matrix pipe's in-flight reads ahead of what follows.
+__device__ __forceinline__ void mfma_drain() {
+#ifndef TAE_L1F_NO_DRAIN
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 15");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 
 template <int N, class F, int I = 0>
@@ -110,6 +127,7 @@ struct Ctx {
     lds_cptr lds;
     int lane, n, q, dir, L;
     float inv, inv_head;
+    float mul = 1.0f;       // fused layer 1: what rnn_proj_u multiplies GI by (its 2^-S times the recurrence's 2^S)
 };
 
 // ---- unit wave: units 16 ut .. 16 ut + 15, G gate tiles -------------------------------------------------------------------------
@@ -194,6 +212,9 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
                     hn[i] = cell<G>(a, cc);
                     cs[nt][i] = cc;
                 }
+#ifdef TAE_L1F_DBG_H
+                if (!LAYER0 && grp == 0 && (lane == 12) && nt == 0 && dir == 0) printf("H dir %d s %d nt %d ut %d lane %d: %.9g %.9g c %.9g acc %.9g %.9g %.9g %.9g\n", dir, s, nt, ut, lane, hn[0], hn[1], cs[nt][0], acc[nt][0][0], acc[nt][1][0], acc[nt][2][0], acc[nt][3][0]);
+#endif
                 h4 nhi, nlo;
                 split4(hn, nhi, nlo);
                 const lds_ptr hn_w = hw + p1 * kHBsz + nt * 8192;
@@ -258,6 +279,9 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
 #pragma unroll
             for (int sl = 0; sl < 3; ++sl) mma1(a, hd_hi[sl], hd_lo[sl], lds_h8(hc + sl * 2048), lds_h8(hc + sl * 2048 + 1024));
             mma1r(a, hd_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
+#ifdef TAE_L1F_DBG_H
+            if (grp == 0 && (lane == 12) && nt == 0 && dir == 0) printf("HEAD dir %d t %d nt %d lane %d: %.9g %.9g\n", dir, t, nt, lane, a[0] * inv_head, a[1] * inv_head);
+#endif
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, a * inv_head), rs_h[nt], v_h, (uint32_t)t * 1024u, 0);
         };
         float cs[kNT];
@@ -291,6 +315,9 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) a[g] = acc[g] * inv;
                 const float hr = cell<G>(a, cs[nt]);
+#ifdef TAE_L1F_DBG_H
+                if (!LAYER0 && grp == 0 && (lane == 12) && nt == 0 && dir == 0) printf("R dir %d s %d nt %d lane %d: %.9g c %.9g acc %.9g\n", dir, s, nt, lane, hr, cs[nt], acc[0]);
+#endif
                 const _Float16 hi = (_Float16)hr;
                 const _Float16 lo = (_Float16)(hr - (float)hi);
                 const h8 b1 = {lo, 0, 0, 0, hi, 0, 0, 0}, b2 = {hi, 0, 0, 0, 0, 0, 0, 0};
@@ -368,6 +395,422 @@ __global__ __launch_bounds__(512) void rnn_rec_u_kernel(RnnUParams P) {
     else unit_wave<G, LAYER0, NT>(c, wave < 3 ? wave : wave - 1);
 }
 
+// ---- layer 1 with the projection INSIDE (r06): rnn_l1f_u_kernel -------------------------------------------------------------------------
+// rnn_proj_u writes 3.2 KB of GI per position (5.1 GB per launch at 16 384 blocks) and is bound by exactly that (2.5 TB/s of writes,
+// pipes 41 % busy); the recurrence reads it back.  Here every wave projects ITS OWN gate tiles, two steps at a time
+// (a chunk = kTC steps x NT N tiles = NS N-tile-steps), into the registers that then serve as the recurrence's accumulators:
+//   P phase   gi[ns][g] = bias + sum over 7 k-slabs of W_ih1 (A fragments streamed L2 -> registers through a ring of kRingF pairs, straight
+//             from rnn_proj_u's own image) x Y0 rows (B fragments in LDS, put there by the staging wave with LDS-DMA while the PREVIOUS
+//             chunk's recurrence ran), then x mul - per accumulator the same products in the same order as rnn_proj_u, so the two forms
+//             are bit-identical (tests/test_gpu_generic.py::test_rnn_layer1_forms_are_bit_identical);
+//   R phase   kTC steps of rnn_rec_u's layer-1 step with acc = gi (no GI fetch).
+// One more barrier per chunk (the B fragments are free for the next chunk's DMA).  GI never exists; Y0 is read once per direction.
+constexpr int kRingF = 4;
+template <int G, int NT> struct GeoF {
+    using GE = Geo<G, NT>;
+    static constexpr int kTC = NT == 1 ? 4 : 2;                  // steps per chunk: four N-tile-steps either way (64 accumulator registers)
+    static constexpr int NS = NT * kTC;                          // N-tile-steps of a chunk, ns = tc * NT + nt
+    static constexpr int kTileB = 14 * 1024;                     // B fragments of one N-tile-step: [slab 7][hi | lo][lane][8 halves]
+    static constexpr int kYB = GE::kXB;                          // layer 1 stages no x_t: the region begins where layer 0's would
+    static constexpr int kHR = kYB + NS * kTileB;                // W_hh fragments of the unit waves kept in LDS instead of registers, [ut][gate][2][1 KB]:
+    static constexpr int kLds = kHR + 6 * G * 2048;              // the remainder slab and slab 2's lo halves - 32 registers a wave that the chunk's
+                                                                 // accumulators need (LSTM, two N tiles: 256 registers and 20 spilled without)
+    static constexpr int GB = G < 2 ? G : 2;                     // a block of the P phase: GB gates x NB N-tile-steps = independent accumulators
+    static constexpr int NB = (4 / GB) < NS ? (4 / GB) : NS;
+};
+
+template <int G, int NT>
+__device__ __forceinline__ void unit_wave_f(const Ctx& c, int ut) {
+    using GE = Geo<G, NT>;
+    using GF = GeoF<G, NT>;
+    constexpr int kNT = NT, kTC = GF::kTC, NS = GF::NS, kHBsz = GE::kHBsz, CTT = 6 * G + 1, GB = GF::GB, NB = GF::NB;
+    constexpr int NPAIR = kProjSlabs * G;                       // A-fragment pairs of a chunk, in the order (slab, gate)
+    constexpr uint32_t DIRB = kProjSlabs * CTT * 2048u;
+    const int lane = c.lane, L = c.L, n = c.n, q = c.q, dir = c.dir;
+    const char* wr = c.wdir + (size_t)ut * GE::kFragU * 1024 + lane * 16;
+    h8 hh_hi[3][G], hh_lo[2][G];
+    const lds_cptr hrl = c.lds + GF::kHR + (ut * G) * 2048 + lane * 16;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) hh_hi[sl][g] = glb_h8(wr + (g * 8 + 2 * sl) * 1024);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) hh_lo[sl][g] = glb_h8(wr + (g * 8 + 2 * sl + 1) * 1024);
+        *reinterpret_cast<lds_w4*>((lds_ptr)hrl + g * 2048) = *reinterpret_cast<const u32x4v*>(wr + (g * 8 + 6) * 1024);             // read back by this wave only
+        *reinterpret_cast<lds_w4*>((lds_ptr)hrl + g * 2048 + 1024) = *reinterpret_cast<const u32x4v*>(wr + (g * 8 + 5) * 1024);      // slab 2, lo
+    }
+    const lds_cptr bias = c.lds + ut * (G * 64) + q * 16;          // the PROJECTION's bias rows (the kernel prologue put them there)
+    const lds_cptr hb = c.lds + GE::kHB + lane * 16, yb = c.lds + GF::kYB + lane * 16;
+    const lds_ptr hw = (lds_ptr)(c.lds + GE::kHB + (ut >> 1) * 2048 + lane * 16 + (ut & 1) * 8);
+    const float inv = c.inv, mul = c.mul;
+    const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(c.P.wproj), 0, (int)(2 * DIRB + 2 * CTT * 64 + 16), 0x00020000);
+    const uint32_t va = (uint32_t)lane * 16u + (uint32_t)dir * DIRB + (uint32_t)(G * ut) * 2048u;
+    h8 ah[kRingF], al[kRingF];
+    auto a_issue = [&](auto I) {                                // pair i = (slab i / G, gate i % G) into ring slot i % kRingF
+        constexpr int i = decltype(I)::value, r = i % kRingF;
+        constexpr uint32_t off = (uint32_t)(i / G) * (CTT * 2048u) + (uint32_t)(i % G) * 2048u;
+        ah[r] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsp, va + off, 0, 0));
+        al[r] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsp, va + off + 1024, 0, 0));
+    };
+    static_for<GB>(a_issue);                                     // the first block's fragments (every chunk starts with the same ones)
+
+    for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+            *reinterpret_cast<lds_w2*>(hw + nt * 8192) = u32x2v{0, 0};          // h_{-1} = 0: this wave's slots of buffer 0
+            *reinterpret_cast<lds_w2*>(hw + nt * 8192 + 1024) = u32x2v{0, 0};
+        }
+        f32x4 cs[kNT];
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) cs[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        step_barrier();                                   // B0: h buffer 0 cleared, the first chunk's Y0 fragments landed
+#pragma unroll 1
+        for (int s0 = 0; s0 < L; s0 += kTC) {
+            // ---- P phase -------------------------------------------------------------------------------------------------------
+#ifdef TAE_L1F_DBG_NOPRE
+            if (s0 > 0) static_for<GB>(a_issue);
+#endif
+            f32x4 gi[NS][G];
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+                for (int g = 0; g < G; ++g) gi[ns][g] = *reinterpret_cast<lds_f4c*>(bias + g * 64);
+            static_for<NPAIR / GB>([&](auto BI) {
+                constexpr int b = decltype(BI)::value, i0 = b * GB, sl = i0 / G, g0 = i0 % G;
+                if constexpr (i0 + GB < NPAIR) static_for<GB>([&](auto J) { a_issue(std::integral_constant<int, i0 + GB + decltype(J)::value>{}); });
+#pragma unroll
+                for (int n0 = 0; n0 < NS; n0 += NB) {
+                    h8 bh[NB], bl[NB];
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        bh[j] = lds_h8(yb + (n0 + j) * GF::kTileB + sl * 2048);
+                        bl[j] = lds_h8(yb + (n0 + j) * GF::kTileB + sl * 2048 + 1024);
+                    }
+                    // per accumulator hi*lo, hi*hi, lo*hi of this slab (mma_tile_h's order, TAE_MMA_ORDER 1, which rnn_proj_u runs on), each product across the block's accumulators
+#pragma unroll
+                    for (int k = 0; k < GB; ++k)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) gi[n0 + j][g0 + k] = mfma16x16x32h(ah[(i0 + k) % kRingF], bl[j], gi[n0 + j][g0 + k]);
+#pragma unroll
+                    for (int k = 0; k < GB; ++k)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) gi[n0 + j][g0 + k] = mfma16x16x32h(ah[(i0 + k) % kRingF], bh[j], gi[n0 + j][g0 + k]);
+#pragma unroll
+                    for (int k = 0; k < GB; ++k)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) gi[n0 + j][g0 + k] = mfma16x16x32h(al[(i0 + k) % kRingF], bh[j], gi[n0 + j][g0 + k]);
+                    __builtin_amdgcn_sched_barrier(0);      // one block at a time: hoisted operand reads of later blocks cost registers the chunk's accumulators need
+                }
+            });
+#ifndef TAE_L1F_DBG_NOPRE
+            static_for<GB>(a_issue);                             // the next chunk's first block: in flight through the whole R phase
+#endif
+            mfma_drain();
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+                for (int g = 0; g < G; ++g) gi[ns][g] *= mul;
+#ifdef TAE_L1F_DBG_GI
+            if (c.P.gi) {      // debug build: the chunk's accumulators against rnn_proj_u's GI (the caller ran it first)
+#pragma unroll
+                for (int ns = 0; ns < NS; ++ns) {
+                    const int tcd = ns / kNT, ntd = ns % kNT, sd = s0 + tcd < L ? s0 + tcd : L - 1;
+                    const size_t g16 = (size_t)grp * kNT + ntd;
+                    const float* gp = c.P.gi + g16 * L * 2 * (CTT * 256) + (size_t)(((dir ? L - 1 - sd : sd) * 2 + dir)) * (CTT * 256) + (G * ut) * 256 + (n * 4 + q) * 4;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const f32x4 r = *reinterpret_cast<const f32x4*>(gp + g * 256);
+                        const bool bad = r.x != gi[ns][g].x || r.y != gi[ns][g].y || r.z != gi[ns][g].z || r.w != gi[ns][g].w;
+                        if (bad && grp == 0 && ntd == 0) printf("gi mismatch dir %d s0 %d ns %d ut %d g %d lane %d (n %d q %d): %g vs %g\n", dir, s0, ns, ut, g, lane, n, q, gi[ns][g].x, r.x);
+                    }
+                }
+            }
+#endif
+            step_barrier();                                   // BA: every wave has read the chunk's Y0 fragments (the staging wave refills them)
+            // ---- R phase: kTC steps of rnn_rec_u's layer 1 ---------------------------------------------------------------------
+            static_for<kTC>([&](auto TI) {
+                constexpr int tc = decltype(TI)::value;
+                const int s = s0 + tc;
+                if (s < L) {
+                    const int p0 = s & 1, p1 = p0 ^ 1;
+#ifdef TAE_L1F_DBG_H
+                    if (s == 0 && grp == 0 && ut == 0 && dir == 0) {
+                        for (int f = 0; f < 8; ++f) {
+                            const u32x4v v = *reinterpret_cast<lds_q4*>(hb + f * 1024);
+                            if (v.x | v.y | v.z | v.w) printf("HB0 nonzero frag %d lane %d: %08x %08x %08x %08x\n", f, lane, v.x, v.y, v.z, v.w);
+                        }
+                    }
+#endif
+#pragma unroll
+                    for (int nt = 0; nt < kNT; ++nt) {
+                        const lds_cptr hc = hb + p0 * kHBsz + nt * 8192;
+#pragma unroll
+                        for (int sl = 0; sl < 2; ++sl) mma_g<G>(gi[tc * kNT + nt], hh_hi[sl], hh_lo[sl], lds_h8(hc + sl * 2048), lds_h8(hc + sl * 2048 + 1024));
+                        h8 hh_l2[G], hh_r[G];
+#ifdef TAE_L1F_DBG_HREG
+#pragma unroll
+                        for (int g = 0; g < G; ++g) hh_l2[g] = glb_h8(wr + (g * 8 + 5) * 1024);
+#else
+#pragma unroll
+                        for (int g = 0; g < G; ++g) hh_l2[g] = lds_h8(hrl + g * 2048 + 1024);
+#endif
+                        mma_g<G>(gi[tc * kNT + nt], hh_hi[2], hh_l2, lds_h8(hc + 2 * 2048), lds_h8(hc + 2 * 2048 + 1024));
+#ifdef TAE_L1F_DBG_HREG
+#pragma unroll
+                        for (int g = 0; g < G; ++g) hh_r[g] = glb_h8(wr + (g * 8 + 6) * 1024);
+#else
+#pragma unroll
+                        for (int g = 0; g < G; ++g) hh_r[g] = lds_h8(hrl + g * 2048);
+#endif
+                        mma_gr<G>(gi[tc * kNT + nt], hh_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
+                    }
+                    mfma_drain();
+#pragma unroll
+                    for (int nt = 0; nt < kNT; ++nt) {
+                        f32x4 hn;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float a[G];
+#pragma unroll
+                            for (int g = 0; g < G; ++g) a[g] = gi[tc * kNT + nt][g][i] * inv;
+                            float cc = cs[nt][i];
+                            hn[i] = cell<G>(a, cc);
+                            cs[nt][i] = cc;
+                        }
+#ifdef TAE_L1F_DBG_H
+                        if (grp == 0 && (lane == 12) && nt == 0 && dir == 0) printf("H dir %d s %d nt %d ut %d lane %d: %.9g %.9g c %.9g acc %.9g %.9g %.9g %.9g\n", dir, s, nt, ut, lane, hn[0], hn[1], cs[nt][0], gi[tc * kNT + nt][0][0], gi[tc * kNT + nt][1][0], gi[tc * kNT + nt][2][0], gi[tc * kNT + nt][3][0]);
+#endif
+                        h4 nhi, nlo;
+                        split4(hn, nhi, nlo);
+                        const lds_ptr hn_w = hw + p1 * kHBsz + nt * 8192;
+                        *reinterpret_cast<lds_w2*>(hn_w) = __builtin_bit_cast(u32x2v, nhi);
+                        *reinterpret_cast<lds_w2*>(hn_w + 1024) = __builtin_bit_cast(u32x2v, nlo);
+                    }
+                    step_barrier();
+                }
+            });
+        }
+        step_barrier();                                   // the remainder wave's last head product has read the h buffer
+    }
+}
+
+template <int G, int NT>
+__device__ __forceinline__ void rem_wave_f(const Ctx& c) {
+    using GE = Geo<G, NT>;
+    using GF = GeoF<G, NT>;
+    constexpr int kNT = NT, kTC = GF::kTC, NS = GF::NS, kHBsz = GE::kHBsz, CTT = 6 * G + 1;
+    constexpr uint32_t DIRB = kProjSlabs * CTT * 2048u;
+    const int lane = c.lane, L = c.L, n = c.n, q = c.q, dir = c.dir;
+    const char* wr = c.wdir + (size_t)6 * GE::kFragU * 1024 + lane * 16;
+    h8 hh_hi[3], hh_lo[3], hh_r, hd_hi[3], hd_lo[3], hd_r, pa_hi[kProjSlabs], pa_lo[kProjSlabs];
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) { hh_hi[sl] = glb_h8(wr + (2 * sl) * 1024); hh_lo[sl] = glb_h8(wr + (2 * sl + 1) * 1024); }
+    hh_r = glb_h8(wr + 6 * 1024);
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) { hd_hi[sl] = glb_h8(wr + (8 + 2 * sl) * 1024); hd_lo[sl] = glb_h8(wr + (9 + 2 * sl) * 1024); }
+    hd_r = glb_h8(wr + 14 * 1024);
+    {   // the mixed tile's W_ih1 fragments (tile 6 G of the projection image) stay in registers: this wave has them to spare
+        const char* pa = c.P.wproj + (size_t)dir * DIRB + (size_t)(6 * G) * 2048 + lane * 16;
+#pragma unroll
+        for (int sl = 0; sl < kProjSlabs; ++sl) { pa_hi[sl] = glb_h8(pa + (size_t)sl * (CTT * 2048)); pa_lo[sl] = glb_h8(pa + (size_t)sl * (CTT * 2048) + 1024); }
+    }
+    const lds_cptr bias = c.lds + 6 * (G * 64) + q * 16;
+    const lds_cptr hb = c.lds + GE::kHB + lane * 16, yb = c.lds + GF::kYB + lane * 16;
+    const lds_ptr hw = (lds_ptr)(c.lds + GE::kHB + 6144 + lane * 16);
+    const float inv = c.inv, inv_head = c.inv_head, mul = c.mul;
+    auto mma1 = [](f32x4& a, h8 ah, h8 al, h8 bh, h8 bl) {
+        a = mfma16x16x32h(ah, bl, a); a = mfma16x16x32h(al, bh, a); a = mfma16x16x32h(ah, bh, a);
+    };
+    auto mma1r = [](f32x4& a, h8 ar, h8 b1, h8 b2) { a = mfma16x16x32h(ar, b1, a); a = mfma16x16x32h(ar, b2, a); };
+
+    for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
+        __amdgpu_buffer_rsrc_t rs_h[kNT];
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+            const size_t g16 = (size_t)grp * kNT + nt;
+            rs_h[nt] = __builtin_amdgcn_make_buffer_rsrc(c.P.hpart + g16 * L * 256, 0, L * 1024, 0x00020000);
+        }
+        const uint32_t v_h = q < 2 ? (uint32_t)(n * 64 + dir * 32 + q * 16) : 0x80000000u;
+        auto head = [&](lds_cptr hc, int nt, int t) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) mma1(a, hd_hi[sl], hd_lo[sl], lds_h8(hc + sl * 2048), lds_h8(hc + sl * 2048 + 1024));
+            mma1r(a, hd_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
+            mfma_drain();
+#ifdef TAE_L1F_DBG_H
+            if (grp == 0 && (lane == 12) && nt == 0 && dir == 0) printf("HEAD dir %d t %d nt %d lane %d: %.9g %.9g\n", dir, t, nt, lane, a[0] * inv_head, a[1] * inv_head);
+#endif
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, a * inv_head), rs_h[nt], v_h, (uint32_t)t * 1024u, 0);
+        };
+        float cs[kNT];
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+            *reinterpret_cast<lds_w4*>(hw + nt * 8192) = u32x4v{0, 0, 0, 0};
+            *reinterpret_cast<lds_w4*>(hw + nt * 8192 + 1024) = u32x4v{0, 0, 0, 0};
+            cs[nt] = 0.0f;
+        }
+        step_barrier();                                   // B0
+#pragma unroll 1
+        for (int s0 = 0; s0 < L; s0 += kTC) {
+            f32x4 gi[NS];
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) gi[ns] = *reinterpret_cast<lds_f4c*>(bias);
+#pragma unroll
+            for (int sl = 0; sl < kProjSlabs; ++sl)
+#pragma unroll
+                for (int ns = 0; ns < NS; ++ns) {           // mma_tile_h's product order (hi*lo, hi*hi, lo*hi), not the recurrence's
+                    const h8 bh = lds_h8(yb + ns * GF::kTileB + sl * 2048), bl = lds_h8(yb + ns * GF::kTileB + sl * 2048 + 1024);
+                    gi[ns] = mfma16x16x32h(pa_hi[sl], bl, gi[ns]);
+                    gi[ns] = mfma16x16x32h(pa_hi[sl], bh, gi[ns]);
+                    gi[ns] = mfma16x16x32h(pa_lo[sl], bh, gi[ns]);
+                }
+            mfma_drain();
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) gi[ns] *= mul;
+#ifdef TAE_L1F_DBG_GI
+            if (c.P.gi) {
+#pragma unroll
+                for (int ns = 0; ns < NS; ++ns) {
+                    const int tcd = ns / kNT, ntd = ns % kNT, sd = s0 + tcd < L ? s0 + tcd : L - 1;
+                    const size_t g16 = (size_t)grp * kNT + ntd;
+                    const float* gp = c.P.gi + g16 * L * 2 * (CTT * 256) + (size_t)(((dir ? L - 1 - sd : sd) * 2 + dir)) * (CTT * 256) + (6 * G) * 256 + (n * 4 + q) * 4;
+                    const f32x4 r = *reinterpret_cast<const f32x4*>(gp);
+                    const bool bad = r.x != gi[ns].x || r.y != gi[ns].y || r.z != gi[ns].z || r.w != gi[ns].w;
+                    if (bad && grp == 0 && ntd == 0) printf("REM gi mismatch dir %d s0 %d ns %d lane %d (n %d q %d): %g %g %g %g vs %g %g %g %g\n", dir, s0, ns, lane, n, q, gi[ns].x, gi[ns].y, gi[ns].z, gi[ns].w, r.x, r.y, r.z, r.w);
+                }
+            }
+#endif
+            step_barrier();                                   // BA
+            static_for<kTC>([&](auto TI) {
+                constexpr int tc = decltype(TI)::value;
+                const int s = s0 + tc;
+                if (s < L) {
+                    const int p0 = s & 1, p1 = p0 ^ 1;
+#pragma unroll
+                    for (int nt = 0; nt < kNT; ++nt) {
+                        const lds_cptr hc = hb + p0 * kHBsz + nt * 8192;
+                        f32x4 acc = gi[tc * kNT + nt];
+#pragma unroll
+                        for (int sl = 0; sl < 3; ++sl) mma1(acc, hh_hi[sl], hh_lo[sl], lds_h8(hc + sl * 2048), lds_h8(hc + sl * 2048 + 1024));
+                        mma1r(acc, hh_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
+                        if (s > 0) head(hc, nt, dir ? L - s : s - 1);        // Linear head on h_{s-1} (the state this step started from)
+                        mfma_drain();
+                        float a[G];
+#pragma unroll
+                        for (int g = 0; g < G; ++g) a[g] = acc[g] * inv;
+                        const float hr = cell<G>(a, cs[nt]);
+#ifdef TAE_L1F_DBG_H
+                        if (grp == 0 && (lane == 12) && nt == 0 && dir == 0) printf("R dir %d s %d nt %d lane %d: %.9g c %.9g acc %.9g\n", dir, s, nt, lane, hr, cs[nt], acc[0]);
+#endif
+                        const _Float16 hi = (_Float16)hr;
+                        const _Float16 lo = (_Float16)(hr - (float)hi);
+                        const h8 b1 = {lo, 0, 0, 0, hi, 0, 0, 0}, b2 = {hi, 0, 0, 0, 0, 0, 0, 0};
+                        const lds_ptr hn_w = hw + p1 * kHBsz + nt * 8192;
+                        *reinterpret_cast<lds_w4*>(hn_w) = __builtin_bit_cast(u32x4v, b1);
+                        *reinterpret_cast<lds_w4*>(hn_w + 1024) = __builtin_bit_cast(u32x4v, b2);
+                    }
+                    step_barrier();
+                }
+            });
+        }
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) head(hb + (L & 1) * kHBsz + nt * 8192, nt, dir ? 0 : L - 1);
+        step_barrier();
+    }
+}
+
+// the eighth wave: Y0 rows of the next chunk -> B fragments in LDS by LDS-DMA (every lane's 16 bytes land at the tile base + lane * 16:
+// the rows never touch a register), issued right after the barrier that frees the buffer, waited for before the chunk's last step barrier
+template <int G, int NT>
+__device__ __forceinline__ void stage_wave_f(const Ctx& c) {
+    using GF = GeoF<G, NT>;
+    constexpr int kNT = NT, kTC = GF::kTC;
+    const int L = c.L, n = c.n, q = c.q, dir = c.dir;
+    const lds_ptr ybu = (lds_ptr)(c.lds + GF::kYB);                  // tile bases (no lane term)
+    const uint32_t v0 = (uint32_t)(n * 800 + q * 16);
+    for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
+        __amdgpu_buffer_rsrc_t rs[kNT];
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt)
+            rs[nt] = __builtin_amdgcn_make_buffer_rsrc(c.P.y0 + ((size_t)grp * kNT + nt) * L * (16 * 800), 0, L * 16 * 800, 0x00020000);
+        auto dma_chunk = [&](int s0) {
+#pragma unroll
+            for (int tc = 0; tc < kTC; ++tc) {
+                const int s = s0 + tc < L ? s0 + tc : L - 1;      // a chunk past the end repeats the last step: fetched, never used
+                const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(dir ? L - 1 - s : s) * (16 * 800u);
+#pragma unroll
+                for (int nt = 0; nt < kNT; ++nt) {
+                    const lds_ptr y = ybu + (tc * kNT + nt) * GF::kTileB;
+#ifdef TAE_L1F_DBG_NODMA
+                    u32x4v tmp[2 * kProjSlabs];
+#pragma unroll
+                    for (int sl = 0; sl < kProjSlabs; ++sl) {
+                        tmp[2 * sl] = __builtin_amdgcn_raw_buffer_load_b128(rs[nt], v0 + sl * 64, so, 0);
+                        tmp[2 * sl + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs[nt], v0 + 400 + sl * 64, so, 0);
+                    }
+#pragma unroll
+                    for (int f = 0; f < 2 * kProjSlabs; ++f) *reinterpret_cast<lds_w4*>(y + f * 1024 + c.lane * 16) = tmp[f];
+#else
+#pragma unroll
+                    for (int sl = 0; sl < kProjSlabs; ++sl) {
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[nt], y + (2 * sl) * 1024, 16, v0 + sl * 64, so, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[nt], y + (2 * sl + 1) * 1024, 16, v0 + 400 + sl * 64, so, 0, 0);
+                    }
+#endif
+#ifdef TAE_L1F_DBG_WAIT
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+                }
+            }
+        };
+        dma_chunk(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): an LDS-DMA is a pending LDS write on the VM counter
+        step_barrier();                                   // B0
+#pragma unroll 1
+        for (int s0 = 0; s0 < L; s0 += kTC) {
+            step_barrier();                                   // BA: the chunk's fragments have been read
+            if (s0 + kTC < L) dma_chunk(s0 + kTC);
+#pragma unroll
+            for (int tc = 0; tc < kTC; ++tc) {
+                if (s0 + tc < L) {
+                    if (tc == kTC - 1 || s0 + tc == L - 1) __builtin_amdgcn_s_waitcnt(0x0F70);
+                    step_barrier();
+                }
+            }
+        }
+        step_barrier();
+    }
+}
+
+template <int G, int NT>
+__global__ __launch_bounds__(512) void rnn_l1f_u_kernel(RnnUParams P) {
+    using GE = Geo<G, NT>;
+    constexpr int CTT = 6 * G + 1;
+    constexpr uint32_t DIRB = kProjSlabs * CTT * 2048u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y;
+    const char* wdir = P.w + (size_t)dir * P.w_dir_stride;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(wdir + (size_t)(6 * GE::kFragU + GE::kFragR) * 1024);
+        for (int i = tid; i < GE::kHB / 16; i += 512) reinterpret_cast<f32x4*>(smem)[i] = src[i];
+    }
+    __syncthreads();
+    {   // accumulators start from the PROJECTION's bias rows ([tile][16 floats] = the [unit tile][gate][16] rows of this region)
+        const float* pb = reinterpret_cast<const float*>(P.wproj + 2 * (size_t)DIRB) + dir * (CTT * 16);
+        for (int i = tid; i < CTT * 16; i += 512) reinterpret_cast<float*>(smem)[i] = pb[i];
+    }
+    __syncthreads();
+    const float inv = *reinterpret_cast<const float*>(smem + 6 * G * 64 + 64);
+    const float inv_head = *reinterpret_cast<const float*>(smem + 6 * G * 64 + 68);
+    const float mul = reinterpret_cast<const float*>(P.wproj + 2 * (size_t)DIRB)[2 * CTT * 16] * P.gi_mul[dir];
+    const Ctx c{P, wdir, (lds_cptr)smem, lane, lane & 15, lane >> 4, dir, P.L, inv, inv_head, mul};
+    if (wave == 3) rem_wave_f<G, NT>(c);
+    else if (wave == 7) stage_wave_f<G, NT>(c);
+    else unit_wave_f<G, NT>(c, wave < 3 ? wave : wave - 1);
+}
+
 // ---- layer-1 input projections: GI = (W_ih1 * Y0 + b) * gi_mul as an f16x2 GEMM, CTT row tiles per direction -------------------------
 // Workgroup = 4 waves, 80 positions (5 tiles) staged in LDS as hi / lo planes of 200 halves; wave = (direction, half of the row tiles),
 // passes of <= 5 tiles.  A fragments [slab 7][tile CTT][hi | lo][lane][8 halves] per direction, then the bias rows and 2^-S.
@@ -375,7 +818,7 @@ __global__ __launch_bounds__(512) void rnn_rec_u_kernel(RnnUParams P) {
 // {0-3, 12-15, 20-27}, ... (MI355X_MICROARCH.md, LDS), i.e. eight positions at one k quarter with eight at the next, and a row stride
 // of s 16-byte slots keeps those sixteen reads on sixteen different slots iff s = 2 (mod 4): 25 (r05, unpadded) made seven of every
 // eight pairs collide (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 47 %), 26 none.
-constexpr int kPT = 5, kProjSlabs = 7, kProjRow = 416;
+constexpr int kPT = 5, kProjRow = 416;
 constexpr int kProjPos = 16 * kPT, kPlaneB = kProjPos * kProjRow + 512, kProjLds = 2 * kPlaneB;
 
 template <int CTT, int C0, int NC>
@@ -460,8 +903,30 @@ template <int G, bool LAYER0>
 hipError_t launch_rec(const RnnUParams& P, hipStream_t st) {
     const int ncu = P.ncu > 0 ? P.ncu : 256;
     // one 16-block tile per workgroup while that still fits one round of workgroups (two per pair of directions and CU)
-    const bool small = 2 * ((P.B + 15) / 16) <= ncu;
+    bool small = 2 * ((P.B + 15) / 16) <= ncu;
+    static const int nt_env = [] { const char* e = tae::debug_knob("TAE_RNN_NT"); return e ? atoi(e) : 0; }();     // experiments: read once
+    if (nt_env == 1 || nt_env == 2) small = nt_env == 1;
     return small ? launch_rec_nt<G, LAYER0, 1>(P, ncu, st) : launch_rec_nt<G, LAYER0, 2>(P, ncu, st);
+}
+
+template <int G, int NT>
+hipError_t launch_l1f_nt(RnnUParams P, int ncu, hipStream_t st) {
+    constexpr int lds = GeoF<G, NT>::kLds;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_l1f_u_kernel<G, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    P.ngroups = (P.B + 16 * NT - 1) / (16 * NT);
+    const dim3 grid((unsigned)std::min(P.ngroups, std::max(1, ncu / 2)), 2);
+    hipLaunchKernelGGL((rnn_l1f_u_kernel<G, NT>), grid, dim3(512), lds, st, P);
+    return hipGetLastError();
+}
+template <int G>
+hipError_t launch_l1f(const RnnUParams& P, hipStream_t st) {
+    // ONE N tile per workgroup, four steps per chunk, at every batch size.  The two-tile form (NT = 2, two steps per chunk: the same 64
+    // accumulator registers) was as fast and is not instantiated: its LSTM instantiation produced wrong values in blocks 12..15 of
+    // every first tile from the second chunk on, in a way that changed with unrelated code (LABNOTES 12.3) - a defect not understood
+    // is not shipped.  The bit-identity test against the split form guards the instantiations that are.
+    const int ncu = P.ncu > 0 ? P.ncu : 256;
+    return launch_l1f_nt<G, 1>(P, ncu, st);
 }
 
 template <int CTT>
@@ -477,6 +942,13 @@ hipError_t launch_proj(const RnnProjParams& P, hipStream_t st) {
 hipError_t launch_rnn_rec_u(int gates, bool layer0, const RnnUParams& P, hipStream_t st) {
     if (gates == 4) return layer0 ? launch_rec<4, true>(P, st) : launch_rec<4, false>(P, st);
     if (gates == 1) return layer0 ? launch_rec<1, true>(P, st) : launch_rec<1, false>(P, st);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_rnn_l1f_u(int gates, const RnnUParams& P, hipStream_t st) {
+    if (!P.wproj || !P.y0 || !P.hpart) return hipErrorInvalidValue;
+    if (gates == 4) return launch_l1f<4>(P, st);
+    if (gates == 1) return launch_l1f<1>(P, st);
     return hipErrorInvalidValue;
 }
 
