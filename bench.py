@@ -304,7 +304,8 @@ def time_other_config(name: str, cfg: TurboAEConfig, sd, B: int, dev, snr: float
     if cfg.generic:
         kern = "generic fp32 MFMA kernels: " + ("tae::gen_proj_mfma_kernel / tae::gen_rnn_mfma_kernel" if cfg.decoder == "TurboAE_rate3_rnn" else "tae::gen_conv_mfma_kernel")
     elif cfg.decoder == "TurboAE_rate3_rnn" and cfg.dec_rnn != "gru":
-        kern = f"rnn_rec_u<layer 0> / rnn_proj_u / rnn_rec_u<layer 1> / gru_head_part x {2 * cfg.num_iteration} stacks ({cfg.dec_rnn.upper()} decoder, unit-split f16x2 kernels)"
+        kern = (f"rnn_rec_u<layer 0> / rnn_l1f_u (layer 1: projection + recurrence + head tile; batches below 6 blocks per CU: rnn_proj_u + rnn_rec_u) / "
+                f"gru_head_part x {2 * cfg.num_iteration} stacks ({cfg.dec_rnn.upper()} decoder, unit-split f16x2 kernels)")
     elif cfg.decoder == "TurboAE_rate3_rnn":
         kern = ("gru_rec_h<layer 0> / gru_l1f / gru_head_part" if is_h2 else "gru_rec / gru_proj / gru_head") + f" x {2 * cfg.num_iteration} stacks (GRU decoder)"
     elif nb == 0:

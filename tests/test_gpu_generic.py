@@ -56,19 +56,29 @@ def test_generic_configurations_match_reference_golden(gpu_device, name):
     assert torch.equal(model.dec(torch.from_numpy(codes + g["noise"]).to(gpu_device)).cpu(), torch.from_numpy(xd))
 
 
-@pytest.mark.parametrize("name", ["gen_dec_lstm", "gen_dec_rnn_tanh"])
-def test_lstm_and_rnn_decoders_on_the_unit_split_f16x2_kernels(gpu_device, name):
+@pytest.mark.parametrize("form", ["auto", "fused"])
+@pytest.mark.parametrize("name", ["gen_dec_lstm", "gen_dec_rnn_tanh", "fwd_lstm_u100_L100_b3_it3", "fwd_rnntanh_u100_L64_b3_it2",
+                                  "fwd_encrnn_declstm_u100_L64_b3_it2"])
+def test_lstm_and_rnn_decoders_on_the_unit_split_f16x2_kernels(gpu_device, monkeypatch, name, form):
     """`-dec_rnn lstm | rnn` (decoders.py:27-32) behind the CNN encoder run on turboae_rnn_u.hip in the default
     arithmetic - the reference's golden vectors, the GRU tests' tolerances; the generic fp32 kernels stay the second implementation
-    (precision = f32) and agree with it."""
+    (precision = f32) and agree with it.  r06: the goldens' small batches run layer 1 as projection + recurrence; `fused` forces
+    rnn_l1f_u_kernel (what full batches run) onto the same reference vectors."""
     from dataclasses import replace
     meta = MANIFEST["cases"][name]
     cfg = TurboAEConfig(**meta["config"])
     assert not cfg.generic and cfg.decoder == "TurboAE_rate3_rnn" and cfg.dec_rnn in ("lstm", "rnn")
+    if form == "fused":
+        monkeypatch.setenv("TAE_DEBUG_KNOBS", "1")
+        monkeypatch.setenv("TAE_RNN_L1", "fused")
+    else:
+        monkeypatch.delenv("TAE_RNN_L1", raising=False)
     model, g, xd, codes = _run(gpu_device, cfg, meta, name)
+    if form == "fused":
+        assert "TAE_RNN_L1=fused" in model.overrides()
     assert model.range_status() == ("f16x2", False)
     assert np.abs(codes - g["codes"]).max() <= 1e-5
-    d = note(f"golden_u:{name}", np.abs(xd - g["x_dec"]).max())
+    d = note(f"golden_u:{name}:{form}", np.abs(xd - g["x_dec"]).max())
     assert d <= ATOL_XDEC_RNN, d
     flips = (xd > 0.5) != (g["x_dec"] > 0.5)
     assert np.all(np.abs(g["logits"][flips]) < 2e-4)

@@ -39,6 +39,7 @@ BENCH_KERNELS = [r"tae::dec_kernel_h<100, 5, false", r"tae::enc_kernel_h<100, 5,
                  r"tae::dec_kernel<100, 5, false>", r"tae::enc_kernel<100, 5>",
                  r"tae::gru_rec_h_kernel<true>", r"tae::gru_rec0u_kernel", r"tae::(anonymous namespace)::gru_l1f_kernel", r"tae::gru_head_part_kernel",
                  r"tae::(anonymous namespace)::rnn_rec_u_kernel<4, ", r"tae::(anonymous namespace)::rnn_proj_u_kernel<25>",      # LSTM decoder line
+                 r"tae::(anonymous namespace)::rnn_l1f_u_kernel<4, 1>",                                                              # ... its fused layer 1 (r06)
                  # roofline.generic_configs (LSTM decoder, 256-wide CNN pair) and what bench.py times beside the kernels above
                  r"tae::(anonymous namespace)::gen_conv_mfma_kernel", r"tae::(anonymous namespace)::gen_proj_mfma_kernel",
                  r"tae::(anonymous namespace)::gen_rnn_mfma_kernel", r"tae::normalize_kernel", r"tae::count_errors_vec4_kernel"]

@@ -18,7 +18,7 @@ for r in rows: gmax[r["Kernel_Name"]] = max(gmax[r["Kernel_Name"]], int(r.get("G
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in rows:
     k = r["Kernel_Name"]
-    if not any(s in k for s in ("gru_", "rnn_rec_u", "rnn_proj_u")) or int(r.get("Grid_Size", 0) or 0) != gmax[k]: continue
+    if not any(s in k for s in ("gru_", "rnn_rec_u", "rnn_proj_u", "rnn_l1f_u")) or int(r.get("Grid_Size", 0) or 0) != gmax[k]: continue
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
 with open(sys.argv[2], "a") as fh:
     for k in sorted(agg):

@@ -33,6 +33,6 @@ for i in range(n):
     k = B // 2
     sub = torch.equal(model.dec((codes + torch.from_numpy(noise).to(dev))[k:k + 1].contiguous()), xd[k:k + 1])
     worst = max(worst, dx)
-    flag = "" if (dc <= 1e-5 and dx <= 1e-5 and sub and mode == ("f16x2", False)) else "   <-- FAIL"
+    flag = "" if (dc <= 1e-5 and dx <= 1e-5 and sub and mode == ("f16x2", False)) else "   <-- FAIL"      # TAE_DEBUG_KNOBS=1 TAE_RNN_L1=fused in the environment: the fused layer 1 at these (small) batches
     print(f"{i:3d} {cell:4s} B={B:3d} L={L:3d} U={U:3d} F={cfg.num_iter_ft} it={cfg.num_iteration} ex={cfg.extrinsic} act={cfg.dec_act:7s} dc={dc:.1e} dx={dx:.1e} sub={sub} {mode}{flag}", flush=True)
 print("worst dx", worst)

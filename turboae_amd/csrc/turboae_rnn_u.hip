@@ -412,9 +412,9 @@ template <int G, int NT> struct GeoF {
     static constexpr int NS = NT * kTC;                          // N-tile-steps of a chunk, ns = tc * NT + nt
     static constexpr int kTileB = 14 * 1024;                     // B fragments of one N-tile-step: [slab 7][hi | lo][lane][8 halves]
     static constexpr int kYB = GE::kXB;                          // layer 1 stages no x_t: the region begins where layer 0's would
-    static constexpr int kHR = kYB + NS * kTileB;                // W_hh fragments of the unit waves kept in LDS instead of registers, [ut][gate][2][1 KB]:
-    static constexpr int kLds = kHR + 6 * G * 2048;              // the remainder slab and slab 2's lo halves - 32 registers a wave that the chunk's
-                                                                 // accumulators need (LSTM, two N tiles: 256 registers and 20 spilled without)
+    static constexpr int kHR = kYB + NS * kTileB;                // W_hh fragments of the unit waves kept in LDS instead of registers, [ut][gate][3][1 KB]:
+    static constexpr int kLds = kHR + 6 * G * 3072;              // the remainder slab and the lo halves of slabs 1, 2 - 48 registers a wave that the
+                                                                 // chunk's accumulators need (LSTM: 256 registers and 20 spilled with all of W_hh in registers)
     static constexpr int GB = G < 2 ? G : 2;                     // a block of the P phase: GB gates x NB N-tile-steps = independent accumulators
     static constexpr int NB = (4 / GB) < NS ? (4 / GB) : NS;
 };
@@ -428,16 +428,16 @@ __device__ __forceinline__ void unit_wave_f(const Ctx& c, int ut) {
     constexpr uint32_t DIRB = kProjSlabs * CTT * 2048u;
     const int lane = c.lane, L = c.L, n = c.n, q = c.q, dir = c.dir;
     const char* wr = c.wdir + (size_t)ut * GE::kFragU * 1024 + lane * 16;
-    h8 hh_hi[3][G], hh_lo[2][G];
-    const lds_cptr hrl = c.lds + GF::kHR + (ut * G) * 2048 + lane * 16;
+    h8 hh_hi[3][G], hh_lo[1][G];
+    const lds_cptr hrl = c.lds + GF::kHR + (ut * G) * 3072 + lane * 16;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
 #pragma unroll
         for (int sl = 0; sl < 3; ++sl) hh_hi[sl][g] = glb_h8(wr + (g * 8 + 2 * sl) * 1024);
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) hh_lo[sl][g] = glb_h8(wr + (g * 8 + 2 * sl + 1) * 1024);
-        *reinterpret_cast<lds_w4*>((lds_ptr)hrl + g * 2048) = *reinterpret_cast<const u32x4v*>(wr + (g * 8 + 6) * 1024);             // read back by this wave only
-        *reinterpret_cast<lds_w4*>((lds_ptr)hrl + g * 2048 + 1024) = *reinterpret_cast<const u32x4v*>(wr + (g * 8 + 5) * 1024);      // slab 2, lo
+        hh_lo[0][g] = glb_h8(wr + (g * 8 + 1) * 1024);
+        *reinterpret_cast<lds_w4*>((lds_ptr)hrl + g * 3072) = *reinterpret_cast<const u32x4v*>(wr + (g * 8 + 6) * 1024);             // read back by this wave only
+        *reinterpret_cast<lds_w4*>((lds_ptr)hrl + g * 3072 + 1024) = *reinterpret_cast<const u32x4v*>(wr + (g * 8 + 5) * 1024);      // slab 2, lo
+        *reinterpret_cast<lds_w4*>((lds_ptr)hrl + g * 3072 + 2048) = *reinterpret_cast<const u32x4v*>(wr + (g * 8 + 3) * 1024);      // slab 1, lo
     }
     const lds_cptr bias = c.lds + ut * (G * 64) + q * 16;          // the PROJECTION's bias rows (the kernel prologue put them there)
     const lds_cptr hb = c.lds + GE::kHB + lane * 16, yb = c.lds + GF::kYB + lane * 16;
@@ -544,15 +544,17 @@ __device__ __forceinline__ void unit_wave_f(const Ctx& c, int ut) {
 #pragma unroll
                     for (int nt = 0; nt < kNT; ++nt) {
                         const lds_cptr hc = hb + p0 * kHBsz + nt * 8192;
-#pragma unroll
-                        for (int sl = 0; sl < 2; ++sl) mma_g<G>(gi[tc * kNT + nt], hh_hi[sl], hh_lo[sl], lds_h8(hc + sl * 2048), lds_h8(hc + sl * 2048 + 1024));
+                        mma_g<G>(gi[tc * kNT + nt], hh_hi[0], hh_lo[0], lds_h8(hc), lds_h8(hc + 1024));
                         h8 hh_l2[G], hh_r[G];
+#pragma unroll
+                        for (int g = 0; g < G; ++g) hh_l2[g] = lds_h8(hrl + g * 3072 + 2048);
+                        mma_g<G>(gi[tc * kNT + nt], hh_hi[1], hh_l2, lds_h8(hc + 2048), lds_h8(hc + 2048 + 1024));
 #ifdef TAE_L1F_DBG_HREG
 #pragma unroll
                         for (int g = 0; g < G; ++g) hh_l2[g] = glb_h8(wr + (g * 8 + 5) * 1024);
 #else
 #pragma unroll
-                        for (int g = 0; g < G; ++g) hh_l2[g] = lds_h8(hrl + g * 2048 + 1024);
+                        for (int g = 0; g < G; ++g) hh_l2[g] = lds_h8(hrl + g * 3072 + 1024);
 #endif
                         mma_g<G>(gi[tc * kNT + nt], hh_hi[2], hh_l2, lds_h8(hc + 2 * 2048), lds_h8(hc + 2 * 2048 + 1024));
 #ifdef TAE_L1F_DBG_HREG
@@ -560,7 +562,7 @@ __device__ __forceinline__ void unit_wave_f(const Ctx& c, int ut) {
                         for (int g = 0; g < G; ++g) hh_r[g] = glb_h8(wr + (g * 8 + 6) * 1024);
 #else
 #pragma unroll
-                        for (int g = 0; g < G; ++g) hh_r[g] = lds_h8(hrl + g * 2048);
+                        for (int g = 0; g < G; ++g) hh_r[g] = lds_h8(hrl + g * 3072);
 #endif
                         mma_gr<G>(gi[tc * kNT + nt], hh_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
                     }
