@@ -62,24 +62,9 @@ __device__ __forceinline__ h8 glb_h8(const char* p) { return __builtin_bit_cast(
 
 // LDS writes of this wave are done and visible, then the workgroup barrier (LDS-only fence: global loads / stores stay in flight)
 __device__ __forceinline__ void step_barrier() {
-#ifdef TAE_L1F_DBG_SYNC
-    __syncthreads();
-    return;
-#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
-// gfx950 hazard guard (r06, found with rnn_l1f_u_kernel<4, 2>): a vector-ALU write to a register that an MFMA issued a few cycles earlier
-// still reads as srcB corrupts that MFMA's LAST columns (blocks 12..15 of the tile) - the compiler reuses dead operand registers for
-// gate temporaries without wait states.  mfma_drain() keeps the matrix pipe's in-flight reads ahead of what follows.
-__device__ __forceinline__ void mfma_drain() {
-#ifndef TAE_L1F_NO_DRAIN
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 15\n\ts_nop 15");
-    __builtin_amdgcn_sched_barrier(0);
-#endif
 }
 
 template <int N, class F, int I = 0>
@@ -212,9 +197,6 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
                     hn[i] = cell<G>(a, cc);
                     cs[nt][i] = cc;
                 }
-#ifdef TAE_L1F_DBG_H
-                if (!LAYER0 && grp == 0 && (lane == 12) && nt == 0 && dir == 0) printf("H dir %d s %d nt %d ut %d lane %d: %.9g %.9g c %.9g acc %.9g %.9g %.9g %.9g\n", dir, s, nt, ut, lane, hn[0], hn[1], cs[nt][0], acc[nt][0][0], acc[nt][1][0], acc[nt][2][0], acc[nt][3][0]);
-#endif
                 h4 nhi, nlo;
                 split4(hn, nhi, nlo);
                 const lds_ptr hn_w = hw + p1 * kHBsz + nt * 8192;
@@ -279,9 +261,6 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
 #pragma unroll
             for (int sl = 0; sl < 3; ++sl) mma1(a, hd_hi[sl], hd_lo[sl], lds_h8(hc + sl * 2048), lds_h8(hc + sl * 2048 + 1024));
             mma1r(a, hd_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
-#ifdef TAE_L1F_DBG_H
-            if (grp == 0 && (lane == 12) && nt == 0 && dir == 0) printf("HEAD dir %d t %d nt %d lane %d: %.9g %.9g\n", dir, t, nt, lane, a[0] * inv_head, a[1] * inv_head);
-#endif
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, a * inv_head), rs_h[nt], v_h, (uint32_t)t * 1024u, 0);
         };
         float cs[kNT];
@@ -315,9 +294,6 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) a[g] = acc[g] * inv;
                 const float hr = cell<G>(a, cs[nt]);
-#ifdef TAE_L1F_DBG_H
-                if (!LAYER0 && grp == 0 && (lane == 12) && nt == 0 && dir == 0) printf("R dir %d s %d nt %d lane %d: %.9g c %.9g acc %.9g\n", dir, s, nt, lane, hr, cs[nt], acc[0]);
-#endif
                 const _Float16 hi = (_Float16)hr;
                 const _Float16 lo = (_Float16)(hr - (float)hi);
                 const h8 b1 = {lo, 0, 0, 0, hi, 0, 0, 0}, b2 = {hi, 0, 0, 0, 0, 0, 0, 0};
@@ -467,9 +443,6 @@ __device__ __forceinline__ void unit_wave_f(const Ctx& c, int ut) {
 #pragma unroll 1
         for (int s0 = 0; s0 < L; s0 += kTC) {
             // ---- P phase -------------------------------------------------------------------------------------------------------
-#ifdef TAE_L1F_DBG_NOPRE
-            if (s0 > 0) static_for<GB>(a_issue);
-#endif
             f32x4 gi[NS][G];
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns)
@@ -502,10 +475,7 @@ __device__ __forceinline__ void unit_wave_f(const Ctx& c, int ut) {
                     __builtin_amdgcn_sched_barrier(0);      // one block at a time: hoisted operand reads of later blocks cost registers the chunk's accumulators need
                 }
             });
-#ifndef TAE_L1F_DBG_NOPRE
             static_for<GB>(a_issue);                             // the next chunk's first block: in flight through the whole R phase
-#endif
-            mfma_drain();
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
@@ -533,14 +503,6 @@ __device__ __forceinline__ void unit_wave_f(const Ctx& c, int ut) {
                 const int s = s0 + tc;
                 if (s < L) {
                     const int p0 = s & 1, p1 = p0 ^ 1;
-#ifdef TAE_L1F_DBG_H
-                    if (s == 0 && grp == 0 && ut == 0 && dir == 0) {
-                        for (int f = 0; f < 8; ++f) {
-                            const u32x4v v = *reinterpret_cast<lds_q4*>(hb + f * 1024);
-                            if (v.x | v.y | v.z | v.w) printf("HB0 nonzero frag %d lane %d: %08x %08x %08x %08x\n", f, lane, v.x, v.y, v.z, v.w);
-                        }
-                    }
-#endif
 #pragma unroll
                     for (int nt = 0; nt < kNT; ++nt) {
                         const lds_cptr hc = hb + p0 * kHBsz + nt * 8192;
@@ -549,24 +511,13 @@ __device__ __forceinline__ void unit_wave_f(const Ctx& c, int ut) {
 #pragma unroll
                         for (int g = 0; g < G; ++g) hh_l2[g] = lds_h8(hrl + g * 3072 + 2048);
                         mma_g<G>(gi[tc * kNT + nt], hh_hi[1], hh_l2, lds_h8(hc + 2048), lds_h8(hc + 2048 + 1024));
-#ifdef TAE_L1F_DBG_HREG
-#pragma unroll
-                        for (int g = 0; g < G; ++g) hh_l2[g] = glb_h8(wr + (g * 8 + 5) * 1024);
-#else
 #pragma unroll
                         for (int g = 0; g < G; ++g) hh_l2[g] = lds_h8(hrl + g * 3072 + 1024);
-#endif
                         mma_g<G>(gi[tc * kNT + nt], hh_hi[2], hh_l2, lds_h8(hc + 2 * 2048), lds_h8(hc + 2 * 2048 + 1024));
-#ifdef TAE_L1F_DBG_HREG
-#pragma unroll
-                        for (int g = 0; g < G; ++g) hh_r[g] = glb_h8(wr + (g * 8 + 6) * 1024);
-#else
 #pragma unroll
                         for (int g = 0; g < G; ++g) hh_r[g] = lds_h8(hrl + g * 3072);
-#endif
                         mma_gr<G>(gi[tc * kNT + nt], hh_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
                     }
-                    mfma_drain();
 #pragma unroll
                     for (int nt = 0; nt < kNT; ++nt) {
                         f32x4 hn;
@@ -579,9 +530,6 @@ __device__ __forceinline__ void unit_wave_f(const Ctx& c, int ut) {
                             hn[i] = cell<G>(a, cc);
                             cs[nt][i] = cc;
                         }
-#ifdef TAE_L1F_DBG_H
-                        if (grp == 0 && (lane == 12) && nt == 0 && dir == 0) printf("H dir %d s %d nt %d ut %d lane %d: %.9g %.9g c %.9g acc %.9g %.9g %.9g %.9g\n", dir, s, nt, ut, lane, hn[0], hn[1], cs[nt][0], gi[tc * kNT + nt][0][0], gi[tc * kNT + nt][1][0], gi[tc * kNT + nt][2][0], gi[tc * kNT + nt][3][0]);
-#endif
                         h4 nhi, nlo;
                         split4(hn, nhi, nlo);
                         const lds_ptr hn_w = hw + p1 * kHBsz + nt * 8192;
@@ -638,10 +586,6 @@ __device__ __forceinline__ void rem_wave_f(const Ctx& c) {
 #pragma unroll
             for (int sl = 0; sl < 3; ++sl) mma1(a, hd_hi[sl], hd_lo[sl], lds_h8(hc + sl * 2048), lds_h8(hc + sl * 2048 + 1024));
             mma1r(a, hd_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
-            mfma_drain();
-#ifdef TAE_L1F_DBG_H
-            if (grp == 0 && (lane == 12) && nt == 0 && dir == 0) printf("HEAD dir %d t %d nt %d lane %d: %.9g %.9g\n", dir, t, nt, lane, a[0] * inv_head, a[1] * inv_head);
-#endif
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, a * inv_head), rs_h[nt], v_h, (uint32_t)t * 1024u, 0);
         };
         float cs[kNT];
@@ -666,7 +610,6 @@ __device__ __forceinline__ void rem_wave_f(const Ctx& c) {
                     gi[ns] = mfma16x16x32h(pa_hi[sl], bh, gi[ns]);
                     gi[ns] = mfma16x16x32h(pa_lo[sl], bh, gi[ns]);
                 }
-            mfma_drain();
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns) gi[ns] *= mul;
 #ifdef TAE_L1F_DBG_GI
@@ -696,14 +639,10 @@ __device__ __forceinline__ void rem_wave_f(const Ctx& c) {
                         for (int sl = 0; sl < 3; ++sl) mma1(acc, hh_hi[sl], hh_lo[sl], lds_h8(hc + sl * 2048), lds_h8(hc + sl * 2048 + 1024));
                         mma1r(acc, hh_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
                         if (s > 0) head(hc, nt, dir ? L - s : s - 1);        // Linear head on h_{s-1} (the state this step started from)
-                        mfma_drain();
                         float a[G];
 #pragma unroll
                         for (int g = 0; g < G; ++g) a[g] = acc[g] * inv;
                         const float hr = cell<G>(a, cs[nt]);
-#ifdef TAE_L1F_DBG_H
-                        if (grp == 0 && (lane == 12) && nt == 0 && dir == 0) printf("R dir %d s %d nt %d lane %d: %.9g c %.9g acc %.9g\n", dir, s, nt, lane, hr, cs[nt], acc[0]);
-#endif
                         const _Float16 hi = (_Float16)hr;
                         const _Float16 lo = (_Float16)(hr - (float)hi);
                         const h8 b1 = {lo, 0, 0, 0, hi, 0, 0, 0}, b2 = {hi, 0, 0, 0, 0, 0, 0, 0};
@@ -743,25 +682,11 @@ __device__ __forceinline__ void stage_wave_f(const Ctx& c) {
 #pragma unroll
                 for (int nt = 0; nt < kNT; ++nt) {
                     const lds_ptr y = ybu + (tc * kNT + nt) * GF::kTileB;
-#ifdef TAE_L1F_DBG_NODMA
-                    u32x4v tmp[2 * kProjSlabs];
-#pragma unroll
-                    for (int sl = 0; sl < kProjSlabs; ++sl) {
-                        tmp[2 * sl] = __builtin_amdgcn_raw_buffer_load_b128(rs[nt], v0 + sl * 64, so, 0);
-                        tmp[2 * sl + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs[nt], v0 + 400 + sl * 64, so, 0);
-                    }
-#pragma unroll
-                    for (int f = 0; f < 2 * kProjSlabs; ++f) *reinterpret_cast<lds_w4*>(y + f * 1024 + c.lane * 16) = tmp[f];
-#else
 #pragma unroll
                     for (int sl = 0; sl < kProjSlabs; ++sl) {
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[nt], y + (2 * sl) * 1024, 16, v0 + sl * 64, so, 0, 0);
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[nt], y + (2 * sl + 1) * 1024, 16, v0 + 400 + sl * 64, so, 0, 0);
                     }
-#endif
-#ifdef TAE_L1F_DBG_WAIT
-                    __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
                 }
             }
         };
