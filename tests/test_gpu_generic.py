@@ -146,6 +146,26 @@ def test_rnn_layer1_forms_are_bit_identical(gpu_device, monkeypatch, cell, B, L,
         assert np.abs(xa.cpu().numpy() - xo.numpy()).max() <= ATOL_XDEC_RNN
 
 
+def test_lstm_eval_sweep_as_hipgraphs_on_the_fused_layer1(gpu_device):
+    """evaluate.test (trainer.test restated) on a reference-trained LSTM decoder at a batch the fused layer-1 kernel serves (2 048 blocks
+    per call >= 6 per CU): one hipGraph per SNR point gives the eager sweep's counts, eval_snr (the C sweep entry) agrees, and the BER at
+    2 dB sits where the reference measured this network."""
+    from turboae_amd import Channel_AE_HIP, evaluate
+    cfg = TurboAEConfig(decoder="TurboAE_rate3_rnn", dec_rnn="lstm")
+    sd = W.unpack_blob(cfg, np.load(os.path.join(GOLD, "trained_cnn_lstm_u100_fp32.npz"))["weights_fp32"])
+    B = 2048
+    model = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    kw = dict(snr_test_start=1.0, snr_test_end=3.0, snr_points=3, num_block=2 * B, batch_size=B, seed=11, verbose=False)
+    res = evaluate.test(model, **kw)
+    gr = evaluate.test(model, hip_graph=True, **kw)
+    assert gr["bit_errors"] == res["bit_errors"] and gr["block_errors"] == res["block_errors"]
+    c = model.eval_snr(res["snrs"][1], B, 2, seed=11, first_block=2 * B).sum(dim=0).cpu().tolist()
+    assert c == [res["bit_errors"][1], res["block_errors"][1]]
+    ref = MANIFEST["trained_cnn_lstm_fp32"]["ber"]["2dB"]
+    assert abs(res["ber"][1] - ref) <= 0.15 * ref, (res["ber"][1], ref)
+    model.check_range()
+
+
 @pytest.mark.parametrize("name", ["fwd_dense_u100_L100_b3_it2", "fwd_dense_k3_k1_u32_L64", "var_kernel_e7_d9", "var_kernel_e9_d7_L500"])
 def test_precision_f32_for_dense_stacks_and_kernel_sizes_7_9(gpu_device, name):
     """the second arithmetic for the variants the fp32 MFMA kernels do not cover: the same reference vectors, fp32 end to end"""
