@@ -115,7 +115,7 @@ def test_lstm_rnn_unit_split_kernels_batch_independence_and_oracle(gpu_device, c
 
 @pytest.mark.parametrize("cell,B,L,U", [("lstm", 1, 100, 100), ("lstm", 37, 100, 100), ("rnn", 70, 33, 100), ("lstm", 5, 7, 100), ("lstm", 33, 1, 64),
                                          ("rnn", 16, 2, 100), ("lstm", 16, 3, 100), ("lstm", 500, 100, 100), ("rnn", 2100, 40, 80), ("lstm", 2049, 101, 100),
-                                         ("lstm", 16400, 9, 100)])
+                                         ("lstm", 16400, 9, 100), ("lstm", 1650, 1000, 100), ("rnn", 3000, 321, 100)])
 def test_rnn_layer1_forms_are_bit_identical(gpu_device, monkeypatch, cell, B, L, U):
     """Layer 1 of the LSTM / vanilla-RNN decoder stacks exists in two forms: rnn_l1f_u_kernel (r06: the input projection inside the
     recurrence, four steps at a time, GI never written) and the r05 pair rnn_proj_u -> rnn_rec_u<layer 1>.  The library picks by
