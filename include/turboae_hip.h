@@ -79,7 +79,8 @@ typedef struct tae_config {
                                  level; exists to price the fp32-tolerance requirement (bench.py `f16x1_*`), carries no parity claim */
     int32_t dec_act;          /* -dec_act (get_args.py:101, decoders.py:59-73): TAE_ACT_* on the GRU decoder's Linear outputs (DEC_LargeCNN
                                  has no dec_act; ignored for dec_type = 0).  The reference default is TAE_ACT_LINEAR (= 1, NOT 0) */
-    int32_t enc_rnn;          /* -enc_rnn (get_args.py:79, encoders.py:242-247): TAE_RNN_GRU / LSTM / RNN cell of ENC_interRNN (enc_type = 1) */
+    int32_t enc_rnn;          /* -enc_rnn (get_args.py:79, encoders.py:242-247): TAE_RNN_GRU / LSTM / RNN cell of ENC_interRNN (enc_type = 1); since r06 every cell
+                                 runs on tuned kernels with enc_num_layer = 2 in TAE_PREC_AUTO, whatever cell the decoder uses */
     int32_t dec_rnn;          /* -dec_rnn (get_args.py:80, decoders.py:27-32): the cell of DEC_LargeRNN (dec_type = 1) */
     int32_t range_calibration;/* fp16-split conv kernels (no reference counterpart: the reference's fp32 F.conv1d, cnn_utils.py:36-46, has 24
                                  significant bits at any magnitude; an fp16 hi/lo pair has them only for values in about [2^-3, 2^16)):
@@ -100,7 +101,8 @@ typedef struct tae_config {
 /* Configurations the fused MFMA kernels do not instantiate run on generic fp32 kernels (one launch per layer, fp32 operands on the
  * fp32 matrix cores, activations through HBM: 3..8 times slower than the kernels above, same results): channel widths 125..1024
  * (recurrent cells: 101..1024), odd kernel sizes 11..63,
- * num_iter_ft 7..64, LSTM / vanilla-RNN cells, ENC_interRNN with enc_num_layer != 2 or in front of a CNN decoder (which the
+ * num_iter_ft 7..64, LSTM / vanilla-RNN cells in TAE_PREC_F32 (in TAE_PREC_AUTO they have unit-split fp16-split kernels of their own, decoder
+ * and 2-layer encoder alike), ENC_interRNN with enc_num_layer != 2 or in front of a CNN decoder (which the
  * reference then builds from DenseSameShapeConv1d, decoders.py:173-176), and TAE_PREC_F32 for dense stacks / kernel sizes 7, 9. */
 #define TAE_RNN_GRU 0
 #define TAE_RNN_LSTM 1

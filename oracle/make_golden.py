@@ -119,6 +119,11 @@ CASES = [
     # r06: ENC_interRNN (GRU) in front of an LSTM decoder - GRU kernels for the encoder, unit-split LSTM kernels for the decoder in one handle
     ("fwd_encrnn_declstm_u100_L64_b3_it2", dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", dec_rnn="lstm", num_iteration=2, block_len=64),
      3, 65, 1.0, 2.0),
+    # r06: LSTM / vanilla-RNN cells in ENC_interRNN itself (-enc_rnn lstm | rnn, encoders.py:242-253; 2 layers) on the unit-split kernels
+    ("fwd_rnn_enclstm_decgru_u100_L64_b3_it2", dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_rnn="lstm", num_iteration=2, block_len=64),
+     3, 68, 1.0, 2.0),
+    ("fwd_rnn_encrnn_declstm_e64_d48_L40_b3", dict(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_rnn="rnn", dec_rnn="lstm", enc_num_unit=64,
+                                                   dec_num_unit=48, num_iteration=1, block_len=40, enc_act="tanh"), 3, 67, 1.0, 2.0),
 ]
 
 FADING_SEED = 20190020
@@ -127,7 +132,7 @@ FADING_SEED = 20190020
 # iteration), captured from the REAL reference with forward hooks on its dec1_outputs / dec2_outputs Linear modules
 TAP_CASES = ("fwd_enc2dec5_u100_L100_b4", "fwd_u32_L100_b8", "fwd_u32_L64_b6_ft3_noext", "fwd_u100_L1000_b2", "fwd_u100_L150_b3_it2",
              # r06: DEC_LargeRNN has the same dec{1,2}_outputs Linear modules (decoders.py:60-66,84-149); the same hooks give its taps
-             "fwd_rnn_u100_L100_b4", "fwd_rnn_u100_L40_b3_it2_ft3", "fwd_lstm_u100_L100_b3_it3", "fwd_rnntanh_u100_L64_b3_it2", "gen_dec_lstm", "fwd_encrnn_declstm_u100_L64_b3_it2")
+             "fwd_rnn_u100_L100_b4", "fwd_rnn_u100_L40_b3_it2_ft3", "fwd_lstm_u100_L100_b3_it3", "fwd_rnntanh_u100_L64_b3_it2", "gen_dec_lstm", "fwd_encrnn_declstm_u100_L64_b3_it2", "fwd_rnn_enclstm_decgru_u100_L64_b3_it2")
 
 
 def reference_taps(model, cfg, u, noise):

@@ -58,7 +58,7 @@ def test_generic_configurations_match_reference_golden(gpu_device, name):
 
 @pytest.mark.parametrize("form", ["auto", "fused"])
 @pytest.mark.parametrize("name", ["gen_dec_lstm", "gen_dec_rnn_tanh", "fwd_lstm_u100_L100_b3_it3", "fwd_rnntanh_u100_L64_b3_it2",
-                                  "fwd_encrnn_declstm_u100_L64_b3_it2"])
+                                  "fwd_encrnn_declstm_u100_L64_b3_it2", "fwd_rnn_encrnn_declstm_e64_d48_L40_b3", "fwd_rnn_enclstm_decgru_u100_L64_b3_it2"])
 def test_lstm_and_rnn_decoders_on_the_unit_split_f16x2_kernels(gpu_device, monkeypatch, name, form):
     """`-dec_rnn lstm | rnn` (decoders.py:27-32) behind the CNN encoder run on turboae_rnn_u.hip in the default
     arithmetic - the reference's golden vectors, the GRU tests' tolerances; the generic fp32 kernels stay the second implementation
@@ -67,7 +67,7 @@ def test_lstm_and_rnn_decoders_on_the_unit_split_f16x2_kernels(gpu_device, monke
     from dataclasses import replace
     meta = MANIFEST["cases"][name]
     cfg = TurboAEConfig(**meta["config"])
-    assert not cfg.generic and cfg.decoder == "TurboAE_rate3_rnn" and cfg.dec_rnn in ("lstm", "rnn")
+    assert not cfg.generic and cfg.decoder == "TurboAE_rate3_rnn" and (cfg.dec_rnn in ("lstm", "rnn") or cfg.enc_rnn in ("lstm", "rnn"))
     if form == "fused":
         monkeypatch.setenv("TAE_DEBUG_KNOBS", "1")
         monkeypatch.setenv("TAE_RNN_L1", "fused")
@@ -144,6 +144,37 @@ def test_rnn_layer1_forms_are_bit_identical(gpu_device, monkeypatch, cell, B, L,
     if B * L <= 5000:
         xo, _ = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict(), {})
         assert np.abs(xa.cpu().numpy() - xo.numpy()).max() <= ATOL_XDEC_RNN
+
+
+@pytest.mark.parametrize("enc_rnn,dec_rnn", [("lstm", "gru"), ("rnn", "lstm"), ("lstm", "lstm")])
+def test_lstm_rnn_encoder_cells_on_the_tuned_kernels(gpu_device, monkeypatch, enc_rnn, dec_rnn):
+    """r06: -enc_rnn lstm | rnn (ENC_interRNN, encoders.py:242-253, 2 layers) on turboae_rnn_u.hip, in front of any recurrent decoder: a batch
+    large enough for the fused layer 1 (1 600 blocks >= 6 per CU) against the CPU oracle, and the split / fused forms bit-identical
+    (the encoder shares the decoder's chunk workspace: GI is sized for the wider of the two cells)."""
+    from turboae_amd import Channel_AE_HIP
+    cfg = TurboAEConfig(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_rnn=enc_rnn, dec_rnn=dec_rnn, block_len=24, num_iteration=1,
+                        enc_num_unit=100 if enc_rnn == "lstm" else 72)
+    assert not cfg.generic
+    B, L = 1600, cfg.block_len
+    sd = W.generate_state_dict(cfg, seed=321, gain=1.0)
+    u = philox.random_bits(29, 0, B * L).reshape(B, L, 1)
+    noise = (np.float32(O.snr_db2sigma(2.0)) * philox.random_normal(29, 0, B * L * 3)).reshape(B, L, 3).astype(np.float32)
+    ud, nd = torch.from_numpy(u).to(gpu_device), torch.from_numpy(noise).to(gpu_device)
+    out = {}
+    monkeypatch.setenv("TAE_DEBUG_KNOBS", "1")
+    for form in ("split", "fused"):
+        monkeypatch.setenv("TAE_RNN_L1", form)
+        m = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+        out[form] = [t.clone() for t in m(ud, nd)]
+        assert m.range_status() == ("f16x2", False)
+    assert torch.equal(out["split"][0], out["fused"][0]) and torch.equal(out["split"][1], out["fused"][1])
+    monkeypatch.delenv("TAE_RNN_L1")
+    m = Channel_AE_HIP(cfg, sd, device=gpu_device, max_batch=B)
+    xd, codes = m(ud, nd)
+    assert torch.equal(xd, out["fused"][0]) and torch.equal(codes, out["fused"][1])
+    xo, co = O.channel_ae_forward(torch.from_numpy(u), torch.from_numpy(noise), O.to_torch(sd), cfg.to_dict(), {})
+    assert np.abs(codes.cpu().numpy() - co.numpy()).max() <= 1e-5
+    assert note(f"oracle_enc:{enc_rnn}:{dec_rnn}", np.abs(xd.cpu().numpy() - xo.numpy()).max()) <= ATOL_XDEC_RNN
 
 
 def test_lstm_eval_sweep_as_hipgraphs_on_the_fused_layer1(gpu_device):

@@ -113,6 +113,10 @@ def test_config_validation():
     for over in (dict(decoder="TurboAE_rate3_rnn"), dict(dec_num_unit=32), dict(block_len=321), dict(dec_num_unit=128, enc_num_unit=128)):
         with pytest.raises(ValueError):
             TurboAEConfig(precision="f16x1", **over).validate()
+    # r06: LSTM / vanilla-RNN cells in the 2-layer encoder itself run on the tuned kernels in precision auto, on the generic ones in f32
+    assert not TurboAEConfig(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_rnn="lstm").generic
+    assert TurboAEConfig(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_rnn="lstm", precision="f32").generic
+    assert TurboAEConfig(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", enc_rnn="rnn", enc_num_layer=1).generic
     # r06: the 2-layer GRU encoder in front of an LSTM / vanilla-RNN decoder runs on the tuned kernels (GRU kernels + turboae_rnn_u.hip)
     assert not TurboAEConfig(encoder="TurboAE_rate3_rnn", decoder="TurboAE_rate3_rnn", dec_rnn="lstm").generic
     # r05: LSTM / vanilla-RNN decoders behind the CNN encoder have unit-split f16x2 kernels (turboae_rnn_u.hip)

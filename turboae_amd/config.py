@@ -76,7 +76,8 @@ class TurboAEConfig:
         enc_max, dec_max = (100 if enc_rnn else cnn_max), (100 if dec_rnn else cnn_max)
         if max(ks) > 9 or self.enc_num_unit > enc_max or self.dec_num_unit > dec_max or self.num_iter_ft > 6:
             return True
-        if enc_rnn and self.enc_rnn != "gru":
+        # LSTM / vanilla-RNN encoder cells (2 layers): unit-split f16x2 kernels since r06; fp32 stays generic
+        if enc_rnn and self.enc_rnn != "gru" and self.precision == "f32":
             return True
         # LSTM / vanilla-RNN decoder: unit-split f16x2 kernels (csrc/turboae_rnn_u.hip) behind the CNN or the 2-layer GRU encoder; fp32 stays generic
         if dec_rnn and self.dec_rnn != "gru" and self.precision == "f32":

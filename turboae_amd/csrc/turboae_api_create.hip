@@ -793,7 +793,7 @@ void walk_weights(const tae_config* c, Fn&& f) {
     size_t U = c->enc_num_unit;
     const size_t F = c->num_iter_ft;
     for (int s = 0; s < 3; ++s) {
-        if (c->enc_type == 1) { f(false, rnn_stack_floats(U, 1, 1), 0, 0); continue; }
+        if (c->enc_type == 1) { f(false, rnn_stack_floats(U, 1, 1, (size_t)cell_gates(c->enc_rnn)), 0, 0); continue; }
         for (int l = 0; l < c->enc_num_layer; ++l) {
             f(true, U, c->dense ? 1 + l * U : (l == 0 ? 1 : U), (size_t)c->enc_kernel_size);
             f(false, U, 0, 0);
@@ -884,7 +884,7 @@ std::vector<float> embed_weights(const tae_config* c, const float* w, tae_config
         out_cfg->enc_num_unit = (int32_t)U2;
         out_cfg->enc_kernel_size = (int32_t)ks2;
         for (int s = 0; s < 3; ++s) {
-            if (c->enc_type == 1) { rnn(U, U2, 1, 1); continue; }
+            if (c->enc_type == 1) { rnn(U, U2, 1, 1, (size_t)cell_gates(c->enc_rnn)); continue; }
             // dense stacks (widths are exact there, check_cfg): layer l sees cat(input, out_0 .. out_{l-1}) = 1 + l * U channels
             for (int l = 0; l < c->enc_num_layer; ++l) {
                 if (c->dense) conv(U, U2, 1 + l * U, false, ks, ks2);
@@ -1245,7 +1245,7 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     h->dec_bytes = (uint32_t)(pdec.size() * sizeof(float));
     const float* src = weights;
     if (cfg->dense || big_taps) src = weights + n_weights;                 // dense stacks / kernel sizes 7, 9: f16x2 packing only (below)
-    else if (cfg->enc_type == 1) src += 3 * rnn_stack_floats(100, 1, 1);   // ENC_interRNN: packed with the GRU kernels' layouts below
+    else if (cfg->enc_type == 1) src += 3 * rnn_stack_floats(100, 1, 1, (size_t)cell_gates(cfg->enc_rnn));   // ENC_interRNN: packed with the recurrent kernels' layouts below
     else for (int s = 0; s < 3; ++s) src += pack_stack(src, lo, cfg->enc_num_layer, 1, 1, penc.data() + (size_t)s * h->enc_stride);
     const float* dec_src;                   // first decoder weight in the canonical blob
     {
@@ -1357,10 +1357,21 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
     TAE_HIP_H(hipMemcpy(h->d_wenc, penc.data(), penc.size() * sizeof(float), hipMemcpyHostToDevice));
     TAE_HIP_H(hipMemcpy(h->d_wdec, pdec.data(), pdec.size() * sizeof(float), hipMemcpyHostToDevice));
     h->dec_gates = cfg->dec_type == 1 ? cell_gates(cfg->dec_rnn) : 3;
+    h->enc_gates = cfg->enc_type == 1 ? cell_gates(cfg->enc_rnn) : 3;
     // ENC_interRNN (GRU cells, 2 layers) on the GRU kernels, whatever cell the decoder uses (r06: also in front of an LSTM / vanilla-RNN
     // decoder; the encoder shares the decoder's chunk workspace, not its kernels)
     auto pack_rnn_encoder = [&]() -> int {
         const std::vector<size_t> en(3, 1);
+        if (h->enc_gates != 3) {      // r06: LSTM / vanilla-RNN cells of ENC_interRNN (encoders.py:242-253) on the unit-split f16x2 kernels
+            if (h->prec != 1) { tae_destroy(h); return fail(TAE_EINVAL, "internal: the LSTM / RNN encoder kernels exist in the fp16-split arithmetic only"); }
+            size_t bytes = 0;
+            for (size_t nout : en) bytes += rnn_u_stack_bytes(nout, h->enc_gates);
+            std::vector<char> pu(bytes, 0);
+            repack_rnn_u(weights, pu.data(), 1, en, h->enc_gates, h->rnn_u_gimul_enc);
+            TAE_HIP_H(hipMalloc(&h->d_wernn_u, pu.size()));
+            TAE_HIP_H(hipMemcpy(h->d_wernn_u, pu.data(), pu.size(), hipMemcpyHostToDevice));
+            return TAE_OK;
+        }
         std::vector<float> pe(rnn_packed_floats(en), 0.0f);
         repack_rnn(weights, pe.data(), 100, 1, en);
         TAE_HIP_H(hipMalloc(&h->d_wernn, pe.size() * sizeof(float)));
@@ -1440,7 +1451,7 @@ int tae_destroy(tae_handle* h) {
     (void)hipFree(h->d_wrnn); (void)hipFree(h->d_gxa); (void)hipFree(h->d_gxb); (void)hipFree(h->d_gy0); (void)hipFree(h->d_gy1);
     (void)hipFree(h->d_ggi);
     (void)hipFree(h->d_wenc_h); (void)hipFree(h->d_wdec_h); (void)hipFree(h->d_flags); (void)hipFree(h->d_wrnn_h);
-    (void)hipFree(h->d_wernn); (void)hipFree(h->d_wernn_h); (void)hipFree(h->d_rnn_partials); (void)hipFree(h->d_wrnn_u);
+    (void)hipFree(h->d_wernn); (void)hipFree(h->d_wernn_h); (void)hipFree(h->d_rnn_partials); (void)hipFree(h->d_wrnn_u); (void)hipFree(h->d_wernn_u);
     (void)hipFree(h->d_eval_u); (void)hipFree(h->d_eval_noise); (void)hipFree(h->d_eval_xdec);
     delete h;
     return TAE_OK;
@@ -1488,11 +1499,14 @@ int tae_reserve(tae_handle* h, int32_t max_batch) {
         // r04 split form of the f16x2 path: the fused layer-1 kernel (turboae_gru_l1f.hip) never writes it
         // LSTM / RNN (r06): GI only where the split form of layer 1 runs - calls below rnn_l1_split_below(h) blocks (or every call with the
         // debug knob TAE_RNN_L1=split); the fused kernel never writes it
-        const bool rnn_u = h->dec_gates != 3;
-        const bool need_gi = rnn_u ? (h->rnn_l1_mode != 2 || h->rnn_l1_check) : (h->prec != 1 || h->gru_l1_split);
-        const size_t gi_row = (size_t)2 * (6 * h->dec_gates + 1) * 16;          // floats per position: 2 directions x row tiles x 16 rows (GRU: 608)
+        // (the encoder's cell counts too: an LSTM encoder in front of a GRU decoder uses the same buffer for its own small calls)
+        const bool gru_gi = (h->dec_gates == 3 || (h->cfg.enc_type == 1 && h->enc_gates == 3)) && (h->prec != 1 || h->gru_l1_split);
+        const bool rnn_u = h->dec_gates != 3 || (h->cfg.enc_type == 1 && h->enc_gates != 3);
+        const bool need_gi = gru_gi || (rnn_u && (h->rnn_l1_mode != 2 || h->rnn_l1_check));
+        const int gmax = std::max(h->dec_gates, h->cfg.enc_type == 1 ? h->enc_gates : 1);
+        const size_t gi_row = (size_t)2 * (6 * gmax + 1) * 16;          // floats per position: 2 directions x row tiles x 16 rows (GRU: 608)
         size_t np_gi = np;
-        if (rnn_u && h->rnn_l1_mode == 0 && !h->rnn_l1_check) {
+        if (!gru_gi && h->rnn_l1_mode == 0 && !h->rnn_l1_check) {
             const size_t cap = (size_t)((rnn_l1_split_below(h) + 31) / 32 * 32) * h->cfg.block_len;
             if (cap < np_gi) np_gi = cap;
         }

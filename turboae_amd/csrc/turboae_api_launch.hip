@@ -300,10 +300,11 @@ int run_decoder_long(tae_handle* h, const float* rx, float* xdec, int32_t B, hip
 }
 
 int run_encoder_rnn(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st);
+int run_encoder_rnn_u(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st);
 
 int run_encoder(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st) {
     if (h->gen) return tae::generic_encode(h->gen, u, xtx, stats, h->d_perm, B, st);
-    if (h->cfg.enc_type == 1) return run_encoder_rnn(h, u, xtx, stats, B, st);
+    if (h->cfg.enc_type == 1) return h->enc_gates != 3 ? run_encoder_rnn_u(h, u, xtx, stats, B, st) : run_encoder_rnn(h, u, xtx, stats, B, st);
     if (h->nb < 1) return run_encoder_long(h, u, xtx, stats, B, st);
     tae::FusedParams P = base_params(h, B, false);
     P.wpack = h->d_wenc;
@@ -412,6 +413,67 @@ int run_encoder_rnn(tae_handle* h, const float* u, float* xtx, double* stats, in
             if (h->prec == 1) TAE_HIP(tae::launch_gru_head_part(HP, st));
             else TAE_HIP(tae::launch_gru_head(HP, st));
             slot += tae::gru_head_grid(HP.npos);
+        }
+    }
+    TAE_HIP(tae::launch_reduce_partials(h->d_rnn_partials, slot, (double)B * L * 3.0, stats, st));
+    return TAE_OK;
+}
+
+// One LSTM / vanilla-RNN stack on turboae_rnn_u.hip: layer 0 -> layer 1 (fused, or projection + recurrence below rnn_l1_split_below blocks;
+// bit-identical) -> per-direction head products in d_gy1.  `wb`: the stack's image (repack_rnn_u), `gimul`: its two layer-1 scales.
+int run_rnn_u_stack(tae_handle* h, int G, const char* wb, const float* xin, const float* gimul, int32_t Bc, size_t npg, hipStream_t st) {
+    const size_t dirb = tae::RnnULayout::dir_bytes(G), projb = tae::RnnULayout::proj_bytes(G);
+    tae::RnnUParams R;
+    memset(&R, 0, sizeof(R));
+    R.w = wb; R.w_dir_stride = (uint32_t)dirb; R.x = xin; R.y0 = reinterpret_cast<char*>(h->d_gy0);
+    R.B = Bc; R.L = h->cfg.block_len; R.ncu = h->ncu;
+    TAE_HIP(tae::launch_rnn_rec_u(G, true, R, st));
+    R.w = wb + 2 * dirb + projb; R.x = nullptr; R.hpart = h->d_gy1;
+    if (h->rnn_l1_mode == 1 || (h->rnn_l1_mode == 0 && Bc < rnn_l1_split_below(h))) {
+        tae::RnnProjParams PP;
+        memset(&PP, 0, sizeof(PP));
+        PP.yin = h->d_gy0; PP.w = reinterpret_cast<const float*>(wb + 2 * dirb); PP.gi = h->d_ggi; PP.npos = npg;
+        PP.gi_mul[0] = gimul[0]; PP.gi_mul[1] = gimul[1];
+        TAE_HIP(tae::launch_rnn_proj_u(G, PP, st));
+        R.gi = h->d_ggi; R.y0 = nullptr;
+        TAE_HIP(tae::launch_rnn_rec_u(G, false, R, st));
+    } else {
+        R.wproj = wb + 2 * dirb; R.gi_mul[0] = gimul[0]; R.gi_mul[1] = gimul[1];
+        TAE_HIP(tae::launch_rnn_l1f_u(G, R, st));
+    }
+    return TAE_OK;
+}
+
+// ENC_interRNN.forward with LSTM / vanilla-RNN cells (encoders.py:242-253,281-296) on the unit-split f16x2 kernels (r06): three stacks,
+// each closed by gru_head_part in encoder mode (enc_act, x_tx column, partial sums for the power constraint)
+int run_encoder_rnn_u(tae_handle* h, const float* u, float* xtx, double* stats, int32_t B, hipStream_t st) {
+    const int L = h->cfg.block_len, H = 100, G = h->enc_gates;
+    int slot = 0;
+    {
+        long need = 0;
+        for (int32_t c0 = 0; c0 < B; c0 += h->rnn_chunk) {
+            const int32_t Bc = (B - c0 < h->rnn_chunk) ? B - c0 : h->rnn_chunk;
+            need += 3L * tae::gru_head_grid((size_t)((Bc + 15) / 16) * 16 * L);
+        }
+        if (need > h->rnn_partial_slots) return fail(TAE_ESTATE, "internal: recurrent-encoder partial-sum slots exceeded");
+    }
+    for (int32_t c0 = 0; c0 < B; c0 += h->rnn_chunk) {
+        const int32_t Bc = (B - c0 < h->rnn_chunk) ? B - c0 : h->rnn_chunk;
+        const size_t npg = (size_t)((Bc + 15) / 16) * 16 * L;
+        const char* wb = h->d_wernn_u;
+        for (int s = 0; s < 3; ++s) {
+            TAE_HIP(tae::launch_gru_prep_enc(u + (size_t)c0 * L, h->d_perm, h->d_gxa, Bc, L, s == 2 ? 1 : 0, st));
+            const int rc = run_rnn_u_stack(h, G, wb, h->d_gxa, &h->rnn_u_gimul_enc[2 * s], Bc, npg, st);
+            if (rc != TAE_OK) return rc;
+            const float* wl = reinterpret_cast<const float*>(wb + 4 * tae::RnnULayout::dir_bytes(G) + tae::RnnULayout::proj_bytes(G));
+            tae::GruHeadParams HP;
+            memset(&HP, 0, sizeof(HP));
+            HP.y = h->d_gy1; HP.w = wl; HP.b = wl + 2 * H; HP.npos = npg; HP.L = L; HP.F = 1; HP.nout = 1;
+            HP.grouped = 1; HP.B = Bc; HP.enc_stack = s; HP.act = h->cfg.enc_act; HP.xtx = xtx + (size_t)c0 * L * 3;
+            HP.partials = h->d_rnn_partials + (size_t)slot * 2;
+            TAE_HIP(tae::launch_gru_head_part(HP, st));
+            slot += tae::gru_head_grid(HP.npos);
+            wb += rnn_u_stack_bytes(1, G);
         }
     }
     TAE_HIP(tae::launch_reduce_partials(h->d_rnn_partials, slot, (double)B * L * 3.0, stats, st));

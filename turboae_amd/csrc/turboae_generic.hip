@@ -701,7 +701,8 @@ bool generic_needed(const tae_config* c) {
     const int cnn_max = 124;
     const int enc_max = c->enc_type == 1 ? 100 : cnn_max, dec_max = c->dec_type == 1 ? 100 : cnn_max;
     if (big_k || c->enc_num_unit > enc_max || c->dec_num_unit > dec_max || c->num_iter_ft > 6) return true;
-    if (c->enc_type == 1 && c->enc_rnn != 0) return true;
+    // LSTM / vanilla-RNN encoder cells: unit-split f16x2 kernels since r06 (2 layers, checked below); in fp32 here
+    if (c->enc_type == 1 && c->enc_rnn != 0 && c->precision == TAE_PREC_F32) return true;
     // LSTM / vanilla-RNN decoder: unit-split f16x2 kernels (turboae_rnn_u.hip, r05) behind the CNN encoder or (r06) the 2-layer GRU
     // encoder; in fp32 here
     if (c->dec_type == 1 && c->dec_rnn != 0 && c->precision == TAE_PREC_F32) return true;

@@ -107,6 +107,9 @@ struct tae_handle {
     float* d_gy0 = nullptr;  // (chunk, L, 2H) layer-0 outputs
     float* d_gy1 = nullptr;  // (chunk, L, 2H) layer-1 outputs
     float* d_ggi = nullptr;  // (chunk, L, 2, 19, 16) layer-1 input projections in gate-tile order
+    int enc_gates = 3;           // recurrent encoder cell (ENC_interRNN), as dec_gates
+    char* d_wernn_u = nullptr;   // ... its three stacks packed for turboae_rnn_u.hip (enc_gates != 3)
+    std::vector<float> rnn_u_gimul_enc;
     int dec_gates = 3;           // recurrent decoder cell: 3 GRU (turboae_gru*.hip), 4 LSTM / 1 vanilla RNN (turboae_rnn_u.hip, f16x2 only)
     char* d_wrnn_u = nullptr;    // LSTM / RNN decoder stacks in the unit-split layouts
     std::vector<float> rnn_u_gimul;   // [stack][dir]: scale the projection kernel folds into GI (the layer-1 recurrence's own 2^S)
