@@ -471,6 +471,44 @@ def sweep_cfg1(sd, dev):
     return out
 
 
+def pcie_inclusive(cfg: TurboAEConfig, sd, B: int, dev, snr: float, runs: int = 5):
+    """NOT `value`: the same step when the caller's buffers live on the HOST (pinned): u and noise cross PCIe in, x_dec and codes cross
+    back (32 bytes per information bit at the fp32 ABI), copies and kernels in order on one stream.  The contract's `value` has its
+    inputs resident in HBM; this says what a host-buffer boundary would cost on this box."""
+    L = cfg.block_len
+    model = Channel_AE_HIP(cfg, sd, device=dev, max_batch=B)
+    u, noise = model.generate_inputs(B, snr, seed=SEED)
+    hu, hn = u.cpu().pin_memory(), noise.cpu().pin_memory()
+    hx = torch.empty((B, L, 1), dtype=torch.float32).pin_memory()
+    hc = torch.empty((B, L, 3), dtype=torch.float32).pin_memory()
+    du, dn = torch.empty_like(u), torch.empty_like(noise)
+
+    def step():
+        du.copy_(hu, non_blocking=True)
+        dn.copy_(hn, non_blocking=True)
+        x_dec, codes = model(du, dn)
+        hx.copy_(x_dec, non_blocking=True)
+        hc.copy_(codes, non_blocking=True)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(runs):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        step()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ms = float(np.median(ts))
+    nbytes = float(B) * L * 32.0
+    out = {"what": "host-resident (pinned) u / noise in, x_dec / codes out, copies + forward in order on one stream; NOT the contract's value",
+           "ms_per_step": ms, "bits_per_s": B * L / (ms * 1e-3), "bytes_over_pcie_per_step": nbytes, "blocks": B}
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def pmc_child(batch: int, block_len: int, snr: float, precision: str) -> None:
     """`bench.py --pmc-child`: what the two rocprofv3 --pmc passes of measure_traffic_pmc profile - the benchmark's own decoder launch
     (trained weights, `batch` resident blocks), one warm-up + two more dispatches, nothing else at full size."""
@@ -613,7 +651,7 @@ TAIL_KEYS = (
     "cfg0_b500_frac", "cfg0_b500_enc_frac", "cfg0_b500_bits_per_s", "cfg2_enc5_frac", "cfg2_enc5_bits_per_s", "cfg3_l1000_frac",
     "cfg3_l1000_enc_frac", "cfg3_l1000_bits_per_s", "cfg1_head2_decoder_over_plain", "wide256_frac",
     "f16x1_bits_per_s", "f16x1_decoder_ms", "f16x1_ber", "f16x1_ber_f32", "f16x1_flips_vs_f32", "f16x1_max_abs_x_dec_vs_f32",
-    "graph_replay_ms", "sweep_cfg1_s", "sweep_cfg1_bits_per_s", "sweep_cfg1_ber_2dB",
+    "pcie_inclusive_bits_per_s", "graph_replay_ms", "sweep_cfg1_s", "sweep_cfg1_bits_per_s", "sweep_cfg1_ber_2dB",
     "roofline_frac", "roofline_kernel_ms", "roofline_traffic_gb", "roofline_frac_of_sustained", "sustained_probe_tflops",
     "parity_decision_flips", "parity_max_abs_x_dec", "parity_max_abs_codes", "parity_ber_abs_diff", "parity_decision_flips_f16x2_vs_f32",
     "cpu_baseline_bits_per_s", "cpu_baseline_cores", "cpu_baseline_b2000_over_b500", "cpu_baseline_b2000_as_4x500_over_b500",
@@ -1166,6 +1204,12 @@ def main():
                 out["f16x1"] = f16x1_line(cfg, sd, B, dev, args.snr)
             except Exception as e:       # a side measurement: never takes the headline line down
                 out["f16x1"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_other_configs:
+            try:
+                out["pcie_inclusive"] = pcie_inclusive(cfg, sd, B, dev, args.snr)
+                out["pcie_inclusive_bits_per_s"], out["pcie_inclusive_ms_per_step"] = out["pcie_inclusive"]["bits_per_s"], out["pcie_inclusive"]["ms_per_step"]
+            except Exception as e:       # a side measurement: never takes the headline line down
+                out["pcie_inclusive"] = {"error": f"{type(e).__name__}: {e}"}
         if main_res.get("graph") is not None:
             gr = dict(main_res["graph"])
             gr["eager_ms_per_step"] = elapsed / steps * 1e3
