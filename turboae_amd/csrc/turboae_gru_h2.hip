@@ -17,7 +17,7 @@
 //     their gate arithmetic overlaps the next unit tile's MFMAs.
 // gru_proj_h: GI = W_ih1 * Y0 + b on conv_accumulate_h (K = 200 -> 7 slabs), 160 positions per workgroup
 // staged in LDS as hi / lo planes; the layer-0 recurrence writes Y0 directly as halves
-// [pos][hi 200 | lo 200], so staging is a copy.
+// [hi 200 | lo 200] per (position, block) - since late r06 in the three-region layout of turboae_y0.hpp - so staging is a copy.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -25,6 +25,7 @@
 #include <type_traits>
 #include "turboae_internal.hpp"
 #include "turboae_device.hpp"
+#include "turboae_y0.hpp"
 
 namespace tae {
 
@@ -156,15 +157,18 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
         : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.gi), 0, -1, 0x00020000);
     const uint32_t v_in = LAYER0 ? (uint32_t)(nc * L * kGXW * 4) : (uint32_t)((n * 4 + q) * 16);
     const uint32_t gi_wave = (uint32_t)(b0 / 16) * (uint32_t)L * (2 * 19 * 1024u) + (uint32_t)dir * (19 * 1024u);
-    // outputs: layer 0 -> Y0 as halves [pos][hi 200 | lo 200] (the projection kernel's operand); layer 1 -> this direction's
+    // outputs: layer 0 -> Y0 as halves, logically [pos][hi 200 | lo 200] (the projection kernel's operand; HBM layout: turboae_y0.hpp); layer 1 -> this direction's
     // share of the Linear head, W_lin[:, dir * H .. dir * H + H) * h_t, as [pos][dir][8] floats (Y1 itself is never written:
     // the head contracts it away, 16 instead of 200 floats per position leave the kernel)
     const __amdgpu_buffer_rsrc_t rs_y = LAYER0
         ? __builtin_amdgcn_make_buffer_rsrc(P.y + (size_t)b0 * L * 2 * kGH, 0, 16 * L * 2 * kGH * 4, 0x00020000)
         : __builtin_amdgcn_make_buffer_rsrc(P.hpart + (size_t)b0 * L * 16, 0, 16 * L * 16 * 4, 0x00020000);
-    const uint32_t v_y = !valid ? 0x80000000u
-        : (LAYER0 ? (uint32_t)(n * 800 + (dir * kGH + 4 * q) * 2) : (q < 2 ? (uint32_t)(n * 64 + dir * 32 + q * 16) : 0x80000000u));
-    const uint32_t v_yr = !valid ? 0x80000000u : (uint32_t)(n * 800 + (dir * kGH + 96 + q) * 2);
+    const uint32_t v_y = !valid ? 0x80000000u : (q < 2 ? (uint32_t)(n * 64 + dir * 32 + q * 16) : 0x80000000u);      // layer 1: head rows
+    // layer 0: Y0 in the three-region layout of turboae_y0.hpp (unit tile 0 has the one lane whose units live in region C)
+    Y0UnitOff yo_u = y0_unit_offsets(dir, n, q);
+    if (!valid) yo_u.hi0 = yo_u.lo0 = yo_u.hi1 = 0x80000000u;
+    const uint32_t v_yr = !valid ? 0x80000000u : y0_half(n, dir * kGH + 96 + q);
+    const uint32_t v_yr_lo = !valid ? 0x80000000u : y0_half_lo(n, dir * kGH + 96 + q);
 
     f32x4 h[6];
 #pragma unroll
@@ -275,8 +279,9 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
             h[u] = hn;
             split4(hn, nhi[u], nlo[u]);
             if (LAYER0 && !(TAE_REC_X & 4)) {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nhi[u]), rs_y, v_y + u * 32, yo, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nlo[u]), rs_y, v_y + u * 32 + 400, yo, 0);
+                const uint32_t vh = u == 0 ? yo_u.hi0 : yo_u.hi1 + (u - 1) * 32, vl = u == 0 ? yo_u.lo0 : yo_u.hi1 + (u - 1) * 32 + kY0PlaneAB;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nhi[u]), rs_y, vh, yo, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nlo[u]), rs_y, vl, yo, 0);
             }
         }
         // remainder tile: rows 4qq + i = gate i of unit 96 + qq (i = 3: layer-0 n-gate input part)
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(512) void gru_rec_h_kernel(GruRecParams P) {
             rl[0] = lo;
             if (LAYER0) {
                 __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, hi), rs_y, v_yr, yo, 0);
-                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, lo), rs_y, v_yr + 400, yo, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, lo), rs_y, v_yr_lo, yo, 0);
                 set_x(xa, xb);
             }
             set_rb();
@@ -393,7 +398,8 @@ __global__ __launch_bounds__(448, 4) void gru_rec0u_kernel(GruRecParams P) {
             fq.a[g] = u0_glb(fr + g * kRecTileB + 6144);
         }
         fn.a[0] = u0_glb(img + kRecFragB + u * 1024 + lane * 16);
-        const uint32_t v_y = !valid ? 0x80000000u : (uint32_t)(n * 800 + (dir * kGH + 4 * q) * 2 + u * 32);
+        uint32_t v_y = 0x80000000u, v_ylo = 0x80000000u;              // Y0: turboae_y0.hpp
+        if (valid) y0_unit_tile(dir, u, n, q, v_y, v_ylo);
         const lds_ptr hw = (lds_ptr)smem + (u >> 1) * 2048 + lane * 16 + (u & 1) * 8;
         f32x4 h = {0.f, 0.f, 0.f, 0.f};
         u0_barrier();                                         // B0: the remainder wave's b1 | b2 of step 0 are in buffer 0
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(448, 4) void gru_rec0u_kernel(GruRecParams P) {
             split4(hn, nhi, nlo);
             const uint32_t yo = (uint32_t)t * (16 * 800u);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nhi), rs_y, v_y, yo, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nlo), rs_y, v_y + 400, yo, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nlo), rs_y, v_ylo, yo, 0);
             const lds_ptr hn_w = hw + ((s + 1) & 1) * kU0HB;
             *reinterpret_cast<lds_w2*>(hn_w) = __builtin_bit_cast(u32x2v, nhi);
             *reinterpret_cast<lds_w2*>(hn_w + 1024) = __builtin_bit_cast(u32x2v, nlo);
@@ -443,7 +449,8 @@ __global__ __launch_bounds__(448, 4) void gru_rec0u_kernel(GruRecParams P) {
         fq.a[0] = u0_glb(fr + 6144);
         const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x + (size_t)b0 * L * kGXW), 0, nb * L * kGXW * 4, 0x00020000);
         const uint32_t v_in = (uint32_t)(nc * L * kGXW * 4);
-        const uint32_t v_yr = !valid ? 0x80000000u : (uint32_t)(n * 800 + (dir * kGH + 96 + q) * 2);
+        const uint32_t v_yr = !valid ? 0x80000000u : y0_half(n, dir * kGH + 96 + q);
+        const uint32_t v_yr_lo = !valid ? 0x80000000u : y0_half_lo(n, dir * kGH + 96 + q);
         h4 rh = {0, 0, 0, 0}, rl = {0, 0, 0, 0};           // k0 = h of unit 96 + q, k1..3 = this lane group's share of x_t
         h8 rb1, rb2;
         auto set_rb = [&]() {
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(448, 4) void gru_rec0u_kernel(GruRecParams P) {
             rl[0] = lo;
             const uint32_t yo = (uint32_t)t * (16 * 800u);
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, hi), rs_y, v_yr, yo, 0);
-            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, lo), rs_y, v_yr + 400, yo, 0);
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, lo), rs_y, v_yr_lo, yo, 0);
             set_x(xa, xb);
             set_rb();
             const lds_ptr rn = rw + ((s + 1) & 1) * kU0HB;
@@ -588,13 +595,14 @@ __global__ __launch_bounds__(256 * NPG, MINW) void gru_proj_h_kernel(GruProjPara
     const size_t p0 = (size_t)blockIdx.x * G::kPos;
     const int np = (int)min((size_t)G::kPos, P.npos - p0);
     {
-        // Y0 arrives as halves [pos][hi 200 | lo 200]: 50 16-byte pieces per position, 25 per plane
-        const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(P.yin) + p0 * 800);
+        // Y0 arrives as halves, logically [pos][hi 200 | lo 200]: 50 16-byte pieces per position, 25 per plane
         for (int i = tid; i < G::kLds / 16; i += G::kThreads) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
         for (int i = tid; i < ((TAE_PROJ_X & 4) ? 0 : np * 50); i += G::kThreads) {
             const int pos = i / 50, c = i - pos * 50, plane = c >= 25 ? 1 : 0, cc = c - plane * 25;
-            *reinterpret_cast<f32x4*>(smem + plane * G::kPlaneB + pos * 400 + cc * 16) = src[i];
+            const size_t row = p0 + pos;                     // (group, step, block) -> the step's regions (turboae_y0.hpp)
+            const char* piece = reinterpret_cast<const char*>(P.yin) + (row >> 4) * kY0StepB + y0_piece((int)(row & 15), cc) + (plane ? y0_lo_add(cc) : 0u);
+            *reinterpret_cast<f32x4*>(smem + plane * G::kPlaneB + pos * 400 + cc * 16) = *reinterpret_cast<const f32x4*>(piece);
         }
     }
     __syncthreads();

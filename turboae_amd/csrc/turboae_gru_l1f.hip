@@ -13,7 +13,7 @@
 //   * the remainder wave: units 96..99 as one mixed row tile (row 4 qq + i = r, z, n_h, n_i of unit 96 + qq; all in registers),
 //     plus the head tile: W_lin[:, dir H .. dir H + H) * h_t - 16 floats per position leave the kernel, as before; its four
 //     single-accumulator chains are issued product by product in turn;
-//   * the staging wave: y0 rows (16 x 800 bytes per step) from HBM into LDS in B-fragment order by LDS-DMA (buffer_load ... lds: the
+//   * the staging wave: y0 rows (16 x 800 bytes per step, in the three regions of turboae_y0.hpp) from HBM into LDS in B-fragment order by LDS-DMA (buffer_load ... lds: the
 //     fragment tiles are lane-linear), issued at the top of the step before the one that reads them and waited for at its barrier.
 // Waves w and w + 4 share a SIMD, so the two light waves are 3 and 7 and every other SIMD carries two unit waves.  To level the
 // SIMDs (r05 v1 had 2 x 93 MFMAs per step on three of them and 42 on the fourth, and ran at exactly the 81 % of the sustained
@@ -30,6 +30,7 @@
 #include <type_traits>
 #include "turboae_internal.hpp"
 #include "turboae_device.hpp"
+#include "turboae_y0.hpp"
 
 // timing experiments on this kernel (results wrong; -DTAE_EXPERIMENT builds only): 1 linear gates (no exp / rcp), 2 no step barrier,
 // 4 no projection MFMAs in the unit waves' step, 8 no recurrence MFMAs in the unit waves' step, 16 no y0 loads in the staging wave's step,
@@ -483,25 +484,39 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, lds_ptr dst, uint32_t v, uint32_t so) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, v, so, 0, 0);
 }
-__device__ __forceinline__ void ym_dma(__amdgpu_buffer_rsrc_t rs, lds_ptr y, uint32_t v0, uint32_t so) {       // y: tile base (no lane term)
-#pragma unroll
-    for (int sl = 0; sl < kMS; ++sl) {
-        dma16(rs, y + (2 * sl) * 1024, v0 + sl * 64, so);
-        dma16(rs, y + (2 * sl + 1) * 1024, v0 + 400 + sl * 64, so);
-    }
+// Lane (n, q) takes piece 4 sl + q of row n for k-slab sl, from the three regions of a step (turboae_y0.hpp): slabs 0..2 lie in A,
+// slab 3 is the shared piece 12 (q = 0) | the first three of B, slabs 4 and 5 the next eight of B, the K = 16 remainder B's last one.
+struct Y0Lane { uint32_t vA, v3, v3lo, vB; };
+__device__ __forceinline__ Y0Lane y0_lane(int n, int q) {
+    Y0Lane v;
+    v.vA = y0_piece(n, q);
+    v.v3 = y0_piece(n, 12 + q);
+    v.v3lo = v.v3 + y0_lo_add(12 + q);
+    v.vB = y0_piece(n, 16 + q);
+    return v;
 }
-__device__ __forceinline__ void yh_dma(__amdgpu_buffer_rsrc_t rs, lds_ptr y, uint32_t v0, uint32_t so) {
+__device__ __forceinline__ void ym_dma(__amdgpu_buffer_rsrc_t rs, lds_ptr y, const Y0Lane& v, uint32_t so) {       // y: tile base (no lane term)
+    static_assert(kMS == 4 && kHS == 2, "slab split of the Y0 regions");
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+        dma16(rs, y + (2 * sl) * 1024, v.vA + sl * 64, so);
+        dma16(rs, y + (2 * sl + 1) * 1024, v.vA + kY0PlaneAB + sl * 64, so);
+    }
+    dma16(rs, y + 6 * 1024, v.v3, so);
+    dma16(rs, y + 7 * 1024, v.v3lo, so);
+}
+__device__ __forceinline__ void yh_dma(__amdgpu_buffer_rsrc_t rs, lds_ptr y, const Y0Lane& v, uint32_t so) {
 #pragma unroll
     for (int sl = 0; sl < kHS; ++sl) {
-        dma16(rs, y + (2 * sl) * 1024, v0 + (kMS + sl) * 64, so);
-        dma16(rs, y + (2 * sl + 1) * 1024, v0 + 400 + (kMS + sl) * 64, so);
+        dma16(rs, y + (2 * sl) * 1024, v.vB + sl * 64, so);
+        dma16(rs, y + (2 * sl + 1) * 1024, v.vB + kY0PlaneAB + sl * 64, so);
     }
 }
 // the K = 16 remainder of a step goes through registers (its halves are re-paired into b1 = [lo | hi], b2 = [hi | 0])
 struct YR { u32x2v rh, rl; };
 __device__ __forceinline__ void yr_load(YR& r, __amdgpu_buffer_rsrc_t rs, uint32_t vr, uint32_t so) {
     r.rh = __builtin_amdgcn_raw_buffer_load_b64(rs, vr, so, 0);               // out-of-range lanes read zeros
-    r.rl = __builtin_amdgcn_raw_buffer_load_b64(rs, vr + 400, so, 0);
+    r.rl = __builtin_amdgcn_raw_buffer_load_b64(rs, vr + kY0PlaneAB, so, 0);
 }
 __device__ __forceinline__ void yr_store(const YR& r, lds_ptr y) {            // y: this lane's slot of the M part
     *reinterpret_cast<lds_w4*>(y + kMS * 2048) = u32x4v{r.rl.x, r.rl.y, r.rh.x, r.rh.y};
@@ -522,8 +537,8 @@ __device__ __forceinline__ void stage_wave(const Ctx& c) {
     const lds_ptr ymu = (lds_ptr)(c.lds + kYM), yhu = (lds_ptr)(c.lds + kYH);          // tile bases of the DMA
     const lds_ptr ymw = (lds_ptr)(c.lds + kYM + lane * 16);
     const lds_ptr pbw = (lds_ptr)(c.lds + kPB + lane * 16);
-    const uint32_t v0 = (uint32_t)(n * 800 + q * 16);
-    const uint32_t vr = q < 2 ? (uint32_t)(n * 800 + 384 + q * 8) : 0x80000000u;        // remainder k = 192 + 4 kq .. + 3 (kq < 2)
+    const Y0Lane v0 = y0_lane(n, q);
+    const uint32_t vr = q < 2 ? y0_half(n, 192 + 4 * q) : 0x80000000u;                   // remainder k = 192 + 4 kq .. + 3 (kq < 2): piece 24, region B
     for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(c.P.y0) + (size_t)grp * L * (16 * 800), 0, L * 16 * 800, 0x00020000);
         // byte offset of step k's 16 rows (steps past the end: the last step again - fetched, never used)

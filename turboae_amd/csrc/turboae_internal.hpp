@@ -124,7 +124,7 @@ struct GruL1fLayout {
 struct GruL1fParams {
     const char* w;         // two GruL1fLayout images (forward, backward)
     uint32_t w_dir_stride; // bytes between them
-    const char* y0;        // layer-0 outputs as halves [pos'][hi 200 | lo 200], pos' = ((b / 16) L + t) 16 + b % 16
+    const char* y0;        // layer-0 outputs as halves, logically [pos'][hi 200 | lo 200], pos' = ((b / 16) L + t) 16 + b % 16; per (group, step) in the regions of turboae_y0.hpp
     float* hpart;          // [pos'][dir][8]: this direction's share of the Linear head
     int32_t B, L, ngroups; // ngroups = ceil(B / 16)
 };
@@ -143,7 +143,7 @@ struct RnnUParams {
     uint32_t w_dir_stride;
     const float* x;         // layer 0: stack-input panel (B, L, 8)
     const float* gi;        // layer 1: projections [(g16 L + t) 2 + dir][6 G + 1][lane][4], already times the recurrence's 2^S
-    char* y0;               // layer 0: outputs as halves [pos'][hi 200 | lo 200], pos' = ((b / 16) L + t) 16 + b % 16
+    char* y0;               // layer 0: outputs as halves, logically [pos'][hi 200 | lo 200], pos' = ((b / 16) L + t) 16 + b % 16; per (group, step) in the regions of turboae_y0.hpp
     float* hpart;           // layer 1: [pos'][dir][8] this direction's share of the Linear head
     int32_t B, L, ngroups;  // ngroups: set by the launcher (ceil(B / 16 NT), NT = N tiles per workgroup, picked by batch)
     int32_t ncu;            // compute units of the handle's device (grid size and the NT choice)

@@ -22,6 +22,7 @@
 #include <type_traits>
 #include "turboae_internal.hpp"
 #include "turboae_device.hpp"
+#include "turboae_y0.hpp"
 
 namespace tae {
 
@@ -149,7 +150,8 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
                             : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.P.gi) + g16 * L * 2 * (CTT * 256), 0, L * 2 * CTT * 1024, 0x00020000);
         }
         const uint32_t v_gi = (uint32_t)((G * ut) * 1024 + (n * 4 + q) * 16);        // the projection's D layout: block n major, row quad q minor
-        const uint32_t v_y = (uint32_t)(n * 800 + (dir * 100 + 16 * ut + 4 * q) * 2);
+        uint32_t v_y, v_ylo;                                   // Y0 (layer 0): turboae_y0.hpp
+        y0_unit_tile(dir, ut, n, q, v_y, v_ylo);
         f32x4 gi[kNT][G];
         auto fetch_gi = [&](int s, int nt) {
             const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(((dir ? L - 1 - s : s) * 2 + dir) * (CTT * 1024));
@@ -202,10 +204,10 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
                 const lds_ptr hn_w = hw + p1 * kHBsz + nt * 8192;
                 *reinterpret_cast<lds_w2*>(hn_w) = __builtin_bit_cast(u32x2v, nhi);
                 *reinterpret_cast<lds_w2*>(hn_w + 1024) = __builtin_bit_cast(u32x2v, nlo);
-                if (LAYER0) {        // Y0 as halves [pos'][hi 200 | lo 200] (the projection kernel's operand)
+                if (LAYER0) {        // Y0 as halves, logically [pos'][hi 200 | lo 200] (the projection kernel's operand; turboae_y0.hpp)
                     const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(t * (16 * 800));
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nhi), rs[nt], v_y, so, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nlo), rs[nt], v_y + 400, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, nlo), rs[nt], v_ylo, so, 0);
                 }
             }
             step_barrier();
@@ -249,7 +251,7 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
             rs_h[nt] = __builtin_amdgcn_make_buffer_rsrc(c.P.hpart + g16 * L * 256, 0, L * 1024, 0x00020000);
         }
         const uint32_t v_gi = (uint32_t)((6 * G) * 1024 + (n * 4 + q) * 16);
-        const uint32_t v_y = (uint32_t)(n * 800 + (dir * 100 + 96 + q) * 2);
+        const uint32_t v_y = y0_half(n, dir * 100 + 96 + q), v_ylo = y0_half_lo(n, dir * 100 + 96 + q);
         const uint32_t v_h = q < 2 ? (uint32_t)(n * 64 + dir * 32 + q * 16) : 0x80000000u;
         f32x4 gi[kNT];
         auto fetch_gi = [&](int s, int nt) {
@@ -303,7 +305,7 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
                 if (LAYER0) {
                     const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(t * (16 * 800));
                     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, hi), rs[nt], v_y, so, 0);
-                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, lo), rs[nt], v_y + 400, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, lo), rs[nt], v_ylo, so, 0);
                 }
             }
             step_barrier();
@@ -668,7 +670,9 @@ __device__ __forceinline__ void stage_wave_f(const Ctx& c) {
     constexpr int kNT = NT, kTC = GF::kTC;
     const int L = c.L, n = c.n, q = c.q, dir = c.dir;
     const lds_ptr ybu = (lds_ptr)(c.lds + GF::kYB);                  // tile bases (no lane term)
-    const uint32_t v0 = (uint32_t)(n * 800 + q * 16);
+    // lane (n, q) takes piece 4 sl + q of row n for slab sl (turboae_y0.hpp): slabs 0..2 from region A, slab 3 = the shared piece 12 | B,
+    // slabs 4.. from region B (the last slab's pieces past 24 are K padding: zero weights, initialised halves)
+    const uint32_t vA = y0_piece(n, q), v3 = y0_piece(n, 12 + q), v3lo = v3 + y0_lo_add(12 + q), vB = y0_piece(n, 16 + q);
     for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
         __amdgpu_buffer_rsrc_t rs[kNT];
 #pragma unroll
@@ -684,8 +688,10 @@ __device__ __forceinline__ void stage_wave_f(const Ctx& c) {
                     const lds_ptr y = ybu + (tc * kNT + nt) * GF::kTileB;
 #pragma unroll
                     for (int sl = 0; sl < kProjSlabs; ++sl) {
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[nt], y + (2 * sl) * 1024, 16, v0 + sl * 64, so, 0, 0);
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[nt], y + (2 * sl + 1) * 1024, 16, v0 + 400 + sl * 64, so, 0, 0);
+                        const uint32_t vh = sl < 3 ? vA + sl * 64 : (sl == 3 ? v3 : vB + (sl - 4) * 64);
+                        const uint32_t vl = sl < 3 ? vA + kY0PlaneAB + sl * 64 : (sl == 3 ? v3lo : vB + kY0PlaneAB + (sl - 4) * 64);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[nt], y + (2 * sl) * 1024, 16, vh, so, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[nt], y + (2 * sl + 1) * 1024, 16, vl, so, 0, 0);
                     }
                 }
             }
@@ -792,12 +798,13 @@ __global__ __launch_bounds__(256, 2) void rnn_proj_u_kernel(RnnProjParams P) {
     const size_t p0 = (size_t)blockIdx.x * kProjPos;
     const int np = (int)min((size_t)kProjPos, P.npos - p0);
     {
-        const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(P.yin) + p0 * 800);
         for (int i = tid; i < kProjLds / 16; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
-        for (int i = tid; i < np * 50; i += 256) {      // Y0 rows are halves [hi 200 | lo 200]: 25 16-byte pieces per plane
+        for (int i = tid; i < np * 50; i += 256) {      // Y0 rows are halves, logically [hi 200 | lo 200]: 25 16-byte pieces per plane
             const int pos = i / 50, c = i - pos * 50, plane = c >= 25 ? 1 : 0, cc = c - plane * 25;
-            *reinterpret_cast<f32x4*>(smem + plane * kPlaneB + pos * kProjRow + cc * 16) = src[i];
+            const size_t row = p0 + pos;                     // (group, step, block) -> the step's regions (turboae_y0.hpp)
+            const char* piece = reinterpret_cast<const char*>(P.yin) + (row >> 4) * kY0StepB + y0_piece((int)(row & 15), cc) + (plane ? y0_lo_add(cc) : 0u);
+            *reinterpret_cast<f32x4*>(smem + plane * kPlaneB + pos * kProjRow + cc * 16) = *reinterpret_cast<const f32x4*>(piece);
         }
     }
     __syncthreads();
