@@ -209,3 +209,60 @@ def test_isa_audit_flags_a_mixed_shape_kernel_and_inline_asm_loads(tmp_path):
                                  '    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(v));\n}\n')
     bad = A.audit_sources(str(src))
     assert len(bad) == 1 and "global_load" in bad[0] and "bad.hip:2" in bad[0], bad
+
+
+def test_y0_region_layout_is_a_direction_private_bijection(tmp_path):
+    """turboae_y0.hpp (layer-0 outputs of the f16x2 recurrent stacks in HBM): the header's own offset functions, compiled for the host,
+    map the 16 rows x 2 planes x 200 halves of a (group, step) one-to-one onto its 12 800 bytes; region A holds forward units only,
+    region B backward units only, region C the one shared 16-byte piece per row; the writers' linear-in-tile shortcut and the readers'
+    three per-lane bases (slabs 0..2 | slab 3 | slabs 4..) agree with the per-half definition."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.isfile(hipcc):
+        pytest.skip("needs hipcc")
+    src = tmp_path / "y0.cpp"
+    src.write_text('#include <hip/hip_runtime.h>\n#include <stdio.h>\n#include "turboae_y0.hpp"\n'
+                   'int main() {\n'
+                   '  for (int n = 0; n < 16; ++n) for (int j = 0; j < 200; ++j) printf("H %d %d %u %u\\n", n, j, tae::y0_half(n, j), tae::y0_half_lo(n, j));\n'
+                   '  for (int n = 0; n < 16; ++n) for (int p = 0; p < 25; ++p) printf("P %d %d %u %u\\n", n, p, tae::y0_piece(n, p), tae::y0_lo_add(p));\n'
+                   '  printf("K %u %u %u %u %u %u\\n", tae::kY0StepB, tae::kY0A, tae::kY0B, tae::kY0C, tae::kY0PlaneAB, tae::kY0PlaneC);\n  return 0;\n}\n')
+    exe = str(tmp_path / "y0")
+    subprocess.check_call([hipcc, "-O1", "-I", os.path.join(ROOT, "turboae_amd", "csrc"), str(src), "-o", exe])
+    hi, lo, piece = {}, {}, {}
+    for line in subprocess.check_output([exe], text=True).splitlines():
+        f = line.split()
+        if f[0] == "H":
+            hi[(int(f[1]), int(f[2]))], lo[(int(f[1]), int(f[2]))] = int(f[3]), int(f[4])
+        elif f[0] == "P":
+            piece[(int(f[1]), int(f[2]))] = (int(f[3]), int(f[4]))
+        else:
+            step, a0, b0, c0, plane_ab, plane_c = map(int, f[1:])
+    assert (step, a0) == (16 * 800, 0) and b0 < c0 < step
+    offs = list(hi.values()) + list(lo.values())
+    assert len(set(offs)) == 2 * 16 * 200 and min(offs) == 0 and max(offs) == step - 2 and all(o % 2 == 0 for o in offs)      # a bijection on halves
+    for (n, j), o in hi.items():
+        assert o == piece[(n, j >> 3)][0] + 2 * (j & 7) and lo[(n, j)] == o + piece[(n, j >> 3)][1]                            # halves sit in their 16-byte piece
+        region = "A" if o < b0 else ("B" if o < c0 else "C")
+        assert region == ("A" if j < 96 else ("C" if j < 104 else "B"))                                                         # forward | shared piece 12 | backward
+        assert (lo[(n, j)] - o) == (plane_c if region == "C" else plane_ab)
+    line = lambda o: o // 128
+    fwd = {line(o) for (n, j), o in list(hi.items()) + list(lo.items()) if j < 96}
+    bwd = {line(o) for (n, j), o in list(hi.items()) + list(lo.items()) if j >= 104}
+    assert not (fwd & bwd) and len(fwd) == len(bwd) == 48                                                                       # no 128-byte line has two writers outside region C
+    for d in (0, 1):                                       # writers: tile u >= 1 = tile 1 + 32 (u - 1), lo = hi + kY0PlaneAB; four units are 8 contiguous bytes
+        for n in range(16):
+            for q in range(4):
+                for u in range(6):
+                    j = d * 100 + 16 * u + 4 * q
+                    assert [hi[(n, j + k)] for k in range(4)] == [hi[(n, j)] + 2 * k for k in range(4)]
+                    if u >= 1:
+                        assert hi[(n, j)] == hi[(n, d * 100 + 16 + 4 * q)] + 32 * (u - 1) and lo[(n, j)] == hi[(n, j)] + plane_ab
+    for n in range(16):                                    # readers: lane (n, q) takes piece 4 sl + q of slab sl from vA / v3 / vB
+        for q in range(4):
+            vA, v3, vB = piece[(n, q)][0], piece[(n, 12 + q)][0], piece[(n, 16 + q)][0]
+            for sl in range(6):
+                want = piece[(n, 4 * sl + q)][0]
+                assert want == (vA + 64 * sl if sl < 3 else (v3 if sl == 3 else vB + 64 * (sl - 4)))
+            if q == 0:
+                assert piece[(n, 24)][0] == vB + 128
