@@ -545,10 +545,14 @@ void pack_gru_l1f_dir(const float* Wih, const float* Whh, const float* bih, cons
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) put_split(dst, hi + lane * 16 + j * 2, lo + lane * 16 + j * 2, w(lane & 15, lane >> 4, j));
     };
-    // K = 16 remainder fragment: [lane][4 hi halves | 4 lo halves]
+    // K = 8 remainder fragment of the fused kernel (late r06: the three products of the slab in ONE MFMA): [lane][hi k0 k1 | hi k0 k1 | lo k0 k1 | 0 0]
     auto rem = [&](size_t off, auto&& w) {
         for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < 4; ++j) put_split(dst, off + lane * 16 + j * 2, off + lane * 16 + 8 + j * 2, w(lane & 15, lane >> 4, j));
+            for (int j = 0; j < 2; ++j) {
+                const float v = w(lane & 15, lane >> 4, j);
+                put_split(dst, off + lane * 16 + j * 2, off + lane * 16 + 8 + j * 2, v);
+                put_split(dst, off + lane * 16 + 4 + j * 2, off + lane * 16 + 8 + j * 2, v);
+            }
     };
     const size_t lo01 = (size_t)6 * Lay::kUnitB + Lay::kRemB, lds0 = lo01 + Lay::kLo01B;
     // W_ih1 lo fragment of tile (ut, g), k-slab sl: slabs 0, 1 in the unit waves' register image, 2..5 in the LDS image
@@ -566,8 +570,7 @@ void pack_gru_l1f_dir(const float* Wih, const float* Whh, const float* bih, cons
             for (int sl = 0; sl < 6; ++sl)
                 slab(ub + (21 + g * 7 + sl) * 1024, ih_lo_off(ut, g, sl),
                      [&](int m, int kq, int j) { return Wih[row(m) * 2 * H + 32 * sl + 8 * kq + j] * scale; });
-            rem(ub + (21 + g * 7 + 6) * 1024,
-                [&](int m, int kq, int j) { return kq < 2 ? Wih[row(m) * 2 * H + 192 + 4 * kq + j] * scale : 0.0f; });
+            rem(ub + (21 + g * 7 + 6) * 1024, [&](int m, int kq, int j) { return Wih[row(m) * 2 * H + 192 + 2 * kq + j] * scale; });
         }
     }
     {   // remainder wave: mixed tile, row 4 qq + i = (r, z, n_h, n_i) of unit 96 + qq; then the head tile
@@ -581,8 +584,7 @@ void pack_gru_l1f_dir(const float* Wih, const float* Whh, const float* bih, cons
         for (int sl = 0; sl < 6; ++sl)
             slab(rb + (7 + 2 * sl) * 1024, rb + (8 + 2 * sl) * 1024,
                  [&](int m, int kq, int j) { return rowi(m) >= 0 ? Wih[(size_t)rowi(m) * 2 * H + 32 * sl + 8 * kq + j] * scale : 0.0f; });
-        rem(rb + 19 * 1024,
-            [&](int m, int kq, int j) { return (kq < 2 && rowi(m) >= 0) ? Wih[(size_t)rowi(m) * 2 * H + 192 + 4 * kq + j] * scale : 0.0f; });
+        rem(rb + 19 * 1024, [&](int m, int kq, int j) { return rowi(m) >= 0 ? Wih[(size_t)rowi(m) * 2 * H + 192 + 2 * kq + j] * scale : 0.0f; });
         for (int sl = 0; sl < 3; ++sl)
             slab(rb + (20 + 2 * sl) * 1024, rb + (21 + 2 * sl) * 1024,
                  [&](int m, int kq, int j) { return m < nout ? Wlin[(size_t)m * 2 * H + d * H + hh_unit(sl, kq, j)] * scale_h : 0.0f; });

@@ -124,22 +124,19 @@ __device__ __forceinline__ void mma3_lo_last(f32x4 (&acc)[3], const h8 (&ah)[3],
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = mfma16x16x32h(al[g], bh, acc[g]);
 }
-// K = 16 remainder slab: A = [4 hi | 4 lo] of the lane's k = 0..3, b1 = [lo | hi], b2 = [hi | 0] (gru_rec_h's mma_rem)
-__device__ __forceinline__ void mma3r(f32x4 (&acc)[3], const h8 (&ar)[3], h8 b1, h8 b2) {
+// K = 8 remainder slab, the three products of a slab in ONE MFMA (late r06; through r06 two, on gru_rec_h's [4 hi | 4 lo] fragments):
+// per lane A = [hi k0 k1 | hi k0 k1 | lo k0 k1 | 0 0], B = [hi k0 k1 | lo k0 k1 | hi k0 k1 | 0 0] - the 32 k slots of the instruction
+// hold hi*hi, hi*lo and lo*hi of the lane group's two real k (recurrence: unit 96 + kq and nothing; projection: y0 halves 192 + 2 kq, + 1)
+__device__ __forceinline__ void mma3r(f32x4 (&acc)[3], const h8 (&ar)[3], h8 b) {
 #pragma unroll
-    for (int g = 0; g < 3; ++g) acc[g] = mfma16x16x32h(ar[g], b1, acc[g]);
-#pragma unroll
-    for (int g = 0; g < 3; ++g) acc[g] = mfma16x16x32h(ar[g], b2, acc[g]);
+    for (int g = 0; g < 3; ++g) acc[g] = mfma16x16x32h(ar[g], b, acc[g]);
 }
 __device__ __forceinline__ void mma1(f32x4& acc, h8 ah, h8 al, h8 bh, h8 bl) {
     acc = mfma16x16x32h(ah, bl, acc);
     acc = mfma16x16x32h(al, bh, acc);
     acc = mfma16x16x32h(ah, bh, acc);
 }
-__device__ __forceinline__ void mma1r(f32x4& acc, h8 ar, h8 b1, h8 b2) {
-    acc = mfma16x16x32h(ar, b1, acc);
-    acc = mfma16x16x32h(ar, b2, acc);
-}
+__device__ __forceinline__ void mma1r(f32x4& acc, h8 ar, h8 b) { acc = mfma16x16x32h(ar, b, acc); }
 
 template <int N, class F, int I = 0>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -248,7 +245,7 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
                 for (int g = 0; g < 3; ++g) al[g] = sl < 2 ? ih_lo[sl < 2 ? sl : 0][g] : lds_h8(wl + (g * 4 + sl - 2) * 1024);
                 mma3(gi, ih_hi[sl], al, bh, bl);
             }
-            mma3r(gi, ih_r, lds_h8(ym + kMS * 2048), lds_h8(ym + kMS * 2048 + 1024));
+            mma3r(gi, ih_r, lds_h8(ym + kMS * 2048));
         }
         f32x4 h = {0.f, 0.f, 0.f, 0.f};
         step_barrier();                                   // B2: M[0], pb[0] may be refilled
@@ -271,19 +268,20 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
             xh[0] = lds_h8(hc + 4096); xl[0] = lds_h8(hc + 5120);
             if (kL1fX & 8) skip3(acc, hh_hi[1], xh[1], xl[1]); else mma3(acc, hh_hi[1], hh_lo[1], xh[1], xl[1]);
             pin<2, 9, 0>();
-            xh[1] = lds_h8(hc + 6144); xl[1] = lds_h8(hc + 7168);       // remainder slab: b1, b2
+            xh[1] = lds_h8(hc + 6144);                                  // remainder slab: one B tile
             if (kL1fX & 8) skip3(acc, hh_hi[2], xh[0], xl[0]); else mma3(acc, hh_hi[2], hh_lo[2], xh[0], xl[0]);
-            pin<2, 9, 0>();
+            pin<1, 9, 0>();
             xh[0] = lds_h8(y); xl[0] = lds_h8(y + 1024);
 #pragma unroll
             for (int g = 0; g < 3; ++g) gi[g] = *reinterpret_cast<lds_f4c*>(pbn + g * 1024);       // helpers' partial (bias + slabs 4, 5)
-            if (kL1fX & 8) skip3(acc, hh_r, xh[1], xl[1]); else mma3r(acc, hh_r, xh[1], xl[1]);
-            pin<5, 6, 0>();
+            if (kL1fX & 8) skip3(acc, hh_r, xh[1], xh[1]); else mma3r(acc, hh_r, xh[1]);
+            pin<5, 3, 0>();
             stamp(c, grp == (int)blockIdx.x, s, 1);
             f32x4 hn;
             static_for<kMS>([&](auto SL) {
                 constexpr int sl = decltype(SL)::value, cur = sl & 1, nxt = cur ^ 1;
-                xh[nxt] = lds_h8(y + (sl + 1) * 2048); xl[nxt] = lds_h8(y + (sl + 1) * 2048 + 1024);      // (the slab after the last one is the remainder's b1 | b2)
+                xh[nxt] = lds_h8(y + (sl + 1) * 2048);                                                       // (the slab after the last one is the remainder's one tile)
+                if constexpr (sl + 1 < kMS) xl[nxt] = lds_h8(y + (sl + 1) * 2048 + 1024);
                 if constexpr (sl < 2) {
                     if (kL1fX & 4) skip3(gi, ih_hi[sl], xh[cur], xl[cur]); else mma3_lo_last(gi, ih_hi[sl], ih_lo[sl], xh[cur], xl[cur]);
                 } else {
@@ -308,8 +306,8 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
             const lds_ptr hn_w = hw + p1 * kHBsz;
             *reinterpret_cast<lds_w2*>(hn_w) = __builtin_bit_cast(u32x2v, nhi);
             *reinterpret_cast<lds_w2*>(hn_w + 1024) = __builtin_bit_cast(u32x2v, nlo);
-            if (kL1fX & 4) skip3(gi, ih_r, xh[kMS & 1], xl[kMS & 1]); else mma3r(gi, ih_r, xh[kMS & 1], xl[kMS & 1]);
-            pin<0, 6, 1>();
+            if (kL1fX & 4) skip3(gi, ih_r, xh[kMS & 1], xh[kMS & 1]); else mma3r(gi, ih_r, xh[kMS & 1]);
+            pin<0, 3, 2>();
             stamp(c, grp == (int)blockIdx.x, s, 3);
             step_barrier();
         }
@@ -383,7 +381,7 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
     auto own_main = [&](f32x4& gi, lds_cptr y) {
 #pragma unroll
         for (int sl = 0; sl < kMS; ++sl) mma1(gi, ih_hi[sl], ih_lo[sl], lds_h8(y + sl * 2048), lds_h8(y + sl * 2048 + 1024));
-        mma1r(gi, ih_r, lds_h8(y + kMS * 2048), lds_h8(y + kMS * 2048 + 1024));
+        mma1r(gi, ih_r, lds_h8(y + kMS * 2048));
     };
     // head products of the state in h buffer `hc` -> hpart[(grp L + t) 16 + n][dir][8]
     auto head = [&](lds_cptr hc, const __amdgpu_buffer_rsrc_t& rs, int t) {
@@ -393,8 +391,7 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
             const h8 bh = lds_h8(hc + sl * 2048), bl = lds_h8(hc + sl * 2048 + 1024);
             mma1(a, hd_hi[sl], hd_lo[sl], bh, bl);
         }
-        const h8 b1 = lds_h8(hc + 6144), b2 = lds_h8(hc + 7168);
-        mma1r(a, hd_r, b1, b2);
+        mma1r(a, hd_r, lds_h8(hc + 6144));
         const uint32_t v = q < 2 ? (uint32_t)(n * 64 + dir * 32 + q * 16) : 0x80000000u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, a * inv_head), rs, v, (uint32_t)t * 1024u, 0);
     };
@@ -402,7 +399,6 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
     for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(c.P.hpart + (size_t)grp * L * 256, 0, L * 1024, 0x00020000);
         *reinterpret_cast<lds_w4*>(hw) = u32x4v{0, 0, 0, 0};
-        *reinterpret_cast<lds_w4*>(hw + 1024) = u32x4v{0, 0, 0, 0};
         step_barrier();                                   // B0
         helper_partials<1>(hp_hi, c.lds, lane, 0, q, yh, pbw);                             // steps 0 and 1
         __builtin_amdgcn_sched_barrier(0);
@@ -437,20 +433,20 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
                 if (r < kHS) gp = mfma16x16x32h(ih_hi[kMS + r], kh, gp);
             }
             {
-                const h8 b1 = lds_h8(hc + 6144), b2 = lds_h8(hc + 7168);
+                const h8 br = lds_h8(hc + 6144);
 #pragma unroll
-                for (int r = 3; r < kMS; ++r) {                     // the projection's remaining slabs, the K = 16 remainders between its products
+                for (int r = 3; r < kMS; ++r) {                     // the projection's remaining slabs, the remainders of the two h chains between its products
                     const h8 mh = lds_h8(y + r * 2048), ml = lds_h8(y + r * 2048 + 1024);
                     gi = mfma16x16x32h(ih_hi[r], ml, gi);
-                    if (r == 3) { acc = mfma16x16x32h(hh_r, b1, acc); hd = mfma16x16x32h(hd_r, b1, hd); }
+                    if (r == 3) acc = mfma16x16x32h(hh_r, br, acc);
                     gi = mfma16x16x32h(ih_lo[r], mh, gi);
-                    if (r == 3) { acc = mfma16x16x32h(hh_r, b2, acc); hd = mfma16x16x32h(hd_r, b2, hd); }
+                    if (r == 3) hd = mfma16x16x32h(hd_r, br, hd);
                     gi = mfma16x16x32h(ih_hi[r], mh, gi);
                 }
             }
             stamp(c, grp == (int)blockIdx.x, s, 1);
             if (!(kL1fX & 32)) helper_partials<1>(hp_hi, c.lds, lane, 0, q, yk, pbw + p0 * kPBsz);   // unit tile 0, step s + 2
-            mma1r(gi, ih_r, lds_h8(y + kMS * 2048), lds_h8(y + kMS * 2048 + 1024));
+            mma1r(gi, ih_r, lds_h8(y + kMS * 2048));
             gp1 = gp;
             stamp(c, grp == (int)blockIdx.x, s, 2);
             if (s > 0) {                                            // Linear head on h_{s-1} (the state this step started from)
@@ -465,10 +461,9 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
             hr = fmaf(z, hr - nn, nn);
             const _Float16 hi = (_Float16)hr;
             const _Float16 lo = (_Float16)(hr - (float)hi);
-            const h8 b1 = {lo, 0, 0, 0, hi, 0, 0, 0}, b2 = {hi, 0, 0, 0, 0, 0, 0, 0};
+            const h8 br = {hi, 0, lo, 0, hi, 0, 0, 0};               // [hi k0 k1 | lo k0 k1 | hi k0 k1 | 0 0], k0 = unit 96 + q, no k1
             const lds_ptr hn_w = hw + p1 * kHBsz;
-            *reinterpret_cast<lds_w4*>(hn_w) = __builtin_bit_cast(u32x4v, b1);
-            *reinterpret_cast<lds_w4*>(hn_w + 1024) = __builtin_bit_cast(u32x4v, b2);
+            *reinterpret_cast<lds_w4*>(hn_w) = __builtin_bit_cast(u32x4v, br);
             stamp(c, grp == (int)blockIdx.x, s, 5);
             step_barrier();
         }
@@ -512,15 +507,15 @@ __device__ __forceinline__ void yh_dma(__amdgpu_buffer_rsrc_t rs, lds_ptr y, con
         dma16(rs, y + (2 * sl + 1) * 1024, v.vB + kY0PlaneAB + sl * 64, so);
     }
 }
-// the K = 16 remainder of a step goes through registers (its halves are re-paired into b1 = [lo | hi], b2 = [hi | 0])
-struct YR { u32x2v rh, rl; };
+// the K = 8 remainder of a step (y0 halves 192..199) goes through registers: lane (n, kq) takes k = 192 + 2 kq, + 1 of row n, re-paired
+// into the one B tile of mma3r: [hi k0 k1 | lo k0 k1 | hi k0 k1 | 0 0]
+struct YR { uint32_t rh, rl; };
 __device__ __forceinline__ void yr_load(YR& r, __amdgpu_buffer_rsrc_t rs, uint32_t vr, uint32_t so) {
-    r.rh = __builtin_amdgcn_raw_buffer_load_b64(rs, vr, so, 0);               // out-of-range lanes read zeros
-    r.rl = __builtin_amdgcn_raw_buffer_load_b64(rs, vr + kY0PlaneAB, so, 0);
+    r.rh = __builtin_amdgcn_raw_buffer_load_b32(rs, vr, so, 0);
+    r.rl = __builtin_amdgcn_raw_buffer_load_b32(rs, vr + kY0PlaneAB, so, 0);
 }
 __device__ __forceinline__ void yr_store(const YR& r, lds_ptr y) {            // y: this lane's slot of the M part
-    *reinterpret_cast<lds_w4*>(y + kMS * 2048) = u32x4v{r.rl.x, r.rl.y, r.rh.x, r.rh.y};
-    *reinterpret_cast<lds_w4*>(y + kMS * 2048 + 1024) = u32x4v{r.rh.x, r.rh.y, 0, 0};
+    *reinterpret_cast<lds_w4*>(y + kMS * 2048) = u32x4v{r.rh, r.rl, r.rh, 0};
 }
 __device__ __forceinline__ void dma_landed() { __builtin_amdgcn_s_waitcnt(0x0F70); }       // vmcnt(0): an LDS-DMA is a pending LDS write on the VM counter
 
@@ -538,7 +533,7 @@ __device__ __forceinline__ void stage_wave(const Ctx& c) {
     const lds_ptr ymw = (lds_ptr)(c.lds + kYM + lane * 16);
     const lds_ptr pbw = (lds_ptr)(c.lds + kPB + lane * 16);
     const Y0Lane v0 = y0_lane(n, q);
-    const uint32_t vr = q < 2 ? y0_half(n, 192 + 4 * q) : 0x80000000u;                   // remainder k = 192 + 4 kq .. + 3 (kq < 2): piece 24, region B
+    const uint32_t vr = y0_half(n, 192 + 2 * q);                                         // remainder k = 192 + 2 kq, + 1: piece 24, region B
     for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(c.P.y0) + (size_t)grp * L * (16 * 800), 0, L * 16 * 800, 0x00020000);
         // byte offset of step k's 16 rows (steps past the end: the last step again - fetched, never used)
