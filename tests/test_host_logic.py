@@ -186,7 +186,10 @@ def test_isa_audit_is_clean_on_the_built_library():
     for inst in ("tae::dec_kernel_h<100, 5, false, false, 3>", "tae::dec_kernel_h<100, 5, false, true, 3>", "tae::dec_kernel_h<100, 5, false, false, 1>",
                  "tae::(anonymous namespace)::gru_l1f_kernel"):
         k = res["kernels"][[n for n in names if n.startswith(inst)][0]]       # plain decoder, its both-branch-head twin, the one-product (f16x1) decoder, the fused GRU layer 1
-        assert list(k["mfma"]) == ["v_mfma_f32_16x16x32_f16"] and k["scratch"] == 0 and k["vgpr_spill"] == 0 and k["vgpr"] <= 256, inst
+        # (the both-branch-head twin may hold the audit's documented cold-scratch allowance since the two-MFMA tail slabs, isa_audit.COLD_SCRATCH_OK)
+        cold = any(inst.startswith(p) for p in A.COLD_SCRATCH_OK)
+        assert list(k["mfma"]) == ["v_mfma_f32_16x16x32_f16"] and k["vgpr"] <= 256, inst
+        assert (k["scratch"] == 0 and k["vgpr_spill"] == 0) or (cold and k["scratch"] <= A.COLD_SCRATCH_MAX), inst
     assert len(names) >= 88
 
 

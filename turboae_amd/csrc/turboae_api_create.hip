@@ -91,6 +91,7 @@ size_t pack_stack(const float* src, const Layout& lo, int n_layer, int cin0, int
 struct LayoutH {   // must mirror tae::GeoH<U> / tae::tap_geo<U>(taps)
     int U, CT, CP, nsl_mid, nsl_l0, taps;
     uint32_t slb, midb, l0b, tailb;
+    bool tail20 = false;      // whole-block 100-wide 5-tap engines: every layer's last slab in the two-MFMA form (GeoH<100>::TAIL20, run_stack_h<.., T20>)
     explicit LayoutH(int u, int taps_ = 5) : U(u), taps(taps_) {
         CT = (U + 15) / 16;
         CP = CT * 16;
@@ -125,14 +126,31 @@ inline float max_abs(const float* p, size_t n) {
 
 // Conv1d weight (U, cin, 5) -> [slab][channel tile][hi | lo][lane][8 halves]: lane (i = lane & 15, kq = lane >> 4) holds
 // W'[co = 16 ct + i][k = 32 slab + 8 kq + j] * scale, split into hi = f16(w), lo = f16(w - hi)
-void pack_conv_h(const float* W, int U, int cin, int cin_pad, int nslab, int CT, float scale, uint16_t* dst, int taps = 5) {
+// tail20 (100-channel, 5-tap U -> U layers: K = 500 = 15 slabs + 20 k): the last slab in the two-MFMA form of conv_accumulate_h -
+// where its hi fragments go: A1 = [hi k 4kq.. | hi k 4kq..]; in place of its lo fragments: A2 = [lo k 4kq.. | X(kq)] with
+// X = hi, hi, lo, 0 (kq = 0..3) of k 16..19 (k relative to the slab)
+void pack_conv_h(const float* W, int U, int cin, int cin_pad, int nslab, int CT, float scale, uint16_t* dst, int taps = 5, bool tail20 = false) {
     for (int sl = 0; sl < nslab; ++sl)
         for (int ct = 0; ct < CT; ++ct)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
-                    const float w = wflat(W, U, cin, cin_pad, ct * 16 + (lane & 15), 32 * sl + 8 * (lane >> 4) + j, taps) * scale;
-                    const uint16_t hi = f2h(w), lo = f2h(w - h2f(hi));
                     const size_t base = ((size_t)(sl * CT + ct) * 2) * 512 + (size_t)lane * 8 + j;
+                    const int kq = lane >> 4;
+                    auto split = [&](int k, uint16_t& hi, uint16_t& lo) {
+                        const float w = wflat(W, U, cin, cin_pad, ct * 16 + (lane & 15), k, taps) * scale;
+                        hi = f2h(w);
+                        lo = f2h(w - h2f(hi));
+                    };
+                    uint16_t hi, lo;
+                    if (tail20 && sl == nslab - 1) {
+                        uint16_t h0, l0, h1 = 0, l1 = 0;
+                        split(32 * sl + 4 * kq + (j & 3), h0, l0);
+                        if (kq < 3) split(32 * sl + 16 + (j & 3), h1, l1);
+                        dst[base] = h0;                                                        // A1: both quarters hi of k 4kq..
+                        dst[base + 512] = j < 4 ? l0 : (kq < 2 ? h1 : (kq == 2 ? l1 : (uint16_t)0));      // A2
+                        continue;
+                    }
+                    split(32 * sl + 8 * kq + j, hi, lo);
                     dst[base] = hi;
                     dst[base + 512] = lo;
                 }
@@ -181,7 +199,8 @@ size_t pack_stack_h(const float* src, const LayoutH& lo, int n_layer, int cin0, 
             memset(d, 0, lo.l0b);
             memcpy(d, one.data(), one.size() * sizeof(uint16_t));
         } else
-        pack_conv_h(s, lo.U, cin, l == 0 ? 8 : lo.U, l == 0 ? lo.nsl_l0 : lo.nsl_mid, lo.CT, scale, reinterpret_cast<uint16_t*>(d), lo.taps);
+        pack_conv_h(s, lo.U, cin, l == 0 ? 8 : lo.U, l == 0 ? lo.nsl_l0 : lo.nsl_mid, lo.CT, scale, reinterpret_cast<uint16_t*>(d), lo.taps,
+                    lo.tail20);       // first layer 1 slab + tail (8 real k), U -> U layers 15 + tail (20 real k)
         d += l == 0 ? lo.l0b : lo.midb;
         const float* b = s + nw;
         float* t = reinterpret_cast<float*>(d);
@@ -826,6 +845,7 @@ size_t num_weights(const tae_config* c) {
 // with zero weights and biases for the extra channels (ELU(0) = 0: they stay zero and feed nothing), and a SameShapeConv1d
 // of kernel size 1 or 3 (padding ks / 2) is the 5-tap convolution whose outer taps are zero - so such configurations
 // are embedded, exactly, into the instantiated geometry before packing.  `out_cfg` receives that geometry.
+int conv_kernel_width(int u, int ks);
 std::vector<float> embed_weights(const tae_config* c, const float* w, tae_config* out_cfg) {
     std::vector<float> out;
     *out_cfg = *c;
@@ -881,7 +901,7 @@ std::vector<float> embed_weights(const tae_config* c, const float* w, tae_config
         w += nout;
     };
     {
-        const size_t U = c->enc_num_unit, U2 = c->enc_type == 1 ? 100 : (size_t)kernel_width((int)U);
+        const size_t U = c->enc_num_unit, U2 = c->enc_type == 1 ? 100 : (size_t)conv_kernel_width((int)U, c->enc_kernel_size);
         const size_t ks = c->enc_kernel_size, ks2 = ks < 5 ? 5 : ks;
         out_cfg->enc_num_unit = (int32_t)U2;
         out_cfg->enc_kernel_size = (int32_t)ks2;
@@ -896,7 +916,7 @@ std::vector<float> embed_weights(const tae_config* c, const float* w, tae_config
         }
     }
     {
-        const size_t U = c->dec_num_unit, U2 = c->dec_type == 1 ? 100 : (size_t)kernel_width((int)U);
+        const size_t U = c->dec_num_unit, U2 = c->dec_type == 1 ? 100 : (size_t)conv_kernel_width((int)U, c->dec_kernel_size);
         const size_t ks = c->dec_kernel_size, ks2 = ks < 5 ? 5 : ks;
         out_cfg->dec_num_unit = (int32_t)U2;
         out_cfg->dec_kernel_size = (int32_t)ks2;
@@ -914,10 +934,17 @@ std::vector<float> embed_weights(const tae_config* c, const float* w, tae_config
     return out;
 }
 
+// The 100-wide f16x2 conv kernels are 5-tap kernels since late r06 (GeoH<100>::TAIL20: every layer ends in a two-MFMA tail slab, a
+// compile-time property): kernel sizes 7 and 9 at widths 65..100 run, exactly, embedded in the 124-wide instantiation (whose slab
+// count follows the kernel size at run time); kernel sizes 1 and 3 are embedded in 5 taps as before.
+int conv_kernel_width(int u, int ks) {
+    const int w = kernel_width(u);
+    return (w == 100 && ks > 5) ? 124 : w;
+}
 bool needs_embedding(const tae_config* c) {
     return c->enc_kernel_size < 5 || c->dec_kernel_size < 5 ||
-           (c->enc_type == 0 ? kernel_width(c->enc_num_unit) : 100) != c->enc_num_unit ||
-           (c->dec_type == 0 ? kernel_width(c->dec_num_unit) : 100) != c->dec_num_unit;
+           (c->enc_type == 0 ? conv_kernel_width(c->enc_num_unit, c->enc_kernel_size) : 100) != c->enc_num_unit ||
+           (c->dec_type == 0 ? conv_kernel_width(c->dec_num_unit, c->dec_kernel_size) : 100) != c->dec_num_unit;
 }
 
 
@@ -1313,7 +1340,9 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
             if (h->Ud != 100 || h->nbd < 1) { delete h; return fail(TAE_EINVAL, "TAE_PREC_F16X1 needs the 100-wide whole-block decoder kernel (block_len <= 320)"); }
             h->x1 = true;
         }
-        const LayoutH lh(h->U, taps_e), lhd(h->Ud, taps_d);
+        LayoutH lh(h->U, taps_e), lhd(h->Ud, taps_d);
+        lh.tail20 = h->U == 100 && taps_e == 5 && h->nb >= 1;        // the whole-block 100-wide kernels (run_stack_h<.., T20>); the long-block kernels keep the padded slab
+        lhd.tail20 = h->Ud == 100 && taps_d == 5 && h->nbd >= 1;
         h->enc_stride_h = (uint32_t)lh.stack_bytes(cfg->enc_num_layer);
         h->dec_stride_h = (uint32_t)lhd.stack_bytes(cfg->dec_num_layer);
         penc_h.assign((size_t)3 * h->enc_stride_h, 0);

@@ -548,6 +548,32 @@ __device__ __forceinline__ void mma_tile_h(f32x4 (&acc)[NC], const OpsHA<NC>& a,
 #endif
 }
 
+// The 20-k tail slab of a 100-channel, 5-tap layer (K = 500 = 15 x 32 + 20; late r06): its three products are 60 k slots - TWO
+// MFMAs instead of a padded slab's three.  In quarters of a lane's 8 k slots, lane group kq:
+//     MFMA 1   A1 = [hi k 4kq.. | hi k 4kq..]        B1 = [hi k 4kq.. | lo k 4kq..]                      hi*hi and hi*lo of k 0..15
+//     MFMA 2   A2 = [lo k 4kq.. | X(kq)]              B2 = [hi k 4kq.. | Y(kq)]                           lo*hi of k 0..15, and k 16..19:
+//              X = hi, hi, lo, 0 (kq = 0..3) of k 16..19;  Y = hi, lo, hi, (hi) of k 16..19
+// The host stores A1 where the slab's hi fragments go and A2 in place of its lo fragments (pack_conv_h, tail20), so the weight stream
+// does not change; the B operands are three 8-byte reads per tile (H = hi plane k 4kq.., Lq = lo plane k 4kq.., Y).
+template <int NC>
+__device__ __forceinline__ void mma_tile_h_tail20(f32x4 (&acc)[NC], const OpsHA<NC>& a, const OpsHB& b) {
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma16x16x32h(a.hi[ct], b.hi, acc[ct]);
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma16x16x32h(a.lo[ct], b.lo, acc[ct]);
+}
+// ph / pl: the lane's fragment addresses of the slab BEFORE the tail slab in the hi / lo plane (row + 32 slab + 16 kq bytes) MINUS 8 kq
+// (conv_accumulate_h moves its pointers there once they have served the last full slab): k = 4 kq of the tail slab is 64 bytes on,
+// k = 16 another 32 - 8 kq, in the lo plane for lane group 1
+__device__ __forceinline__ void load_xh_tail20(OpsHB& o, lds_cptr ph, lds_cptr pl, uint32_t voff) {
+    using lds_u2 = const u32x2v __attribute__((address_space(3)));
+    const uint32_t k8 = (voff >> 5) & ~7u;                            // voff = lane * 16: 8 kq
+    const lds_cptr y = ((voff >> 8) == 1u ? pl : ph) - k8;
+    const u32x2v H = *reinterpret_cast<lds_u2*>(ph + 64), Lq = *reinterpret_cast<lds_u2*>(pl + 64), Y = *reinterpret_cast<lds_u2*>(y + 96);
+    o.hi = __builtin_bit_cast(h8, u32x4w{H.x, H.y, Lq.x, Lq.y});
+    o.lo = __builtin_bit_cast(h8, u32x4w{H.x, H.y, Y.x, Y.y});
+}
+
 // acc += W (16*NC x 32*NSLAB) * im2col (32*NSLAB x PT*16) in the f16x2 representation.
 // `a0` arrives with slab 0's A fragments loaded.  Slabs are processed in pairs (A fragments ping-pong
 // between two register sets, fetched one slab = ~1000 cycles ahead); within a slab the position tiles are
@@ -555,7 +581,9 @@ __device__ __forceinline__ void mma_tile_h(f32x4 (&acc)[NC], const OpsHA<NC>& a,
 // soff  : wave-uniform byte offset of this layer's A fragments
 // bh/bl : per position tile, LDS byte address of (row-2)*stride + 16*kq in the hi / lo plane
 // NSLAB = 0: the slab count is the (wave-uniform) run-time argument `nslab_rt` (conv stacks: it follows the kernel size).
-template <int CTT, int C0, int NC, int PT, int NSLAB, bool B128 = false, int PROD = 3>
+// TAIL20: `nslab_rt` is ODD and counts the full slabs; one more slab follows them in the packed layer, in the two-MFMA tail form above
+// (a compile-time property of the instantiation: with the choice at run time the allocator spilled 57 vector registers of the decoder).
+template <int CTT, int C0, int NC, int PT, int NSLAB, bool B128 = false, int PROD = 3, bool TAIL20 = false>
 __device__ __forceinline__ void conv_accumulate_h(f32x4 (&acc)[PT][NC], OpsHA<NC>& a0, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff,
                                                   uint32_t soff, const char* lds, const uint32_t (&bh)[PT], const uint32_t (&bl)[PT],
                                                   int nslab_rt = 0) {
@@ -602,6 +630,55 @@ __device__ __forceinline__ void conv_accumulate_h(f32x4 (&acc)[PT][NC], OpsHA<NC
         soff += 2 * SB;
 #pragma unroll
         for (int p = 0; p < PT; ++p) { ch[p] += 128; cl[p] += 128; }
+    }
+    if constexpr (TAIL20) {
+        {
+            // the last full slab (a0, fetched by the loop's last pair) with the tail slab's fragments and first B tile on their way,
+            // then the tail slab: per tile three 8-byte LDS reads (of the next tile) and 2 * NC MFMAs
+            load_wh<CTT, C0, NC>(a1, rsrc, voff, soff + SB);
+            _Pragma("unroll") for (int p = 0; p + 1 < PT; ++p) {
+                load_xh<0, B128>(b[(p + 1) % 2], ch[p + 1], cl[p + 1]);
+                mma_tile_h<NC, PROD>(acc[p], a0, b[p % 2]);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                if (p < NVS) {
+                    _Pragma("unroll") for (int v = 0; v < NVT; ++v) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, PROD * NC / NVT, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * NC - NVT * (PROD * NC / NVT), 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, PROD * NC, 0);
+                }
+            }
+            {   // last tile of the last full slab: the tail slab's first B tile is fetched behind the products that end the hi fragments'
+                // life (sixteen registers fewer at the kernel's tightest point than fetching it ahead of the tile)
+                constexpr int p = PT - 1;
+                const OpsHB& bb = b[p % 2];
+                static_assert(TAE_MMA_ORDER == 1, "the split below keeps mma_tile_h's per-accumulator product order (hi*lo, hi*hi, lo*hi)");
+                if constexpr (PROD == 3) {
+#pragma unroll
+                    for (int ct = 0; ct < NC; ++ct) {
+                        acc[p][ct] = mfma16x16x32h(a0.hi[ct], bb.lo, acc[p][ct]);
+                        acc[p][ct] = mfma16x16x32h(a0.hi[ct], bb.hi, acc[p][ct]);
+                    }
+                }
+                const uint32_t k8 = (voff >> 5) & ~7u;
+                _Pragma("unroll") for (int r = 0; r < PT; ++r) { ch[r] -= k8; cl[r] -= k8; }      // the full slabs are done with them
+                load_xh_tail20(b[(p + 1) % 2], ch[0], cl[0], voff);
+#pragma unroll
+                for (int ct = 0; ct < NC; ++ct) acc[p][ct] = PROD == 3 ? mfma16x16x32h(a0.lo[ct], bb.hi, acc[p][ct]) : mfma16x16x32h(a0.hi[ct], bb.hi, acc[p][ct]);
+                __builtin_amdgcn_sched_group_barrier(0x008, (PROD - 1) * NC, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NC, 0);
+            }
+            _Pragma("unroll") for (int p = 0; p < PT; ++p) {
+                if (p + 1 < PT) load_xh_tail20(b[(PT + p + 1) % 2], ch[p + 1 < PT ? p + 1 : 0], cl[p + 1 < PT ? p + 1 : 0], voff);
+                mma_tile_h_tail20<NC>(acc[p], a1, b[(PT + p) % 2]);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * NC, 0);
+            }
+            return;
+        }
     }
     if (nslab & 1) { TAE_H_SLAB(a0, 0, 0) }
 #undef TAE_H_SLAB

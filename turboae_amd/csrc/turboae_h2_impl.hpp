@@ -40,6 +40,7 @@ struct GeoH {
     static constexpr uint32_t MIDB = NSL_MID * SLB;
     static constexpr uint32_t L0B = NSL_L0 * SLB;
     static constexpr uint32_t TAILB = CP * 4u + 32u;    // bias + scale block (8 floats) after the fragments
+    static constexpr bool TAIL20 = (U == 100);          // 5 taps only; the whole-block kernels end every layer in a two-MFMA tail slab (conv_accumulate_h; the host packs it so)
 };
 
 // The same for a kernel size known at run time (5, 7, 9): the plain conv stacks take it from the launch parameters; the
@@ -413,7 +414,7 @@ __device__ __forceinline__ void stamp_h(char* smem, int lane, int layer, int i) 
 // (the first layer's packed 2^-(S + A_x) undoes it).
 // `l0_slabs` > 0: the first layer walks that many K slabs instead of the tap_geo count (encoder stacks: C_in = 1 folds all taps
 // into ONE slab, see fold_enc_input).
-template <int U, int PT, int C0, int NC, int TRACK = 1, bool HEAD2 = (TRACK == 2), int PROD = 3, class Epi>
+template <int U, int PT, int C0, int NC, int TRACK = 1, bool HEAD2 = (TRACK == 2), int PROD = 3, bool T20 = GeoH<U>::TAIL20, class Epi>
 __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint32_t soff, uint32_t snext, int n_layer, char* smem,
                                             const PanelsH& pn, const XPlane& xin, const TileH<PT>& tc, int g, int lane,
                                             WeightStreamH<U, C0, NC>& ws, const RangeH& rg, Epi epi, int l0_slabs = 0) {
@@ -421,7 +422,7 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
     constexpr int CTT = G::CT;
     const int q = lane >> 4;
     const int dump_row = pn.dump;
-    const TapGeo tg = tap_geo<U>(tc.pad * 2 + 1);
+    const TapGeo tg = tap_geo<U>(G::TAIL20 ? 5 : tc.pad * 2 + 1);      // the 100-wide instantiations run 5 taps only (conv_kernel_width on the host): constants
     f32x4 acc[PT][NC];
     uint32_t lo = soff;
     float inv_scale = 1.0f;
@@ -454,8 +455,11 @@ __device__ __forceinline__ void run_stack_h(const char* __restrict__ wpack, uint
             bh[p] = ph + o;
             bl[p] = pl + o;
         }
-        conv_accumulate_h<CTT, C0, NC, PT, 0, false, PROD>(acc, ws.a, ws.rsrc, ws.voff, lo, smem, bh, bl,
-                                              first ? (l0_slabs > 0 ? l0_slabs : tg.nsl_l0) : tg.nsl_mid);
+        // T20 (the whole-block 100-wide kernels; the host packs their layers so, LayoutH::tail20): every layer ends in a two-MFMA tail
+        // slab (5 taps only - other kernel sizes at these widths run on the 124-wide instantiation): first layer 1 full slab + tail (the
+        // encoder's folded input: its tail fragments are zero), U -> U layers 15 + tail
+        conv_accumulate_h<CTT, C0, NC, PT, 0, false, PROD, T20>(acc, ws.a, ws.rsrc, ws.voff, lo, smem, bh, bl,
+                                              T20 ? (first ? 1 : tg.nsl_mid - 1) : (first ? (l0_slabs > 0 ? l0_slabs : tg.nsl_l0) : tg.nsl_mid));
         stamp_h(smem, lane, l, 1);
         lo += fragb + G::TAILB;
         {
@@ -806,7 +810,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
     // lower wave gets the lighter upper one (18 tiles: 32 / 32 / 31 / 31 tile pairs per SIMD instead of 35 / 35 / 28 / 28)
     const int h = wave / kGroups, g = TAE_PAIR_REVERSE && h ? (kGroups - 1) - (wave & (kGroups - 1)) : (wave & (kGroups - 1));
     const int L = P.L, nb = P.nb;
-    const int pad = P.taps >> 1;
+    const int pad = GeoH<U>::TAIL20 ? 2 : (P.taps >> 1);       // TAIL20 instantiations run 5 taps only
     const int rows = nb * (L + pad) + pad;
     const PanelsH pn = carve_h<U>(smem, rows, L);
     // workgroups [0, n_full) own nb blocks, the tail workgroups nb_tail (fewer position tiles: a cheaper last round)
@@ -856,7 +860,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_kernel_h(FusedParams P) {
     };
     dispatch_tiles<PT>(gs.live, run);
     // every stack ends with a barrier: all rows are in place.  Row i = (stack i / n_layer, layer i % n_layer); the last layer of a stack has no panel
-    if (TAE_RANGE_BOOK == 1) range_finish(pn.RNG, 2 * P.n_iter * P.n_layer, 1, [&](int i) { return plain_tail<U>(P.wpack, P.stack_stride, P.n_layer, P.taps, i); });
+    if (TAE_RANGE_BOOK == 1) range_finish(pn.RNG, 2 * P.n_iter * P.n_layer, 1, [&](int i) { return plain_tail<U>(P.wpack, P.stack_stride, P.n_layer, GeoH<U>::TAIL20 ? 5 : P.taps, i); });
     if constexpr ((TAE_X & 1024) != 0) {
         __syncthreads();
         if (blockIdx.x == 0 && lane == 0) {
@@ -909,7 +913,7 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
     // lower wave gets the lighter upper one (18 tiles: 32 / 32 / 31 / 31 tile pairs per SIMD instead of 35 / 35 / 28 / 28)
     const int h = wave / kGroups, g = TAE_PAIR_REVERSE && h ? (kGroups - 1) - (wave & (kGroups - 1)) : (wave & (kGroups - 1));
     const int L = P.L, nb = P.nb;
-    const int pad = P.taps >> 1;
+    const int pad = GeoH<U>::TAIL20 ? 2 : (P.taps >> 1);       // TAIL20 instantiations run 5 taps only
     const int rows = nb * (L + pad) + pad;
     const PanelsH pn = carve_h<U>(smem, rows, L);
     // workgroups [0, n_full) own nb blocks, the tail workgroups nb_tail (fewer position tiles: a cheaper last round)
@@ -948,7 +952,7 @@ __global__ __launch_bounds__(kThreads, 2) void enc_kernel_h(FusedParams P) {
         else enc_body_h<U, T, Split<U>::CTA, Split<U>::CTB, TRACK, HEAD2>(P, smem, pn, tc, gs.gt0, lane, blk0, sum, sumsq);
     };
     dispatch_tiles<PT>(gs.live, run);
-    if (TAE_RANGE_BOOK == 1 && TRACK) range_finish(pn.RNG, 3 * P.n_layer, 1, [&](int i) { return plain_tail<U>(P.wpack, P.stack_stride, P.n_layer, P.taps, i); });
+    if (TAE_RANGE_BOOK == 1 && TRACK) range_finish(pn.RNG, 3 * P.n_layer, 1, [&](int i) { return plain_tail<U>(P.wpack, P.stack_stride, P.n_layer, GeoH<U>::TAIL20 ? 5 : P.taps, i); });
     block_reduce_stats(smem, tid, sum, sumsq, P.partials);
 }
 
@@ -970,7 +974,7 @@ __device__ __forceinline__ void seg_body_h(const SegParams& P, char* smem, const
     const RangeH rg{range_rows(pn.RNG)};
     auto run = [&](auto epi) {
         if constexpr (DENSE) run_stack_h_dense<U, PT, C0, NC>(wpack, soff, P.n_layer, smem, pn, X, tc, g, lane, ws, rg, active, epi);
-        else run_stack_h<U, PT, C0, NC, 1>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, rg, epi, P.mode == 0 ? 1 : 0);     // (long blocks: the last layers keep exp2 - 1)
+        else run_stack_h<U, PT, C0, NC, 1, false, 3, false>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, rg, epi, P.mode == 0 ? 1 : 0);     // (long blocks: the last layers keep exp2 - 1, and the padded last slab: no tail20)
     };
     if (P.mode == 0) {
         const int act = P.act;
@@ -1029,7 +1033,7 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
     // (3 tiles) of group 3 - s: group_span deals the extra position tiles to the low groups, so the SIMD that carries the heavier
     // lower wave gets the lighter upper one (18 tiles: 32 / 32 / 31 / 31 tile pairs per SIMD instead of 35 / 35 / 28 / 28)
     const int h = wave / kGroups, g = TAE_PAIR_REVERSE && h ? (kGroups - 1) - (wave & (kGroups - 1)) : (wave & (kGroups - 1));
-    const int pad = P.taps >> 1;                       // 2 for the dense stacks (5 taps)
+    const int pad = GeoH<U>::TAIL20 ? 2 : (P.taps >> 1);                       // 2 for the dense stacks (5 taps) and for the 5-tap-only 100-wide kernels
     const int L = P.L, H = pad * P.n_layer;
     int bid = blockIdx.x;
     int stack = P.stack;
@@ -1133,7 +1137,7 @@ __global__ __launch_bounds__(kThreads, 2) void seg_kernel_h(SegParams P) {
         // one stack per workgroup: rows 0 .. n_layer - 1; calibration slots of stack `stack`
         const int nl = P.n_layer;
         if (P.dense) range_finish(pn.RNG, nl, 1 + stack * nl, [&](int i) { return dense_tail<U>(P.wpack, (uint32_t)stack * P.stack_stride, nl, i); });
-        else range_finish(pn.RNG, nl, 1 + stack * nl, [&](int i) { return plain_tail<U>(P.wpack, P.stack_stride, nl, P.taps, stack * nl + i); });
+        else range_finish(pn.RNG, nl, 1 + stack * nl, [&](int i) { return plain_tail<U>(P.wpack, P.stack_stride, nl, GeoH<U>::TAIL20 ? 5 : P.taps, stack * nl + i); });
     }
     if (P.mode == 0) { __syncthreads(); block_reduce_stats(smem, tid, sum, sumsq, P.partials); }
 }
