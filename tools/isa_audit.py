@@ -49,7 +49,7 @@ BENCH_KERNELS = [r"tae::dec_kernel_h<100, 5, false", r"tae::enc_kernel_h<100, 5,
                  r"tae::(anonymous namespace)::gen_rnn_mfma_kernel", r"tae::normalize_kernel", r"tae::count_errors_vec4_kernel"]
 # (ii)'s exception: the both-branch-head twin of the decoder spills seven loop-invariant registers since the two-MFMA tail slabs
 # (run_stack_h<.., T20>, late r06); the plain decoder - the headline kernel - has none
-COLD_SCRATCH_OK = [r"tae::dec_kernel_h<100, 5, false, true, 3>"]
+COLD_SCRATCH_OK = [r"tae::dec_kernel_h<100, 5, false, true, 3>", r"tae::seg_kernel_h<100, 5>"]      # ... and the long-block kernel: six (same-box A/B with them: -1.0 % per forward at L = 1000)
 COLD_SCRATCH_MAX = 64
 MEM_ASM = re.compile(r"\b(global_load|global_store|global_atomic|buffer_load|buffer_store|buffer_atomic|flat_load|flat_store|flat_atomic|"
                      r"scratch_load|scratch_store|ds_read|ds_write|ds_load|ds_store|ds_bpermute|ds_permute|s_load|s_buffer_load|"

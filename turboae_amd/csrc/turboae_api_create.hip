@@ -1341,8 +1341,8 @@ int tae_create(const tae_config* cfg, const float* weights, size_t n_weights, ta
             h->x1 = true;
         }
         LayoutH lh(h->U, taps_e), lhd(h->Ud, taps_d);
-        lh.tail20 = h->U == 100 && taps_e == 5 && h->nb >= 1;        // the whole-block 100-wide kernels (run_stack_h<.., T20>); the long-block kernels keep the padded slab
-        lhd.tail20 = h->Ud == 100 && taps_d == 5 && h->nbd >= 1;
+        lh.tail20 = h->U == 100 && taps_e == 5 && !cfg->dense;       // the plain-stack 100-wide kernels, whole-block and long-block (run_stack_h<.., T20>)
+        lhd.tail20 = h->Ud == 100 && taps_d == 5 && !cfg->dense;
         h->enc_stride_h = (uint32_t)lh.stack_bytes(cfg->enc_num_layer);
         h->dec_stride_h = (uint32_t)lhd.stack_bytes(cfg->dec_num_layer);
         penc_h.assign((size_t)3 * h->enc_stride_h, 0);

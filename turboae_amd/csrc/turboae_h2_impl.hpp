@@ -974,7 +974,7 @@ __device__ __forceinline__ void seg_body_h(const SegParams& P, char* smem, const
     const RangeH rg{range_rows(pn.RNG)};
     auto run = [&](auto epi) {
         if constexpr (DENSE) run_stack_h_dense<U, PT, C0, NC>(wpack, soff, P.n_layer, smem, pn, X, tc, g, lane, ws, rg, active, epi);
-        else run_stack_h<U, PT, C0, NC, 1, false, 3, false>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, rg, epi, P.mode == 0 ? 1 : 0);     // (long blocks: the last layers keep exp2 - 1, and the padded last slab: no tail20)
+        else run_stack_h<U, PT, C0, NC, 1>(wpack, soff, 0xffffffffu, P.n_layer, smem, pn, X, tc, g, lane, ws, rg, epi, P.mode == 0 ? 1 : 0);     // (long blocks: the last layers keep exp2 - 1)
     };
     if (P.mode == 0) {
         const int act = P.act;
