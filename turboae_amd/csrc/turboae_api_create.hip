@@ -639,16 +639,21 @@ void pack_rnn_u_dir(int G, const float* Wx, int cin, const float* Whh, const flo
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) put_split(dst, hi + lane * 16 + j * 2, lo + lane * 16 + j * 2, w(lane & 15, lane >> 4, j));
     };
+    // K = 8 fragment (the three products of the slab in ONE MFMA since late r06, turboae_rnn_u.hip::mma_gr): [lane][hi k0 k1 | hi k0 k1 | lo k0 k1 | 0 0]
     auto rem = [&](size_t off, auto&& w) {
         for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < 4; ++j) put_split(dst, off + lane * 16 + j * 2, off + lane * 16 + 8 + j * 2, w(lane & 15, lane >> 4, j));
+            for (int j = 0; j < 2; ++j) {
+                const float v = w(lane & 15, lane >> 4, j);
+                put_split(dst, off + lane * 16 + j * 2, off + lane * 16 + 8 + j * 2, v);
+                put_split(dst, off + lane * 16 + 4 + j * 2, off + lane * 16 + 8 + j * 2, v);
+            }
     };
     auto tile = [&](size_t base, auto&& row) {       // 8 fragments of one gate tile: W_hh slabs, remainder, input slab
         for (int sl = 0; sl < 3; ++sl)
             slab(base + (2 * sl) * 1024, base + (2 * sl + 1) * 1024,
                  [&](int m, int kq, int j) { return row(m) >= 0 ? Whh[(size_t)row(m) * H + hh_unit(sl, kq, j)] * scale : 0.0f; });
         rem(base + 6 * 1024, [&](int m, int kq, int j) { return (j == 0 && row(m) >= 0) ? Whh[(size_t)row(m) * H + 96 + kq] * scale : 0.0f; });
-        if (Wx) rem(base + 7 * 1024, [&](int m, int kq, int j) { return (kq < 2 && 4 * kq + j < cin && row(m) >= 0) ? Wx[(size_t)row(m) * cin + 4 * kq + j] * scale : 0.0f; });
+        if (Wx) rem(base + 7 * 1024, [&](int m, int kq, int j) { return (2 * kq + j < cin && row(m) >= 0) ? Wx[(size_t)row(m) * cin + 2 * kq + j] * scale : 0.0f; });
     };
     for (int ut = 0; ut < 6; ++ut)
         for (int g = 0; g < G; ++g) tile(((size_t)ut * G + g) * 8 * 1024, [&](int m) { return g * H + 16 * ut + m; });

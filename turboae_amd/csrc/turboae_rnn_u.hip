@@ -86,13 +86,13 @@ __device__ __forceinline__ void mma_g(f32x4 (&acc)[G], const h8 (&ah)[G], const 
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = mfma16x16x32h(ah[g], bh, acc[g]);
 }
-// K = 16 slab: A = [4 hi | 4 lo] of the lane's k = 0..3, b1 = [lo | hi], b2 = [hi | 0] (gru_rec_h's mma_rem)
+// K = 8 slab (the W_hh remainder: units 96..99, one real k per lane group; layer 0's inputs: k = 2 kq, 2 kq + 1), the three products
+// in ONE MFMA (late r06, as gru_l1f's mma3r; through r06 two, on [4 hi | 4 lo] x ([lo | hi], [hi | 0])): per lane
+// A = [hi k0 k1 | hi k0 k1 | lo k0 k1 | 0 0], B = [hi k0 k1 | lo k0 k1 | hi k0 k1 | 0 0]
 template <int G>
-__device__ __forceinline__ void mma_gr(f32x4 (&acc)[G], const h8 (&ar)[G], h8 b1, h8 b2) {
+__device__ __forceinline__ void mma_gr(f32x4 (&acc)[G], const h8 (&ar)[G], h8 b) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) acc[g] = mfma16x16x32h(ar[g], b1, acc[g]);
-#pragma unroll
-    for (int g = 0; g < G; ++g) acc[g] = mfma16x16x32h(ar[g], b2, acc[g]);
+    for (int g = 0; g < G; ++g) acc[g] = mfma16x16x32h(ar[g], b, acc[g]);
 }
 
 // cell arithmetic on the de-scaled pre-activations of one (unit, block): returns h', updates c (LSTM)
@@ -181,10 +181,10 @@ __device__ __forceinline__ void unit_wave(const Ctx& c, int ut) {
                 if (!LAYER0) fetch_gi(s + 1 < L ? s + 1 : s, nt);            // next step's tiles into the registers just consumed
 #pragma unroll
                 for (int sl = 0; sl < 3; ++sl) mma_g<G>(acc[nt], hh_hi[sl], hh_lo[sl], lds_h8(hc + sl * 2048), lds_h8(hc + sl * 2048 + 1024));
-                mma_gr<G>(acc[nt], hh_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
+                mma_gr<G>(acc[nt], hh_r, lds_h8(hc + 6144));
                 if (LAYER0) {
                     const lds_cptr xc = xb + p0 * kXBsz + nt * 2048;
-                    mma_gr<G>(acc[nt], xw, lds_h8(xc), lds_h8(xc + 1024));
+                    mma_gr<G>(acc[nt], xw, lds_h8(xc));
                 }
             }
 #pragma unroll
@@ -239,7 +239,7 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
     auto mma1 = [](f32x4& a, h8 ah, h8 al, h8 bh, h8 bl) {
         a = mfma16x16x32h(ah, bl, a); a = mfma16x16x32h(al, bh, a); a = mfma16x16x32h(ah, bh, a);
     };
-    auto mma1r = [](f32x4& a, h8 ar, h8 b1, h8 b2) { a = mfma16x16x32h(ar, b1, a); a = mfma16x16x32h(ar, b2, a); };
+    auto mma1r = [](f32x4& a, h8 ar, h8 b) { a = mfma16x16x32h(ar, b, a); };
 
     for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
         __amdgpu_buffer_rsrc_t rs[kNT], rs_h[kNT];
@@ -262,7 +262,7 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int sl = 0; sl < 3; ++sl) mma1(a, hd_hi[sl], hd_lo[sl], lds_h8(hc + sl * 2048), lds_h8(hc + sl * 2048 + 1024));
-            mma1r(a, hd_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
+            mma1r(a, hd_r, lds_h8(hc + 6144));
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, a * inv_head), rs_h[nt], v_h, (uint32_t)t * 1024u, 0);
         };
         float cs[kNT];
@@ -285,10 +285,10 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
                 if (!LAYER0) fetch_gi(s + 1 < L ? s + 1 : s, nt);
 #pragma unroll
                 for (int sl = 0; sl < 3; ++sl) mma1(acc, hh_hi[sl], hh_lo[sl], lds_h8(hc + sl * 2048), lds_h8(hc + sl * 2048 + 1024));
-                mma1r(acc, hh_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
+                mma1r(acc, hh_r, lds_h8(hc + 6144));
                 if (LAYER0) {
                     const lds_cptr xc = xb + p0 * kXBsz + nt * 2048;
-                    mma1r(acc, xw, lds_h8(xc), lds_h8(xc + 1024));
+                    mma1r(acc, xw, lds_h8(xc));
                 } else if (s > 0) {
                     head(hc, nt, dir ? L - s : s - 1);        // Linear head on h_{s-1} (the state this step started from)
                 }
@@ -298,10 +298,9 @@ __device__ __forceinline__ void rem_wave(const Ctx& c) {
                 const float hr = cell<G>(a, cs[nt]);
                 const _Float16 hi = (_Float16)hr;
                 const _Float16 lo = (_Float16)(hr - (float)hi);
-                const h8 b1 = {lo, 0, 0, 0, hi, 0, 0, 0}, b2 = {hi, 0, 0, 0, 0, 0, 0, 0};
+                const h8 br = {hi, 0, lo, 0, hi, 0, 0, 0};               // [hi k0 k1 | lo k0 k1 | hi k0 k1 | 0 0], k0 = unit 96 + q, no k1
                 const lds_ptr hn_w = hw + p1 * kHBsz + nt * 8192;
-                *reinterpret_cast<lds_w4*>(hn_w) = __builtin_bit_cast(u32x4v, b1);
-                *reinterpret_cast<lds_w4*>(hn_w + 1024) = __builtin_bit_cast(u32x4v, b2);
+                *reinterpret_cast<lds_w4*>(hn_w) = __builtin_bit_cast(u32x4v, br);
                 if (LAYER0) {
                     const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane(t * (16 * 800));
                     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(uint16_t, hi), rs[nt], v_y, so, 0);
@@ -326,19 +325,18 @@ __device__ __forceinline__ void stage_wave(const Ctx& c) {
     const int lane = c.lane, L = c.L, n = c.n, q = c.q, dir = c.dir;
     const lds_ptr xw = (lds_ptr)(c.lds + GE::kXB + lane * 16);
     for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
-        // lane (n, kq) supplies k = 4 kq .. 4 kq + 3 of block n (kq < 2: the panel is 8 wide)
+        // lane (n, kq) supplies k = 2 kq, 2 kq + 1 of block n (the panel is 8 wide)
         auto stage = [&](int s, int buf) {
             const int t = dir ? L - 1 - s : s;
 #pragma unroll
             for (int nt = 0; nt < kNT; ++nt) {
                 const size_t b = (size_t)grp * (16 * kNT) + nt * 16 + n;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (q < 2 && b < (size_t)c.P.B) v = *reinterpret_cast<const f32x4*>(c.P.x + (b * L + t) * 8 + 4 * q);
+                float2 v2 = {0.f, 0.f};
+                if (b < (size_t)c.P.B) v2 = *reinterpret_cast<const float2*>(c.P.x + (b * L + t) * 8 + 2 * q);
                 h4 hi, lo;
-                split4(v, hi, lo);
+                split4(f32x4{v2.x, v2.y, 0.f, 0.f}, hi, lo);
                 const u32x2v h2 = __builtin_bit_cast(u32x2v, hi), l2 = __builtin_bit_cast(u32x2v, lo);
-                *reinterpret_cast<lds_w4*>(xw + buf * kXBsz + nt * 2048) = u32x4v{l2.x, l2.y, h2.x, h2.y};          // b1 = [lo | hi]
-                *reinterpret_cast<lds_w4*>(xw + buf * kXBsz + nt * 2048 + 1024) = u32x4v{h2.x, h2.y, 0, 0};          // b2 = [hi | 0]
+                *reinterpret_cast<lds_w4*>(xw + buf * kXBsz + nt * 2048) = u32x4v{h2.x, l2.x, h2.x, 0};              // [hi k0 k1 | lo k0 k1 | hi k0 k1 | 0 0]
             }
         };
         if (LAYER0) stage(0, 0);
@@ -518,7 +516,7 @@ __device__ __forceinline__ void unit_wave_f(const Ctx& c, int ut) {
                         mma_g<G>(gi[tc * kNT + nt], hh_hi[2], hh_l2, lds_h8(hc + 2 * 2048), lds_h8(hc + 2 * 2048 + 1024));
 #pragma unroll
                         for (int g = 0; g < G; ++g) hh_r[g] = lds_h8(hrl + g * 3072);
-                        mma_gr<G>(gi[tc * kNT + nt], hh_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
+                        mma_gr<G>(gi[tc * kNT + nt], hh_r, lds_h8(hc + 6144));
                     }
 #pragma unroll
                     for (int nt = 0; nt < kNT; ++nt) {
@@ -573,7 +571,7 @@ __device__ __forceinline__ void rem_wave_f(const Ctx& c) {
     auto mma1 = [](f32x4& a, h8 ah, h8 al, h8 bh, h8 bl) {
         a = mfma16x16x32h(ah, bl, a); a = mfma16x16x32h(al, bh, a); a = mfma16x16x32h(ah, bh, a);
     };
-    auto mma1r = [](f32x4& a, h8 ar, h8 b1, h8 b2) { a = mfma16x16x32h(ar, b1, a); a = mfma16x16x32h(ar, b2, a); };
+    auto mma1r = [](f32x4& a, h8 ar, h8 b) { a = mfma16x16x32h(ar, b, a); };
 
     for (int grp = blockIdx.x; grp < c.P.ngroups; grp += gridDim.x) {
         __amdgpu_buffer_rsrc_t rs_h[kNT];
@@ -587,7 +585,7 @@ __device__ __forceinline__ void rem_wave_f(const Ctx& c) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int sl = 0; sl < 3; ++sl) mma1(a, hd_hi[sl], hd_lo[sl], lds_h8(hc + sl * 2048), lds_h8(hc + sl * 2048 + 1024));
-            mma1r(a, hd_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
+            mma1r(a, hd_r, lds_h8(hc + 6144));
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, a * inv_head), rs_h[nt], v_h, (uint32_t)t * 1024u, 0);
         };
         float cs[kNT];
@@ -639,7 +637,7 @@ __device__ __forceinline__ void rem_wave_f(const Ctx& c) {
                         f32x4 acc = gi[tc * kNT + nt];
 #pragma unroll
                         for (int sl = 0; sl < 3; ++sl) mma1(acc, hh_hi[sl], hh_lo[sl], lds_h8(hc + sl * 2048), lds_h8(hc + sl * 2048 + 1024));
-                        mma1r(acc, hh_r, lds_h8(hc + 6144), lds_h8(hc + 7168));
+                        mma1r(acc, hh_r, lds_h8(hc + 6144));
                         if (s > 0) head(hc, nt, dir ? L - s : s - 1);        // Linear head on h_{s-1} (the state this step started from)
                         float a[G];
 #pragma unroll
@@ -647,10 +645,9 @@ __device__ __forceinline__ void rem_wave_f(const Ctx& c) {
                         const float hr = cell<G>(a, cs[nt]);
                         const _Float16 hi = (_Float16)hr;
                         const _Float16 lo = (_Float16)(hr - (float)hi);
-                        const h8 b1 = {lo, 0, 0, 0, hi, 0, 0, 0}, b2 = {hi, 0, 0, 0, 0, 0, 0, 0};
+                        const h8 br = {hi, 0, lo, 0, hi, 0, 0, 0};
                         const lds_ptr hn_w = hw + p1 * kHBsz + nt * 8192;
-                        *reinterpret_cast<lds_w4*>(hn_w) = __builtin_bit_cast(u32x4v, b1);
-                        *reinterpret_cast<lds_w4*>(hn_w + 1024) = __builtin_bit_cast(u32x4v, b2);
+                        *reinterpret_cast<lds_w4*>(hn_w) = __builtin_bit_cast(u32x4v, br);
                     }
                     step_barrier();
                 }
