@@ -693,9 +693,20 @@ void pack_rnn_u_proj(int G, const float* l1, size_t per1, char* dst) {
                 for (int sl = 0; sl < 7; ++sl)
                     for (int kq = 0; kq < 4; ++kq)
                         for (int j = 0; j < 8; ++j) {
-                            const int k = 32 * sl + 8 * kq + j, lane = kq * 16 + m;
-                            const float w = (row >= 0 && k < 2 * H) ? Wih[(size_t)row * cin1 + k] * scale : 0.0f;
+                            const int lane = kq * 16 + m;
                             const size_t o = d * dirb + ((size_t)(sl * CTT + T) * 2) * 1024 + lane * 16 + j * 2;
+                            if (sl == 6) {
+                                // the K = 8 tail (k = 192..199) as ONE MFMA (late r06, turboae_rnn_u.hip::lds_tail8): where the slab's hi fragment goes,
+                                // [hi k0 k1 | hi k0 k1 | lo k0 k1 | 0 0] with k = 192 + 2 kq + j; its lo fragment stays zero and is never fetched
+                                if (j >= 2) continue;
+                                const int k = 192 + 2 * kq + j;
+                                const float w = row >= 0 ? Wih[(size_t)row * cin1 + k] * scale : 0.0f;
+                                put_split(dst, o, o + 8, w);           // hi -> slots 0, 1; lo -> slots 4, 5
+                                put_split(dst, o + 4, o + 8, w);       // hi -> slots 2, 3
+                                continue;
+                            }
+                            const int k = 32 * sl + 8 * kq + j;
+                            const float w = (row >= 0 && k < 2 * H) ? Wih[(size_t)row * cin1 + k] * scale : 0.0f;
                             put_split(dst, o, o + 1024, w);
                         }
             }

@@ -95,6 +95,14 @@ __device__ __forceinline__ void mma_gr(f32x4 (&acc)[G], const h8 (&ar)[G], h8 b)
     for (int g = 0; g < G; ++g) acc[g] = mfma16x16x32h(ar[g], b, acc[g]);
 }
 
+// B operand of the projection's K = 8 tail slab (y0 halves 192..199, late r06): `p` = the lane's address of halves 192 + 2 kq, + 1 in the
+// hi plane, `lo_off` bytes further in the lo plane -> [hi k0 k1 | lo k0 k1 | hi k0 k1 | 0 0] (A: pack_rnn_u_proj, slab 6)
+__device__ __forceinline__ h8 lds_tail8(lds_cptr p, int lo_off) {
+    using lds_u1 = const uint32_t __attribute__((address_space(3)));
+    const uint32_t h = *reinterpret_cast<lds_u1*>(p), l = *reinterpret_cast<lds_u1*>(p + lo_off);
+    return __builtin_bit_cast(h8, u32x4v{h, l, h, 0u});
+}
+
 // cell arithmetic on the de-scaled pre-activations of one (unit, block): returns h', updates c (LSTM)
 template <int G>
 __device__ __forceinline__ float cell(const float (&a)[G], float& c) {
@@ -426,7 +434,7 @@ __device__ __forceinline__ void unit_wave_f(const Ctx& c, int ut) {
         constexpr int i = decltype(I)::value, r = i % kRingF;
         constexpr uint32_t off = (uint32_t)(i / G) * (CTT * 2048u) + (uint32_t)(i % G) * 2048u;
         ah[r] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsp, va + off, 0, 0));
-        al[r] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsp, va + off + 1024, 0, 0));
+        if constexpr (i / G < kProjSlabs - 1) al[r] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsp, va + off + 1024, 0, 0));     // the tail slab has one fragment
     };
     static_for<GB>(a_issue);                                     // the first block's fragments (every chunk starts with the same ones)
 
@@ -451,6 +459,20 @@ __device__ __forceinline__ void unit_wave_f(const Ctx& c, int ut) {
             static_for<NPAIR / GB>([&](auto BI) {
                 constexpr int b = decltype(BI)::value, i0 = b * GB, sl = i0 / G, g0 = i0 % G;
                 if constexpr (i0 + GB < NPAIR) static_for<GB>([&](auto J) { a_issue(std::integral_constant<int, i0 + GB + decltype(J)::value>{}); });
+                if constexpr (sl == kProjSlabs - 1) {
+                    // the K = 8 tail slab: ONE MFMA per accumulator; piece 24 of a row sits in lane (n, 0)'s slot of the slab's tiles
+#pragma unroll
+                    for (int n0 = 0; n0 < NS; n0 += NB) {
+                        h8 bt[NB];
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) bt[j] = lds_tail8(yb - 252 * q + (n0 + j) * GF::kTileB + sl * 2048, 1024);
+#pragma unroll
+                        for (int k = 0; k < GB; ++k)
+#pragma unroll
+                            for (int j = 0; j < NB; ++j) gi[n0 + j][g0 + k] = mfma16x16x32h(ah[(i0 + k) % kRingF], bt[j], gi[n0 + j][g0 + k]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else
 #pragma unroll
                 for (int n0 = 0; n0 < NS; n0 += NB) {
                     h8 bh[NB], bl[NB];
@@ -562,7 +584,7 @@ __device__ __forceinline__ void rem_wave_f(const Ctx& c) {
     {   // the mixed tile's W_ih1 fragments (tile 6 G of the projection image) stay in registers: this wave has them to spare
         const char* pa = c.P.wproj + (size_t)dir * DIRB + (size_t)(6 * G) * 2048 + lane * 16;
 #pragma unroll
-        for (int sl = 0; sl < kProjSlabs; ++sl) { pa_hi[sl] = glb_h8(pa + (size_t)sl * (CTT * 2048)); pa_lo[sl] = glb_h8(pa + (size_t)sl * (CTT * 2048) + 1024); }
+        for (int sl = 0; sl < kProjSlabs; ++sl) { pa_hi[sl] = glb_h8(pa + (size_t)sl * (CTT * 2048)); pa_lo[sl] = glb_h8(pa + (size_t)sl * (CTT * 2048) + 1024); }     // (the tail slab's lo fragment is zero and unused)
     }
     const lds_cptr bias = c.lds + 6 * (G * 64) + q * 16;
     const lds_cptr hb = c.lds + GE::kHB + lane * 16, yb = c.lds + GF::kYB + lane * 16;
@@ -602,7 +624,7 @@ __device__ __forceinline__ void rem_wave_f(const Ctx& c) {
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns) gi[ns] = *reinterpret_cast<lds_f4c*>(bias);
 #pragma unroll
-            for (int sl = 0; sl < kProjSlabs; ++sl)
+            for (int sl = 0; sl < kProjSlabs - 1; ++sl)
 #pragma unroll
                 for (int ns = 0; ns < NS; ++ns) {           // mma_tile_h's product order (hi*lo, hi*hi, lo*hi), not the recurrence's
                     const h8 bh = lds_h8(yb + ns * GF::kTileB + sl * 2048), bl = lds_h8(yb + ns * GF::kTileB + sl * 2048 + 1024);
@@ -610,6 +632,9 @@ __device__ __forceinline__ void rem_wave_f(const Ctx& c) {
                     gi[ns] = mfma16x16x32h(pa_hi[sl], bh, gi[ns]);
                     gi[ns] = mfma16x16x32h(pa_lo[sl], bh, gi[ns]);
                 }
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns)                  // the K = 8 tail slab: one MFMA
+                gi[ns] = mfma16x16x32h(pa_hi[kProjSlabs - 1], lds_tail8(yb - 252 * q + ns * GF::kTileB + (kProjSlabs - 1) * 2048, 1024), gi[ns]);
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns) gi[ns] *= mul;
 #ifdef TAE_L1F_DBG_GI
@@ -775,7 +800,20 @@ __device__ __forceinline__ void proj_pass(const RnnProjParams& P, const char* sm
 #pragma unroll
         for (int p = 0; p < kPT; ++p) acc[p][ct] = bv;
     }
-    conv_accumulate_h<CTT, C0, NC, kPT, kProjSlabs, true>(acc, a0, rsrc, voff, soff, smem, bh, bl);
+    conv_accumulate_h<CTT, C0, NC, kPT, kProjSlabs - 1, true>(acc, a0, rsrc, voff, soff, smem, bh, bl);
+    {   // the K = 8 tail slab as ONE MFMA per accumulator, exactly as rnn_l1f_u's P phase issues it (the two forms of layer 1 are bit-identical);
+        // its fragments are fetched here, behind the K loop: this kernel serves the small calls, where the projection is a small part
+        constexpr uint32_t SB = CTT * 2048;
+        h8 at[NC];
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) at[ct] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (C0 + ct) * 2048, soff + (kProjSlabs - 1) * SB, 0));
+#pragma unroll
+        for (int p = 0; p < kPT; ++p) {
+            const h8 bt = lds_tail8((lds_cptr)smem + bh[p] + (kProjSlabs - 1) * 64 - 12 * kq, kPlaneB);
+#pragma unroll
+            for (int ct = 0; ct < NC; ++ct) acc[p][ct] = mfma16x16x32h(at[ct], bt, acc[p][ct]);
+        }
+    }
 #pragma unroll
     for (int p = 0; p < kPT; ++p) {
         const size_t pos = p0 + p * 16 + n;
