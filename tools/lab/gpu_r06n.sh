@@ -1,7 +1,7 @@
 #!/bin/bash
 # r06: final-tree verification after the Y0 re-layout: whole suite both orders + smoke, recurrent fuzz (both layer-1 forms), determinism soak, bench + kernel traces
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
-TAG=${1:-r06q}
+TAG=${1:-r06r}
 bash tools/gpu_final.sh $TAG > /dev/null 2>&1
 grep "passed\|failed\|smoke:" $OUT/pytest_final_$TAG.txt
 { echo "== fuzz_rnn_u 120 cases seed 43"; timeout 1200 python tools/lab/probes/fuzz_rnn_u.py 120 43 2>&1 | grep -v amdgpu.ids | tail -130;
